@@ -1,0 +1,39 @@
+/*
+ * nifti_min.h -- minimal NIfTI-1 / Analyze-7.5 volume I/O for featExtract.
+ *
+ * Replaces, for this path only, what the reference gets from the vendored
+ * niftilib through fioReadNifti (R/featExtract/featExtract.cpp:84-220, where
+ * R/ = /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/): read the
+ * header, load the voxels (.nii, .nii.gz, .hdr + .img[.gz]), cast them to
+ * float32 with a plain C cast (scl_slope / scl_inter ignored, as
+ * reg_changeDatatype does, featExtract.cpp:18-77), and expose the qform /
+ * sform matrices needed by the -w / -ws options.
+ */
+#ifndef NIFTI_MIN_H
+#define NIFTI_MIN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int nx, ny, nz, nt;
+    float dx, dy, dz;
+    int datatype;      /* NIfTI datatype code of the file */
+    int qform_code, sform_code;
+    float qto_xyz[4][4];
+    float sto_xyz[4][4];
+    float *data;       /* nx*ny*nz*nt float32, x fastest; free() it */
+} nifti_min_image;
+
+/* Returns 0 on success; -1 cannot open/parse header, -2 no voxel data,
+ * -3 unsupported datatype, -4 out of memory. */
+int nifti_min_read(const char *path, nifti_min_image *img);
+/* Writes a float32 single-file .nii (or .nii.gz by extension), voxel size (dx,dy,dz). */
+int nifti_min_write_f32(const char *path, const float *data, int nx, int ny, int nz, float dx, float dy, float dz);
+void nifti_min_free(nifti_min_image *img);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

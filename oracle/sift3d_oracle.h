@@ -1,0 +1,157 @@
+/*
+ * sift3d_oracle.h -- CPU restatement of the reference 3D-SIFT extraction path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (3d_sift_cuda_amd/, the
+ * featExtract CLI, libsift3d_hip.so) may include, link or call this.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
+ * only as the checker / the timed CPU baseline.
+ *
+ * Every function cites the reference file:line it restates.  R/ stands for
+ * /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/.
+ *
+ * Parity pin status (see oracle/README.md and DESIGN.md):
+ *   - Gaussian taps, 3x3 SVD + eigen sort, 3x3 inverse, high-low sort: pinned
+ *     against oracle/_ref (those reference files compile from source as-is).
+ *   - blur / DoG / subsample / extrema / per-keypoint / descriptor / .key:
+ *     the reference's own translation units need <cuda.h>, <cuda_runtime.h>
+ *     and an un-vendored <znzlib.h>, which this image lacks, so they are
+ *     unbuildable here; these stages are pinned end-to-end against the .key
+ *     files written by the CPU featExtract binary the reference repository
+ *     ships (R/bin/Linux/featExtract), committed under tests/golden/.
+ *
+ * Build: gcc -O2 -ffp-contract=off (no -march=native, no -ffast-math): FMA
+ * contraction changes keypoints.
+ */
+#ifndef SIFT3D_ORACLE_H
+#define SIFT3D_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define O3_PATCH_DIM 11
+#define O3_PATCH_VOX (11 * 11 * 11)
+#define O3_DESC_LEN 64
+#define O3_MAX_TAPS 129
+
+/* R/src_common/MultiScale.h:28-30 */
+#define O3_INFO_MIN0MAX1 0x00000010u
+#define O3_INFO_REORIENT 0x00000020u
+
+/* descriptor modes: /root/reference/README.md:26-34, R/src_common/MultiScale.cpp:1037-1045 */
+enum { O3_DESC_SIFT = 0, O3_DESC_BRIEF = 1, O3_DESC_RRIEF = 2, O3_DESC_NRRIEF = 3 };
+
+/* R/src_common/LocationValue.h:41-47 */
+typedef struct {
+    int x, y, z;
+    float value;
+} o3_extremum;
+
+/* R/src_common/MultiScale.h:42-164 (Feature3DInfo + Feature3DData) */
+typedef struct {
+    float x, y, z, scale;
+    float ori[3][3];
+    float eigs[3];
+    uint32_t info;
+    float pc[O3_DESC_LEN];
+    float data[O3_PATCH_VOX]; /* data_zyx flattened, x fastest */
+} o3_feature;
+
+/* public (data-free) record, same layout as the product's sift3d_feature */
+typedef struct {
+    float x, y, z, scale;
+    float ori[9];
+    float eigs[3];
+    uint32_t info;
+    float desc[O3_DESC_LEN];
+} o3_record;
+
+/* ---- Gaussian taps ---------------------------------------------------- */
+int o3_gauss_filter_size(float sigma, float min_value);
+/* returns tap count; taps normalised as gb3d_blur3d_interleave does */
+int o3_gauss_taps(float sigma, float min_value, float *taps);
+/* normalise = 0: the taps as generate_gaussian_filter1d leaves them */
+int o3_gauss_taps_raw(float sigma, float min_value, float *taps, int normalise);
+
+/* ---- volume ops (x fastest, then y, then z) ------------------------------ */
+void o3_filter3d(const float *in, float *out, int64_t X, int64_t Y, int64_t Z, const float *taps, int ntaps);
+int o3_blur(const float *in, float *out, int64_t X, int64_t Y, int64_t Z, float sigma, float min_value);
+void o3_dog(const float *a, const float *b, float *out, int64_t n);
+void o3_subsample(const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
+void o3_double_size(const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
+void o3_halve_center(const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
+
+/* detect in C against H (26 + 27 neighbours); lists in raster order.
+ * Returns 0, or -1 if a capacity was exceeded (counts still exact). */
+int o3_detect(const float *H, const float *C, int64_t X, int64_t Y, int64_t Z,
+              o3_extremum *minima, int64_t cap_min, int64_t *n_min,
+              o3_extremum *maxima, int64_t cap_max, int64_t *n_max);
+/* validation against the next DoG (computed on the fly as G1 - G2) */
+int o3_validate_peak(const o3_extremum *e, const float *G1, const float *G2, int64_t X, int64_t Y, int64_t Z);
+int o3_validate_valley(const o3_extremum *e, const float *G1, const float *G2, int64_t X, int64_t Y, int64_t Z);
+/* full 26+27+27 test over three stored DoG levels (what the GPU path does) */
+int o3_detect3(const float *Dprev, const float *Dcur, const float *Dnext, int64_t X, int64_t Y, int64_t Z,
+               o3_extremum *minima, int64_t cap_min, int64_t *n_min,
+               o3_extremum *maxima, int64_t cap_max, int64_t *n_max);
+
+/* ---- per-keypoint -------------------------------------------------------- */
+double o3_interp_quadratic(double x0, double x1, double x2, double f0, double f1, double f2);
+void o3_interp_point(const float *C, int64_t X, int64_t Y, int64_t Z, int ix, int iy, int iz, float *fx, float *fy, float *fz);
+float o3_trilinear(const float *img, int64_t X, int64_t Y, int64_t Z, float x, float y, float z);
+int o3_sample_patch(const o3_feature *f, const float *img, int64_t X, int64_t Y, int64_t Z, float *patch);
+void o3_normalize_patch(float *patch);
+void o3_svd3(float mat[3][3], float w[3], float v[3][3]);
+void o3_sort_eig(float w[3], float v[3][3]);
+void o3_invert3(float in[3][3], float out[3][3]);
+void o3_orientation(o3_feature *f);
+int o3_canonical_orientations(o3_feature *f, float *ori_out, int max_ori);
+void o3_sort_high_low(o3_extremum *e, int n);
+
+/* ---- descriptors ---------------------------------------------------------- */
+void o3_desc_sift(o3_feature *f);
+void o3_desc_brief(o3_feature *f, int mode);
+void o3_rank(float *pc);
+void o3_brief_tables(int *x_idx, int *y_idx); /* 64 patch-linear indices each */
+
+/* ---- pipeline ------------------------------------------------------------- */
+typedef struct {
+    int64_t n_octaves;
+    int64_t n_extrema;   /* validated extrema over all levels */
+    int64_t n_keypoints; /* extrema surviving bounds + eigen test */
+    double t_blur, t_dog, t_subsample, t_detect, t_features, t_desc;
+} o3_stats;
+
+/* msGeneratePyramidDOG3D_efficient + descriptor loop of main().  vol is
+ * clobbered-free (copied).  Returns malloc'ed records in *out (free with
+ * o3_free).  size_factor multiplies x,y,z,scale at the end
+ * (featExtract.cpp:423-427,502-505). */
+int o3_extract(const float *vol, int64_t X, int64_t Y, int64_t Z, float initial_image_scale,
+               int desc_mode, float eig_thres, float size_factor, o3_record **out, int64_t *n_out,
+               o3_stats *stats);
+/* as o3_extract but keeps the full features (with patches, before the
+ * descriptor loop) for stage-level tests */
+int o3_pyramid_features(const float *vol, int64_t X, int64_t Y, int64_t Z, float initial_image_scale,
+                        float eig_thres, o3_feature **out, int64_t *n_out, o3_stats *stats);
+/* pyramid + detection only (no per-keypoint work): validated extrema with
+ * their H/L values, tagged octave/level; for kernel-level parity */
+typedef struct {
+    int octave, level; /* level 1..3 = DoG index inside the octave */
+    int is_max;
+    int x, y, z;
+    float value, h_value, l_value;
+} o3_candidate;
+int o3_pyramid_candidates(const float *vol, int64_t X, int64_t Y, int64_t Z, float initial_image_scale,
+                          o3_candidate **out, int64_t *n_out);
+/* one octave's Gaussians/DoGs for tests: G has 6 levels, D has 5 levels, each X*Y*Z */
+int o3_octave_levels(const float *g0, int64_t X, int64_t Y, int64_t Z, float *G, float *D);
+void o3_free(void *p);
+
+/* .key writer: R/src_common/MultiScale.h:386-474 */
+int o3_write_key(const char *path, const o3_record *recs, int64_t n, float eig_thres, int n_comments, const char **comments);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
