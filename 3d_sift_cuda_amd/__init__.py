@@ -1,0 +1,306 @@
+"""3d_sift_cuda_amd -- MI355X-native 3D SIFT extraction path (Python mirror of the C-ABI).
+
+Thin ctypes layer over ``csrc/_build/libsift3d_hip.so`` (``include/sift3d.h``).  The
+names follow the reference's operator interface for this path
+(R/cuda_common/SIFT_cuda_Tools.cuh, R/src_common/MultiScale.h; R/ =
+/root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/):
+
+=====================  =====================================================================
+here                   reference entry point it replaces
+=====================  =====================================================================
+``gauss_blur``         gb3d_blur3d -> blur_3d_simpleborders_CUDA_Row_Col_Shared_mem (.cuh:69-76)
+``dog``                fioMultSum_interleave(.., -1.0f) -> fioCudaMultSum (.cuh:213-217)
+``subsample2``         Subsample_interleave -> SubSampleInterpolateCuda (.cuh:202-205)
+``extrema``            detectExtrema4D_test_interleave -> detectExtrema4D_test_cuda (.cuh:32-38)
+``detect``/``extract`` msGeneratePyramidDOG3D_efficient (MultiScale.h:534-543) + main()'s descriptor loop
+=====================  =====================================================================
+
+There is no CPU fallback: importing works everywhere (the library is only
+dlopen'ed on first use), but every compute call raises if the HIP library is
+missing or no HIP device is usable.  The package name starts with a digit, so
+load it with ``importlib.import_module("3d_sift_cuda_amd")``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_HIP = os.path.join(CSRC, "_build", "libsift3d_hip.so")
+LIB_HOST = os.path.join(CSRC, "_build", "libsift3d_host.so")
+FEATEXTRACT = os.path.join(CSRC, "_build", "featExtract")
+
+DESC_SIFT, DESC_BRIEF, DESC_RRIEF, DESC_NRRIEF = 0, 1, 2, 3
+INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
+STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor")
+
+EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
+FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),
+                          ("eigs", "<f4", (3,)), ("info", "<u4"), ("desc", "<f4", (64,))])
+CANDIDATE_DTYPE = np.dtype([("octave", "<i4"), ("level", "<i4"), ("is_max", "<i4"), ("x", "<i4"), ("y", "<i4"),
+                            ("z", "<i4"), ("value", "<f4"), ("h_value", "<f4"), ("l_value", "<f4")])
+
+
+class Sift3DError(RuntimeError):
+    pass
+
+
+class _Timings(C.Structure):
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7), ("alg_bytes", C.c_double * 7),
+                ("n_octaves", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
+                ("n_records", C.c_int64), ("total_ms", C.c_double)]
+
+
+def build(verbose=False):
+    """Compile the HIP library, the host helpers and the CLI for gfx950 (in-tree)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise Sift3DError("building 3d_sift_cuda_amd/csrc failed")
+
+
+_hip = None
+_host = None
+
+
+def _sig(fn, res, *args):
+    fn.restype = res
+    fn.argtypes = list(args)
+
+
+def hip_lib():
+    """dlopen libsift3d_hip.so and declare the C-ABI; raises if it is not built."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    if not os.path.exists(LIB_HIP):
+        raise Sift3DError("%s is missing: run __graft_entry__.build() (there is no CPU fallback)" % LIB_HIP)
+    L = C.CDLL(LIB_HIP)
+    P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
+    _sig(L.sift3d_device_count, I)
+    _sig(L.sift3d_create, P, I, I64, I64, I64)
+    _sig(L.sift3d_destroy, None, P)
+    _sig(L.sift3d_last_error, C.c_char_p, P)
+    _sig(L.sift3d_set_stream, I, P, P)
+    _sig(L.sift3d_sync, I, P)
+    _sig(L.sift3d_free, None, P)
+    _sig(L.sift3d_gauss_taps, I, F, F, P)
+    _sig(L.sift3d_gauss_blur, I, P, P, P, I64, I64, I64, F, F)
+    _sig(L.sift3d_gauss_blur_dev, I, P, P, P, I64, I64, I64, F, F)
+    _sig(L.sift3d_gauss_blur_dog_dev, I, P, P, P, P, I64, I64, I64, F, F)
+    _sig(L.sift3d_dog, I, P, P, P, P, I64)
+    _sig(L.sift3d_dog_dev, I, P, P, P, P, I64)
+    _sig(L.sift3d_subsample2, I, P, P, I64, I64, I64, P)
+    _sig(L.sift3d_subsample2_dev, I, P, P, I64, I64, I64, P)
+    _sig(L.sift3d_extrema, I, P, P, P, P, I64, I64, I64, P, I64, P, P, I64, P)
+    _sig(L.sift3d_double_size, I, P, P, I64, I64, I64, P)
+    _sig(L.sift3d_halve_size, I, P, P, I64, I64, I64, P)
+    _sig(L.sift3d_set_volume, I, P, P, I64, I64, I64)
+    _sig(L.sift3d_set_volume_dev, I, P, P, I64, I64, I64)
+    _sig(L.sift3d_detect, I, P, F, P, P)
+    _sig(L.sift3d_extract, I, P, F, I, F, F, P, P)
+    _sig(L.sift3d_enable_timing, I, P, I)
+    _sig(L.sift3d_get_timings, I, P, P)
+    _hip = L
+    return L
+
+
+def host_lib():
+    """dlopen libsift3d_host.so (NIfTI I/O, .key writer, synthetic volumes; no GPU needed)."""
+    global _host
+    if _host is not None:
+        return _host
+    if not os.path.exists(LIB_HOST):
+        raise Sift3DError("%s is missing: run __graft_entry__.build()" % LIB_HOST)
+    L = C.CDLL(LIB_HOST)
+    P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
+    _sig(L.sift3d_synth_blobs, None, P, I64, I64, I64, C.c_uint32)
+    _sig(L.nifti_min_write_f32, I, C.c_char_p, P, I, I, I, F, F, F)
+    _sig(L.sift3d_write_key, I, C.c_char_p, P, I64, F, I, P)
+    _host = L
+    return L
+
+
+def device_count():
+    return int(hip_lib().sift3d_device_count())
+
+
+def gauss_taps(sigma, min_value=0.01):
+    t = np.zeros(129, np.float32)
+    n = hip_lib().sift3d_gauss_taps(float(sigma), float(min_value), t.ctypes.data)
+    if n < 0:
+        raise Sift3DError("sift3d_gauss_taps(%r, %r) -> %d" % (sigma, min_value, n))
+    return t[:n].copy()
+
+
+def synth_blobs(nx, ny, nz, seed=12345):
+    """Deterministic blob-field volume, shape (nz, ny, nx) float32."""
+    v = np.empty((nz, ny, nx), np.float32)
+    host_lib().sift3d_synth_blobs(v.ctypes.data, nx, ny, nz, seed)
+    return v
+
+
+def write_nifti(path, vol, voxel=(1.0, 1.0, 1.0)):
+    vol = np.ascontiguousarray(vol, np.float32)
+    nz, ny, nx = vol.shape
+    rc = host_lib().nifti_min_write_f32(os.fsencode(path), vol.ctypes.data, nx, ny, nz, *[float(v) for v in voxel])
+    if rc != 0:
+        raise Sift3DError("could not write %s" % path)
+
+
+def write_key(path, feats, eig_thres=140.0, comments=()):
+    feats = np.ascontiguousarray(feats, FEATURE_DTYPE)
+    arr = (C.c_char_p * max(1, len(comments)))(*[c.encode() for c in comments])
+    rc = host_lib().sift3d_write_key(os.fsencode(path), feats.ctypes.data, len(feats), float(eig_thres), len(comments),
+                                     C.cast(arr, C.c_void_p))
+    if rc != 0:
+        raise Sift3DError("could not write %s" % path)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """Device-resident pyramid for volumes of up to nx*ny*nz voxels on one HIP device."""
+
+    def __init__(self, nx, ny, nz, device=0):
+        self._L = hip_lib()
+        if self._L.sift3d_device_count() <= 0:
+            raise Sift3DError("no HIP device visible and there is no CPU fallback")
+        self._h = self._L.sift3d_create(int(device), int(nx), int(ny), int(nz))
+        if not self._h:
+            raise Sift3DError("sift3d_create(device=%d, %d x %d x %d) failed" % (device, nx, ny, nz))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sift3d_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Sift3DError("%s -> %d: %s" % (what, rc, self._L.sift3d_last_error(self._h).decode()))
+
+    # ---- operator level (host arrays shaped (nz, ny, nx)) ----
+    def gauss_blur(self, vol, sigma, min_value=0.01):
+        vol = _f32(vol)
+        nz, ny, nx = vol.shape
+        out = np.empty_like(vol)
+        self._chk(self._L.sift3d_gauss_blur(self._h, vol.ctypes.data, out.ctypes.data, nx, ny, nz, float(sigma),
+                                            float(min_value)), "sift3d_gauss_blur")
+        return out
+
+    def dog(self, a, b):
+        a, b = _f32(a), _f32(b)
+        out = np.empty_like(a)
+        self._chk(self._L.sift3d_dog(self._h, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size), "sift3d_dog")
+        return out
+
+    def subsample2(self, vol):
+        vol = _f32(vol)
+        nz, ny, nx = vol.shape
+        out = np.empty((nz // 2, ny // 2, nx // 2), np.float32)
+        self._chk(self._L.sift3d_subsample2(self._h, vol.ctypes.data, nx, ny, nz, out.ctypes.data), "sift3d_subsample2")
+        return out
+
+    def double_size(self, vol):
+        vol = _f32(vol)
+        nz, ny, nx = vol.shape
+        out = np.empty((2 * nz, 2 * ny, 2 * nx), np.float32)
+        self._chk(self._L.sift3d_double_size(self._h, vol.ctypes.data, nx, ny, nz, out.ctypes.data), "sift3d_double_size")
+        return out
+
+    def halve_size(self, vol):
+        vol = _f32(vol)
+        nz, ny, nx = vol.shape
+        out = np.empty((nz // 2, ny // 2, nx // 2), np.float32)
+        self._chk(self._L.sift3d_halve_size(self._h, vol.ctypes.data, nx, ny, nz, out.ctypes.data), "sift3d_halve_size")
+        return out
+
+    def extrema(self, d_prev, d_cur, d_next=None, capacity=None):
+        """Returns (minima, maxima) structured arrays in raster order."""
+        d_prev, d_cur = _f32(d_prev), _f32(d_cur)
+        nz, ny, nx = d_cur.shape
+        d_next = None if d_next is None else _f32(d_next)
+        cap = int(capacity) if capacity is not None else d_cur.size // 8 + 1024
+        mins = np.zeros(cap, EXTREMUM_DTYPE)
+        maxs = np.zeros(cap, EXTREMUM_DTYPE)
+        nmin, nmax = C.c_int64(0), C.c_int64(0)
+        rc = self._L.sift3d_extrema(self._h, d_prev.ctypes.data, d_cur.ctypes.data,
+                                    None if d_next is None else d_next.ctypes.data, nx, ny, nz, mins.ctypes.data, cap,
+                                    C.byref(nmin), maxs.ctypes.data, cap, C.byref(nmax))
+        self._chk(rc, "sift3d_extrema")
+        return mins[:nmin.value].copy(), maxs[:nmax.value].copy()
+
+    # ---- pipeline level ----
+    def set_volume(self, vol):
+        vol = _f32(vol)
+        nz, ny, nx = vol.shape
+        self._chk(self._L.sift3d_set_volume(self._h, vol.ctypes.data, nx, ny, nz), "sift3d_set_volume")
+
+    def set_volume_dev(self, dev_ptr, nx, ny, nz):
+        self._chk(self._L.sift3d_set_volume_dev(self._h, C.c_void_p(int(dev_ptr)), nx, ny, nz), "sift3d_set_volume_dev")
+
+    def detect(self, initial_image_scale=1.0):
+        out, n = C.c_void_p(), C.c_int64(0)
+        self._chk(self._L.sift3d_detect(self._h, float(initial_image_scale), C.byref(out), C.byref(n)), "sift3d_detect")
+        try:
+            buf = (C.c_char * (n.value * CANDIDATE_DTYPE.itemsize)).from_address(out.value) if n.value else b""
+            return np.frombuffer(buf, CANDIDATE_DTYPE, n.value).copy()
+        finally:
+            self._L.sift3d_free(out)
+
+    def extract(self, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
+        out, n = C.c_void_p(), C.c_int64(0)
+        self._chk(self._L.sift3d_extract(self._h, float(initial_image_scale), int(desc_mode), float(eig_thres),
+                                         float(size_factor), C.byref(out), C.byref(n)), "sift3d_extract")
+        try:
+            buf = (C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(out.value) if n.value else b""
+            return np.frombuffer(buf, FEATURE_DTYPE, n.value).copy()
+        finally:
+            self._L.sift3d_free(out)
+
+    # ---- device-pointer forms (bench) ----
+    def gauss_blur_dog_dev(self, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value=0.01):
+        self._chk(self._L.sift3d_gauss_blur_dog_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)),
+                                                    C.c_void_p(int(d_dog)) if d_dog else None, nx, ny, nz, float(sigma),
+                                                    float(min_value)), "sift3d_gauss_blur_dog_dev")
+
+    def sync(self):
+        self._chk(self._L.sift3d_sync(self._h), "sift3d_sync")
+
+    def set_stream(self, hip_stream):
+        self._chk(self._L.sift3d_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None), "sift3d_set_stream")
+
+    def enable_timing(self, on=True):
+        self._chk(self._L.sift3d_enable_timing(self._h, 1 if on else 0), "sift3d_enable_timing")
+
+    def timings(self):
+        t = _Timings()
+        self._chk(self._L.sift3d_get_timings(self._h, C.byref(t)), "sift3d_get_timings")
+        d = {"total_ms": t.total_ms, "n_octaves": t.n_octaves, "n_extrema": t.n_extrema,
+             "n_keypoints": t.n_keypoints, "n_records": t.n_records, "stages": {}}
+        for i, s in enumerate(STAGES):
+            d["stages"][s] = {"ms": t.ms[i], "launches": t.launches[i], "alg_bytes": t.alg_bytes[i]}
+        return d

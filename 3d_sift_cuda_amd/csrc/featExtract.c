@@ -1,0 +1,160 @@
+/*
+ * featExtract.c -- the reference's command line over the MI355X C-ABI.
+ *
+ * Mirrors main() of R/featExtract/featExtract.cpp:273-585 (R/ =
+ * /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/): same option
+ * letters, same usage text and exit codes, same stdout lines, same .key file.
+ * -b / -br / -bn are the descriptor switches documented in the reference's
+ * README (/root/reference/README.md:26-34).  Differences, all listed in
+ * -d<N> allocates and runs on HIP device N (the reference
+ * allocates on device 0 and launches on N); without -d the reference runs its
+ * CPU code, this build has no CPU path and runs on device 0 (results are
+ * those of the CPU path by construction); -w / -ws are not in this round.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "keyfile.h"
+#include "nifti_min.h"
+#include "sift3d.h"
+
+static int print_options(void)
+{
+    printf("Volumetric local feature extraction v1.1\n");
+    printf("Usage: %s [options] <input image> <output features>\n", "featExtract");
+    printf("  <input image>: nifti (.nii,.hdr,.nii.gz).\n");
+    printf("  <output features>: output file with features.\n");
+    printf(" [options]\n");
+    printf("  -w         : output feature geometry in world coordinates, NIFTI qto_xyz matrix (default is voxel units).\n");
+    printf("  -2+        : double input image size.\n");
+    printf("  -2-        : halve input image size.\n");
+    printf("  -d[1-9]    : set device id to be used.\n");
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) {
+        print_options();
+        return -1;
+    }
+    int device = -1;
+    int iArg = 1;
+    int bDoubleImageSize = 0;
+    int desc_mode = SIFT3D_DESC_SIFT;
+    const float fEigThres = 140;
+    while (iArg < argc && argv[iArg][0] == '-') {
+        switch (argv[iArg][1]) {
+        case '2':
+            bDoubleImageSize = 1;
+            if (argv[iArg][2] == '-') bDoubleImageSize = -1;
+            iArg++;
+            break;
+        case 'd':
+            if (argv[iArg][2] - '0' < 0 || argv[iArg][2] - '0' > sift3d_device_count()) {
+                printf("Error: unknown device: %d\n", argv[iArg][2] - '0');
+                print_options();
+                return -1;
+            }
+            device = argv[iArg][2] - '0';
+            iArg++;
+            break;
+        case 'b':
+            desc_mode = argv[iArg][2] == 'r' ? SIFT3D_DESC_RRIEF : (argv[iArg][2] == 'n' ? SIFT3D_DESC_NRRIEF : SIFT3D_DESC_BRIEF);
+            iArg++;
+            break;
+        case 'w':
+        case 'W':
+            printf("Error: world coordinate output (-w) is not available in this build.\n");
+            return -1;
+        default:
+            printf("Error: unknown command line argument: %s\n", argv[iArg]);
+            print_options();
+            return -1;
+        }
+    }
+    if (argc - iArg < 2) {
+        print_options();
+        return -1;
+    }
+    printf("Extracting features: %s\n", argv[iArg]);
+
+    nifti_min_image img;
+    if (nifti_min_read(argv[iArg], &img) < 0) {
+        printf("Error: could not read input file: %s\n", argv[iArg]);
+        return -1;
+    }
+    if (device < 0) device = 0; /* no CPU path in this build */
+    if (sift3d_device_count() <= 0 || device >= sift3d_device_count()) {
+        fprintf(stderr, "Error: no usable HIP device %d (this build has no CPU fallback).\n", device);
+        return -1;
+    }
+    int64_t X = img.nx, Y = img.ny, Z = img.nz;
+    int64_t PX = X, PY = Y, PZ = Z; /* processing size */
+    float fInitialBlurScale = 1.0f;
+    if (bDoubleImageSize == 1) {
+        PX *= 2; PY *= 2; PZ *= 2;
+    } else if (bDoubleImageSize == -1) {
+        PX /= 2; PY /= 2; PZ /= 2;
+    }
+    if (PZ <= 1 || PX <= 0 || PY <= 0) {
+        printf("Could not read volume: %s\n", argv[iArg]);
+        return -1;
+    }
+    int64_t cx = PX > X ? PX : X, cy = PY > Y ? PY : Y, cz = PZ > Z ? PZ : Z;
+    sift3d_ctx *ctx = sift3d_create(device, cx, cy, cz);
+    if (!ctx) {
+        printf("Error: could not extract features, insufficient memory.\n");
+        return -1;
+    }
+    float *vol = img.data;
+    if (bDoubleImageSize == 1) {
+        float *d = (float *)malloc(sizeof(float) * (size_t)(PX * PY * PZ));
+        if (!d || sift3d_double_size(ctx, vol, X, Y, Z, d) != SIFT3D_OK) {
+            printf("Error: could not extract features, insufficient memory.\n");
+            return -1;
+        }
+        free(vol);
+        vol = d;
+        fInitialBlurScale *= 0.5;
+    } else if (bDoubleImageSize == -1) {
+        float *d = (float *)malloc(sizeof(float) * (size_t)(PX * PY * PZ));
+        if (!d || sift3d_halve_size(ctx, vol, X, Y, Z, d) != SIFT3D_OK) {
+            printf("Error: could not extract features, insufficient memory.\n");
+            return -1;
+        }
+        free(vol);
+        vol = d;
+    }
+    printf("Input image: i=%d j=%d k=%d\n", (int)PX, (int)PY, (int)PZ);
+
+    float fSizeFactor = 1;
+    if (bDoubleImageSize > 0) fSizeFactor /= 2;
+    else if (bDoubleImageSize < 0) fSizeFactor *= 2;
+
+    sift3d_feature *feats = NULL;
+    int64_t n = 0;
+    int rc = sift3d_set_volume(ctx, vol, PX, PY, PZ);
+    if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
+    if (rc != SIFT3D_OK) {
+        fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
+        printf("Error: could not extract features, insufficient memory.\n");
+        return -1;
+    }
+
+    char c1[200], c2[200], c3[400];
+    sprintf(c1, "Extraction Voxel Resolution (ijk) : %d %d %d", (int)PX, (int)PY, (int)PZ);
+    sprintf(c2, "Extraction Voxel Size (mm)  (ijk) : %f %f %f", 1.0f * img.dx, 1.0f * img.dy, 1.0f * img.dz);
+    sprintf(c3, "Feature Coordinate Space: voxels: 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0");
+    const char *cm[3] = {c1, c2, c3};
+    if (sift3d_write_key(argv[iArg + 1], feats, n, fEigThres, 3, cm) != 0) {
+        fprintf(stderr, "Error: could not write %s\n", argv[iArg + 1]);
+        return -1;
+    }
+    printf("\nDone.\n");
+    sift3d_free(feats);
+    free(vol);
+    sift3d_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,893 @@
+/*
+ * kernels_keypoint.hip -- per-keypoint stage for gfx950: sub-voxel refinement,
+ * 11^3 patch sampling, structure-tensor eigen test, canonical orientation
+ * frames (phase A, one wavefront per extremum) and patch re-sampling +
+ * 64-value descriptor + rank transform (phase B, one wavefront per output
+ * record).  The patch and every histogram live in LDS.
+ *
+ * Parity contract: the reference does all of this in scalar CPU code whose
+ * float accumulations are order dependent (R/src_common/MultiScale.cpp, R/ =
+ * /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/).  Work is
+ * spread over the 64 lanes only where the result does not depend on the
+ * order (sampling, gradients, per-voxel terms, 3/5-tap patch blurs, peak
+ * tests, rank counting); every order-dependent sum is kept as ONE sequential
+ * chain in the reference's raster order, with one lane per independent chain
+ * (9 lanes for the structure tensor, 8 lanes for the 8 corners of a splat, 64
+ * lanes for the 64 descriptor bins).  Compiled with -ffp-contract=off.
+ */
+#include "sift3d_internal.h"
+
+#define PD SIFT3D_PATCH_DIM
+#define PV SIFT3D_PATCH_VOX
+
+/* ---------------------------------------------------------------------- */
+/* scalar helpers (each mirrors one reference routine)                     */
+/* ---------------------------------------------------------------------- */
+
+/* _fioDetermineInterpCoord, R/src_common/FeatureIO.cpp:757-782 */
+__device__ __forceinline__ void interp_coord(float fX, float fMin, float fMax, int &ix, float &w)
+{
+    if (fX < fMin + 0.5f) {
+        ix = (int)fMin;
+        w = 1.0f;
+    } else if (fX >= fMax - 0.5f) {
+        ix = (int)(fMax - 2);
+        w = 0.0f;
+    } else {
+        float mh = fX - 0.5f;
+        ix = (int)floorf(mh);
+        w = 1.0f - (mh - ((float)ix));
+    }
+}
+
+/* fioGetPixelTrilinearInterp, R/src_common/FeatureIO.cpp:812-850 */
+__device__ __forceinline__ float trilinear(const float *__restrict__ img, int X, int Y, int Z, float x, float y, float z)
+{
+    float wx, wy, wz;
+    int ix, iy, iz;
+    interp_coord(x, 0, (float)X, ix, wx);
+    interp_coord(y, 0, (float)Y, iy, wy);
+    interp_coord(z, 0, (float)Z, iz, wz);
+    const long long XY = (long long)X * Y;
+    const float *p = img + (long long)iz * XY + (long long)iy * X + ix;
+    float f000 = p[0], f100 = p[1], f010 = p[X], f110 = p[X + 1];
+    float f001 = p[XY], f101 = p[XY + 1], f011 = p[XY + X], f111 = p[XY + X + 1];
+    float fn00 = wx * f000 + (1.0f - wx) * f100;
+    float fn01 = wx * f001 + (1.0f - wx) * f101;
+    float fn10 = wx * f010 + (1.0f - wx) * f110;
+    float fn11 = wx * f011 + (1.0f - wx) * f111;
+    float fnn0 = wy * fn00 + (1.0f - wy) * fn10;
+    float fnn1 = wy * fn01 + (1.0f - wy) * fn11;
+    return wz * fnn0 + (1.0f - wz) * fnn1;
+}
+
+/* finddet + interpolate_extremum_quadratic, R/src_common/MultiScale.cpp:2531-2534, 1641-1697 */
+__device__ __forceinline__ double finddet(double a1, double a2, double a3, double b1, double b2, double b3, double c1,
+                                          double c2, double c3)
+{
+    return ((a1 * b2 * c3) - (a1 * b3 * c2) - (a2 * b1 * c3) + (a3 * b1 * c2) + (a2 * b3 * c1) - (a3 * b2 * c1));
+}
+__device__ double interp_quadratic(double x0, double x1, double x2, double fx0, double fx1, double fx2)
+{
+    if (!(fx1 < fx0 && fx1 < fx2) && !(fx1 > fx0 && fx1 > fx2)) return x1;
+    double a1 = x0 * x0, b1 = x0, c1 = 1;
+    double a2 = x1 * x1, b2 = x1, c2 = 1;
+    double a3 = x2 * x2, b3 = x2, c3 = 1;
+    double d1 = fx0, d2 = fx1, d3 = fx2;
+    double det = finddet(a1, a2, a3, b1, b2, b3, c1, c2, c3);
+    double detx = finddet(d1, d2, d3, b1, b2, b3, c1, c2, c3);
+    double dety = finddet(a1, a2, a3, d1, d2, d3, c1, c2, c3);
+    if (d1 == 0 && d2 == 0 && d3 == 0) return x1;
+    if (det != 0) {
+        if (detx != 0) return dety / (-2.0 * detx);
+    }
+    return x1;
+}
+
+/* invert_3x3<float,double>, R/src_common/MultiScale.h:192-222 */
+__device__ void invert3(const float *in, float *out) /* row-major 3x3 */
+{
+    float a11 = in[0], a21 = in[3], a31 = in[6];
+    float a12 = in[1], a22 = in[4], a32 = in[7];
+    float a13 = in[2], a23 = in[5], a33 = in[8];
+    float det = a11 * (a33 * a22 - a32 * a23) - a21 * (a33 * a12 - a32 * a13) + a31 * (a23 * a12 - a22 * a13);
+    double div = 1 / (double)det;
+    out[0] = (float)((a33 * a22 - a32 * a23) * div);
+    out[3] = (float)(-(a33 * a21 - a31 * a23) * div);
+    out[6] = (float)((a32 * a21 - a31 * a22) * div);
+    out[1] = (float)(-(a33 * a12 - a32 * a13) * div);
+    out[4] = (float)((a33 * a11 - a31 * a13) * div);
+    out[7] = (float)(-(a32 * a11 - a31 * a12) * div);
+    out[2] = (float)((a23 * a12 - a22 * a13) * div);
+    out[5] = (float)(-(a23 * a11 - a21 * a13) * div);
+    out[8] = (float)((a22 * a11 - a21 * a12) * div);
+}
+
+/* vec3D_norm_3d / vec3D_mag / vec3D_dot_3d, R/src_common/MultiScale.cpp:1092-1127, 1571-1578 */
+__device__ __forceinline__ void v3_norm(float *p)
+{
+    float ss = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    if (ss > 0) {
+        float div = (float)(1.0 / (double)sqrtf(ss));
+        p[0] *= div;
+        p[1] *= div;
+        p[2] *= div;
+    } else {
+        p[0] = 1;
+        p[1] = 0;
+        p[2] = 0;
+    }
+}
+__device__ __forceinline__ float v3_mag(const float *p)
+{
+    float ss = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    if (ss > 0) return sqrtf(ss);
+    return 0;
+}
+__device__ __forceinline__ float v3_dot(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* SingularValueDecomp<float,3,3> + SortEigenDecomp<float,3>, R/src_common/SVD.h:15-228:
+ * Numerical Recipes svdcmp, double temporaries, float storage. */
+#define SVD_SIGN(a, b) ((b) >= 0.0 ? fabs(a) : -fabs(a))
+#define SVD_PYTHAG(a, b) (sqrt((a) * (a) + (b) * (b)))
+__device__ void svd3(float mat[3][3], float w[3], float v[3][3])
+{
+    const int m = 3, n = 3;
+    int flag, i, its, j, jj, k, l = 0, nm = 0;
+    double anorm, c, f, g, h, s, scale, x, y, z;
+    double rv1[3];
+    g = scale = anorm = 0.0;
+    for (i = 1; i <= n; i++) {
+        l = i + 1;
+        rv1[i - 1] = scale * g;
+        g = s = scale = 0.0;
+        if (i <= m) {
+            for (k = i; k <= m; k++) scale += fabsf(mat[k - 1][i - 1]);
+            if (scale) {
+                for (k = i; k <= m; k++) {
+                    mat[k - 1][i - 1] = (float)(mat[k - 1][i - 1] / scale);
+                    s += mat[k - 1][i - 1] * mat[k - 1][i - 1];
+                }
+                f = mat[i - 1][i - 1];
+                g = -SVD_SIGN(sqrt(s), f);
+                h = f * g - s;
+                mat[i - 1][i - 1] = (float)(f - g);
+                for (j = l; j <= n; j++) {
+                    for (s = 0.0, k = i; k <= m; k++) s += mat[k - 1][i - 1] * mat[k - 1][j - 1];
+                    f = s / h;
+                    for (k = i; k <= m; k++) mat[k - 1][j - 1] = (float)(mat[k - 1][j - 1] + f * mat[k - 1][i - 1]);
+                }
+                for (k = i; k <= m; k++) mat[k - 1][i - 1] = (float)(mat[k - 1][i - 1] * scale);
+            }
+        }
+        w[i - 1] = (float)(scale * g);
+        g = s = scale = 0.0;
+        if (i <= m && i != n) {
+            for (k = l; k <= n; k++) scale += fabsf(mat[i - 1][k - 1]);
+            if (scale) {
+                for (k = l; k <= n; k++) {
+                    mat[i - 1][k - 1] = (float)(mat[i - 1][k - 1] / scale);
+                    s += mat[i - 1][k - 1] * mat[i - 1][k - 1];
+                }
+                f = mat[i - 1][l - 1];
+                g = -SVD_SIGN(sqrt(s), f);
+                h = f * g - s;
+                mat[i - 1][l - 1] = (float)(f - g);
+                for (k = l; k <= n; k++) rv1[k - 1] = mat[i - 1][k - 1] / h;
+                for (j = l; j <= m; j++) {
+                    for (s = 0.0, k = l; k <= n; k++) s += mat[j - 1][k - 1] * mat[i - 1][k - 1];
+                    for (k = l; k <= n; k++) mat[j - 1][k - 1] = (float)(mat[j - 1][k - 1] + s * rv1[k - 1]);
+                }
+                for (k = l; k <= n; k++) mat[i - 1][k - 1] = (float)(mat[i - 1][k - 1] * scale);
+            }
+        }
+        {
+            double tt = (fabsf(w[i - 1]) + fabs(rv1[i - 1]));
+            anorm = (anorm > tt ? anorm : tt);
+        }
+    }
+    for (i = n; i >= 1; i--) {
+        if (i < n) {
+            if (g) {
+                for (j = l; j <= n; j++) v[j - 1][i - 1] = (float)((mat[i - 1][j - 1] / mat[i - 1][l - 1]) / g);
+                for (j = l; j <= n; j++) {
+                    for (s = 0.0, k = l; k <= n; k++) s += mat[i - 1][k - 1] * v[k - 1][j - 1];
+                    for (k = l; k <= n; k++) v[k - 1][j - 1] = (float)(v[k - 1][j - 1] + s * v[k - 1][i - 1]);
+                }
+            }
+            for (j = l; j <= n; j++) v[i - 1][j - 1] = v[j - 1][i - 1] = 0.0;
+        }
+        v[i - 1][i - 1] = 1.0;
+        g = rv1[i - 1];
+        l = i;
+    }
+    for (i = (m < n ? m : n); i >= 1; i--) {
+        l = i + 1;
+        g = w[i - 1];
+        for (j = l; j <= n; j++) mat[i - 1][j - 1] = 0.0;
+        if (g) {
+            g = 1.0 / g;
+            for (j = l; j <= n; j++) {
+                for (s = 0.0, k = l; k <= m; k++) s += mat[k - 1][i - 1] * mat[k - 1][j - 1];
+                f = (s / mat[i - 1][i - 1]) * g;
+                for (k = i; k <= m; k++) mat[k - 1][j - 1] = (float)(mat[k - 1][j - 1] + f * mat[k - 1][i - 1]);
+            }
+            for (j = i; j <= m; j++) mat[j - 1][i - 1] = (float)(mat[j - 1][i - 1] * g);
+        } else
+            for (j = i; j <= m; j++) mat[j - 1][i - 1] = 0.0;
+        mat[i - 1][i - 1] = mat[i - 1][i - 1] + 1;
+    }
+    for (k = n; k >= 1; k--) {
+        for (its = 1; its <= 30; its++) {
+            flag = 1;
+            for (l = k; l >= 1; l--) {
+                nm = l - 1;
+                if ((double)(fabs(rv1[l - 1]) + anorm) == anorm) {
+                    flag = 0;
+                    break;
+                }
+                if ((double)(fabsf(w[nm - 1]) + anorm) == anorm) break;
+            }
+            if (flag) {
+                c = 0.0;
+                s = 1.0;
+                for (i = l; i <= k; i++) {
+                    f = s * rv1[i - 1];
+                    rv1[i - 1] = c * rv1[i - 1];
+                    if ((double)(fabs(f) + anorm) == anorm) break;
+                    g = w[i - 1];
+                    h = SVD_PYTHAG(f, g);
+                    w[i - 1] = (float)h;
+                    h = 1.0 / h;
+                    c = g * h;
+                    s = -f * h;
+                    for (j = 1; j <= m; j++) {
+                        y = mat[j - 1][nm - 1];
+                        z = mat[j - 1][i - 1];
+                        mat[j - 1][nm - 1] = (float)(y * c + z * s);
+                        mat[j - 1][i - 1] = (float)(z * c - y * s);
+                    }
+                }
+            }
+            z = w[k - 1];
+            if (l == k) {
+                if (z < 0.0) {
+                    w[k - 1] = (float)(-z);
+                    for (j = 1; j <= n; j++) v[j - 1][k - 1] = -v[j - 1][k - 1];
+                }
+                break;
+            }
+            x = w[l - 1];
+            nm = k - 1;
+            y = w[nm - 1];
+            g = rv1[nm - 1];
+            h = rv1[k - 1];
+            f = ((y - z) * (y + z) + (g - h) * (g + h)) / (2.0 * h * y);
+            g = SVD_PYTHAG(f, 1.0);
+            f = ((x - z) * (x + z) + h * ((y / (f + SVD_SIGN(g, f))) - h)) / x;
+            c = s = 1.0;
+            for (j = l; j <= nm; j++) {
+                i = j + 1;
+                g = rv1[i - 1];
+                y = w[i - 1];
+                h = s * g;
+                g = c * g;
+                z = SVD_PYTHAG(f, h);
+                rv1[j - 1] = z;
+                c = f / z;
+                s = h / z;
+                f = x * c + g * s;
+                g = g * c - x * s;
+                h = y * s;
+                y *= c;
+                for (jj = 1; jj <= n; jj++) {
+                    x = v[jj - 1][j - 1];
+                    z = v[jj - 1][i - 1];
+                    v[jj - 1][j - 1] = (float)(x * c + z * s);
+                    v[jj - 1][i - 1] = (float)(z * c - x * s);
+                }
+                z = SVD_PYTHAG(f, h);
+                w[j - 1] = (float)z;
+                if (z) {
+                    z = 1.0 / z;
+                    c = f * z;
+                    s = h * z;
+                }
+                f = c * g + s * y;
+                x = c * y - s * g;
+                for (jj = 1; jj <= m; jj++) {
+                    y = mat[jj - 1][j - 1];
+                    z = mat[jj - 1][i - 1];
+                    mat[jj - 1][j - 1] = (float)(y * c + z * s);
+                    mat[jj - 1][i - 1] = (float)(z * c - y * s);
+                }
+            }
+            rv1[l - 1] = 0.0;
+            rv1[k - 1] = f;
+            w[k - 1] = (float)x;
+        }
+    }
+}
+__device__ void sort_eig(float w[3], float v[3][3])
+{
+    float t;
+    for (int i = 0; i < 3; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (w[i] < w[j]) {
+                t = w[j]; w[j] = w[i]; w[i] = t;
+                for (int k = 0; k < 3; k++) {
+                    t = v[k][j]; v[k][j] = v[k][i]; v[k][i] = t;
+                }
+            }
+}
+
+/* ---------------------------------------------------------------------- */
+/* wave-cooperative building blocks (block = one wavefront of 64 lanes)    */
+/* ---------------------------------------------------------------------- */
+
+/* sampleImage3D, R/src_common/MultiScale.cpp:2614-2714 (bounds test done by the caller) */
+__device__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, float fx, float fy,
+                                  float fz, float scale, const float *ori9)
+{
+    float inv[9];
+    invert3(ori9, inv);
+    const float rad = 2.0f * scale;
+    const int sr = PD / 2;
+    const float sc = rad / (float)(sr);
+    for (int s = threadIdx.x; s < PV; s += 64) {
+        const int xx = s % PD - sr, yy = (s / PD) % PD - sr, zz = s / (PD * PD) - sr;
+        float in3[3] = {(float)xx, (float)yy, (float)zz};
+        float o[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            float a = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) a += inv[i * 3 + j] * in3[j];
+            o[i] = a;
+        }
+        o[0] *= sc; o[1] *= sc; o[2] *= sc;
+        o[0] += fx; o[1] += fy; o[2] += fz;
+        float pix;
+        if (o[0] < 0 || o[0] >= X) pix = 0;
+        else pix = trilinear(img, X, Y, Z, o[0], o[1], o[2]);
+        patch[s] = pix;
+    }
+    __syncthreads();
+}
+
+/* Feature3D::NormalizeData, R/src_common/MultiScale.cpp:127-205: the two
+ * 1331-term sums are single sequential chains (lane 0). */
+__device__ void wave_normalize_patch(float *d, float *scratch2)
+{
+    if (threadIdx.x == 0) {
+        float sum = 0;
+        for (int i = 0; i < PV; i++) sum += d[i];
+        scratch2[0] = sum / (PD * PD * PD);
+    }
+    __syncthreads();
+    const float mean = scratch2[0];
+    for (int i = threadIdx.x; i < PV; i += 64) d[i] -= mean;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ss = 0;
+        for (int i = 0; i < PV; i++) ss += d[i] * d[i];
+        scratch2[1] = 1.0f / sqrtf(ss);
+    }
+    __syncthreads();
+    const float div = scratch2[1];
+    for (int i = threadIdx.x; i < PV; i += 64) d[i] *= div;
+    __syncthreads();
+}
+
+/* fioGenerateEdgeImages3D on the patch, R/src_common/FeatureIO.cpp:2284-2326 */
+__device__ void wave_patch_edges(const float *d, float *dx, float *dy, float *dz)
+{
+    for (int s = threadIdx.x; s < PV; s += 64) {
+        const int x = s % PD, y = (s / PD) % PD, z = s / (PD * PD);
+        float gx = 0, gy = 0, gz = 0;
+        if (x >= 1 && x < PD - 1 && y >= 1 && y < PD - 1 && z >= 1 && z < PD - 1) {
+            gx = d[s + 1] - d[s - 1];
+            gy = d[s + PD] - d[s - PD];
+            gz = d[s + PD * PD] - d[s - PD * PD];
+        }
+        dx[s] = gx; dy[s] = gy; dz[s] = gz;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool in_radius(int s)
+{
+    const int x = s % PD - PD / 2, y = (s / PD) % PD - PD / 2, z = s / (PD * PD) - PD / 2;
+    const float fx = (float)x, fy = (float)y, fz = (float)z;
+    return fz * fz + fy * fy + fx * fx < (float)((PD / 2) * (PD / 2));
+}
+
+/* 3- or 5-tap separable blur of an 11^3 LDS volume, pass order x,y,z, zero
+ * borders (gb3d_blur3d on the patch: R/src_common/MultiScale.cpp:2850,2972,1032) */
+__device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis, const float *taps, int ntaps)
+{
+    const int h = ntaps / 2;
+    const int st = axis == 0 ? 1 : (axis == 1 ? PD : PD * PD);
+    for (int s = threadIdx.x; s < PV; s += 64) {
+        const int c = axis == 0 ? s % PD : (axis == 1 ? (s / PD) % PD : s / (PD * PD));
+        float acc = 0;
+        for (int j = 0; j < ntaps; j++) {
+            const int cc = c + j - h;
+            if (cc >= 0 && cc < PD) acc = acc + taps[j] * src[s + (cc - c) * st];
+        }
+        dst[s] = acc;
+    }
+    __syncthreads();
+}
+/* taps must be in LDS; out may alias tmp_a */
+__device__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, float *out, const float *taps, int ntaps)
+{
+    blur_pass(in, tmp_a, 0, taps, ntaps);
+    blur_pass(tmp_a, tmp_b, 1, taps, ntaps);
+    blur_pass(tmp_b, out, 2, taps, ntaps);
+}
+
+/* regFindFEATUREIOPeaks without callback (R/src_common/MultiScale.cpp:1987-2121)
+ * + lvSortHighLow (R/src_common/LocationValue.cpp:28-56, stable): peaks of g in
+ * raster order via ballot compaction, then a stable descending rank by
+ * counting.  Returns the count; pk_idx/pk_val hold the sorted list. */
+__device__ int wave_peaks_sorted(const float *g, int *raw_idx, float *raw_val, int *pk_idx, float *pk_val)
+{
+    int n = 0;
+    for (int base = 0; base < PV; base += 64) {
+        const int s = base + threadIdx.x;
+        bool pk = false;
+        float c = 0;
+        if (s < PV) {
+            const int x = s % PD, y = (s / PD) % PD, z = s / (PD * PD);
+            if (x >= 1 && x < PD - 1 && y >= 1 && y < PD - 1 && z >= 1 && z < PD - 1) {
+                c = g[s];
+                pk = true;
+                for (int dz = -1; dz <= 1; dz++)
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (!dz && !dy && !dx) continue;
+                            pk = pk && (g[s + (dz * PD + dy) * PD + dx] < c);
+                        }
+            }
+        }
+        const unsigned long long m = __ballot(pk);
+        if (pk) {
+            const int pos = n + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+            raw_idx[pos] = s;
+            raw_val[pos] = c;
+        }
+        n += __popcll(m);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float vi = raw_val[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const float vj = raw_val[j];
+            rank += (vj > vi || (vj == vi && j < i)) ? 1 : 0;
+        }
+        pk_idx[rank] = raw_idx[i];
+        pk_val[rank] = vi;
+    }
+    __syncthreads();
+    return n;
+}
+
+/* interpolate_discrete_3D_point on an 11^3 grid, R/src_common/MultiScale.cpp:1614-1639 */
+__device__ void interp_point_patch(const float *g, int s, float *o)
+{
+    const int ix = s % PD, iy = (s / PD) % PD, iz = s / (PD * PD);
+    const float c = g[s];
+    o[0] = (float)interp_quadratic(ix - 1, ix, ix + 1, g[s - 1], c, g[s + 1]);
+    o[1] = (float)interp_quadratic(iy - 1, iy, iy + 1, g[s - PD], c, g[s + PD]);
+    o[2] = (float)interp_quadratic(iz - 1, iz, iz + 1, g[s - PD * PD], c, g[s + PD * PD]);
+}
+
+/* Sequential trilinear splat of the in-radius voxels into an 11^3 grid
+ * (fioIncPixelTrilinearInterp, R/src_common/FeatureIO.cpp:853-889): per voxel
+ * the eight corner adds go to eight different cells, so lanes 0..7 take one
+ * corner each; voxels follow one another in raster order.  coords holds, per
+ * voxel, the splat position (x,y,z) and the value; value <= 0 means skip. */
+__device__ void wave_splat_sequence(float *grid, const float *cx, const float *cy, const float *cz, const float *val)
+{
+    const int lane = threadIdx.x;
+    for (int s = 0; s < PV; s++) {
+        if (!in_radius(s)) continue;
+        const float v = val[s];
+        if (!(v > 0)) continue; /* uniform: every lane reads the same LDS word */
+        if (lane < 8) {
+            float wx, wy, wz;
+            int ix, iy, iz;
+            interp_coord(cx[s], 0, (float)PD, ix, wx);
+            interp_coord(cy[s], 0, (float)PD, iy, wy);
+            interp_coord(cz[s], 0, (float)PD, iz, wz);
+            const int a = lane & 1, b = (lane >> 1) & 1, c = (lane >> 2) & 1;
+            const float ux = a ? (1.0f - wx) : wx;
+            const float uy = b ? (1.0f - wy) : wy;
+            const float uz = c ? (1.0f - wz) : wz;
+            float *cell = grid + ((iz + c) * PD + (iy + b)) * PD + (ix + a);
+            *cell = *cell + v * ux * uy * uz;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
+/* ---------------------------------------------------------------------- */
+/* Phase A: extremum -> keypoint (geometry, eigen test, orientation frames) */
+/* ---------------------------------------------------------------------- */
+struct kpA_smem {
+    float patch[PV];
+    float dx[PV], dy[PV], dz[PV];
+    float t0[PV], t1[PV], t2[PV], t3[PV];
+    float cx[PV], cy[PV], cz[PV], mag[PV];
+    int raw_idx[128];
+    float raw_val[128];
+    int pk_idx[128];
+    float pk_val[128];
+    int pk2_idx[128];
+    float pk2_val[128];
+    float ori_data[PD * 3];
+    float sc[16];
+    float taps[8];
+};
+
+__global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const sift3d_dcand *__restrict__ cands,
+                                                      long long ncand, sift3d_dkp *__restrict__ kps, sift3d_taps taps3)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    kpA_smem &sm = *reinterpret_cast<kpA_smem *>(smem_raw);
+    const long long k = blockIdx.x;
+    if (k >= ncand) return;
+    const int lane = threadIdx.x;
+    if (lane < 3) sm.taps[lane] = taps3.f[lane];
+    const sift3d_dcand cd = cands[k];
+    sift3d_dkp *kp = kps + k;
+    const int X = p.X, Y = p.Y, Z = p.Z;
+    const long long XY = (long long)X * Y;
+    const int ix = (int)(cd.idx % X), iy = (int)((cd.idx / X) % Y), iz = (int)(cd.idx / XY);
+
+    /* generateFeatures3D_efficient, R/src_common/MultiScale.cpp:1361-1421 (every lane, identical) */
+    const float *C = p.dogc;
+    const float cv = C[cd.idx];
+    float fx = (float)interp_quadratic(ix - 1, ix, ix + 1, C[cd.idx - 1], cv, C[cd.idx + 1]);
+    float fy = (float)interp_quadratic(iy - 1, iy, iy + 1, C[cd.idx - X], cv, C[cd.idx + X]);
+    float fz = (float)interp_quadratic(iz - 1, iz, iz + 1, C[cd.idx - XY], cv, C[cd.idx + XY]);
+    float scale = (float)(2 * interp_quadratic(p.sigma_h, p.sigma_c, p.sigma_l, cd.h, cv, cd.l));
+    fx += 0.5f; fy += 0.5f; fz += 0.5f;
+
+    /* sampleImage3D bounds test, MultiScale.cpp:2630-2643 */
+    const float rad = 2.0f * scale;
+    const int rmax = (int)(rad + 2);
+    if (fx - rmax < 0 || fy - rmax < 0 || fz - rmax < 0 || fx + rmax >= X || fy + rmax >= Y || fz + rmax >= Z) {
+        if (lane == 0) kp->nrec = 0;
+        return;
+    }
+    const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    wave_sample_patch(sm.patch, p.img, X, Y, Z, fx, fy, fz, scale, ident);
+    wave_normalize_patch(sm.patch, sm.sc);
+
+    /* determineOrientation3D, MultiScale.cpp:2541-2607 */
+    wave_patch_edges(sm.patch, sm.dx, sm.dy, sm.dz);
+    if (lane < 9) {
+        const float *ei = lane / 3 == 0 ? sm.dx : (lane / 3 == 1 ? sm.dy : sm.dz);
+        const float *ej = lane % 3 == 0 ? sm.dx : (lane % 3 == 1 ? sm.dy : sm.dz);
+        float acc = 0;
+        for (int s = 0; s < PV; s++)
+            if (in_radius(s)) acc += ei[s] * ej[s];
+        sm.sc[lane] = acc;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float mat[3][3], w[3], v[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                mat[i][j] = sm.sc[i * 3 + j];
+                v[i][j] = 0;
+            }
+        w[0] = w[1] = w[2] = 0;
+        svd3(mat, w, v);
+        sort_eig(w, v);
+        /* eigen test, MultiScale.cpp:1748-1769 */
+        float es = w[0] + w[1] + w[2];
+        float ep = w[0] * w[1] * w[2];
+        float esp = es * es * es;
+        int keep = (esp < p.eig_thres * ep || p.eig_thres < 0) ? 1 : 0;
+        sm.sc[15] = keep ? 1.0f : 0.0f;
+        if (keep) {
+            kp->x = fx; kp->y = fy; kp->z = fz; kp->scale = scale;
+            kp->eigs[0] = w[0]; kp->eigs[1] = w[1]; kp->eigs[2] = w[2];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) kp->ori0[i * 3 + j] = v[i][j];
+            kp->info = cd.is_max ? SIFT3D_INFO_MIN0MAX1 : 0u;
+        } else {
+            kp->nrec = 0;
+        }
+    }
+    __syncthreads();
+    if (sm.sc[15] == 0.0f) return;
+
+    /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037 */
+    const float radius = (float)(PD / 2);
+    for (int s = lane; s < PV; s += 64) {
+        sm.t0[s] = 0;
+        float e[3] = {sm.dx[s], sm.dy[s], sm.dz[s]};
+        float m2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        float mg = 0, u0 = 0, u1 = 0, u2 = 0;
+        if (m2 != 0) {
+            mg = sqrtf(m2);
+            float u[3];
+            for (int i = 0; i < 3; i++) u[i] = e[i] * radius / mg;
+            for (int i = 0; i < 3; i++) u[i] += radius;
+            u0 = (float)(u[0] + 0.5); u1 = (float)(u[1] + 0.5); u2 = (float)(u[2] + 0.5);
+        }
+        sm.cx[s] = u0; sm.cy[s] = u1; sm.cz[s] = u2; sm.mag[s] = mg;
+    }
+    __syncthreads();
+    wave_splat_sequence(sm.t0, sm.cx, sm.cy, sm.cz, sm.mag);
+    wave_blur_patch(sm.t0, sm.t1, sm.t3, sm.t2, sm.taps, 3);
+    const int npk = wave_peaks_sorted(sm.t2, sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
+
+    if (lane < npk && lane < PD && lane < 30) {
+        float o[3];
+        interp_point_patch(sm.t2, sm.pk_idx[lane], o);
+        o[0] -= radius; o[1] -= radius; o[2] -= radius;
+        v3_norm(o);
+        sm.ori_data[lane * 3 + 0] = o[0];
+        sm.ori_data[lane * 3 + 1] = o[1];
+        sm.ori_data[lane * 3 + 2] = o[2];
+    }
+    __syncthreads();
+
+    int nret = 0;
+    const float pk0 = npk > 0 ? sm.pk_val[0] : 0.0f;
+    for (int i = 0; i < npk && i < PD && nret < 30; i++) {
+        if ((double)sm.pk_val[i] < 0.8 * (double)pk0) break;
+        const float p1[3] = {sm.ori_data[i * 3], sm.ori_data[i * 3 + 1], sm.ori_data[i * 3 + 2]};
+        __syncthreads();
+        for (int s = lane; s < PV; s += 64) {
+            sm.t0[s] = 0;
+            float e[3] = {sm.dx[s], sm.dy[s], sm.dz[s]};
+            float mg = v3_mag(e);
+            float c0 = 0, c1 = 0, c2 = 0;
+            if (mg != 0) {
+                float u[3] = {e[0], e[1], e[2]};
+                v3_norm(u);
+                float par = v3_dot(p1, u);
+                float pp[3];
+                pp[0] = u[0] - par * p1[0];
+                pp[1] = u[1] - par * p1[1];
+                pp[2] = u[2] - par * p1[2];
+                v3_norm(pp);
+                for (int q = 0; q < 3; q++) {
+                    pp[q] *= radius;
+                    pp[q] += radius;
+                }
+                c0 = (float)(pp[0] + 0.5); c1 = (float)(pp[1] + 0.5); c2 = (float)(pp[2] + 0.5);
+            }
+            sm.cx[s] = c0; sm.cy[s] = c1; sm.cz[s] = c2; sm.mag[s] = mg;
+        }
+        __syncthreads();
+        wave_splat_sequence(sm.t0, sm.cx, sm.cy, sm.cz, sm.mag);
+        wave_blur_patch(sm.t0, sm.t1, sm.t3, sm.t2, sm.taps, 3);
+        const int npk2 = wave_peaks_sorted(sm.t2, sm.raw_idx, sm.raw_val, sm.pk2_idx, sm.pk2_val);
+        const float pk20 = npk2 > 0 ? sm.pk2_val[0] : 0.0f;
+        for (int j = 0; j < npk2 && nret < PD && nret < 30; j++) {
+            if (sm.pk2_val[j] < 0.5f * pk20) break;
+            if (lane == 0) {
+                float p2[3], p3[3];
+                interp_point_patch(sm.t2, sm.pk2_idx[j], p2);
+                p2[0] -= radius; p2[1] -= radius; p2[2] -= radius;
+                v3_norm(p2);
+                float par = v3_dot(p1, p2);
+                p2[0] = p2[0] - par * p1[0];
+                p2[1] = p2[1] - par * p1[1];
+                p2[2] = p2[2] - par * p1[2];
+                v3_norm(p2);
+                p3[0] = p1[1] * p2[2] - p1[2] * p2[1];
+                p3[1] = -p1[0] * p2[2] + p1[2] * p2[0];
+                p3[2] = p1[0] * p2[1] - p1[1] * p2[0];
+                float *m = kp->frames + 9 * nret;
+                for (int iv = 0; iv < 3; iv++) {
+                    m[0 * 3 + iv] = p1[iv];
+                    m[1 * 3 + iv] = p2[iv];
+                    m[2 * 3 + iv] = p3[iv];
+                }
+            }
+            nret++;
+        }
+    }
+    if (lane == 0) {
+        kp->nframes = nret;
+        kp->nrec = 1 + nret;
+    }
+}
+
+/* ---------------------------------------------------------------------- */
+/* Phase B: one output record per wavefront: re-sample, normalise, describe */
+/* ---------------------------------------------------------------------- */
+/* pair tables of msGenerateBRIEFindex method 2 (data, R/src_common/MultiScale.cpp:805-807) */
+__constant__ unsigned char c_brief_x[192] = {
+    5,4,4,4,4,2,6,5,5,4,4,4,3,8,5,5,6,3,5,5,5,5,6,5,4,6,6,6,3,4,4,4,5,3,4,5,4,5,5,4,2,7,7,5,3,5,4,5,3,5,7,3,5,5,2,3,5,5,6,6,4,6,5,4,
+    4,6,5,3,5,6,4,3,6,4,4,5,3,3,3,6,6,5,2,4,4,6,3,6,3,2,3,5,4,5,3,4,3,6,5,4,3,6,4,5,2,4,3,7,2,3,6,5,2,6,3,3,5,6,3,6,3,5,3,6,5,7,4,2,
+    5,5,5,2,5,7,4,2,5,3,4,3,3,7,4,4,7,6,4,4,2,8,7,6,5,4,7,3,6,6,5,2,4,5,3,2,5,5,1,6,3,6,3,6,2,5,4,4,7,2,6,3,2,2,4,3,3,2,3,4,2,5,6,7};
+__constant__ unsigned char c_brief_y[192] = {
+    6,5,3,4,5,3,7,4,6,4,3,2,4,7,5,3,5,1,5,4,7,6,8,4,4,5,6,5,2,5,4,6,4,0,4,3,3,4,4,2,1,7,8,6,4,4,1,6,1,3,7,2,3,3,1,3,6,1,6,6,4,7,6,4,
+    3,5,4,2,3,6,4,5,6,3,3,5,1,3,1,6,7,4,1,4,3,5,2,4,2,1,2,5,4,5,2,3,3,3,3,4,2,6,3,4,3,3,3,6,1,2,5,4,2,4,1,4,6,7,3,6,2,4,3,6,5,6,4,0,
+    6,6,5,1,4,7,2,1,5,3,4,2,2,7,3,3,6,4,2,4,1,9,7,7,5,2,7,1,7,5,5,1,5,4,1,3,3,4,0,5,1,6,3,5,3,2,3,3,7,2,5,1,1,0,4,1,3,1,0,3,1,6,5,9};
+
+struct kpB_smem {
+    float patch[PV];
+    float dx[PV], dy[PV], dz[PV];
+    float t1[PV], t2[PV], t3[PV];
+    float mag[PV];
+    int bin[PV];
+    float sc[16];
+    float taps[8];
+    float wtab[2][PD + 1];
+};
+
+__global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
+                                                        const int *__restrict__ rec_kp, const int *__restrict__ rec_frame,
+                                                        long long nrec, sift3d_drec *__restrict__ recs,
+                                                        sift3d_taps taps5)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    kpB_smem &sm = *reinterpret_cast<kpB_smem *>(smem_raw);
+    const long long r = blockIdx.x;
+    if (r >= nrec) return;
+    const int lane = threadIdx.x;
+    if (lane < 5) sm.taps[lane] = taps5.f[lane];
+    const sift3d_dkp *kp = kps + rec_kp[r];
+    const int fr = rec_frame[r]; /* -1: the un-reoriented record */
+    float ori[9];
+    if (fr < 0) {
+        ori[0] = 1; ori[1] = 0; ori[2] = 0; ori[3] = 0; ori[4] = 1; ori[5] = 0; ori[6] = 0; ori[7] = 0; ori[8] = 1;
+    } else {
+        for (int i = 0; i < 9; i++) ori[i] = kp->frames[fr * 9 + i];
+    }
+    wave_sample_patch(sm.patch, p.img, p.X, p.Y, p.Z, kp->x, kp->y, kp->z, kp->scale, ori);
+    /* record 0 was normalised once inside generateFeature3D (MultiScale.cpp:1742) and
+     * every record once more in main (featExtract.cpp:480) */
+    if (fr < 0) wave_normalize_patch(sm.patch, sm.sc);
+    wave_normalize_patch(sm.patch, sm.sc);
+
+    float myval;
+    if (p.desc_mode == SIFT3D_DESC_SIFT) {
+        /* msResampleFeaturesGradientOrientationHistogram, MultiScale.cpp:583-710 */
+        wave_patch_edges(sm.patch, sm.dx, sm.dy, sm.dz);
+        for (int s = lane; s < PV; s += 64) {
+            float e[3] = {sm.dx[s], sm.dy[s], sm.dz[s]};
+            float mg = v3_mag(e);
+            int best = 0;
+            if (mg > 0) {
+                v3_norm(e);
+                const float oa[8][3] = {{1, 1, 1},  {1, 1, -1},  {1, -1, 1},  {1, -1, -1},
+                                        {-1, 1, 1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}};
+                float bd = v3_dot(oa[0], e);
+#pragma unroll
+                for (int q = 1; q < 8; q++) {
+                    float d = v3_dot(oa[q], e);
+                    if (d > bd) {
+                        bd = d;
+                        best = q;
+                    }
+                }
+            }
+            sm.mag[s] = mg;
+            sm.bin[s] = best;
+        }
+        __syncthreads();
+        /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin */
+        const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
+        if (lane < PD) {
+            /* spatial coordinate of patch index c in the 2-bin grid (MultiScale.cpp:641-671), then the
+             * trilinear weight of bin 0 (wtab[0]) and bin 1 (wtab[1]) along that axis */
+            const float binsz = PD / (float)2;
+            const int c = lane;
+            float v = (int)(c / binsz) + 0.5f;
+            if ((int)((c + 0) / binsz) != (int)((c + 1) / binsz)) {
+                float p0 = ((c + 0) / binsz);
+                float p1 = ((c + 1) / binsz);
+                v = (p0 + p1) / 2.0f;
+            }
+            float w;
+            int i0;
+            interp_coord(v, 0, 2.0f, i0, w);
+            sm.wtab[0][c] = w;
+            sm.wtab[1][c] = 1.0f - w;
+        }
+        __syncthreads();
+        const float *wxs = sm.wtab[bx], *wys = sm.wtab[by], *wzs = sm.wtab[bz];
+        float acc = 0;
+        for (int zz = 0; zz < PD; zz++)
+            for (int yy = 0; yy < PD; yy++) {
+                const float wy = wys[yy], wz = wzs[zz];
+                for (int xx = 0; xx < PD; xx++) {
+                    const int s = (zz * PD + yy) * PD + xx;
+                    const float mg = sm.mag[s];
+                    if (mg > 0 && sm.bin[s] == o) acc += mg * wxs[xx] * wy * wz;
+                }
+            }
+        /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 */
+        float mn = 100000;
+        for (int i = 0; i < 64; i++) {
+            float vi = __shfl(acc, i);
+            if (vi < mn) mn = vi;
+        }
+        float v = acc - mn;
+        float ss = 0;
+        for (int i = 0; i < 64; i++) {
+            float vi = __shfl(v, i);
+            ss += vi * vi;
+        }
+        float div = 1.0f / sqrtf(ss);
+        myval = v * div;
+    } else {
+        /* msResampleFeaturesBRIEF, MultiScale.cpp:989-1049 */
+        wave_blur_patch(sm.patch, sm.t1, sm.t3, sm.t2, sm.taps, 5);
+        const int x1 = c_brief_x[3 * lane], y1 = c_brief_x[3 * lane + 1], z1 = c_brief_x[3 * lane + 2];
+        const int x2 = c_brief_y[3 * lane], y2 = c_brief_y[3 * lane + 1], z2 = c_brief_y[3 * lane + 2];
+        float d = sm.t2[x1 + y1 * PD + z1 * PD * PD] - sm.t2[x2 + y2 * PD + z2 * PD * PD];
+        if (p.desc_mode == SIFT3D_DESC_BRIEF) {
+            myval = (d < 0) ? 1.0f : 0.0f;
+        } else if (p.desc_mode == SIFT3D_DESC_RRIEF) {
+            myval = d;
+        } else {
+            float fdx = x1 - x2, fdy = y1 - y2, fdz = z1 - z2;
+            int dist = (int)sqrtf(fdx * fdx + fdy * fdy + fdz * fdz);
+            myval = d / dist;
+        }
+    }
+    /* NormalizeDataRankedPCs, MultiScale.cpp:207-233, order of :3148-3176 */
+    int rank = 0;
+    for (int j = 0; j < 64; j++) {
+        float vj = __shfl(myval, j);
+        rank += (vj < myval || (vj == myval && j < lane)) ? 1 : 0;
+    }
+    sift3d_drec *out = recs + r;
+    out->desc[lane] = (float)rank;
+    if (lane == 0) {
+        /* octave -> image space (MultiScale.cpp:531-543), then fSizeFactor (featExtract.cpp:502-505) */
+        float sc = kp->scale, xx = kp->x, yy = kp->y, zz = kp->z;
+        const float fac = p.octave_factor, add = 0;
+        sc *= fac;
+        xx = xx * fac + add;
+        yy = yy * fac + add;
+        zz = zz * fac + add;
+        xx *= p.size_factor; yy *= p.size_factor; zz *= p.size_factor; sc *= p.size_factor;
+        out->x = xx; out->y = yy; out->z = zz; out->scale = sc;
+        for (int i = 0; i < 9; i++) out->ori[i] = fr < 0 ? kp->ori0[i] : kp->frames[fr * 9 + i];
+        for (int i = 0; i < 3; i++) out->eigs[i] = kp->eigs[i];
+        out->info = kp->info | (fr < 0 ? 0u : SIFT3D_INFO_REORIENT);
+        out->valid = 1;
+    }
+}
+
+/* ---------------------------------------------------------------------- */
+/* launchers                                                               */
+/* ---------------------------------------------------------------------- */
+hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const sift3d_dcand *cands, int64_t ncand,
+                                    sift3d_dkp *kps, const float *taps3)
+{
+    if (ncand <= 0) return hipSuccess;
+    (void)hipFuncSetAttribute((const void *)keypoint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(kpA_smem));
+    sift3d_taps t;
+    for (int i = 0; i < 17; i++) t.f[i] = i < 3 ? taps3[i] : 0.0f;
+    hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)ncand), dim3(64), sizeof(kpA_smem), s, p, cands, (long long)ncand,
+                       kps, t);
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
+                                     const int *rec_frame, int64_t nrec, sift3d_drec *recs, const float *taps5)
+{
+    if (nrec <= 0) return hipSuccess;
+    (void)hipFuncSetAttribute((const void *)descriptor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(kpB_smem));
+    sift3d_taps t;
+    for (int i = 0; i < 17; i++) t.f[i] = i < 5 ? taps5[i] : 0.0f;
+    hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)nrec), dim3(64), sizeof(kpB_smem), s, p,
+                       kps, rec_kp, rec_frame, (long long)nrec, recs, t);
+    return hipGetLastError();
+}

@@ -1,0 +1,543 @@
+/*
+ * kernels_volume.hip -- whole-volume kernels of the scale-space pyramid for
+ * gfx950 (MI355X): separable Gaussian passes, fused DoG store, 2x2x2
+ * subsample, size doubling/halving, 80-neighbour extrema detection.
+ *
+ * Arithmetic contract (bit-exact with the reference's CPU path,
+ * R/src_common/GaussBlur3D.cpp:43-61,329-479 where R/ =
+ * /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/): every output
+ * is  acc = 0; for j ascending: acc = acc + f[j]*in[c+j-R]  with the multiply
+ * and the add rounded separately (this file is compiled -ffp-contract=off),
+ * zero outside the volume, float32 intermediates between the x, y and z
+ * passes.  A tap that falls outside contributes f*0 = +0, which never changes
+ * a float accumulator that started at +0, so feeding zeros and skipping are
+ * the same thing.
+ *
+ * All kernels are HBM-bound streaming kernels: lanes run along x (the fastest
+ * axis) with 16-byte accesses whenever the row length allows it; nothing here
+ * is GEMM-shaped, so no MFMA.
+ */
+#include "sift3d_internal.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int VEC>
+struct vecT;
+template <>
+struct vecT<4> {
+    typedef v4f type;
+};
+template <>
+struct vecT<1> {
+    typedef float type;
+};
+
+template <int VEC>
+__device__ __forceinline__ typename vecT<VEC>::type vload(const float *p)
+{
+    return *reinterpret_cast<const typename vecT<VEC>::type *>(p);
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float *p, typename vecT<VEC>::type v)
+{
+    *reinterpret_cast<typename vecT<VEC>::type *>(p) = v;
+}
+
+/* ------------------------------------------------------------------------ */
+/* x pass: one wavefront per 64*VEC-float row segment; the segment and its   */
+/* halo are staged in LDS with coalesced 16-byte reads, each lane then pulls */
+/* its 4+2R-float window with aligned ds_read_b128 and keeps it in registers.*/
+/* ------------------------------------------------------------------------ */
+template <int R, int VEC>
+__global__ __launch_bounds__(256) void blur_x_kernel(const float *__restrict__ in, float *__restrict__ out, int X,
+                                                     long long rows, int segs_per_row, sift3d_taps t)
+{
+    constexpr int HALO = (VEC == 4) ? ((R + 3) / 4) * 4 : R;
+    constexpr int SEG = 64 * VEC;
+    constexpr int LROW = SEG + 2 * HALO;
+    __shared__ __attribute__((aligned(16))) float lds[4 * LROW];
+    typedef typename vecT<VEC>::type V;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long w = (long long)blockIdx.x * 4 + wave;
+    const long long nw = rows * segs_per_row;
+    float *my = lds + wave * LROW;
+    const bool live = w < nw;
+    const long long row = live ? w / segs_per_row : 0;
+    const int seg = live ? (int)(w % segs_per_row) : 0;
+    const int x0 = seg * SEG;
+    const float *src = in + row * X;
+    const int xs = x0 + lane * VEC;
+
+    V zero = V(0.0f);
+    V m = (live && xs < X) ? vload<VEC>(src + xs) : zero;
+    vstore<VEC>(my + HALO + lane * VEC, m);
+    constexpr int HV = HALO / VEC; /* halo vectors per side */
+    if (lane < HV) {
+        int xl = x0 - HALO + lane * VEC;
+        V h = (live && xl >= 0) ? vload<VEC>(src + xl) : zero;
+        vstore<VEC>(my + lane * VEC, h);
+    } else if (lane < 2 * HV) {
+        int k = lane - HV;
+        int xr = x0 + SEG + k * VEC;
+        V h = (live && xr < X) ? vload<VEC>(src + xr) : zero;
+        vstore<VEC>(my + HALO + SEG + k * VEC, h);
+    }
+    __syncthreads();
+
+    float win[VEC + 2 * HALO];
+#pragma unroll
+    for (int i = 0; i < (VEC + 2 * HALO) / VEC; i++) {
+        V v = vload<VEC>(my + lane * VEC + i * VEC);
+        if constexpr (VEC == 4) {
+            win[4 * i + 0] = v.x; win[4 * i + 1] = v.y; win[4 * i + 2] = v.z; win[4 * i + 3] = v.w;
+        } else {
+            win[i] = v;
+        }
+    }
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2 * R + 1; j++) acc = acc + t.f[j] * win[HALO - R + e + j];
+        o[e] = acc;
+    }
+    if (live && xs < X) {
+        if constexpr (VEC == 4) {
+            v4f r;
+            r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+            vstore<4>(out + row * X + xs, r);
+        } else {
+            out[row * X + xs] = o[0];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* y / z pass: lanes along x, each lane marches along the filtered axis and  */
+/* keeps the 2R+1 partial sums that are alive in registers.  Input row q of  */
+/* the chunk feeds tap j = q - o of output o, so every output receives its   */
+/* taps in ascending order as the rows stream past; each input row is read   */
+/* once per chunk.  The loop is unrolled by U = 2R+1 so that the slot of     */
+/* every partial sum is a compile-time register.  With DOG the finished row  */
+/* is stored together with prev - row (the fused subtract-and-store).        */
+/* ------------------------------------------------------------------------ */
+template <int R, int VEC, bool DOG>
+__global__ __launch_bounds__(256) void blur_col_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                       const float *__restrict__ prev, float *__restrict__ dog,
+                                                       long long nlines, int XV, long long outer_stride, long long S,
+                                                       int L, int CH, sift3d_taps t)
+{
+    constexpr int U = 2 * R + 1;
+    typedef typename vecT<VEC>::type V;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nlines) return;
+    const long long base = (tid / XV) * outer_stride + (tid % XV) * (long long)VEC;
+    const int c0 = blockIdx.y * CH;
+    const int total = CH + 2 * R;
+    const float *src = in + base;
+    V acc[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) acc[i] = V(0.0f);
+
+    for (int q0 = 0; q0 < total; q0 += U) {
+#pragma unroll
+        for (int s = 0; s < U; s++) {
+            const int q = q0 + s;
+            const int p = c0 - R + q;
+            V v = V(0.0f);
+            if (p >= 0 && p < L && q < total) v = vload<VEC>(src + (long long)p * S);
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const int j = (s - i + U) % U;
+                if (j == 0)
+                    acc[i] = V(0.0f) + V(t.f[0]) * v;
+                else
+                    acc[i] = acc[i] + V(t.f[j]) * v;
+            }
+            const int ic = (s + 1) % U; /* slot whose tap 2R was just added */
+            const int o = q - 2 * R;
+            const int y = c0 + o;
+            if (o >= 0 && o < CH && y < L) {
+                const long long off = base + (long long)y * S;
+                V g = acc[ic];
+                vstore<VEC>(out + off, g);
+                if constexpr (DOG) {
+                    V pv = vload<VEC>(prev + off);
+                    vstore<VEC>(dog + off, pv - g);
+                }
+            }
+        }
+    }
+}
+
+/* Generic fallback for tap counts outside 3..17 (never used by the pyramid):
+ * one thread per voxel, taps from global memory. */
+__global__ void blur_axis_generic_kernel(const float *__restrict__ in, float *__restrict__ out, long long X, long long Y,
+                                         long long Z, int axis, const float *__restrict__ taps, int ntaps,
+                                         const float *__restrict__ prev, float *__restrict__ dog)
+{
+    const long long n = X * Y * Z;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long x = i % X, y = (i / X) % Y, z = i / (X * Y);
+    const long long c = axis == 0 ? x : (axis == 1 ? y : z);
+    const long long len = axis == 0 ? X : (axis == 1 ? Y : Z);
+    const long long stride = axis == 0 ? 1 : (axis == 1 ? X : X * Y);
+    const int h = ntaps / 2;
+    float acc = 0.0f;
+    for (int j = 0; j < ntaps; j++) {
+        long long cc = c + j - h;
+        float v = (cc >= 0 && cc < len) ? in[i + (cc - c) * stride] : 0.0f;
+        acc = acc + taps[j] * v;
+    }
+    out[i] = acc;
+    if (dog) dog[i] = prev[i] - acc;
+}
+
+/* DoG on its own (operator-level API): out = a + (-1)*b, R/src_common/FeatureIO.cpp:1981 */
+__global__ void dog_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, long long n4,
+                           long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        v4f va = vload<4>(a + 4 * i), vb = vload<4>(b + 4 * i);
+        vstore<4>(out + 4 * i, va - vb);
+    }
+    if (i == 0)
+        for (long long k = 4 * n4; k < n; k++) out[k] = a[k] - b[k];
+}
+
+/* 2x2x2 mean, association of R/src_common/FeatureIO.cpp:1532-1538:
+ * ((p000+p010)+p100)+p110, then + (((p001+p011)+p101)+p111), times 0.125 */
+__global__ void subsample_kernel(const float *__restrict__ in, long long X, long long Y, long long Z,
+                                 float *__restrict__ out)
+{
+    const long long ox = X / 2, oy = Y / 2, oz = Z / 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ox * oy * oz) return;
+    const long long x = i % ox, y = (i / ox) % oy, z = i / (ox * oy);
+    const float *p0 = in + ((2 * z) * Y + 2 * y) * X + 2 * x;
+    const float *p1 = p0 + X * Y;
+    float a00, a10, a01, a11, b00, b10, b01, b11;
+    if ((X & 1) == 0) {
+        float2 r0 = *reinterpret_cast<const float2 *>(p0), r1 = *reinterpret_cast<const float2 *>(p0 + X);
+        float2 r2 = *reinterpret_cast<const float2 *>(p1), r3 = *reinterpret_cast<const float2 *>(p1 + X);
+        a00 = r0.x; a10 = r0.y; a01 = r1.x; a11 = r1.y;
+        b00 = r2.x; b10 = r2.y; b01 = r3.x; b11 = r3.y;
+    } else {
+        a00 = p0[0]; a10 = p0[1]; a01 = p0[X]; a11 = p0[X + 1];
+        b00 = p1[0]; b10 = p1[1]; b01 = p1[X]; b11 = p1[X + 1];
+    }
+    float s = 0.0f;
+    s = s + (((a00 + a01) + a10) + a11);
+    s = s + (((b00 + b01) + b10) + b11);
+    out[i] = s * 0.125f;
+}
+
+/* fioDoubleSize, R/src_common/FeatureIO.cpp:2452-2548: one thread per output
+ * voxel (2x,2y,2z)+(dx,dy,dz); edge voxels replicate. */
+__global__ void double_size_kernel(const float *__restrict__ in, long long X, long long Y, long long Z,
+                                   float *__restrict__ out)
+{
+    const long long DX = 2 * X, DY = 2 * Y, DZ = 2 * Z;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DX * DY * DZ) return;
+    const long long hx = i % DX, hy = (i / DX) % DY, hz = i / (DX * DY);
+    const long long x = hx >> 1, y = hy >> 1, z = hz >> 1;
+    const int ox = (int)(hx & 1), oy = (int)(hy & 1), oz = (int)(hz & 1);
+    float lo[2][2][2];
+#pragma unroll
+    for (int zz = 0; zz < 2; zz++)
+#pragma unroll
+        for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+            for (int xx = 0; xx < 2; xx++) {
+                long long sx = x + ((x + xx >= X) ? 0 : xx), sy = y + ((y + yy >= Y) ? 0 : yy),
+                          sz = z + ((z + zz >= Z) ? 0 : zz);
+                lo[zz][yy][xx] = in[(sz * Y + sy) * X + sx];
+            }
+    float v;
+    const int code = oz * 4 + oy * 2 + ox;
+    switch (code) {
+    case 0: v = lo[0][0][0]; break;
+    case 4: v = 0.5f * (lo[0][0][0] + lo[1][0][0]); break;
+    case 2: v = 0.5f * (lo[0][0][0] + lo[0][1][0]); break;
+    case 1: v = 0.5f * (lo[0][0][0] + lo[0][0][1]); break;
+    case 6: v = 0.25f * (lo[0][0][0] + lo[1][0][0] + lo[0][1][0] + lo[1][1][0]); break;
+    case 3: v = 0.25f * (lo[0][0][0] + lo[0][1][0] + lo[0][0][1] + lo[0][1][1]); break;
+    case 5: v = 0.25f * (lo[0][0][0] + lo[1][0][0] + lo[0][0][1] + lo[1][0][1]); break;
+    default:
+        v = 0.125f * (lo[0][0][0] + lo[0][0][1] + lo[0][1][0] + lo[0][1][1] + lo[1][0][0] + lo[1][0][1] + lo[1][1][0] +
+                      lo[1][1][1]);
+        break;
+    }
+    out[i] = v;
+}
+
+/* fioSubSample2DCenterPixel, R/src_common/FeatureIO.cpp:1670-1714: the eight
+ * voxels summed in the order z fastest, then y, then x; divided by 8. */
+__global__ void halve_size_kernel(const float *__restrict__ in, long long X, long long Y, long long Z,
+                                  float *__restrict__ out)
+{
+    const long long ox = X / 2, oy = Y / 2, oz = Z / 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ox * oy * oz) return;
+    const long long x = i % ox, y = (i / ox) % oy, z = i / (ox * oy);
+    const float *p = in + ((2 * z) * Y + 2 * y) * X + 2 * x;
+    const long long XY = X * Y;
+    float v = 0.0f;
+    v = v + p[0];
+    v = v + p[XY];
+    v = v + p[X];
+    v = v + p[XY + X];
+    v = v + p[1];
+    v = v + p[XY + 1];
+    v = v + p[X + 1];
+    v = v + p[XY + X + 1];
+    out[i] = v / 8.0f;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Extrema: strict max/min of d_cur over its 26 neighbours, then centre + 26 */
+/* of d_prev and (when present) of d_next: the decision of regFindFEATUREIO  */
+/* + peak/valleyFunction4D (R/src_common/MultiScale.cpp:2260-2524) followed  */
+/* by validateDifferencePeak/Valley3D (:1135-1318).  Lanes along x; a        */
+/* wavefront leaves as soon as none of its 64 voxels can still be an         */
+/* extremum (__any), so the other two levels are touched only around the     */
+/* rare survivors.  Survivors are appended with a wave-aggregated atomic;    */
+/* the host orders them afterwards (raster order = sort by linear index).    */
+/* ------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
+                                                      const float *__restrict__ dnext, int X, int Y, int Z,
+                                                      sift3d_dcand *__restrict__ out, unsigned long long *count,
+                                                      long long cap)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int z = blockIdx.z + 1;
+    const bool inside = (x >= 1 && x < X - 1 && y >= 1 && y < Y - 1);
+    const long long XY = (long long)X * Y;
+    const long long idx = (long long)z * XY + (long long)y * X + x;
+    bool mx = inside, mn = inside;
+    float c = 0.0f;
+    if (inside) c = dcur[idx];
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++) {
+        if (inside) {
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (dz == 0 && dy == 0 && dx == 0) continue;
+                    float v = dcur[idx + dz * XY + dy * X + dx];
+                    mx = mx && (v < c);
+                    mn = mn && (v > c);
+                }
+        }
+        if (!__any(mx || mn)) return;
+    }
+    if (mx || mn) {
+        const float *lv[2] = {dprev, dnext};
+        for (int l = 0; l < 2; l++) {
+            const float *d = lv[l];
+            if (!d) continue;
+            for (int dz = -1; dz <= 1 && (mx || mn); dz++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        float v = d[idx + dz * XY + dy * X + dx];
+                        mx = mx && (v < c);
+                        mn = mn && (v > c);
+                    }
+        }
+    }
+    if (mx || mn) {
+        unsigned long long slot = atomicAdd(count, 1ull);
+        if ((long long)slot < cap) {
+            sift3d_dcand r;
+            r.idx = idx;
+            r.value = c;
+            r.h = dprev[idx];
+            r.l = dnext ? dnext[idx] : 0.0f;
+            r.is_max = mx ? 1 : 0;
+            out[slot] = r;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* launchers                                                                */
+/* ------------------------------------------------------------------------ */
+static inline sift3d_taps pack_taps(const float *taps, int n)
+{
+    sift3d_taps t;
+    for (int i = 0; i < 2 * SIFT3D_FAST_MAX_R + 1; i++) t.f[i] = i < n ? taps[i] : 0.0f;
+    return t;
+}
+
+template <int R, int VEC>
+static void launch_x(hipStream_t s, const float *in, float *out, int64_t X, int64_t rows, const sift3d_taps &t)
+{
+    const int seg = 64 * VEC;
+    const int spr = (int)((X + seg - 1) / seg);
+    const long long nw = rows * spr;
+    const unsigned blocks = (unsigned)((nw + 3) / 4);
+    hipLaunchKernelGGL((blur_x_kernel<R, VEC>), dim3(blocks), dim3(256), 0, s, in, out, (int)X, (long long)rows, spr, t);
+}
+
+template <int R>
+static void dispatch_x(hipStream_t s, const float *in, float *out, int64_t X, int64_t rows, const sift3d_taps &t)
+{
+    if (X % 4 == 0) launch_x<R, 4>(s, in, out, X, rows, t);
+    else launch_x<R, 1>(s, in, out, X, rows, t);
+}
+
+#define SIFT3D_R_SWITCH(R_, CALL)            \
+    switch (R_) {                            \
+    case 1: { constexpr int RR = 1; CALL; } break; \
+    case 2: { constexpr int RR = 2; CALL; } break; \
+    case 3: { constexpr int RR = 3; CALL; } break; \
+    case 4: { constexpr int RR = 4; CALL; } break; \
+    case 5: { constexpr int RR = 5; CALL; } break; \
+    case 6: { constexpr int RR = 6; CALL; } break; \
+    case 7: { constexpr int RR = 7; CALL; } break; \
+    case 8: { constexpr int RR = 8; CALL; } break; \
+    default: break;                          \
+    }
+
+static void launch_generic(hipStream_t s, const float *in, float *out, int64_t X, int64_t Y, int64_t Z, int axis,
+                           const float *d_taps, int ntaps, const float *prev, float *dog)
+{
+    const long long n = X * Y * Z;
+    hipLaunchKernelGGL(blur_axis_generic_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out,
+                       (long long)X, (long long)Y, (long long)Z, axis, d_taps, ntaps, prev, dog);
+}
+
+hipError_t sift3d_launch_blur_x(hipStream_t s, const float *in, float *out, int64_t X, int64_t Y, int64_t Z,
+                                const float *taps, int ntaps, const float *d_taps)
+{
+    const int R = ntaps / 2;
+    if (R >= 1 && R <= SIFT3D_FAST_MAX_R) {
+        sift3d_taps t = pack_taps(taps, ntaps);
+        SIFT3D_R_SWITCH(R, (dispatch_x<RR>(s, in, out, X, Y * Z, t)));
+    } else {
+        launch_generic(s, in, out, X, Y, Z, 0, d_taps, ntaps, nullptr, nullptr);
+    }
+    return hipGetLastError();
+}
+
+/* chunk length along the marched axis: a multiple of U minus the 2R lead-in
+ * rows, near 128 outputs, so the halo re-read stays around 2R/128 */
+static inline int chunk_len(int R, int64_t L)
+{
+    const int U = 2 * R + 1;
+    int k = (128 + 2 * R + U - 1) / U;
+    int ch = k * U - 2 * R;
+    if (ch > L) {
+        k = (int)((L + 2 * R + U - 1) / U);
+        ch = k * U - 2 * R;
+    }
+    return ch;
+}
+
+template <int R, int VEC, bool DOG>
+static void launch_col(hipStream_t s, const float *in, float *out, const float *prev, float *dog, long long nlines, int XV,
+                       long long outer_stride, long long S, int L, const sift3d_taps &t)
+{
+    const int ch = chunk_len(R, L);
+    const unsigned chunks = (unsigned)((L + ch - 1) / ch);
+    dim3 grid((unsigned)((nlines + 255) / 256), chunks);
+    hipLaunchKernelGGL((blur_col_kernel<R, VEC, DOG>), grid, dim3(256), 0, s, in, out, prev, dog, nlines, XV, outer_stride,
+                       S, L, ch, t);
+}
+
+hipError_t sift3d_launch_blur_y(hipStream_t s, const float *in, float *out, int64_t X, int64_t Y, int64_t Z,
+                                const float *taps, int ntaps, const float *d_taps)
+{
+    const int R = ntaps / 2;
+    if (R >= 1 && R <= SIFT3D_FAST_MAX_R) {
+        sift3d_taps t = pack_taps(taps, ntaps);
+        if (X % 4 == 0) {
+            const int XV = (int)(X / 4);
+            SIFT3D_R_SWITCH(R, (launch_col<RR, 4, false>(s, in, out, nullptr, nullptr, (long long)XV * Z, XV, X * Y, X, (int)Y, t)));
+        } else {
+            SIFT3D_R_SWITCH(R, (launch_col<RR, 1, false>(s, in, out, nullptr, nullptr, (long long)X * Z, (int)X, X * Y, X, (int)Y, t)));
+        }
+    } else {
+        launch_generic(s, in, out, X, Y, Z, 1, d_taps, ntaps, nullptr, nullptr);
+    }
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_blur_z(hipStream_t s, const float *in, float *out, const float *prev, float *dog, int64_t X,
+                                int64_t Y, int64_t Z, const float *taps, int ntaps, const float *d_taps)
+{
+    const int R = ntaps / 2;
+    const long long XY = X * Y;
+    if (R >= 1 && R <= SIFT3D_FAST_MAX_R && XY < (1ll << 31)) {
+        sift3d_taps t = pack_taps(taps, ntaps);
+        if (XY % 4 == 0) {
+            const long long nl = XY / 4;
+            if (dog) {
+                SIFT3D_R_SWITCH(R, (launch_col<RR, 4, true>(s, in, out, prev, dog, nl, (int)nl, 0, XY, (int)Z, t)));
+            } else {
+                SIFT3D_R_SWITCH(R, (launch_col<RR, 4, false>(s, in, out, nullptr, nullptr, nl, (int)nl, 0, XY, (int)Z, t)));
+            }
+        } else {
+            if (dog) {
+                SIFT3D_R_SWITCH(R, (launch_col<RR, 1, true>(s, in, out, prev, dog, XY, (int)XY, 0, XY, (int)Z, t)));
+            } else {
+                SIFT3D_R_SWITCH(R, (launch_col<RR, 1, false>(s, in, out, nullptr, nullptr, XY, (int)XY, 0, XY, (int)Z, t)));
+            }
+        }
+    } else {
+        launch_generic(s, in, out, X, Y, Z, 2, d_taps, ntaps, prev, dog);
+    }
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_dog(hipStream_t s, const float *a, const float *b, float *out, int64_t n)
+{
+    const long long n4 = n / 4;
+    const long long th = n4 > 0 ? n4 : 1;
+    hipLaunchKernelGGL(dog_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, a, b, out, n4, (long long)n);
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out)
+{
+    const long long n = (X / 2) * (Y / 2) * (Z / 2);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, (long long)X, (long long)Y,
+                       (long long)Z, out);
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out)
+{
+    const long long n = 8 * X * Y * Z;
+    hipLaunchKernelGGL(double_size_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, (long long)X,
+                       (long long)Y, (long long)Z, out);
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out)
+{
+    const long long n = (X / 2) * (Y / 2) * (Z / 2);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(halve_size_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, (long long)X,
+                       (long long)Y, (long long)Z, out);
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
+                                 int64_t Y, int64_t Z, sift3d_dcand *out, unsigned long long *count, int64_t cap)
+{
+    if (X < 3 || Y < 3 || Z < 3) return hipSuccess;
+    dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(Z - 2));
+    hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, out, count,
+                       (long long)cap);
+    return hipGetLastError();
+}

@@ -1,0 +1,177 @@
+/*
+ * sift3d.h -- C-ABI of the MI355X-native 3D SIFT extraction path.
+ *
+ * Drop-in boundary for the accelerator back-end of CarluerJB/3D_SIFT_CUDA's
+ * featExtract.  Plain C types only.  Each entry point names the reference
+ * interface it replaces; R/ stands for
+ * /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/.
+ *
+ * Conventions (differences from the reference are deliberate and listed in
+ * INTEGRATION.md): every function returns SIFT3D_OK (0) or a negative
+ * sift3d_status instead of calling exit() like gpuErrchk
+ * (R/cuda_common/SIFT_cuda_Tools.cuh:13-21); sizes are int64_t; volumes are
+ * dense float32, x fastest, index (z*ny + y)*nx + x (FEATUREIO,
+ * R/src_common/FeatureIO.h:21-33); the caller owns every buffer it passes
+ * in; arrays the library returns are released with sift3d_free().
+ * Results are those of the reference's CPU path (-d omitted): pass order
+ * x,y,z, zero borders, separate multiply/add in ascending tap order.
+ *
+ * There is no CPU fallback: without a usable HIP device sift3d_create()
+ * returns NULL and sift3d_device_count() returns 0.
+ */
+#ifndef SIFT3D_H
+#define SIFT3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFT3D_DESC_LEN 64
+#define SIFT3D_INFO_MIN0MAX1 0x00000010u /* R/src_common/MultiScale.h:28 */
+#define SIFT3D_INFO_REORIENT 0x00000020u /* R/src_common/MultiScale.h:30 */
+
+typedef enum {
+    SIFT3D_OK = 0,
+    SIFT3D_ERR_ARG = -1,      /* bad argument / shape */
+    SIFT3D_ERR_DEVICE = -2,   /* HIP runtime error (sift3d_last_error has the text) */
+    SIFT3D_ERR_MEMORY = -3,   /* host or device allocation failed */
+    SIFT3D_ERR_CAPACITY = -4, /* caller-provided output array too small (counts are still exact) */
+    SIFT3D_ERR_COMM = -5      /* slab exchange callback failed */
+} sift3d_status;
+
+/* Descriptor selected by -b / -br / -bn (/root/reference/README.md:26-34;
+ * alternatives at R/src_common/MultiScale.cpp:1037-1045). */
+typedef enum { SIFT3D_DESC_SIFT = 0, SIFT3D_DESC_BRIEF = 1, SIFT3D_DESC_RRIEF = 2, SIFT3D_DESC_NRRIEF = 3 } sift3d_desc_mode;
+
+/* LOCATION_VALUE_XYZ, R/src_common/LocationValue.h:41-47 */
+typedef struct {
+    int32_t x, y, z;
+    float value;
+} sift3d_extremum;
+
+/* What msFeature3DVectorOutputText prints per record
+ * (R/src_common/MultiScale.h:386-474): Feature3DInfo without the patch. */
+typedef struct {
+    float x, y, z, scale;
+    float ori[9];
+    float eigs[3];
+    uint32_t info;
+    float desc[SIFT3D_DESC_LEN];
+} sift3d_feature;
+
+/* One validated scale-space extremum before the per-keypoint stage. */
+typedef struct {
+    int32_t octave, level; /* level 1..3: DoG index inside the octave */
+    int32_t is_max;
+    int32_t x, y, z;
+    float value, h_value, l_value; /* DoG at the extremum, one level below, one above */
+} sift3d_candidate;
+
+typedef struct sift3d_ctx sift3d_ctx;
+
+/* ---- devices and contexts --------------------------------------------------
+ * get_num_device()/check_best_device(), R/featExtract/featExtract.cpp:238-270;
+ * the device-buffer life cycle buried in fioAllocate/fioDelete/fioCopy
+ * (R/src_common/FeatureIO.cpp:384-387,527-530,1857-1860). */
+int sift3d_device_count(void);
+/* Allocates the device-resident pyramid for volumes of up to nx*ny*nz voxels on
+ * HIP device `device` (0-based, as cudaSetDevice receives it in the reference).
+ * NULL on failure. */
+sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz);
+void sift3d_destroy(sift3d_ctx *ctx);
+const char *sift3d_last_error(const sift3d_ctx *ctx);
+/* Optional: run on a caller-owned hipStream_t (e.g. torch's); NULL = the
+ * context's own stream. */
+int sift3d_set_stream(sift3d_ctx *ctx, void *hip_stream);
+int sift3d_sync(sift3d_ctx *ctx);
+void sift3d_free(void *p);
+
+/* ---- Gaussian taps (host) ---------------------------------------------------
+ * calculate_gaussian_filter_size + generate_gaussian_filter1d
+ * (R/src_common/GaussianMask.cpp:12-57,241-265) and the normalisation of
+ * gb3d_blur3d_interleave (R/src_common/GaussBlur3D.cpp:1190-1201).
+ * Returns the (odd) tap count, or a negative status; taps must hold 129 floats. */
+int sift3d_gauss_taps(float sigma, float min_value, float *taps);
+
+/* ---- operator level: the reference's four accelerator entry points ---------
+ * Host-pointer forms copy in, run on the device and copy the result back
+ * (what every reference wrapper does); *_dev forms take device pointers and
+ * stay asynchronous on the context's stream. */
+
+/* gb3d_blur3d -> blur_3d_simpleborders_CUDA_Row_Col_Shared_mem
+ * (R/cuda_common/SIFT_cuda_Tools.cuh:69-76, called from
+ * R/src_common/GaussBlur3D.cpp:1240-1245); the input is NOT clobbered. */
+int sift3d_gauss_blur(sift3d_ctx *ctx, const float *in, float *out, int64_t nx, int64_t ny, int64_t nz, float sigma,
+                      float min_value);
+int sift3d_gauss_blur_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, int64_t nx, int64_t ny, int64_t nz,
+                          float sigma, float min_value);
+/* Fused form used by the pyramid: out = blur(in), dog = in - out. */
+int sift3d_gauss_blur_dog_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, float *d_dog, int64_t nx, int64_t ny,
+                              int64_t nz, float sigma, float min_value);
+/* fioMultSum_interleave(a, b, out, -1.0f) -> fioCudaMultSum
+ * (SIFT_cuda_Tools.cuh:213-217, R/src_common/FeatureIO.cpp:1941-1943) */
+int sift3d_dog(sift3d_ctx *ctx, const float *a, const float *b, float *out, int64_t n);
+int sift3d_dog_dev(sift3d_ctx *ctx, const float *d_a, const float *d_b, float *d_out, int64_t n);
+/* Subsample_interleave -> SubSampleInterpolateCuda (SIFT_cuda_Tools.cuh:202-205,
+ * R/src_common/FeatureIO.cpp:1556-1564): out is (nx/2)*(ny/2)*(nz/2). */
+int sift3d_subsample2(sift3d_ctx *ctx, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out);
+int sift3d_subsample2_dev(sift3d_ctx *ctx, const float *d_in, int64_t nx, int64_t ny, int64_t nz, float *d_out);
+/* detectExtrema4D_test_interleave -> detectExtrema4D_test_cuda
+ * (SIFT_cuda_Tools.cuh:32-38, R/src_common/MultiScale.cpp:1523-1546): strict
+ * extrema of d_cur over its 26 neighbours and centre+26 of d_prev; when d_next
+ * is not NULL also centre+26 of d_next (the reference's later validation,
+ * MultiScale.cpp:425-453).  Lists come back in raster z,y,x order, minima and
+ * maxima separately, as the CPU scan produces them.  *n_min / *n_max always
+ * receive the exact counts. */
+int sift3d_extrema(sift3d_ctx *ctx, const float *d_prev, const float *d_cur, const float *d_next, int64_t nx, int64_t ny,
+                   int64_t nz, sift3d_extremum *minima, int64_t cap_min, int64_t *n_min, sift3d_extremum *maxima,
+                   int64_t cap_max, int64_t *n_max);
+/* fioDoubleSize (R/src_common/FeatureIO.cpp:2452-2548), out is 2nx*2ny*2nz; and
+ * fioSubSample2DCenterPixel (:1670-1714), out is (nx/2)*(ny/2)*(nz/2): the -2+ / -2- options. */
+int sift3d_double_size(sift3d_ctx *ctx, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out);
+int sift3d_halve_size(sift3d_ctx *ctx, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out);
+
+/* ---- pipeline level: msGeneratePyramidDOG3D_efficient + the descriptor loop --
+ * (R/src_common/MultiScale.cpp:236-570, R/featExtract/featExtract.cpp:409,474-505).
+ * Everything stays on the device between the upload of the volume and the
+ * download of the records. */
+int sift3d_set_volume(sift3d_ctx *ctx, const float *vol, int64_t nx, int64_t ny, int64_t nz);
+int sift3d_set_volume_dev(sift3d_ctx *ctx, const float *d_vol, int64_t nx, int64_t ny, int64_t nz);
+/* Scale-space + detection only: validated extrema of every octave/level in the
+ * reference's order.  *out is malloc'ed (sift3d_free). */
+int sift3d_detect(sift3d_ctx *ctx, float initial_image_scale, sift3d_candidate **out, int64_t *n_out);
+/* Full extraction.  initial_image_scale: 1, or 0.5 after -2+; size_factor: what
+ * featExtract.cpp:423-427 applies to x,y,z,scale (0.5 for -2+, 2 for -2-);
+ * eig_thres: 140 in featExtract.cpp:297.  *out is malloc'ed (sift3d_free). */
+int sift3d_extract(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                   sift3d_feature **out, int64_t *n_out);
+
+/* ---- measurement ------------------------------------------------------------
+ * Device time per stage of the last sift3d_detect/sift3d_extract call, from
+ * HIP events recorded on the stream the kernels ran on. */
+typedef enum {
+    SIFT3D_STAGE_BLUR_X = 0, /* separable pass along x */
+    SIFT3D_STAGE_BLUR_Y,     /* pass along y */
+    SIFT3D_STAGE_BLUR_Z_DOG, /* pass along z with fused DoG store */
+    SIFT3D_STAGE_SUBSAMPLE,
+    SIFT3D_STAGE_EXTREMA,
+    SIFT3D_STAGE_KEYPOINT,   /* refinement, patch, orientation frames */
+    SIFT3D_STAGE_DESCRIPTOR,
+    SIFT3D_STAGE_COUNT
+} sift3d_stage;
+typedef struct {
+    double ms[SIFT3D_STAGE_COUNT];        /* summed kernel time */
+    int64_t launches[SIFT3D_STAGE_COUNT];
+    double alg_bytes[SIFT3D_STAGE_COUNT]; /* algorithmic bytes moved */
+    int64_t n_octaves, n_extrema, n_keypoints, n_records;
+    double total_ms;                      /* first kernel to last, on the stream */
+} sift3d_timings;
+int sift3d_enable_timing(sift3d_ctx *ctx, int on);
+int sift3d_get_timings(const sift3d_ctx *ctx, sift3d_timings *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

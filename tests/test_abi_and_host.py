@@ -1,0 +1,101 @@
+"""CPU suite: the C-ABI surface and the host-side helpers (no compute calls)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "sift3d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sift3d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_functions()
+    for must in ("sift3d_device_count", "sift3d_create", "sift3d_destroy", "sift3d_gauss_blur", "sift3d_dog",
+                 "sift3d_subsample2", "sift3d_extrema", "sift3d_extract", "sift3d_detect", "sift3d_free"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = C.CDLL(built.LIB_HIP)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_library_has_gfx950_code_object(built):
+    out = subprocess.run(["strings", "-n", "6", built.LIB_HIP], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    # no CPU fallback hides in the product: the oracle is not linked
+    assert "o3_extract" not in out and "libsift3d_oracle" not in out
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    bad = []
+    for d, _, fs in os.walk(os.path.join(ROOT, "3d_sift_cuda_amd")):
+        if "_build" in d:
+            continue
+        for f in fs:
+            if f.endswith((".c", ".h", ".hip", ".py", "Makefile")):
+                t = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"sift3d_oracle|oracle/|import _oracle|o3_[a-z]+\(", t):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_gauss_taps_host(built, oracle):
+    for s in (0.5, 0.95, 1.2262736558914185, 1.5198684930801392, 3.0900158882141113, 0.0):
+        a = built.gauss_taps(s)
+        b = oracle.taps(s)
+        assert len(a) == len(b) and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_no_gpu_means_loud_failure(built):
+    if built.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(built.Sift3DError):
+        built.Context(8, 8, 8)
+
+
+def test_synth_is_deterministic(built):
+    a = built.synth_blobs(40, 32, 24, seed=9)
+    b = built.synth_blobs(40, 32, 24, seed=9)
+    c = built.synth_blobs(40, 32, 24, seed=10)
+    assert a.shape == (24, 32, 40) and (a == b).all() and not (a == c).all()
+    assert np.isfinite(a).all() and a.std() > 1.0
+
+
+def test_nifti_roundtrip_and_cli_usage(built, tmp_path, oracle):
+    import _oracle
+    vol = built.synth_blobs(20, 18, 16, seed=3)
+    for name in ("v.nii", "v.nii.gz"):
+        p = str(tmp_path / name)
+        built.write_nifti(p, vol, voxel=(1.0, 2.0, 3.0))
+        k = str(tmp_path / (name + ".key"))
+        r = subprocess.run([_oracle.CLI, p, k], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Input image: i=20 j=18 k=16" in r.stdout
+        head = open(k).read().splitlines()
+        assert head[0] == "# featExtract 1.1"
+        assert head[2] == "# Extraction Voxel Size (mm)  (ijk) : 1.000000 2.000000 3.000000"
+    # the product CLI: usage text and exit code of featExtract.cpp:285-289,344-348
+    r = subprocess.run([built.FEATEXTRACT], capture_output=True, text=True)
+    assert r.returncode == 255 and "Usage: featExtract [options] <input image> <output features>" in r.stdout
+    r = subprocess.run([built.FEATEXTRACT, "-q", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Error: unknown command line argument: -q" in r.stdout
+
+
+def test_key_writer_matches_oracle_writer(built, oracle, tmp_path):
+    vol = built.synth_blobs(64, 64, 64)
+    recs, _ = oracle.extract(vol)
+    cm = ["a", "b", "c"]
+    p1, p2 = str(tmp_path / "a.key"), str(tmp_path / "b.key")
+    oracle.write_key(p1, recs, comments=cm)
+    built.write_key(p2, recs.astype(built.FEATURE_DTYPE), comments=cm)
+    assert open(p1, "rb").read() == open(p2, "rb").read()

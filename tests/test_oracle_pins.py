@@ -1,0 +1,151 @@
+"""CPU suite: the oracle against everything that pins it.
+
+1. bit-exact against the partial reference build oracle/_ref (taps, SVD, 3x3
+   inverse, stable high-low sort) when that library is present, and against the
+   committed reference-generated tap fixture always;
+2. end-to-end against the .key files written by the CPU featExtract binary
+   shipped in the reference repository (tests/golden/refbin_*.key): identical
+   record count, info flags and near-identical geometry / ranks (that binary is
+   a different build of the same pipeline);
+3. record counts of the source-built reference measured in the survey;
+4. its own committed outputs (regression).
+"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle
+from keyio import read_key
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_taps_match_reference_fixture(oracle):
+    fx = json.load(open(os.path.join(GOLD, "ref_taps.json")))
+    expect = {"init": 9, "init_2x": 7, "level1": 7, "level2": 9, "level3": 11, "level4": 13, "level5": 17, "ori_hist": 3, "brief": 5}
+    for name, e in fx.items():
+        sigma = float.fromhex(e["sigma_hex"])
+        raw = oracle.taps(sigma, 0.01, normalise=False)
+        assert len(raw) == e["ntaps"] == expect[name], name
+        want = np.array([float.fromhex(h) for h in e["raw_taps_hex"]], np.float32)
+        assert (bits(raw) == bits(want)).all(), name
+        # normalisation of gb3d_blur3d_interleave: float sum ascending, then divide
+        s = np.float32(0)
+        for v in want:
+            s = np.float32(s + v)
+        assert (bits(oracle.taps(sigma, 0.01)) == bits(want / s)).all(), name
+
+
+def test_partial_reference_build(oracle):
+    ref = _oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(1)
+    for sg in list(np.linspace(0.3, 8.0, 120)):
+        n = ref.ref_gauss_filter_size(float(sg), 0.01)
+        t = np.zeros(n, np.float32)
+        ref.ref_gauss_taps_raw(float(sg), n, t.ctypes.data)
+        assert (bits(oracle.taps(sg, 0.01, normalise=False)) == bits(t)).all()
+    for t in range(4000):
+        g = rng.standard_normal((515, 3)).astype(np.float32) * np.float32(rng.uniform(0.01, 10))
+        if t % 3 == 0:
+            g[:, 2] *= np.float32(1e-3)
+        m = (g.T @ g).astype(np.float32)
+        if t % 50 == 0:
+            m = np.diag(rng.uniform(0, 3, 3)).astype(np.float32)
+        m1, m2 = m.copy(), m.copy()
+        w1, w2 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        v1, v2 = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        oracle.L.o3_svd3(m1.ctypes.data, w1.ctypes.data, v1.ctypes.data)
+        ref.ref_svd3(m2.ctypes.data, w2.ctypes.data, v2.ctypes.data)
+        oracle.L.o3_sort_eig(w1.ctypes.data, v1.ctypes.data)
+        ref.ref_sort_eig(w2.ctypes.data, v2.ctypes.data)
+        assert (bits(w1) == bits(w2)).all() and (bits(v1) == bits(v2)).all() and (bits(m1) == bits(m2)).all()
+        a = rng.standard_normal(9).astype(np.float32)
+        b1, b2 = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        oracle.L.o3_invert3(a.ctypes.data, b1.ctypes.data)
+        ref.ref_invert3(a.ctypes.data, b2.ctypes.data)
+        assert (bits(b1) == bits(b2)).all()
+    for t in range(500):
+        n = int(rng.integers(0, 125))
+        a = np.zeros(n, _oracle.EXT)
+        a["x"] = np.arange(n)
+        a["value"] = rng.integers(0, 8, n).astype(np.float32) if t % 2 else rng.standard_normal(n).astype(np.float32)
+        b = a.copy()
+        oracle.L.o3_sort_high_low(a.ctypes.data, n)
+        ref.ref_sort_high_low(b.ctypes.data, n)
+        assert (a == b).all()
+
+
+def _oracle_key(oracle, built, tmp_path, n, mode=0, seed=12345, dims=None):
+    dims = dims or (n, n, n)
+    vol = built.synth_blobs(*dims, seed=seed)
+    recs, st = oracle.extract(vol, desc_mode=mode)
+    p = str(tmp_path / "o.key")
+    oracle.write_key(p, recs, comments=["Extraction Voxel Resolution (ijk) : %d %d %d" % dims,
+                                        "Extraction Voxel Size (mm)  (ijk) : %f %f %f" % (1.0, 1.0, 1.0),
+                                        "Feature Coordinate Space: voxels: 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0"])
+    return p, recs
+
+
+@pytest.mark.parametrize("n,gold", [(64, "refbin_blob64.key"), (128, "refbin_blob128.key.gz")])
+def test_against_shipped_reference_binary(oracle, built, tmp_path, n, gold):
+    p, _ = _oracle_key(oracle, built, tmp_path, n)
+    a = read_key(p)
+    path = os.path.join(GOLD, gold)
+    b = read_key(gzip.open(path, "rt") if gold.endswith(".gz") else path)
+    assert a["header"][:4] == b["header"][:4]          # same four comment lines
+    assert a["count"] == b["count"] == len(a["rows"]) == len(b["rows"])
+    ra, rb = a["rows"], b["rows"]
+    assert (ra[:, 16] == rb[:, 16]).all()               # info flags identical
+    d = np.abs(ra - rb)
+    assert d[:, :4].max() < 2e-4                        # x, y, z, scale
+    assert (d[:, 13:16] / np.abs(rb[:, 13:16])).max() < 2e-4   # eigenvalues
+    same_desc = (d[:, 17:].max(1) == 0).mean()
+    assert same_desc >= 0.995                           # rank descriptors (near-ties may swap)
+    assert d[:, 17:].max() <= 2
+    # orientation rows agree up to the sign ambiguity of an eigenvector
+    o = np.minimum(np.abs(ra[:, 4:13] - rb[:, 4:13]), np.abs(ra[:, 4:13] + rb[:, 4:13]))
+    assert o.max() < 2e-3
+
+
+def test_record_counts_of_source_built_reference(oracle, built):
+    counts = json.load(open(os.path.join(GOLD, "ref_counts.json")))["records"]
+    for n in (64, 128):
+        recs, _ = oracle.extract(built.synth_blobs(n, n, n))
+        assert len(recs) == counts[str(n)]
+
+
+@pytest.mark.parametrize("mode,name", [(0, "sift"), (1, "brief"), (2, "rrief"), (3, "nrrief")])
+def test_oracle_regression_keys(oracle, built, tmp_path, mode, name):
+    p, _ = _oracle_key(oracle, built, tmp_path, 64, mode)
+    assert open(p, "rb").read() == open(os.path.join(GOLD, "oracle_blob64_%s.key" % name), "rb").read()
+
+
+def test_oracle_regression_noncubic(oracle, built, tmp_path):
+    p, recs = _oracle_key(oracle, built, tmp_path, 0, 0, seed=777, dims=(80, 64, 48))
+    assert len(recs) > 50
+    assert open(p, "rb").read() == open(os.path.join(GOLD, "oracle_blob80x64x48_sift.key"), "rb").read()
+
+
+def test_detect3_equals_detect_then_validate(oracle, built):
+    """The stored-DoG 26+27+27 test is the reference's detect + validate."""
+    vol = built.synth_blobs(48, 40, 36, seed=5)
+    g0 = oracle.blur(vol, 1.5198684930801392)
+    G, D = oracle.octave_levels(g0)
+    cands = oracle.candidates(vol)
+    for lvl in (1, 2, 3):
+        mins, maxs = oracle.detect3(D[lvl - 1], D[lvl], D[lvl + 1])
+        c = cands[(cands["octave"] == 0) & (cands["level"] == lvl)]
+        cm, cx = c[c["is_max"] == 0], c[c["is_max"] == 1]
+        assert len(cm) == len(mins) and len(cx) == len(maxs)
+        for got, want in ((mins, cm), (maxs, cx)):
+            assert (got["x"] == want["x"]).all() and (got["y"] == want["y"]).all() and (got["z"] == want["z"]).all()
+            assert (bits(got["value"]) == bits(want["value"])).all()
