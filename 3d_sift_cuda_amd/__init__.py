@@ -53,6 +53,9 @@ class _Timings(C.Structure):
                 ("n_records", C.c_int64), ("total_ms", C.c_double)]
 
 
+LAUNCH_DTYPE = np.dtype([("stage", "<i4"), ("ntaps", "<i4"), ("nvox", "<i8"), ("alg_bytes", "<f8"), ("ms", "<f8")])
+
+
 def build(verbose=False):
     """Compile the HIP library, the host helpers and the CLI for gfx950 (in-tree)."""
     r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
@@ -105,6 +108,7 @@ def hip_lib():
     _sig(L.sift3d_extract, I, P, F, I, F, F, P, P)
     _sig(L.sift3d_enable_timing, I, P, I)
     _sig(L.sift3d_get_timings, I, P, P)
+    _sig(L.sift3d_get_launch_log, I, P, P, I64, P)
     _hip = L
     return L
 
@@ -295,6 +299,14 @@ class Context:
 
     def enable_timing(self, on=True):
         self._chk(self._L.sift3d_enable_timing(self._h, 1 if on else 0), "sift3d_enable_timing")
+
+    def launch_log(self):
+        """Per-launch records (stage, ntaps, nvox, alg_bytes, ms) of the last pipeline/blur call."""
+        n = C.c_int64(0)
+        self._L.sift3d_get_launch_log(self._h, None, 0, C.byref(n))
+        out = np.zeros(max(1, n.value), LAUNCH_DTYPE)
+        self._chk(self._L.sift3d_get_launch_log(self._h, out.ctypes.data, len(out), C.byref(n)), "sift3d_get_launch_log")
+        return out[:n.value]
 
     def timings(self):
         t = _Timings()

@@ -26,6 +26,10 @@
 struct timed_launch {
     int stage;
     hipEvent_t e0, e1;
+    int ntaps;
+    int64_t nvox;
+    double bytes;
+    float ms;
 };
 
 struct sift3d_ctx {
@@ -54,6 +58,7 @@ struct sift3d_ctx {
     std::vector<timed_launch> launches;
     std::vector<hipEvent_t> pool;
     size_t pool_used;
+    size_t resolved; /* launches whose events have been read */
     sift3d_timings last;
     char err[512];
 };
@@ -126,6 +131,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->err[0] = 0;
     c->timing = false;
     c->pool_used = 0;
+    c->resolved = 0;
     c->has_volume = false;
     c->nx = c->ny = c->nz = 0;
     memset(&c->last, 0, sizeof(c->last));
@@ -212,7 +218,11 @@ struct stage_scope {
     sift3d_ctx *c;
     int stage;
     hipEvent_t e0, e1;
-    stage_scope(sift3d_ctx *c_, int stage_, double bytes) : c(c_), stage(stage_), e0(nullptr), e1(nullptr)
+    int ntaps;
+    int64_t nvox;
+    double bytes;
+    stage_scope(sift3d_ctx *c_, int stage_, double bytes_, int ntaps_ = 0, int64_t nvox_ = 0)
+        : c(c_), stage(stage_), e0(nullptr), e1(nullptr), ntaps(ntaps_), nvox(nvox_), bytes(bytes_)
     {
         c->last.launches[stage] += 1;
         c->last.alg_bytes[stage] += bytes;
@@ -226,7 +236,7 @@ struct stage_scope {
     {
         if (c->timing) {
             hipEventRecord(e1, c->stream);
-            c->launches.push_back({stage, e0, e1});
+            c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f});
         }
     }
 };
@@ -236,16 +246,21 @@ static void timing_begin(sift3d_ctx *c)
     memset(&c->last, 0, sizeof(c->last));
     c->launches.clear();
     c->pool_used = 0;
+    c->resolved = 0;
 }
 
+/* Resolves the events of every launch recorded since the last call (idempotent). */
 static void timing_end(sift3d_ctx *c)
 {
     if (!c->timing) return;
     hipStreamSynchronize(c->stream);
-    for (const timed_launch &t : c->launches) {
+    for (size_t i = c->resolved; i < c->launches.size(); i++) {
+        timed_launch &t = c->launches[i];
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) c->last.ms[t.stage] += ms;
+        t.ms = ms;
     }
+    c->resolved = c->launches.size();
     if (!c->launches.empty()) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->launches.front().e0, c->launches.back().e1) == hipSuccess) c->last.total_ms = ms;
@@ -255,15 +270,35 @@ static void timing_end(sift3d_ctx *c)
 extern "C" int sift3d_enable_timing(sift3d_ctx *c, int on)
 {
     if (!c) return SIFT3D_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->timing = on != 0;
+    timing_begin(c); /* operator-level *_dev calls accumulate from here until the log is read */
     return SIFT3D_OK;
 }
 
 extern "C" int sift3d_get_timings(const sift3d_ctx *c, sift3d_timings *t)
 {
     if (!c || !t) return SIFT3D_ERR_ARG;
+    timing_end(const_cast<sift3d_ctx *>(c));
     *t = c->last;
     return SIFT3D_OK;
+}
+
+extern "C" int sift3d_get_launch_log(const sift3d_ctx *c, sift3d_launch_record *out, int64_t cap, int64_t *n)
+{
+    if (!c || !n) return SIFT3D_ERR_ARG;
+    timing_end(const_cast<sift3d_ctx *>(c));
+    *n = (int64_t)c->launches.size();
+    for (int64_t i = 0; i < *n && i < cap && out; i++) {
+        const timed_launch &t = c->launches[(size_t)i];
+        out[i].stage = t.stage;
+        out[i].ntaps = t.ntaps;
+        out[i].nvox = t.nvox;
+        out[i].alg_bytes = t.bytes;
+        out[i].ms = t.ms;
+    }
+    return *n > cap ? SIFT3D_ERR_CAPACITY : SIFT3D_OK;
 }
 
 /* ---- device-level building blocks -------------------------------------- */
@@ -283,15 +318,15 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     if (n / 2 > SIFT3D_FAST_MAX_R)
         HIPCHK(c, hipMemcpyAsync(c->d_taps, taps, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_X, 8.0 * N);
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_X, 8.0 * N, n, (int64_t)N);
         HIPCHK(c, sift3d_launch_blur_x(c->stream, in, c->T[0], X, Y, Z, taps, n, c->d_taps));
     }
     {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_Y, 8.0 * N);
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_Y, 8.0 * N, n, (int64_t)N);
         HIPCHK(c, sift3d_launch_blur_y(c->stream, c->T[0], c->T[1], X, Y, Z, taps, n, c->d_taps));
     }
     {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_Z_DOG, (dog ? 16.0 : 8.0) * N);
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_Z_DOG, (dog ? 16.0 : 8.0) * N, n, (int64_t)N);
         HIPCHK(c, sift3d_launch_blur_z(c->stream, c->T[1], out, dog ? in : nullptr, dog, X, Y, Z, taps, n, c->d_taps));
     }
     return SIFT3D_OK;
@@ -448,7 +483,7 @@ static int extrema_levels(sift3d_ctx *c, const float *const *dp, const float *co
     for (int attempt = 0; attempt < 3; attempt++) {
         HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 4, c->stream));
         for (int l = 0; l < nlev; l++) {
-            stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)X * Y * Z);
+            stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)X * Y * Z, 0, X * Y * Z);
             HIPCHK(c, sift3d_launch_extrema(c->stream, dp[l], dc[l], dn[l], X, Y, Z, c->cand + (size_t)l * c->cand_cap,
                                             c->d_counts + l, c->cand_cap));
         }
@@ -607,7 +642,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             rc = blur_dev(c, c->L[j - 1], c->L[j], c->D[j - 1], X, Y, Z, ex, 0.01f);
             if (rc) return rc;
             if (j == 3) {
-                stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N);
+                stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
                 HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3], X, Y, Z, c->half));
             }
             sigma *= factor;
@@ -653,7 +688,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 p.size_factor = size_factor;
                 p.desc_mode = desc_mode;
                 {
-                    stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0);
+                    stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, nc);
                     HIPCHK(c, sift3d_launch_keypointsA(c->stream, p, seg, nc, c->kps, taps3));
                 }
                 h_kps.resize((size_t)nc);
@@ -676,7 +711,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                     HIPCHK(c, hipMemcpyAsync(c->rec_kp, h_rec_kp.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, c->stream));
                     HIPCHK(c, hipMemcpyAsync(c->rec_frame, h_rec_frame.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, c->stream));
                     {
-                        stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0);
+                        stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nr);
                         HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nr, c->recs, taps5));
                     }
                     h_recs.resize((size_t)nr);

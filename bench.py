@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X 3D-SIFT extraction path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full sift3d_extract (Gaussian pyramid + DoG + extrema + keypoints +
+SIFT-rank descriptors, all octaves, records copied back to the host) of one
+512^3 float32 blob-field volume that is already resident in HBM.  With N > 1
+every rank extracts its own 512^3 volume on its own GPU (independent volumes,
+no data-path collective: weak scaling); the Z-slab split of ONE volume across
+GPUs is described in DESIGN.md and is not what this line measures.
+
+Rank 0 prints ONE JSON line: metric = keypoints/s (.key records per second,
+whole job), plus
+  roofline     the dominant kernel (z pass + fused DoG store): algorithmic bytes
+               (16 B/voxel/launch) / its launch time,
+               measured here with HIP events on the stream the kernels run on
+  pyramid      Gauss-pyramid + DoG GB/s over the x, y and z(+DoG) passes together
+  cpu_baseline the CPU restatement (oracle/, single thread like the reference's
+               extractor) timed on this box on a 256^3 sample, N = 1 only
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def kernel_name(stage, ntaps, dog):
+    r = ntaps // 2
+    if stage == "blur_x":
+        return "blur_x_kernel<%d,4>" % r
+    return "blur_col_kernel<%d,4,%s>" % (r, "true" if dog else "false")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume (512 = the BASELINE metric)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU-baseline sample volume (0 = skip)")
+    ap.add_argument("--desc", type=int, default=0, help="0 SIFT-rank, 1 BRIEF, 2 RRIEF, 3 NRRIEF")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
+
+    pkg = importlib.import_module("3d_sift_cuda_amd")
+    if not os.path.exists(pkg.LIB_HIP):
+        raise SystemExit("libsift3d_hip.so missing: run python __graft_entry__.py (no CPU fallback)")
+    n = args.size
+    vol = pkg.synth_blobs(n, n, n, seed=12345 + rank)
+    ctx = pkg.Context(n, n, n, device=local_rank)
+    dvol = torch.from_numpy(vol).to("cuda:%d" % local_rank)   # the input lives in HBM before timing starts
+    torch.cuda.synchronize(local_rank)
+    ctx.set_volume_dev(dvol.data_ptr(), n, n, n)
+    ctx.sync()
+
+    def barrier():
+        torch.cuda.synchronize(local_rank)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(local_rank)
+
+    nrec = 0
+    for _ in range(args.warmup):
+        nrec = len(ctx.extract(desc_mode=args.desc))
+    ctx.enable_timing(True)
+    logs = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        feats = ctx.extract(desc_mode=args.desc)
+        nrec = len(feats)
+        logs.append(ctx.launch_log())
+    ctx.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tim = ctx.timings()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+    rc = torch.tensor([float(nrec)], dtype=torch.float64, device="cuda:%d" % local_rank)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rc, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_records = float(rc.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    if rank == 0:
+        log = np.concatenate(logs)
+        stage_names = pkg.STAGES
+        # ---- per-kernel grouping: (stage, ntaps) over the timed steps ----
+        groups = {}
+        for r in log:
+            st = stage_names[r["stage"]]
+            key = (st, int(r["ntaps"]), bool(st == "blur_z_dog" and r["alg_bytes"] > 8.5 * r["nvox"]))
+            g = groups.setdefault(key, {"ms": 0.0, "bytes": 0.0, "launches": 0})
+            g["ms"] += float(r["ms"]); g["bytes"] += float(r["alg_bytes"]); g["launches"] += 1
+        blur_groups = {k: v for k, v in groups.items() if k[0].startswith("blur")}
+        dom_key = max(blur_groups, key=lambda k: blur_groups[k]["ms"])
+        dom = blur_groups[dom_key]
+        achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(kernel_name(dom_key[0], dom_key[1], dom_key[2]), {}).get("hbm_bytes_per_launch_512")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": kernel_name(dom_key[0], dom_key[1], dom_key[2]),
+                    "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "alg_bytes_per_voxel": 16 if dom_key[2] else 8,
+                    "note": "all launches of this instantiation in the timed steps (every octave); largest launch is %d^3" % n}
+        pyr_ms = sum(v["ms"] for v in blur_groups.values())
+        pyr_bytes = sum(v["bytes"] for v in blur_groups.values())
+        pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "ms_per_step": round(pyr_ms / args.steps, 3), "alg_bytes_per_step": pyr_bytes / args.steps,
+                   "accounting": "8 B/voxel per x or y pass, 16 B/voxel per z pass with fused DoG (24N + 8N per level)"}
+        stages = {}
+        for i, s in enumerate(stage_names):
+            sel = log[log["stage"] == i]
+            if len(sel):
+                stages[s] = {"ms_per_step": round(float(sel["ms"].sum()) / args.steps, 3), "launches_per_step": len(sel) // args.steps}
+        out = {
+            "metric": "keypoints/s (.key records per second; Gauss-pyramid GB/s vs HBM roofline in `pyramid`/`roofline`)",
+            "value": round(total_records / (ms_per_step * 1e-3), 1),
+            "unit": "keypoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d^3 float32 blob-field volume per GPU, full featExtract path (pyramid + DoG + extrema + keypoints + %s descriptor), all octaves"
+                                   % (n, ["SIFT-rank", "BRIEF", "RRIEF", "NRRIEF"][args.desc]),
+                       "records_per_volume": int(nrec), "octaves": int(tim["n_octaves"]), "extrema": int(tim["n_extrema"]),
+                       "keypoints": int(tim["n_keypoints"]),
+                       "parallelism": "1 volume per GPU (independent volumes, no collective)" if world > 1 else "single GPU"},
+            "roofline": roofline, "pyramid": pyramid, "stages": stages,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _oracle
+            orc = _oracle.load()
+            m = args.cpu_sample
+            svol = pkg.synth_blobs(m, m, m, seed=12345)
+            c0 = time.perf_counter()
+            recs, st = orc.extract(svol, desc_mode=args.desc)
+            cdt = time.perf_counter() - c0
+            out["cpu_baseline"] = {"value": round(len(recs) / cdt, 1), "unit": "keypoints/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle o3_extract (C restatement of the reference CPU path, gcc -O2 -ffp-contract=off, 1 thread) on a %d^3 blob-field volume: %d records in %.2f s (blur %.2f s, DoG %.2f s, detect %.2f s, keypoints %.2f s, descriptors %.2f s)"
+                                             % (m, len(recs), cdt, st.t_blur, st.t_dog, st.t_detect, st.t_features, st.t_desc)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

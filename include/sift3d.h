@@ -170,6 +170,17 @@ typedef struct {
 } sift3d_timings;
 int sift3d_enable_timing(sift3d_ctx *ctx, int on);
 int sift3d_get_timings(const sift3d_ctx *ctx, sift3d_timings *t);
+/* Per-launch log of the same call (needs timing enabled): one entry per kernel
+ * launch in issue order, so a bench can group by kernel instantiation
+ * (stage + tap count) and compare with a rocprofv3 kernel trace. */
+typedef struct {
+    int32_t stage;  /* sift3d_stage */
+    int32_t ntaps;  /* Gaussian tap count of a blur launch, else 0 */
+    int64_t nvox;   /* voxels (or keypoints / records) the launch covered */
+    double alg_bytes;
+    double ms;
+} sift3d_launch_record;
+int sift3d_get_launch_log(const sift3d_ctx *ctx, sift3d_launch_record *out, int64_t cap, int64_t *n);
 
 #ifdef __cplusplus
 }
