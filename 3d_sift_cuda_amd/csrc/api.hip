@@ -50,7 +50,7 @@ struct sift3d_ctx {
     sift3d_dkp *kps;
     int64_t kps_cap;
     int *rec_kp, *rec_frame;
-    sift3d_drec *recs;
+    sift3d_feature *recs;
     int64_t recs_cap;
     int64_t nx, ny, nz;
     bool has_volume;
@@ -596,7 +596,7 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t nrec)
         c->recs = nullptr;
         c->rec_kp = c->rec_frame = nullptr;
         c->recs_cap = nrec + nrec / 2 + 1024;
-        HIPCHK(c, hipMalloc((void **)&c->recs, sizeof(sift3d_drec) * (size_t)c->recs_cap));
+        HIPCHK(c, hipMalloc((void **)&c->recs, sizeof(sift3d_feature) * (size_t)c->recs_cap));
         HIPCHK(c, hipMalloc((void **)&c->rec_kp, sizeof(int) * (size_t)c->recs_cap));
         HIPCHK(c, hipMalloc((void **)&c->rec_frame, sizeof(int) * (size_t)c->recs_cap));
     }
@@ -630,7 +630,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     float sig[7];
     std::vector<sift3d_dkp> h_kps;
     std::vector<int> h_rec_kp, h_rec_frame;
-    std::vector<sift3d_drec> h_recs;
     for (int oct = 0;; oct++) {
         sigma = 1.6f;
         sig[0] = sigma;
@@ -714,19 +713,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                         stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nr);
                         HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nr, c->recs, taps5));
                     }
-                    h_recs.resize((size_t)nr);
-                    HIPCHK(c, hipMemcpyAsync(h_recs.data(), c->recs, sizeof(sift3d_drec) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+                    const size_t at = feats_out->size();
+                    feats_out->resize(at + (size_t)nr);
+                    HIPCHK(c, hipMemcpyAsync(feats_out->data() + at, c->recs, sizeof(sift3d_feature) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
                     HIPCHK(c, hipStreamSynchronize(c->stream));
-                    for (int64_t i = 0; i < nr; i++) {
-                        const sift3d_drec &d = h_recs[(size_t)i];
-                        sift3d_feature f;
-                        f.x = d.x; f.y = d.y; f.z = d.z; f.scale = d.scale;
-                        memcpy(f.ori, d.ori, sizeof(f.ori));
-                        memcpy(f.eigs, d.eigs, sizeof(f.eigs));
-                        f.info = d.info;
-                        memcpy(f.desc, d.desc, sizeof(f.desc));
-                        feats_out->push_back(f);
-                    }
                 }
             }
         }

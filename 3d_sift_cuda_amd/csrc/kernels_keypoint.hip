@@ -320,10 +320,13 @@ __device__ void sort_eig(float w[3], float v[3][3])
                 }
             }
 }
-
 /* ---------------------------------------------------------------------- */
 /* wave-cooperative building blocks (block = one wavefront of 64 lanes)    */
 /* ---------------------------------------------------------------------- */
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define NRAD 515 /* voxels of the 11^3 patch with dx^2+dy^2+dz^2 < 25 (all of them interior) */
+#define NRAD_PAD 516
+#define NINT 729 /* interior voxels 1..9 in each axis */
 
 /* sampleImage3D, R/src_common/MultiScale.cpp:2614-2714 (bounds test done by the caller) */
 __device__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, float fx, float fy,
@@ -355,43 +358,38 @@ __device__ void wave_sample_patch(float *patch, const float *__restrict__ img, i
     __syncthreads();
 }
 
+/* One sequential float sum over the 1331 patch values (optionally of their
+ * squares), in raster order, by one lane; 16-byte LDS reads. d is 16-byte aligned. */
+template <bool SQUARE>
+__device__ __forceinline__ float serial_sum_patch(const float *d)
+{
+    float acc = 0;
+    const v4f *d4 = reinterpret_cast<const v4f *>(d);
+    for (int i = 0; i < PV / 4; i++) {
+        v4f v = d4[i];
+        if (SQUARE) {
+            acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+        } else {
+            acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+        }
+    }
+    for (int i = (PV / 4) * 4; i < PV; i++) acc += SQUARE ? d[i] * d[i] : d[i];
+    return acc;
+}
+
 /* Feature3D::NormalizeData, R/src_common/MultiScale.cpp:127-205: the two
  * 1331-term sums are single sequential chains (lane 0). */
 __device__ void wave_normalize_patch(float *d, float *scratch2)
 {
-    if (threadIdx.x == 0) {
-        float sum = 0;
-        for (int i = 0; i < PV; i++) sum += d[i];
-        scratch2[0] = sum / (PD * PD * PD);
-    }
+    if (threadIdx.x == 0) scratch2[0] = serial_sum_patch<false>(d) / (PD * PD * PD);
     __syncthreads();
     const float mean = scratch2[0];
     for (int i = threadIdx.x; i < PV; i += 64) d[i] -= mean;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float ss = 0;
-        for (int i = 0; i < PV; i++) ss += d[i] * d[i];
-        scratch2[1] = 1.0f / sqrtf(ss);
-    }
+    if (threadIdx.x == 0) scratch2[1] = 1.0f / sqrtf(serial_sum_patch<true>(d));
     __syncthreads();
     const float div = scratch2[1];
     for (int i = threadIdx.x; i < PV; i += 64) d[i] *= div;
-    __syncthreads();
-}
-
-/* fioGenerateEdgeImages3D on the patch, R/src_common/FeatureIO.cpp:2284-2326 */
-__device__ void wave_patch_edges(const float *d, float *dx, float *dy, float *dz)
-{
-    for (int s = threadIdx.x; s < PV; s += 64) {
-        const int x = s % PD, y = (s / PD) % PD, z = s / (PD * PD);
-        float gx = 0, gy = 0, gz = 0;
-        if (x >= 1 && x < PD - 1 && y >= 1 && y < PD - 1 && z >= 1 && z < PD - 1) {
-            gx = d[s + 1] - d[s - 1];
-            gy = d[s + PD] - d[s - PD];
-            gz = d[s + PD * PD] - d[s - PD * PD];
-        }
-        dx[s] = gx; dy[s] = gy; dz[s] = gz;
-    }
     __syncthreads();
 }
 
@@ -402,8 +400,21 @@ __device__ __forceinline__ bool in_radius(int s)
     return fz * fz + fy * fy + fx * fx < (float)((PD / 2) * (PD / 2));
 }
 
-/* 3- or 5-tap separable blur of an 11^3 LDS volume, pass order x,y,z, zero
- * borders (gb3d_blur3d on the patch: R/src_common/MultiScale.cpp:2850,2972,1032) */
+/* Raster-ordered list of the in-radius voxels (ballot compaction); returns the count (515). */
+__device__ int wave_build_radius_list(unsigned short *rlist)
+{
+    int n = 0;
+    for (int base = 0; base < PV; base += 64) {
+        const int s = base + threadIdx.x;
+        const bool in = s < PV && in_radius(s);
+        const unsigned long long m = __ballot(in);
+        if (in) rlist[n + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (unsigned short)s;
+        n += __popcll(m);
+    }
+    __syncthreads();
+    return n;
+}
+
 __device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis, const float *taps, int ntaps)
 {
     const int h = ntaps / 2;
@@ -419,19 +430,21 @@ __device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis
     }
     __syncthreads();
 }
-/* taps must be in LDS; out may alias tmp_a */
-__device__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, float *out, const float *taps, int ntaps)
+/* 3- or 5-tap separable blur of an 11^3 LDS volume, pass order x,y,z, zero
+ * borders (gb3d_blur3d on the patch: R/src_common/MultiScale.cpp:2850,2972,1032).
+ * The result lands in tmp_a (in -> tmp_a -> tmp_b -> tmp_a); taps are in LDS. */
+__device__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, const float *taps, int ntaps)
 {
     blur_pass(in, tmp_a, 0, taps, ntaps);
     blur_pass(tmp_a, tmp_b, 1, taps, ntaps);
-    blur_pass(tmp_b, out, 2, taps, ntaps);
+    blur_pass(tmp_b, tmp_a, 2, taps, ntaps);
 }
 
 /* regFindFEATUREIOPeaks without callback (R/src_common/MultiScale.cpp:1987-2121)
  * + lvSortHighLow (R/src_common/LocationValue.cpp:28-56, stable): peaks of g in
  * raster order via ballot compaction, then a stable descending rank by
  * counting.  Returns the count; pk_idx/pk_val hold the sorted list. */
-__device__ int wave_peaks_sorted(const float *g, int *raw_idx, float *raw_val, int *pk_idx, float *pk_val)
+__device__ int wave_peaks_sorted(const float *g, short *raw_idx, float *raw_val, short *pk_idx, float *pk_val)
 {
     int n = 0;
     for (int base = 0; base < PV; base += 64) {
@@ -443,8 +456,11 @@ __device__ int wave_peaks_sorted(const float *g, int *raw_idx, float *raw_val, i
             if (x >= 1 && x < PD - 1 && y >= 1 && y < PD - 1 && z >= 1 && z < PD - 1) {
                 c = g[s];
                 pk = true;
+#pragma unroll
                 for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
                     for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
                         for (int dx = -1; dx <= 1; dx++) {
                             if (!dz && !dy && !dx) continue;
                             pk = pk && (g[s + (dz * PD + dy) * PD + dx] < c);
@@ -454,7 +470,7 @@ __device__ int wave_peaks_sorted(const float *g, int *raw_idx, float *raw_val, i
         const unsigned long long m = __ballot(pk);
         if (pk) {
             const int pos = n + __popcll(m & ((1ull << threadIdx.x) - 1ull));
-            raw_idx[pos] = s;
+            raw_idx[pos] = (short)s;
             raw_val[pos] = c;
         }
         n += __popcll(m);
@@ -484,32 +500,42 @@ __device__ void interp_point_patch(const float *g, int s, float *o)
     o[2] = (float)interp_quadratic(iz - 1, iz, iz + 1, g[s - PD * PD], c, g[s + PD * PD]);
 }
 
+/* Splat parameters of one in-radius voxel: cell of corner 000 and the three
+ * weights of _fioDetermineInterpCoord for the position (x,y,z) on the 11^3 grid. */
+__device__ __forceinline__ void splat_params(float x, float y, float z, short &base, float &wx, float &wy, float &wz)
+{
+    int ix, iy, iz;
+    interp_coord(x, 0, (float)PD, ix, wx);
+    interp_coord(y, 0, (float)PD, iy, wy);
+    interp_coord(z, 0, (float)PD, iz, wz);
+    base = (short)((iz * PD + iy) * PD + ix);
+}
+
 /* Sequential trilinear splat of the in-radius voxels into an 11^3 grid
  * (fioIncPixelTrilinearInterp, R/src_common/FeatureIO.cpp:853-889): per voxel
  * the eight corner adds go to eight different cells, so lanes 0..7 take one
- * corner each; voxels follow one another in raster order.  coords holds, per
- * voxel, the splat position (x,y,z) and the value; value <= 0 means skip. */
-__device__ void wave_splat_sequence(float *grid, const float *cx, const float *cy, const float *cz, const float *val)
+ * corner each; voxels follow one another in raster order (LDS operations of a
+ * wavefront execute in issue order, so the read-modify-write chain of a cell
+ * is the reference's).  mag == 0 marks a voxel the reference skips. */
+__device__ void wave_splat_sequence(float *grid, int n, const short *sp_base, const float *sp_wx, const float *sp_wy,
+                                    const float *sp_wz, const float *sp_mag)
 {
     const int lane = threadIdx.x;
-    for (int s = 0; s < PV; s++) {
-        if (!in_radius(s)) continue;
-        const float v = val[s];
-        if (!(v > 0)) continue; /* uniform: every lane reads the same LDS word */
-        if (lane < 8) {
-            float wx, wy, wz;
-            int ix, iy, iz;
-            interp_coord(cx[s], 0, (float)PD, ix, wx);
-            interp_coord(cy[s], 0, (float)PD, iy, wy);
-            interp_coord(cz[s], 0, (float)PD, iz, wz);
-            const int a = lane & 1, b = (lane >> 1) & 1, c = (lane >> 2) & 1;
+    if (lane < 8) {
+        const int a = lane & 1, b = (lane >> 1) & 1, c = (lane >> 2) & 1;
+        const int off = (c * PD + b) * PD + a;
+        volatile float *g = grid;
+        for (int i = 0; i < n; i++) {
+            const float v = sp_mag[i];
+            if (v == 0.0f) continue;
+            const float wx = sp_wx[i], wy = sp_wy[i], wz = sp_wz[i];
             const float ux = a ? (1.0f - wx) : wx;
             const float uy = b ? (1.0f - wy) : wy;
             const float uz = c ? (1.0f - wz) : wz;
-            float *cell = grid + ((iz + c) * PD + (iy + b)) * PD + (ix + a);
-            *cell = *cell + v * ux * uy * uz;
+            const int cell = sp_base[i] + off;
+            g[cell] = g[cell] + v * ux * uy * uz;
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
     }
     __syncthreads();
 }
@@ -518,17 +544,15 @@ __device__ void wave_splat_sequence(float *grid, const float *cx, const float *c
 /* Phase A: extremum -> keypoint (geometry, eigen test, orientation frames) */
 /* ---------------------------------------------------------------------- */
 struct kpA_smem {
-    float patch[PV];
-    float dx[PV], dy[PV], dz[PV];
-    float t0[PV], t1[PV], t2[PV], t3[PV];
-    float cx[PV], cy[PV], cz[PV], mag[PV];
-    int raw_idx[128];
-    float raw_val[128];
-    int pk_idx[128];
-    float pk_val[128];
-    int pk2_idx[128];
-    float pk2_val[128];
-    float ori_data[PD * 3];
+    float A[PV + 1];  /* patch, then blur output / splat wz,mag */
+    float B[PV + 1];  /* splat grid t0 */
+    float Cc[PV + 1]; /* blur temporary / splat wx,wy */
+    float gx[NRAD_PAD], gy[NRAD_PAD], gz[NRAD_PAD]; /* gradients of the in-radius voxels */
+    short sp_base[NRAD_PAD];
+    unsigned short rlist[NRAD_PAD];
+    short raw_idx[128], pk_idx[128], pk2_idx[128];
+    float raw_val[128], pk_val[128], pk2_val[128];
+    float ori_data[PD * 3 + 3];
     float sc[16];
     float taps[8];
 };
@@ -536,8 +560,7 @@ struct kpA_smem {
 __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const sift3d_dcand *__restrict__ cands,
                                                       long long ncand, sift3d_dkp *__restrict__ kps, sift3d_taps taps3)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    kpA_smem &sm = *reinterpret_cast<kpA_smem *>(smem_raw);
+    __shared__ __attribute__((aligned(16))) kpA_smem sm;
     const long long k = blockIdx.x;
     if (k >= ncand) return;
     const int lane = threadIdx.x;
@@ -564,18 +587,30 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         if (lane == 0) kp->nrec = 0;
         return;
     }
+    float *patch = sm.A;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    wave_sample_patch(sm.patch, p.img, X, Y, Z, fx, fy, fz, scale, ident);
-    wave_normalize_patch(sm.patch, sm.sc);
+    wave_sample_patch(patch, p.img, X, Y, Z, fx, fy, fz, scale, ident);
+    wave_normalize_patch(patch, sm.sc);
+    const int nrad = wave_build_radius_list(sm.rlist);
 
-    /* determineOrientation3D, MultiScale.cpp:2541-2607 */
-    wave_patch_edges(sm.patch, sm.dx, sm.dy, sm.dz);
+    /* determineOrientation3D, MultiScale.cpp:2541-2607: gradients (fioGenerateEdgeImages3D,
+     * FeatureIO.cpp:2284-2326) are only ever used inside the radius */
+    for (int i = lane; i < NRAD_PAD; i += 64) {
+        float a = 0, b = 0, c = 0;
+        if (i < nrad) {
+            const int s = sm.rlist[i];
+            a = patch[s + 1] - patch[s - 1];
+            b = patch[s + PD] - patch[s - PD];
+            c = patch[s + PD * PD] - patch[s - PD * PD];
+        }
+        sm.gx[i] = a; sm.gy[i] = b; sm.gz[i] = c;
+    }
+    __syncthreads();
     if (lane < 9) {
-        const float *ei = lane / 3 == 0 ? sm.dx : (lane / 3 == 1 ? sm.dy : sm.dz);
-        const float *ej = lane % 3 == 0 ? sm.dx : (lane % 3 == 1 ? sm.dy : sm.dz);
+        const float *ei = lane / 3 == 0 ? sm.gx : (lane / 3 == 1 ? sm.gy : sm.gz);
+        const float *ej = lane % 3 == 0 ? sm.gx : (lane % 3 == 1 ? sm.gy : sm.gz);
         float acc = 0;
-        for (int s = 0; s < PV; s++)
-            if (in_radius(s)) acc += ei[s] * ej[s];
+        for (int i = 0; i < nrad; i++) acc += ei[i] * ej[i];
         sm.sc[lane] = acc;
     }
     __syncthreads();
@@ -608,30 +643,35 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     __syncthreads();
     if (sm.sc[15] == 0.0f) return;
 
-    /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037 */
+    /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
+    float *t0 = sm.B;
+    float *ta = sm.A, *tb = sm.Cc;           /* blur: t0 -> ta -> tb -> ta */
+    float *sp_wx = sm.Cc, *sp_wy = sm.Cc + NRAD_PAD; /* live only between the pre-pass and the end of the splat */
+    float *sp_wz = sm.A, *sp_mag = sm.A + NRAD_PAD;
     const float radius = (float)(PD / 2);
-    for (int s = lane; s < PV; s += 64) {
-        sm.t0[s] = 0;
-        float e[3] = {sm.dx[s], sm.dy[s], sm.dz[s]};
+    for (int s = lane; s < PV; s += 64) t0[s] = 0;
+    for (int i = lane; i < nrad; i += 64) {
+        float e[3] = {sm.gx[i], sm.gy[i], sm.gz[i]};
         float m2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
-        float mg = 0, u0 = 0, u1 = 0, u2 = 0;
+        float mg = 0, wx = 0, wy = 0, wz = 0;
+        short base = 0;
         if (m2 != 0) {
             mg = sqrtf(m2);
             float u[3];
-            for (int i = 0; i < 3; i++) u[i] = e[i] * radius / mg;
-            for (int i = 0; i < 3; i++) u[i] += radius;
-            u0 = (float)(u[0] + 0.5); u1 = (float)(u[1] + 0.5); u2 = (float)(u[2] + 0.5);
+            for (int q = 0; q < 3; q++) u[q] = e[q] * radius / mg;
+            for (int q = 0; q < 3; q++) u[q] += radius;
+            splat_params((float)(u[0] + 0.5), (float)(u[1] + 0.5), (float)(u[2] + 0.5), base, wx, wy, wz);
         }
-        sm.cx[s] = u0; sm.cy[s] = u1; sm.cz[s] = u2; sm.mag[s] = mg;
+        sm.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
     }
     __syncthreads();
-    wave_splat_sequence(sm.t0, sm.cx, sm.cy, sm.cz, sm.mag);
-    wave_blur_patch(sm.t0, sm.t1, sm.t3, sm.t2, sm.taps, 3);
-    const int npk = wave_peaks_sorted(sm.t2, sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
+    wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
+    wave_blur_patch(t0, ta, tb, sm.taps, 3);
+    const int npk = wave_peaks_sorted(ta, sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
 
     if (lane < npk && lane < PD && lane < 30) {
         float o[3];
-        interp_point_patch(sm.t2, sm.pk_idx[lane], o);
+        interp_point_patch(ta, sm.pk_idx[lane], o);
         o[0] -= radius; o[1] -= radius; o[2] -= radius;
         v3_norm(o);
         sm.ori_data[lane * 3 + 0] = o[0];
@@ -646,11 +686,12 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         if ((double)sm.pk_val[i] < 0.8 * (double)pk0) break;
         const float p1[3] = {sm.ori_data[i * 3], sm.ori_data[i * 3 + 1], sm.ori_data[i * 3 + 2]};
         __syncthreads();
-        for (int s = lane; s < PV; s += 64) {
-            sm.t0[s] = 0;
-            float e[3] = {sm.dx[s], sm.dy[s], sm.dz[s]};
+        for (int s = lane; s < PV; s += 64) t0[s] = 0;
+        for (int q = lane; q < nrad; q += 64) {
+            float e[3] = {sm.gx[q], sm.gy[q], sm.gz[q]};
             float mg = v3_mag(e);
-            float c0 = 0, c1 = 0, c2 = 0;
+            float wx = 0, wy = 0, wz = 0;
+            short base = 0;
             if (mg != 0) {
                 float u[3] = {e[0], e[1], e[2]};
                 v3_norm(u);
@@ -660,24 +701,24 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
                 pp[1] = u[1] - par * p1[1];
                 pp[2] = u[2] - par * p1[2];
                 v3_norm(pp);
-                for (int q = 0; q < 3; q++) {
-                    pp[q] *= radius;
-                    pp[q] += radius;
+                for (int r = 0; r < 3; r++) {
+                    pp[r] *= radius;
+                    pp[r] += radius;
                 }
-                c0 = (float)(pp[0] + 0.5); c1 = (float)(pp[1] + 0.5); c2 = (float)(pp[2] + 0.5);
+                splat_params((float)(pp[0] + 0.5), (float)(pp[1] + 0.5), (float)(pp[2] + 0.5), base, wx, wy, wz);
             }
-            sm.cx[s] = c0; sm.cy[s] = c1; sm.cz[s] = c2; sm.mag[s] = mg;
+            sm.sp_base[q] = base; sp_wx[q] = wx; sp_wy[q] = wy; sp_wz[q] = wz; sp_mag[q] = mg;
         }
         __syncthreads();
-        wave_splat_sequence(sm.t0, sm.cx, sm.cy, sm.cz, sm.mag);
-        wave_blur_patch(sm.t0, sm.t1, sm.t3, sm.t2, sm.taps, 3);
-        const int npk2 = wave_peaks_sorted(sm.t2, sm.raw_idx, sm.raw_val, sm.pk2_idx, sm.pk2_val);
+        wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
+        wave_blur_patch(t0, ta, tb, sm.taps, 3);
+        const int npk2 = wave_peaks_sorted(ta, sm.raw_idx, sm.raw_val, sm.pk2_idx, sm.pk2_val);
         const float pk20 = npk2 > 0 ? sm.pk2_val[0] : 0.0f;
         for (int j = 0; j < npk2 && nret < PD && nret < 30; j++) {
             if (sm.pk2_val[j] < 0.5f * pk20) break;
             if (lane == 0) {
                 float p2[3], p3[3];
-                interp_point_patch(sm.t2, sm.pk2_idx[j], p2);
+                interp_point_patch(ta, sm.pk2_idx[j], p2);
                 p2[0] -= radius; p2[1] -= radius; p2[2] -= radius;
                 v3_norm(p2);
                 float par = v3_dot(p1, p2);
@@ -718,11 +759,18 @@ __constant__ unsigned char c_brief_y[192] = {
     6,6,5,1,4,7,2,1,5,3,4,2,2,7,3,3,6,4,2,4,1,9,7,7,5,2,7,1,7,5,5,1,5,4,1,3,3,4,0,5,1,6,3,5,3,2,3,3,7,2,5,1,1,0,4,1,3,1,0,3,1,6,5,9};
 
 struct kpB_smem {
-    float patch[PV];
-    float dx[PV], dy[PV], dz[PV];
-    float t1[PV], t2[PV], t3[PV];
-    float mag[PV];
-    int bin[PV];
+    float patch[PV + 1];
+    union {
+        struct { /* SIFT-rank: per interior voxel gradient magnitude + orientation octant, bucketed by octant */
+            float mag[NINT + 3];
+            unsigned short order[NINT + 3]; /* interior voxels sorted by (octant, raster); packed x | y<<4 | z<<8 */
+            unsigned char bin[NINT + 3];
+            int start[9];
+        } s;
+        struct { /* BRIEF family: blur temporaries */
+            float t1[PV + 1], t2[PV + 1];
+        } b;
+    } u;
     float sc[16];
     float taps[8];
     float wtab[2][PD + 1];
@@ -730,11 +778,10 @@ struct kpB_smem {
 
 __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
                                                         const int *__restrict__ rec_kp, const int *__restrict__ rec_frame,
-                                                        long long nrec, sift3d_drec *__restrict__ recs,
+                                                        long long nrec, sift3d_feature *__restrict__ recs,
                                                         sift3d_taps taps5)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    kpB_smem &sm = *reinterpret_cast<kpB_smem *>(smem_raw);
+    __shared__ __attribute__((aligned(16))) kpB_smem sm;
     const long long r = blockIdx.x;
     if (r >= nrec) return;
     const int lane = threadIdx.x;
@@ -755,32 +802,34 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
 
     float myval;
     if (p.desc_mode == SIFT3D_DESC_SIFT) {
-        /* msResampleFeaturesGradientOrientationHistogram, MultiScale.cpp:583-710 */
-        wave_patch_edges(sm.patch, sm.dx, sm.dy, sm.dz);
-        for (int s = lane; s < PV; s += 64) {
-            float e[3] = {sm.dx[s], sm.dy[s], sm.dz[s]};
+        /* msResampleFeaturesGradientOrientationHistogram, MultiScale.cpp:583-710.  Border voxels
+         * have zero gradient (FeatureIO.cpp:2307-2312) and are skipped there, so only the 9^3
+         * interior takes part. */
+        for (int q = lane; q < NINT; q += 64) {
+            const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
+            const int s = (z * PD + y) * PD + x;
+            float e[3] = {sm.patch[s + 1] - sm.patch[s - 1], sm.patch[s + PD] - sm.patch[s - PD],
+                          sm.patch[s + PD * PD] - sm.patch[s - PD * PD]};
             float mg = v3_mag(e);
-            int best = 0;
+            int best = 8; /* 8 = no contribution */
             if (mg > 0) {
                 v3_norm(e);
                 const float oa[8][3] = {{1, 1, 1},  {1, 1, -1},  {1, -1, 1},  {1, -1, -1},
                                         {-1, 1, 1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}};
+                best = 0;
                 float bd = v3_dot(oa[0], e);
 #pragma unroll
-                for (int q = 1; q < 8; q++) {
-                    float d = v3_dot(oa[q], e);
+                for (int t = 1; t < 8; t++) {
+                    float d = v3_dot(oa[t], e);
                     if (d > bd) {
                         bd = d;
-                        best = q;
+                        best = t;
                     }
                 }
             }
-            sm.mag[s] = mg;
-            sm.bin[s] = best;
+            sm.u.s.mag[q] = mg;
+            sm.u.s.bin[q] = (unsigned char)best;
         }
-        __syncthreads();
-        /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin */
-        const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
         if (lane < PD) {
             /* spatial coordinate of patch index c in the 2-bin grid (MultiScale.cpp:641-671), then the
              * trilinear weight of bin 0 (wtab[0]) and bin 1 (wtab[1]) along that axis */
@@ -799,17 +848,53 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
             sm.wtab[1][c] = 1.0f - w;
         }
         __syncthreads();
-        const float *wxs = sm.wtab[bx], *wys = sm.wtab[by], *wzs = sm.wtab[bz];
-        float acc = 0;
-        for (int zz = 0; zz < PD; zz++)
-            for (int yy = 0; yy < PD; yy++) {
-                const float wy = wys[yy], wz = wzs[zz];
-                for (int xx = 0; xx < PD; xx++) {
-                    const int s = (zz * PD + yy) * PD + xx;
-                    const float mg = sm.mag[s];
-                    if (mg > 0 && sm.bin[s] == o) acc += mg * wxs[xx] * wy * wz;
-                }
+        /* bucket the interior voxels by octant, keeping raster order inside a bucket */
+        int cnt[8];
+#pragma unroll
+        for (int o = 0; o < 8; o++) cnt[o] = 0;
+        for (int base = 0; base < NINT; base += 64) {
+            const int q = base + lane;
+            const int b = q < NINT ? sm.u.s.bin[q] : 8;
+#pragma unroll
+            for (int o = 0; o < 8; o++) cnt[o] += __popcll(__ballot(b == o));
+        }
+        if (lane == 0) {
+            int acc = 0;
+            for (int o = 0; o < 8; o++) {
+                sm.u.s.start[o] = acc;
+                acc += cnt[o];
             }
+            sm.u.s.start[8] = acc;
+        }
+        __syncthreads();
+        int run[8];
+#pragma unroll
+        for (int o = 0; o < 8; o++) run[o] = sm.u.s.start[o];
+        for (int base = 0; base < NINT; base += 64) {
+            const int q = base + lane;
+            const int b = q < NINT ? sm.u.s.bin[q] : 8;
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                const unsigned long long m = __ballot(b == o);
+                if (b == o) {
+                    const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
+                    sm.u.s.order[run[o] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 4) | (z << 8));
+                }
+                run[o] += __popcll(m);
+            }
+        }
+        __syncthreads();
+        /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin over its octant's voxels */
+        const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
+        const float *wxs = sm.wtab[bx], *wys = sm.wtab[by], *wzs = sm.wtab[bz];
+        const int k0 = sm.u.s.start[o], k1 = sm.u.s.start[o + 1];
+        float acc = 0;
+        for (int kk = k0; kk < k1; kk++) {
+            const unsigned v = sm.u.s.order[kk];
+            const int x = v & 15, y = (v >> 4) & 15, z = v >> 8;
+            const float mg = sm.u.s.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
+            acc += mg * wxs[x] * wys[y] * wzs[z];
+        }
         /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 */
         float mn = 100000;
         for (int i = 0; i < 64; i++) {
@@ -826,10 +911,11 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         myval = v * div;
     } else {
         /* msResampleFeaturesBRIEF, MultiScale.cpp:989-1049 */
-        wave_blur_patch(sm.patch, sm.t1, sm.t3, sm.t2, sm.taps, 5);
+        wave_blur_patch(sm.patch, sm.u.b.t1, sm.u.b.t2, sm.taps, 5);
+        const float *bl = sm.u.b.t1;
         const int x1 = c_brief_x[3 * lane], y1 = c_brief_x[3 * lane + 1], z1 = c_brief_x[3 * lane + 2];
         const int x2 = c_brief_y[3 * lane], y2 = c_brief_y[3 * lane + 1], z2 = c_brief_y[3 * lane + 2];
-        float d = sm.t2[x1 + y1 * PD + z1 * PD * PD] - sm.t2[x2 + y2 * PD + z2 * PD * PD];
+        float d = bl[x1 + y1 * PD + z1 * PD * PD] - bl[x2 + y2 * PD + z2 * PD * PD];
         if (p.desc_mode == SIFT3D_DESC_BRIEF) {
             myval = (d < 0) ? 1.0f : 0.0f;
         } else if (p.desc_mode == SIFT3D_DESC_RRIEF) {
@@ -846,7 +932,7 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         float vj = __shfl(myval, j);
         rank += (vj < myval || (vj == myval && j < lane)) ? 1 : 0;
     }
-    sift3d_drec *out = recs + r;
+    sift3d_feature *out = recs + r;
     out->desc[lane] = (float)rank;
     if (lane == 0) {
         /* octave -> image space (MultiScale.cpp:531-543), then fSizeFactor (featExtract.cpp:502-505) */
@@ -861,7 +947,6 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         for (int i = 0; i < 9; i++) out->ori[i] = fr < 0 ? kp->ori0[i] : kp->frames[fr * 9 + i];
         for (int i = 0; i < 3; i++) out->eigs[i] = kp->eigs[i];
         out->info = kp->info | (fr < 0 ? 0u : SIFT3D_INFO_REORIENT);
-        out->valid = 1;
     }
 }
 
@@ -872,22 +957,19 @@ hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, co
                                     sift3d_dkp *kps, const float *taps3)
 {
     if (ncand <= 0) return hipSuccess;
-    (void)hipFuncSetAttribute((const void *)keypoint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(kpA_smem));
     sift3d_taps t;
     for (int i = 0; i < 17; i++) t.f[i] = i < 3 ? taps3[i] : 0.0f;
-    hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)ncand), dim3(64), sizeof(kpA_smem), s, p, cands, (long long)ncand,
-                       kps, t);
+    hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)ncand), dim3(64), 0, s, p, cands, (long long)ncand, kps, t);
     return hipGetLastError();
 }
 
 hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
-                                     const int *rec_frame, int64_t nrec, sift3d_drec *recs, const float *taps5)
+                                     const int *rec_frame, int64_t nrec, sift3d_feature *recs, const float *taps5)
 {
     if (nrec <= 0) return hipSuccess;
-    (void)hipFuncSetAttribute((const void *)descriptor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(kpB_smem));
     sift3d_taps t;
     for (int i = 0; i < 17; i++) t.f[i] = i < 5 ? taps5[i] : 0.0f;
-    hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)nrec), dim3(64), sizeof(kpB_smem), s, p,
-                       kps, rec_kp, rec_frame, (long long)nrec, recs, t);
+    hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)nrec), dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec,
+                       recs, t);
     return hipGetLastError();
 }

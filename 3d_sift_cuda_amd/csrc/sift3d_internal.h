@@ -26,16 +26,6 @@ struct sift3d_dcand {
     int is_max;
 };
 
-/* one record slot of the per-keypoint stage (device) */
-struct sift3d_drec {
-    float x, y, z, scale; /* octave coordinates */
-    float ori[9];
-    float eigs[3];
-    unsigned info;
-    int valid;
-    float desc[SIFT3D_DESC_LEN];
-};
-
 /* ---- kernel launchers (kernels_volume.hip) ---- */
 hipError_t sift3d_launch_blur_x(hipStream_t s, const float *in, float *out, int64_t X, int64_t Y, int64_t Z,
                                 const float *taps, int ntaps, const float *d_taps);
@@ -77,6 +67,6 @@ struct sift3d_dkp {
 hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const sift3d_dcand *cands, int64_t ncand,
                                     sift3d_dkp *kps, const float *taps3);
 hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
-                                     const int *rec_frame, int64_t nrec, sift3d_drec *recs, const float *taps5);
+                                     const int *rec_frame, int64_t nrec, sift3d_feature *recs, const float *taps5);
 
 #endif
