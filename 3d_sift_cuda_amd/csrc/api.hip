@@ -686,6 +686,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 p.octave_factor = fscale;
                 p.size_factor = size_factor;
                 p.desc_mode = desc_mode;
+                p.debug_stop = getenv("SIFT3D_KP_STOP") ? atoi(getenv("SIFT3D_KP_STOP")) : 0;
                 {
                     stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, nc);
                     HIPCHK(c, sift3d_launch_keypointsA(c->stream, p, seg, nc, c->kps, taps3));

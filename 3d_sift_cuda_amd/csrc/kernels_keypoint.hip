@@ -67,7 +67,7 @@ __device__ __forceinline__ double finddet(double a1, double a2, double a3, doubl
 {
     return ((a1 * b2 * c3) - (a1 * b3 * c2) - (a2 * b1 * c3) + (a3 * b1 * c2) + (a2 * b3 * c1) - (a3 * b2 * c1));
 }
-__device__ double interp_quadratic(double x0, double x1, double x2, double fx0, double fx1, double fx2)
+__device__ __forceinline__ double interp_quadratic(double x0, double x1, double x2, double fx0, double fx1, double fx2)
 {
     if (!(fx1 < fx0 && fx1 < fx2) && !(fx1 > fx0 && fx1 > fx2)) return x1;
     double a1 = x0 * x0, b1 = x0, c1 = 1;
@@ -85,7 +85,7 @@ __device__ double interp_quadratic(double x0, double x1, double x2, double fx0, 
 }
 
 /* invert_3x3<float,double>, R/src_common/MultiScale.h:192-222 */
-__device__ void invert3(const float *in, float *out) /* row-major 3x3 */
+__device__ __forceinline__ void invert3(const float *in, float *out) /* row-major 3x3 */
 {
     float a11 = in[0], a21 = in[3], a31 = in[6];
     float a12 = in[1], a22 = in[4], a32 = in[7];
@@ -130,7 +130,7 @@ __device__ __forceinline__ float v3_dot(const float *a, const float *b) { return
  * Numerical Recipes svdcmp, double temporaries, float storage. */
 #define SVD_SIGN(a, b) ((b) >= 0.0 ? fabs(a) : -fabs(a))
 #define SVD_PYTHAG(a, b) (sqrt((a) * (a) + (b) * (b)))
-__device__ void svd3(float mat[3][3], float w[3], float v[3][3])
+__device__ __forceinline__ void svd3(float mat[3][3], float w[3], float v[3][3])
 {
     const int m = 3, n = 3;
     int flag, i, its, j, jj, k, l = 0, nm = 0;
@@ -308,7 +308,7 @@ __device__ void svd3(float mat[3][3], float w[3], float v[3][3])
         }
     }
 }
-__device__ void sort_eig(float w[3], float v[3][3])
+__device__ __forceinline__ void sort_eig(float w[3], float v[3][3])
 {
     float t;
     for (int i = 0; i < 3; i++)
@@ -329,7 +329,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define NINT 729 /* interior voxels 1..9 in each axis */
 
 /* sampleImage3D, R/src_common/MultiScale.cpp:2614-2714 (bounds test done by the caller) */
-__device__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, float fx, float fy,
+__device__ __forceinline__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, float fx, float fy,
                                   float fz, float scale, const float *ori9)
 {
     float inv[9];
@@ -379,7 +379,7 @@ __device__ __forceinline__ float serial_sum_patch(const float *d)
 
 /* Feature3D::NormalizeData, R/src_common/MultiScale.cpp:127-205: the two
  * 1331-term sums are single sequential chains (lane 0). */
-__device__ void wave_normalize_patch(float *d, float *scratch2)
+__device__ __forceinline__ void wave_normalize_patch(float *d, float *scratch2)
 {
     if (threadIdx.x == 0) scratch2[0] = serial_sum_patch<false>(d) / (PD * PD * PD);
     __syncthreads();
@@ -401,7 +401,7 @@ __device__ __forceinline__ bool in_radius(int s)
 }
 
 /* Raster-ordered list of the in-radius voxels (ballot compaction); returns the count (515). */
-__device__ int wave_build_radius_list(unsigned short *rlist)
+__device__ __forceinline__ int wave_build_radius_list(unsigned short *rlist)
 {
     int n = 0;
     for (int base = 0; base < PV; base += 64) {
@@ -433,7 +433,7 @@ __device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis
 /* 3- or 5-tap separable blur of an 11^3 LDS volume, pass order x,y,z, zero
  * borders (gb3d_blur3d on the patch: R/src_common/MultiScale.cpp:2850,2972,1032).
  * The result lands in tmp_a (in -> tmp_a -> tmp_b -> tmp_a); taps are in LDS. */
-__device__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, const float *taps, int ntaps)
+__device__ __forceinline__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, const float *taps, int ntaps)
 {
     blur_pass(in, tmp_a, 0, taps, ntaps);
     blur_pass(tmp_a, tmp_b, 1, taps, ntaps);
@@ -444,7 +444,7 @@ __device__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, con
  * + lvSortHighLow (R/src_common/LocationValue.cpp:28-56, stable): peaks of g in
  * raster order via ballot compaction, then a stable descending rank by
  * counting.  Returns the count; pk_idx/pk_val hold the sorted list. */
-__device__ int wave_peaks_sorted(const float *g, short *raw_idx, float *raw_val, short *pk_idx, float *pk_val)
+__device__ __forceinline__ int wave_peaks_sorted(const float *g, short *raw_idx, float *raw_val, short *pk_idx, float *pk_val)
 {
     int n = 0;
     for (int base = 0; base < PV; base += 64) {
@@ -491,7 +491,7 @@ __device__ int wave_peaks_sorted(const float *g, short *raw_idx, float *raw_val,
 }
 
 /* interpolate_discrete_3D_point on an 11^3 grid, R/src_common/MultiScale.cpp:1614-1639 */
-__device__ void interp_point_patch(const float *g, int s, float *o)
+__device__ __forceinline__ void interp_point_patch(const float *g, int s, float *o)
 {
     const int ix = s % PD, iy = (s / PD) % PD, iz = s / (PD * PD);
     const float c = g[s];
@@ -500,40 +500,51 @@ __device__ void interp_point_patch(const float *g, int s, float *o)
     o[2] = (float)interp_quadratic(iz - 1, iz, iz + 1, g[s - PD * PD], c, g[s + PD * PD]);
 }
 
-/* Splat parameters of one in-radius voxel: cell of corner 000 and the three
- * weights of _fioDetermineInterpCoord for the position (x,y,z) on the 11^3 grid. */
+/* Splat parameters of one in-radius voxel: the cell of corner 000, packed ix | iy<<4 | iz<<8, and
+ * the three weights of _fioDetermineInterpCoord for the position (x,y,z) on the 11^3 grid. */
 __device__ __forceinline__ void splat_params(float x, float y, float z, short &base, float &wx, float &wy, float &wz)
 {
     int ix, iy, iz;
     interp_coord(x, 0, (float)PD, ix, wx);
     interp_coord(y, 0, (float)PD, iy, wy);
     interp_coord(z, 0, (float)PD, iz, wz);
-    base = (short)((iz * PD + iy) * PD + ix);
+    base = (short)(ix | (iy << 4) | (iz << 8));
 }
 
 /* Sequential trilinear splat of the in-radius voxels into an 11^3 grid
- * (fioIncPixelTrilinearInterp, R/src_common/FeatureIO.cpp:853-889): per voxel
- * the eight corner adds go to eight different cells, so lanes 0..7 take one
- * corner each; voxels follow one another in raster order (LDS operations of a
- * wavefront execute in issue order, so the read-modify-write chain of a cell
- * is the reference's).  mag == 0 marks a voxel the reference skips. */
-__device__ void wave_splat_sequence(float *grid, int n, const short *sp_base, const float *sp_wx, const float *sp_wy,
-                                    const float *sp_wz, const float *sp_mag)
+ * (fioIncPixelTrilinearInterp, R/src_common/FeatureIO.cpp:853-889), voxels in
+ * raster order.  64 lanes = 8 consecutive voxels x 8 corners: cell index and
+ * contribution value*wx'*wy'*wz' are computed for eight voxels at once (order
+ * independent), then the eight voxels are applied one after the other, each
+ * as one 8-lane read-modify-write of eight different cells.  LDS operations
+ * of a wavefront execute in issue order, so every cell sees its updates in
+ * voxel order, which is the reference's.  A voxel the reference skips has
+ * mag == 0 and adds +0, which leaves a cell unchanged. */
+__device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const short *sp_base, const float *sp_wx, const float *sp_wy,
+                                                    const float *sp_wz, const float *sp_mag)
 {
     const int lane = threadIdx.x;
-    if (lane < 8) {
-        const int a = lane & 1, b = (lane >> 1) & 1, c = (lane >> 2) & 1;
-        const int off = (c * PD + b) * PD + a;
-        volatile float *g = grid;
-        for (int i = 0; i < n; i++) {
-            const float v = sp_mag[i];
-            if (v == 0.0f) continue;
-            const float wx = sp_wx[i], wy = sp_wy[i], wz = sp_wz[i];
+    const int slot = lane >> 3;
+    const int a = lane & 1, b = (lane >> 1) & 1, c = (lane >> 2) & 1;
+    float *g = grid; /* plain LDS accesses: a volatile generic pointer would turn them into system-scope flat ops */
+    for (int g0 = 0; g0 < n; g0 += 8) {
+        const int i = g0 + slot;
+        const bool ok = i < n;
+        int cell = 0;
+        float contrib = 0.0f;
+        if (ok) {
+            const int packed = sp_base[i];
+            const float wx = sp_wx[i], wy = sp_wy[i], wz = sp_wz[i], v = sp_mag[i];
+            const int ix = packed & 15, iy = (packed >> 4) & 15, iz = packed >> 8;
+            cell = ((iz + c) * PD + (iy + b)) * PD + (ix + a);
             const float ux = a ? (1.0f - wx) : wx;
             const float uy = b ? (1.0f - wy) : wy;
             const float uz = c ? (1.0f - wz) : wz;
-            const int cell = sp_base[i] + off;
-            g[cell] = g[cell] + v * ux * uy * uz;
+            contrib = v * ux * uy * uz;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (slot == j && ok) g[cell] = g[cell] + contrib;
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -590,7 +601,9 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     float *patch = sm.A;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     wave_sample_patch(patch, p.img, X, Y, Z, fx, fy, fz, scale, ident);
+    if (p.debug_stop == 1) { if (lane == 0) kp->nrec = 0; return; }
     wave_normalize_patch(patch, sm.sc);
+    if (p.debug_stop == 2) { if (lane == 0) kp->nrec = 0; return; }
     const int nrad = wave_build_radius_list(sm.rlist);
 
     /* determineOrientation3D, MultiScale.cpp:2541-2607: gradients (fioGenerateEdgeImages3D,
@@ -614,6 +627,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         sm.sc[lane] = acc;
     }
     __syncthreads();
+    if (p.debug_stop == 3) { if (lane == 0) kp->nrec = 0; return; }
     if (lane == 0) {
         float mat[3][3], w[3], v[3][3];
         for (int i = 0; i < 3; i++)
@@ -642,6 +656,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     }
     __syncthreads();
     if (sm.sc[15] == 0.0f) return;
+    if (p.debug_stop == 4) { if (lane == 0) kp->nrec = 0; return; }
 
     /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
     float *t0 = sm.B;
@@ -665,9 +680,13 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         sm.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
     }
     __syncthreads();
+    if (p.debug_stop == 5) { if (lane == 0) kp->nrec = 0; return; }
     wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
+    if (p.debug_stop == 6) { if (lane == 0) kp->nrec = 0; return; }
     wave_blur_patch(t0, ta, tb, sm.taps, 3);
+    if (p.debug_stop == 7) { if (lane == 0) kp->nrec = 0; return; }
     const int npk = wave_peaks_sorted(ta, sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
+    if (p.debug_stop == 8) { if (lane == 0) kp->nrec = 0; return; }
 
     if (lane < npk && lane < PD && lane < 30) {
         float o[3];

@@ -124,53 +124,101 @@ __global__ __launch_bounds__(256) void blur_x_kernel(const float *__restrict__ i
 /* every partial sum is a compile-time register.  With DOG the finished row  */
 /* is stored together with prev - row (the fused subtract-and-store).        */
 /* ------------------------------------------------------------------------ */
-template <int R, int VEC, bool DOG>
-__global__ __launch_bounds__(256) void blur_col_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                       const float *__restrict__ prev, float *__restrict__ dog,
-                                                       long long nlines, int XV, long long outer_stride, long long S,
-                                                       int L, int CH, sift3d_taps t)
+/* one group of U = 2R+1 consecutive input rows q0 .. q0+U-1 of the chunk.
+ * PIPE (full chunks only): software pipeline one group deep.  nxt[s] holds the input row of step s,
+ * loaded while the previous group was being computed, and is refilled with the row of step s of the
+ * NEXT group right after use; pvn[s] does the same for the `prev` row of the fused DoG.  Every
+ * wavefront therefore keeps U (2U with DoG) 16-byte loads per lane in flight, which is what hides the
+ * HBM latency at 2 waves per SIMD. */
+template <int R, int VEC, bool DOG, bool FIRST, bool FULL>
+__device__ __forceinline__ void col_group(typename vecT<VEC>::type (&acc)[2 * R + 1],
+                                          typename vecT<VEC>::type (&nxt)[2 * R + 1],
+                                          typename vecT<VEC>::type (&pvn)[2 * R + 1], const float *__restrict__ src,
+                                          float *__restrict__ out, const float *__restrict__ prev,
+                                          float *__restrict__ dog, long long base, long long S, int L, int CH, int c0,
+                                          int q0, const sift3d_taps &t)
 {
     constexpr int U = 2 * R + 1;
     typedef typename vecT<VEC>::type V;
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= nlines) return;
-    const long long base = (tid / XV) * outer_stride + (tid % XV) * (long long)VEC;
-    const int c0 = blockIdx.y * CH;
-    const int total = CH + 2 * R;
-    const float *src = in + base;
-    V acc[U];
 #pragma unroll
-    for (int i = 0; i < U; i++) acc[i] = V(0.0f);
-
-    for (int q0 = 0; q0 < total; q0 += U) {
+    for (int s = 0; s < U; s++) {
+        const int q = q0 + s;
+        const int p = c0 - R + q;
+        V v;
+        if (FULL) {
+            v = nxt[s];
+            const int pn = p + U; /* same step of the next group */
+            const int pnc = pn < 0 ? 0 : (pn >= L ? L - 1 : pn);
+            nxt[s] = vload<VEC>(src + (long long)pnc * S);
+        } else {
+            const int pc = p < 0 ? 0 : (p >= L ? L - 1 : p);
+            v = vload<VEC>(src + (long long)pc * S);
+        }
+        if (!(p >= 0 && p < L)) v = V(0.0f); /* zero border */
 #pragma unroll
-        for (int s = 0; s < U; s++) {
-            const int q = q0 + s;
-            const int p = c0 - R + q;
-            V v = V(0.0f);
-            if (p >= 0 && p < L && q < total) v = vload<VEC>(src + (long long)p * S);
-#pragma unroll
-            for (int i = 0; i < U; i++) {
-                const int j = (s - i + U) % U;
-                if (j == 0)
-                    acc[i] = V(0.0f) + V(t.f[0]) * v;
-                else
-                    acc[i] = acc[i] + V(t.f[j]) * v;
-            }
-            const int ic = (s + 1) % U; /* slot whose tap 2R was just added */
-            const int o = q - 2 * R;
-            const int y = c0 + o;
-            if (o >= 0 && o < CH && y < L) {
-                const long long off = base + (long long)y * S;
-                V g = acc[ic];
-                vstore<VEC>(out + off, g);
-                if constexpr (DOG) {
-                    V pv = vload<VEC>(prev + off);
-                    vstore<VEC>(dog + off, pv - g);
-                }
+        for (int i = 0; i < U; i++) {
+            const int j = (s - i + U) % U;
+            if (j == 0)
+                acc[i] = V(0.0f) + V(t.f[0]) * v;
+            else
+                acc[i] = acc[i] + V(t.f[j]) * v;
+        }
+        const int ic = (s + 1) % U; /* slot whose tap 2R was just added */
+        const int o = q - 2 * R;
+        const int y = c0 + o;
+        bool st;
+        if (FULL) st = !FIRST || s == 2 * R; /* compile-time: every output of a full chunk is inside the volume */
+        else st = (o >= 0 && o < CH && y < L);
+        if (st) {
+            const long long off = base + (long long)y * S;
+            V g = acc[ic];
+            vstore<VEC>(out + off, g);
+            if constexpr (DOG) {
+                V pv = FULL ? pvn[s] : vload<VEC>(prev + off);
+                vstore<VEC>(dog + off, pv - g);
             }
         }
+        if constexpr (DOG && FULL) {
+            int yn = y + U;
+            yn = yn < 0 ? 0 : (yn >= L ? L - 1 : yn);
+            pvn[s] = vload<VEC>(prev + base + (long long)yn * S);
+        }
     }
+}
+
+/* FULL: L >= CH and CH + 2R is a multiple of U; the last chunk is shifted back to end at L (its
+ * overlap with the previous chunk is recomputed to identical values), so no store needs a test.
+ * !FULL: short axes (L < CH): one chunk with tested stores. */
+template <int R, int VEC, bool DOG, bool FULL>
+__global__ __launch_bounds__(64) void blur_col_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                      const float *__restrict__ prev, float *__restrict__ dog,
+                                                      long long nlines, int XV, long long outer_stride, long long S,
+                                                      int L, int CH, sift3d_taps t)
+{
+    constexpr int U = 2 * R + 1;
+    typedef typename vecT<VEC>::type V;
+    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= nlines) return;
+    const long long base = (tid / XV) * outer_stride + (tid % XV) * (long long)VEC;
+    int c0 = blockIdx.y * CH;
+    if (FULL && c0 > L - CH) c0 = L - CH;
+    const int total = CH + 2 * R;
+    const float *src = in + base;
+    V acc[U], nxt[U], pvn[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) acc[i] = V(0.0f);
+    if (FULL) {
+#pragma unroll
+        for (int s = 0; s < U; s++) { /* prologue: rows of group 0 */
+            const int p = c0 - R + s;
+            const int pc = p < 0 ? 0 : (p >= L ? L - 1 : p);
+            nxt[s] = vload<VEC>(src + (long long)pc * S);
+        }
+        if constexpr (DOG) pvn[2 * R] = vload<VEC>(prev + base + (long long)c0 * S);
+    }
+    col_group<R, VEC, DOG, true, FULL>(acc, nxt, pvn, src, out, prev, dog, base, S, L, CH, c0, 0, t);
+    for (int q0 = U; q0 < total; q0 += U)
+        col_group<R, VEC, DOG, false, FULL>(acc, nxt, pvn, src, out, prev, dog, base, S, L, CH, c0, q0, t);
 }
 
 /* Generic fallback for tap counts outside 3..17 (never used by the pyramid):
@@ -428,29 +476,43 @@ hipError_t sift3d_launch_blur_x(hipStream_t s, const float *in, float *out, int6
     return hipGetLastError();
 }
 
-/* chunk length along the marched axis: a multiple of U minus the 2R lead-in
- * rows, near 128 outputs, so the halo re-read stays around 2R/128 */
-static inline int chunk_len(int R, int64_t L)
+/* chunk length along the marched axis: k*U - 2R outputs (so that the chunk is a whole number of
+ * U-row groups), k chosen so that the grid has a few thousand wavefronts while the 2R lead-in rows
+ * stay a small fraction of the chunk */
+static inline int chunk_len(int R, int64_t L, long long waves_x)
 {
     const int U = 2 * R + 1;
-    int k = (128 + 2 * R + U - 1) / U;
-    int ch = k * U - 2 * R;
-    if (ch > L) {
-        k = (int)((L + 2 * R + U - 1) / U);
-        ch = k * U - 2 * R;
+    int best = 0;
+    for (int k = 2; k <= 64; k++) {
+        const int ch = k * U - 2 * R;
+        if (ch > L) break;
+        const long long chunks = (L + ch - 1) / ch;
+        best = ch;
+        if (chunks * waves_x < 4096 || ch >= 64) {
+            if (chunks * waves_x >= 2048 || ch >= 128) break;
+        }
     }
-    return ch;
+    return best; /* 0: the axis is shorter than the smallest full chunk */
 }
 
 template <int R, int VEC, bool DOG>
 static void launch_col(hipStream_t s, const float *in, float *out, const float *prev, float *dog, long long nlines, int XV,
                        long long outer_stride, long long S, int L, const sift3d_taps &t)
 {
-    const int ch = chunk_len(R, L);
-    const unsigned chunks = (unsigned)((L + ch - 1) / ch);
-    dim3 grid((unsigned)((nlines + 255) / 256), chunks);
-    hipLaunchKernelGGL((blur_col_kernel<R, VEC, DOG>), grid, dim3(256), 0, s, in, out, prev, dog, nlines, XV, outer_stride,
-                       S, L, ch, t);
+    constexpr int U = 2 * R + 1;
+    const long long wx = (nlines + 63) / 64;
+    int ch = chunk_len(R, L, wx);
+    if (ch > 0) {
+        const unsigned chunks = (unsigned)((L + ch - 1) / ch);
+        dim3 grid((unsigned)wx, chunks);
+        hipLaunchKernelGGL((blur_col_kernel<R, VEC, DOG, true>), grid, dim3(64), 0, s, in, out, prev, dog, nlines, XV,
+                           outer_stride, S, L, ch, t);
+    } else {
+        ch = ((L + 2 * R + U - 1) / U) * U - 2 * R; /* one chunk covering the axis */
+        dim3 grid((unsigned)wx, 1);
+        hipLaunchKernelGGL((blur_col_kernel<R, VEC, DOG, false>), grid, dim3(64), 0, s, in, out, prev, dog, nlines, XV,
+                           outer_stride, S, L, ch, t);
+    }
 }
 
 hipError_t sift3d_launch_blur_y(hipStream_t s, const float *in, float *out, int64_t X, int64_t Y, int64_t Z,

@@ -51,6 +51,7 @@ struct sift3d_kp_params {
     float octave_factor; /* 2^octave */
     float size_factor;
     int desc_mode;
+    int debug_stop; /* development aid: phase A returns after stage N (0 = run everything) */
 };
 #define SIFT3D_MAX_FRAMES 11 /* determineCanonicalOrientation3D stops at FEATURE_3D_DIM frames */
 #define SIFT3D_RECS_PER_KP (1 + SIFT3D_MAX_FRAMES)

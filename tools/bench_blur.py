@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the blur passes at one volume size (HIP events via the C-ABI launch log).
+usage: python tools/bench_blur.py [N=512] [reps=10]"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("3d_sift_cuda_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+ctx = pkg.Context(n, n, n)
+a = torch.randn(n, n, n, device="cuda") * 50
+b = torch.empty_like(a); d = torch.empty_like(a)
+torch.cuda.synchronize()
+sig = {7: 1.2262736558914185, 9: 1.5450079441070557, 11: 1.9465880393981934, 13: 2.452547311782837, 17: 3.0900158882141113}
+N = n ** 3
+print("N=%d^3  bytes/pass: %.3f GB" % (n, 8 * N / 1e9))
+for taps, s in sig.items():
+    for _ in range(2):
+        ctx.gauss_blur_dog_dev(a.data_ptr(), b.data_ptr(), d.data_ptr(), n, n, n, s)
+    ctx.enable_timing(True)
+    for _ in range(reps):
+        ctx.gauss_blur_dog_dev(a.data_ptr(), b.data_ptr(), d.data_ptr(), n, n, n, s)
+    log = ctx.launch_log()
+    ctx.enable_timing(False)
+    out = []
+    for st, name in ((0, "x"), (1, "y"), (2, "z+dog")):
+        sel = log[log["stage"] == st]
+        ms = float(np.median(sel["ms"])); by = float(sel["alg_bytes"][0])
+        out.append("%s %.3f ms %.0f GB/s" % (name, ms, by / ms / 1e6))
+    tot = sum(float(np.median(log[log["stage"] == st]["ms"])) for st in range(3))
+    print("taps %2d: %s | total %.3f ms  %.0f GB/s (32N)" % (taps, " | ".join(out), tot, 32 * N / tot / 1e6))
