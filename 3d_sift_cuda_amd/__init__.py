@@ -106,6 +106,7 @@ def hip_lib():
     _sig(L.sift3d_set_volume_dev, I, P, P, I64, I64, I64)
     _sig(L.sift3d_detect, I, P, F, P, P)
     _sig(L.sift3d_extract, I, P, F, I, F, F, P, P)
+    _sig(L.sift3d_extract_view, I, P, F, I, F, F, P, P)
     _sig(L.sift3d_enable_timing, I, P, I)
     _sig(L.sift3d_get_timings, I, P, P)
     _sig(L.sift3d_get_launch_log, I, P, P, I64, P)
@@ -275,15 +276,17 @@ class Context:
         finally:
             self._L.sift3d_free(out)
 
-    def extract(self, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
+    def extract(self, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0, copy=True):
+        """Full extraction -> structured array of records.  copy=False returns a view of the context's
+        pinned download buffer, valid until the next call on this context."""
         out, n = C.c_void_p(), C.c_int64(0)
-        self._chk(self._L.sift3d_extract(self._h, float(initial_image_scale), int(desc_mode), float(eig_thres),
-                                         float(size_factor), C.byref(out), C.byref(n)), "sift3d_extract")
-        try:
-            buf = (C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(out.value) if n.value else b""
-            return np.frombuffer(buf, FEATURE_DTYPE, n.value).copy()
-        finally:
-            self._L.sift3d_free(out)
+        self._chk(self._L.sift3d_extract_view(self._h, float(initial_image_scale), int(desc_mode), float(eig_thres),
+                                              float(size_factor), C.byref(out), C.byref(n)), "sift3d_extract_view")
+        if n.value == 0:
+            return np.zeros(0, FEATURE_DTYPE)
+        buf = (C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(out.value)
+        a = np.frombuffer(buf, FEATURE_DTYPE, n.value)
+        return a.copy() if copy else a
 
     # ---- device-pointer forms (bench) ----
     def gauss_blur_dog_dev(self, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value=0.01):

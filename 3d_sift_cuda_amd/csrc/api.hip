@@ -32,26 +32,39 @@ struct timed_launch {
     float ms;
 };
 
+struct octave_dims {
+    int64_t X, Y, Z, off; /* dims and float offset of this octave inside every level buffer */
+};
+
 struct sift3d_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    int64_t capN;
+    int64_t capN;   /* voxels of the largest volume */
+    int64_t capTot; /* floats per level buffer: all octaves of a capN volume back to back */
     float *vol;   /* input volume */
-    float *L[6];  /* Gaussian levels */
-    float *D[5];  /* DoG levels */
+    float *L[6];  /* Gaussian levels, every octave resident (octave o at offset off_o) */
+    float *D[5];  /* DoG levels, same layout */
     float *T[2];  /* x- and y-pass intermediates */
-    float *half;  /* next octave seed (capN/8) */
-    float *L0_full, *half_small; /* the two allocations L[0] and half alternate between */
     float *d_taps;
-    sift3d_dcand *cand;
-    int64_t cand_cap; /* per level segment */
-    unsigned long long *d_counts;
+    /* extrema as (key, value) pairs, unsorted (a) and sorted (b) */
+    unsigned long long *keys_a, *keys_b;
+    sift3d_cval *vals_a, *vals_b;
+    int64_t cand_cap;
+    unsigned long long *d_count;
+    void *sort_tmp;
+    size_t sort_tmp_bytes;
+    void *scan_tmp;
+    size_t scan_tmp_bytes;
+    sift3d_level *d_levels;
     sift3d_dkp *kps;
+    int *nrec, *offs; /* per-candidate record count and exclusive prefix */
     int64_t kps_cap;
     int *rec_kp, *rec_frame;
     sift3d_feature *recs;
     int64_t recs_cap;
+    sift3d_feature *h_recs; /* pinned host mirror of recs: the download target, reused from call to call */
+    int64_t h_recs_cap;
     int64_t nx, ny, nz;
     bool has_volume;
     bool timing;
@@ -93,29 +106,58 @@ extern "C" void sift3d_free(void *p) { free(p); }
 
 extern "C" const char *sift3d_last_error(const sift3d_ctx *ctx) { return ctx ? ctx->err : "no context"; }
 
-/* L[0] and half swap allocations from octave to octave; every entry point starts from the original roles */
-static void roles_reset(sift3d_ctx *c)
-{
-    c->L[0] = c->L0_full;
-    c->half = c->half_small;
-}
-
 static void free_dev(sift3d_ctx *c)
 {
-    roles_reset(c);
     hipFree(c->vol);
     for (int i = 0; i < 6; i++) hipFree(c->L[i]);
     for (int i = 0; i < 5; i++) hipFree(c->D[i]);
     hipFree(c->T[0]);
     hipFree(c->T[1]);
-    hipFree(c->half);
     hipFree(c->d_taps);
-    hipFree(c->cand);
-    hipFree(c->d_counts);
+    hipFree(c->keys_a);
+    hipFree(c->keys_b);
+    hipFree(c->vals_a);
+    hipFree(c->vals_b);
+    hipFree(c->d_count);
+    hipFree(c->sort_tmp);
+    hipFree(c->scan_tmp);
+    hipFree(c->d_levels);
     hipFree(c->kps);
+    hipFree(c->nrec);
+    hipFree(c->offs);
     hipFree(c->rec_kp);
     hipFree(c->rec_frame);
     hipFree(c->recs);
+    if (c->h_recs) hipHostFree(c->h_recs);
+}
+
+/* octave list of a volume: halve while every dimension stays above 2 (MultiScale.cpp:359-360,546-556) */
+static std::vector<octave_dims> octave_list(int64_t X, int64_t Y, int64_t Z)
+{
+    std::vector<octave_dims> v;
+    int64_t off = 0;
+    while (X > 2 && Y > 2 && Z > 2 && v.size() < 32) {
+        v.push_back({X, Y, Z, off});
+        off += ((X * Y * Z + 63) / 64) * 64; /* keep every octave 256-byte aligned */
+        X /= 2; Y /= 2; Z /= 2;
+    }
+    return v;
+}
+
+static int alloc_cands(sift3d_ctx *c, int64_t cap)
+{
+    hipFree(c->keys_a); hipFree(c->keys_b); hipFree(c->vals_a); hipFree(c->vals_b); hipFree(c->sort_tmp);
+    c->keys_a = c->keys_b = nullptr;
+    c->vals_a = c->vals_b = nullptr;
+    c->sort_tmp = nullptr;
+    c->cand_cap = cap;
+    c->sort_tmp_bytes = sift3d_sort_temp_bytes(cap) + 256;
+    bool ok = hipMalloc((void **)&c->keys_a, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void **)&c->keys_b, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void **)&c->vals_a, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void **)&c->vals_b, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess &&
+              hipMalloc(&c->sort_tmp, c->sort_tmp_bytes) == hipSuccess;
+    return ok ? SIFT3D_OK : SIFT3D_ERR_MEMORY;
 }
 
 extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz)
@@ -138,27 +180,33 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->vol = nullptr;
     for (int i = 0; i < 6; i++) c->L[i] = nullptr;
     for (int i = 0; i < 5; i++) c->D[i] = nullptr;
-    c->T[0] = c->T[1] = c->half = c->d_taps = nullptr;
-    c->L0_full = c->half_small = nullptr;
-    c->cand = nullptr;
-    c->d_counts = nullptr;
+    c->T[0] = c->T[1] = c->d_taps = nullptr;
+    c->keys_a = c->keys_b = nullptr;
+    c->vals_a = c->vals_b = nullptr;
+    c->d_count = nullptr;
+    c->sort_tmp = c->scan_tmp = nullptr;
+    c->sort_tmp_bytes = c->scan_tmp_bytes = 0;
+    c->d_levels = nullptr;
     c->kps = nullptr;
+    c->nrec = c->offs = nullptr;
     c->rec_kp = c->rec_frame = nullptr;
     c->recs = nullptr;
     c->kps_cap = c->recs_cap = 0;
+    c->h_recs = nullptr;
+    c->h_recs_cap = 0;
+    /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
+    c->capTot = c->capN + c->capN / 7 + 64 * 34;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     const size_t vb = sizeof(float) * (size_t)c->capN;
+    const size_t tb = sizeof(float) * (size_t)c->capTot;
     ok = ok && hipMalloc((void **)&c->vol, vb) == hipSuccess;
-    for (int i = 0; i < 6 && ok; i++) ok = hipMalloc((void **)&c->L[i], vb) == hipSuccess;
-    for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->D[i], vb) == hipSuccess;
+    for (int i = 0; i < 6 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess;
+    for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->half, vb / 8 + 64) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
-    c->cand_cap = c->capN / 64 + 4096;
-    ok = ok && hipMalloc((void **)&c->cand, sizeof(sift3d_dcand) * (size_t)c->cand_cap * 3) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_counts, sizeof(unsigned long long) * 4) == hipSuccess;
-    c->L0_full = c->L[0];
-    c->half_small = c->half;
+    ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
+    ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
     if (!ok) {
         free_dev(c);
         if (c->stream) hipStreamDestroy(c->stream);
@@ -335,7 +383,6 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
 static int check_shape(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    roles_reset(c);
     if (nx <= 0 || ny <= 0 || nz <= 0 || nx * ny * nz > c->capN)
         return set_err(c, SIFT3D_ERR_ARG, "volume %lldx%lldx%lld does not fit the context (%lld voxels)", (long long)nx,
                        (long long)ny, (long long)nz, (long long)c->capN);
@@ -456,56 +503,36 @@ extern "C" int sift3d_halve_size(sift3d_ctx *c, const float *in, int64_t nx, int
     return SIFT3D_OK;
 }
 
-/* Runs the extrema kernel for one level into candidate segment `seg`, grows
- * the buffer and reruns on overflow, and returns the raster-ordered list
- * (minima first, then maxima, each by linear index) in host memory. */
-static bool cand_less(const sift3d_dcand &a, const sift3d_dcand &b)
-{
-    if (a.is_max != b.is_max) return a.is_max < b.is_max;
-    return a.idx < b.idx;
-}
+/* One detection level: which buffers, which dims */
+struct level_job {
+    const float *dp, *dc, *dn;
+    int64_t X, Y, Z;
+    int lvl_id;
+};
 
-static int grow_cands(sift3d_ctx *c, int64_t need)
-{
-    int64_t ncap = need + need / 2 + 4096;
-    sift3d_dcand *n = nullptr;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMalloc((void **)&n, sizeof(sift3d_dcand) * (size_t)ncap * 3));
-    hipFree(c->cand);
-    c->cand = n;
-    c->cand_cap = ncap;
-    return SIFT3D_OK;
-}
-
-static int extrema_levels(sift3d_ctx *c, const float *const *dp, const float *const *dc, const float *const *dn, int nlev,
-                          int64_t X, int64_t Y, int64_t Z, std::vector<sift3d_dcand> *out /* nlev vectors */)
+/* Runs the extrema kernel for every job into the shared (key, value) buffer, grows the buffer and
+ * reruns on overflow (the DoG levels stay resident, so nothing else has to be redone), sorts the
+ * pairs on the device and returns the count.  One host synchronisation (the count). */
+static int extrema_sorted(sift3d_ctx *c, const std::vector<level_job> &jobs, int64_t *count_out)
 {
     for (int attempt = 0; attempt < 3; attempt++) {
-        HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 4, c->stream));
-        for (int l = 0; l < nlev; l++) {
-            stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)X * Y * Z, 0, X * Y * Z);
-            HIPCHK(c, sift3d_launch_extrema(c->stream, dp[l], dc[l], dn[l], X, Y, Z, c->cand + (size_t)l * c->cand_cap,
-                                            c->d_counts + l, c->cand_cap));
+        HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+        for (const level_job &j : jobs) {
+            stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z);
+            HIPCHK(c, sift3d_launch_extrema(c->stream, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.lvl_id, c->keys_a, c->vals_a,
+                                            c->d_count, c->cand_cap));
         }
-        unsigned long long cnt[4] = {0, 0, 0, 0};
-        HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+        unsigned long long cnt = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        int64_t mx = 0;
-        for (int l = 0; l < nlev; l++) mx = std::max<int64_t>(mx, (int64_t)cnt[l]);
-        if (mx > c->cand_cap) {
-            int rc = grow_cands(c, mx);
-            if (rc) return rc;
-            /* the relaunch repeats the work; drop this attempt's launch counts */
+        if ((int64_t)cnt > c->cand_cap) {
+            if (alloc_cands(c, (int64_t)cnt + (int64_t)cnt / 4 + 4096) != SIFT3D_OK)
+                return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown to %llu entries", cnt);
             continue;
         }
-        for (int l = 0; l < nlev; l++) {
-            out[l].resize((size_t)cnt[l]);
-            if (cnt[l])
-                HIPCHK(c, hipMemcpyAsync(out[l].data(), c->cand + (size_t)l * c->cand_cap, sizeof(sift3d_dcand) * cnt[l],
-                                         hipMemcpyDeviceToHost, c->stream));
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int l = 0; l < nlev; l++) std::sort(out[l].begin(), out[l].end(), cand_less);
+        HIPCHK(c, sift3d_sort_candidates(c->stream, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a,
+                                         c->vals_b, (int64_t)cnt));
+        *count_out = (int64_t)cnt;
         return SIFT3D_OK;
     }
     return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown");
@@ -524,19 +551,27 @@ extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d
     HIPCHK(c, hipMemcpyAsync(c->D[1], d_cur, b, hipMemcpyHostToDevice, c->stream));
     if (d_next) HIPCHK(c, hipMemcpyAsync(c->D[2], d_next, b, hipMemcpyHostToDevice, c->stream));
     c->has_volume = false;
-    const float *dp[1] = {c->D[0]}, *dc[1] = {c->D[1]}, *dn[1] = {d_next ? c->D[2] : nullptr};
-    std::vector<sift3d_dcand> v[1];
-    rc = extrema_levels(c, dp, dc, dn, 1, nx, ny, nz, v);
+    std::vector<level_job> jobs = {{c->D[0], c->D[1], d_next ? c->D[2] : nullptr, nx, ny, nz, 0}};
+    int64_t cnt = 0;
+    rc = extrema_sorted(c, jobs, &cnt);
     if (rc) return rc;
+    std::vector<unsigned long long> keys((size_t)cnt);
+    std::vector<sift3d_cval> vals((size_t)cnt);
+    if (cnt) {
+        HIPCHK(c, hipMemcpyAsync(keys.data(), c->keys_b, sizeof(unsigned long long) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(vals.data(), c->vals_b, sizeof(sift3d_cval) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     int64_t a = 0, m = 0;
     bool over = false;
-    for (const sift3d_dcand &d : v[0]) {
+    for (int64_t i = 0; i < cnt; i++) {
+        const int64_t idx = (int64_t)(keys[(size_t)i] & SIFT3D_KEY_IDX_MASK);
         sift3d_extremum e;
-        e.x = (int32_t)(d.idx % nx);
-        e.y = (int32_t)((d.idx / nx) % ny);
-        e.z = (int32_t)(d.idx / (nx * ny));
-        e.value = d.value;
-        if (d.is_max) {
+        e.x = (int32_t)(idx % nx);
+        e.y = (int32_t)((idx / nx) % ny);
+        e.z = (int32_t)(idx / (nx * ny));
+        e.value = vals[(size_t)i].value;
+        if ((keys[(size_t)i] >> SIFT3D_KEY_MAX_SHIFT) & 1ull) {
             if (m < cap_max && maxima) maxima[m] = e; else over = true;
             m++;
         } else {
@@ -583,10 +618,16 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t nrec)
 {
     if (ncand > c->kps_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->kps);
+        hipFree(c->kps); hipFree(c->nrec); hipFree(c->offs); hipFree(c->scan_tmp);
         c->kps = nullptr;
+        c->nrec = c->offs = nullptr;
+        c->scan_tmp = nullptr;
         c->kps_cap = ncand + ncand / 2 + 1024;
+        c->scan_tmp_bytes = sift3d_scan_temp_bytes(c->kps_cap) + 256;
         HIPCHK(c, hipMalloc((void **)&c->kps, sizeof(sift3d_dkp) * (size_t)c->kps_cap));
+        HIPCHK(c, hipMalloc((void **)&c->nrec, sizeof(int) * (size_t)c->kps_cap));
+        HIPCHK(c, hipMalloc((void **)&c->offs, sizeof(int) * (size_t)c->kps_cap));
+        HIPCHK(c, hipMalloc(&c->scan_tmp, c->scan_tmp_bytes));
     }
     if (nrec > c->recs_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -600,18 +641,25 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t nrec)
         HIPCHK(c, hipMalloc((void **)&c->rec_kp, sizeof(int) * (size_t)c->recs_cap));
         HIPCHK(c, hipMalloc((void **)&c->rec_frame, sizeof(int) * (size_t)c->recs_cap));
     }
+    if (nrec > c->h_recs_cap) {
+        if (c->h_recs) hipHostFree(c->h_recs);
+        c->h_recs = nullptr;
+        c->h_recs_cap = nrec + nrec / 2 + 1024;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_recs, sizeof(sift3d_feature) * (size_t)c->h_recs_cap, hipHostMallocDefault));
+    }
     return SIFT3D_OK;
 }
 
+/* The whole path.  Host synchronisations: the extrema count, the record count, the final
+ * download -- everything else is queued on the stream. */
 static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_mode, float eig_thres, float size_factor,
-                        std::vector<sift3d_candidate> *cands_out, std::vector<sift3d_feature> *feats_out)
+                        sift3d_candidate **cands_out, sift3d_feature **feats_out, int64_t *n_out)
 {
     if (!c) return SIFT3D_ERR_ARG;
     if (!c->has_volume) return set_err(c, SIFT3D_ERR_ARG, "no volume set (sift3d_set_volume)");
     HIPCHK(c, hipSetDevice(c->device));
-    roles_reset(c);
     timing_begin(c);
-    int64_t X = c->nx, Y = c->ny, Z = c->nz;
+    const std::vector<octave_dims> oct = octave_list(c->nx, c->ny, c->nz);
 
     /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
     float sigma_init = 0.5f;
@@ -623,139 +671,145 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     if (sift3d_gauss_taps(0.5f, 0.01f, taps3) != 3 || sift3d_gauss_taps((float)0.95, (float)0.01, taps5) != 5)
         return set_err(c, SIFT3D_ERR_ARG, "unexpected patch tap counts");
 
-    int rc = blur_dev(c, c->vol, c->L[0], nullptr, X, Y, Z, extra0, 0.01f);
+    int rc = blur_dev(c, c->vol, c->L[0], nullptr, c->nx, c->ny, c->nz, extra0, 0.01f);
     if (rc) return rc;
 
+    std::vector<level_job> jobs;
+    std::vector<sift3d_level> levels(oct.size() * 3);
     float fscale = 1;
     float sig[7];
-    std::vector<sift3d_dkp> h_kps;
-    std::vector<int> h_rec_kp, h_rec_frame;
-    for (int oct = 0;; oct++) {
+    for (size_t o = 0; o < oct.size(); o++) {
+        const octave_dims &d = oct[o];
+        const double N = (double)d.X * d.Y * d.Z;
         sigma = 1.6f;
         sig[0] = sigma;
-        if (X <= 2 || Y <= 2 || Z <= 2) break;
-        const double N = (double)X * Y * Z;
         for (int j = 1; j < 6; j++) {
             const float ex = sigma * sqrtf(factor * factor - 1.0f);
             /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
-            rc = blur_dev(c, c->L[j - 1], c->L[j], c->D[j - 1], X, Y, Z, ex, 0.01f);
+            rc = blur_dev(c, c->L[j - 1] + d.off, c->L[j] + d.off, c->D[j - 1] + d.off, d.X, d.Y, d.Z, ex, 0.01f);
             if (rc) return rc;
-            if (j == 3) {
+            if (j == 3 && o + 1 < oct.size()) {
                 stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
-                HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3], X, Y, Z, c->half));
+                HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off));
             }
             sigma *= factor;
             sig[j] = sigma;
         }
-        /* extrema of DoG 1..3 against their neighbours in scale */
-        const float *dp[3] = {c->D[0], c->D[1], c->D[2]};
-        const float *dc[3] = {c->D[1], c->D[2], c->D[3]};
-        const float *dn[3] = {c->D[2], c->D[3], c->D[4]};
-        std::vector<sift3d_dcand> lv[3];
-        rc = extrema_levels(c, dp, dc, dn, 3, X, Y, Z, lv);
-        if (rc) return rc;
         for (int l = 0; l < 3; l++) {
-            c->last.n_extrema += (int64_t)lv[l].size();
-            if (cands_out) {
-                for (const sift3d_dcand &d : lv[l]) {
-                    sift3d_candidate o;
-                    o.octave = oct;
-                    o.level = l + 1;
-                    o.is_max = d.is_max;
-                    o.x = (int32_t)(d.idx % X);
-                    o.y = (int32_t)((d.idx / X) % Y);
-                    o.z = (int32_t)(d.idx / (X * Y));
-                    o.value = d.value;
-                    o.h_value = d.h;
-                    o.l_value = d.l;
-                    cands_out->push_back(o);
-                }
-            }
-            if (extract && !lv[l].empty()) {
-                const int64_t nc = (int64_t)lv[l].size();
-                rc = ensure_kp_buffers(c, nc, 0);
-                if (rc) return rc;
-                sift3d_dcand *seg = c->cand + (size_t)l * c->cand_cap;
-                HIPCHK(c, hipMemcpyAsync(seg, lv[l].data(), sizeof(sift3d_dcand) * (size_t)nc, hipMemcpyHostToDevice, c->stream));
-                sift3d_kp_params p;
-                p.img = c->L[l + 1];
-                p.dogc = c->D[l + 1];
-                p.X = (int)X; p.Y = (int)Y; p.Z = (int)Z;
-                p.sigma_h = sig[l]; p.sigma_c = sig[l + 1]; p.sigma_l = sig[l + 2];
-                p.eig_thres = eig_thres;
-                p.octave_factor = fscale;
-                p.size_factor = size_factor;
-                p.desc_mode = desc_mode;
-                p.debug_stop = getenv("SIFT3D_KP_STOP") ? atoi(getenv("SIFT3D_KP_STOP")) : 0;
-                {
-                    stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, nc);
-                    HIPCHK(c, sift3d_launch_keypointsA(c->stream, p, seg, nc, c->kps, taps3));
-                }
-                h_kps.resize((size_t)nc);
-                HIPCHK(c, hipMemcpyAsync(h_kps.data(), c->kps, sizeof(sift3d_dkp) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                h_rec_kp.clear();
-                h_rec_frame.clear();
-                for (int64_t k = 0; k < nc; k++) {
-                    if (h_kps[k].nrec <= 0) continue;
-                    c->last.n_keypoints++;
-                    for (int f = -1; f < h_kps[k].nframes; f++) {
-                        h_rec_kp.push_back((int)k);
-                        h_rec_frame.push_back(f);
-                    }
-                }
-                const int64_t nr = (int64_t)h_rec_kp.size();
-                if (nr > 0) {
-                    rc = ensure_kp_buffers(c, 0, nr);
-                    if (rc) return rc;
-                    HIPCHK(c, hipMemcpyAsync(c->rec_kp, h_rec_kp.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, c->stream));
-                    HIPCHK(c, hipMemcpyAsync(c->rec_frame, h_rec_frame.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, c->stream));
-                    {
-                        stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nr);
-                        HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nr, c->recs, taps5));
-                    }
-                    const size_t at = feats_out->size();
-                    feats_out->resize(at + (size_t)nr);
-                    HIPCHK(c, hipMemcpyAsync(feats_out->data() + at, c->recs, sizeof(sift3d_feature) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
-                    HIPCHK(c, hipStreamSynchronize(c->stream));
-                }
-            }
+            const int id = (int)o * 3 + l;
+            jobs.push_back({c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.X, d.Y, d.Z, id});
+            sift3d_level &lv = levels[(size_t)id];
+            lv.img = c->L[l + 1] + d.off;
+            lv.dogc = c->D[l + 1] + d.off;
+            lv.X = (int)d.X; lv.Y = (int)d.Y; lv.Z = (int)d.Z;
+            lv.sigma_h = sig[l]; lv.sigma_c = sig[l + 1]; lv.sigma_l = sig[l + 2];
+            lv.octave_factor = fscale;
+            lv.pad = 0;
         }
         fscale *= 2.0f;
-        X /= 2; Y /= 2; Z /= 2;
-        std::swap(c->L[0], c->half); /* the half buffer holds N/8 floats: enough for every later octave */
         c->last.n_octaves++;
     }
-    roles_reset(c);
+    int64_t ncand = 0;
+    rc = extrema_sorted(c, jobs, &ncand);
+    if (rc) return rc;
+    c->last.n_extrema = ncand;
+
+    if (!extract) {
+        std::vector<unsigned long long> keys((size_t)ncand);
+        std::vector<sift3d_cval> vals((size_t)ncand);
+        if (ncand) {
+            HIPCHK(c, hipMemcpyAsync(keys.data(), c->keys_b, sizeof(unsigned long long) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(vals.data(), c->vals_b, sizeof(sift3d_cval) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
+        }
+        timing_end(c);
+        sift3d_candidate *out = (sift3d_candidate *)malloc(sizeof(sift3d_candidate) * (size_t)(ncand ? ncand : 1));
+        if (!out) return set_err(c, SIFT3D_ERR_MEMORY, "out of host memory");
+        for (int64_t i = 0; i < ncand; i++) {
+            const unsigned long long k = keys[(size_t)i];
+            const int id = (int)(k >> SIFT3D_KEY_LVL_SHIFT);
+            const int64_t idx = (int64_t)(k & SIFT3D_KEY_IDX_MASK);
+            const octave_dims &d = oct[(size_t)(id / 3)];
+            sift3d_candidate &o = out[i];
+            o.octave = id / 3;
+            o.level = id % 3 + 1;
+            o.is_max = (int)((k >> SIFT3D_KEY_MAX_SHIFT) & 1ull);
+            o.x = (int32_t)(idx % d.X);
+            o.y = (int32_t)((idx / d.X) % d.Y);
+            o.z = (int32_t)(idx / (d.X * d.Y));
+            o.value = vals[(size_t)i].value;
+            o.h_value = vals[(size_t)i].h;
+            o.l_value = vals[(size_t)i].l;
+        }
+        *cands_out = out;
+        *n_out = ncand;
+        return SIFT3D_OK;
+    }
+
+    int64_t nrec_total = 0;
+    if (ncand > 0) {
+        rc = ensure_kp_buffers(c, ncand, 0);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->stream));
+        sift3d_kp_params p;
+        p.levels = c->d_levels;
+        p.eig_thres = eig_thres;
+        p.size_factor = size_factor;
+        p.desc_mode = desc_mode;
+        p.debug_stop = getenv("SIFT3D_KP_STOP") ? atoi(getenv("SIFT3D_KP_STOP")) : 0;
+        {
+            stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, ncand);
+            HIPCHK(c, sift3d_launch_keypointsA(c->stream, p, c->keys_b, c->vals_b, ncand, c->kps, c->nrec, taps3));
+        }
+        HIPCHK(c, sift3d_scan_counts(c->stream, c->scan_tmp, c->scan_tmp_bytes, c->nrec, c->offs, ncand));
+        int last[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(&last[0], c->offs + (ncand - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&last[1], c->nrec + (ncand - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        nrec_total = (int64_t)last[0] + last[1];
+        if (nrec_total > 0) {
+            rc = ensure_kp_buffers(c, 0, nrec_total);
+            if (rc) return rc;
+            HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec, c->offs, ncand, c->rec_kp, c->rec_frame));
+            stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nrec_total);
+            HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, c->recs, taps5));
+        }
+    }
+    if (nrec_total)
+        HIPCHK(c, hipMemcpyAsync(c->h_recs, c->recs, sizeof(sift3d_feature) * (size_t)nrec_total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_end(c);
-    if (feats_out) c->last.n_records = (int64_t)feats_out->size();
+    c->last.n_records = nrec_total;
+    *feats_out = c->h_recs; /* pinned, owned by the context */
+    *n_out = nrec_total;
     return SIFT3D_OK;
 }
 
 extern "C" int sift3d_detect(sift3d_ctx *c, float initial_image_scale, sift3d_candidate **out, int64_t *n_out)
 {
     if (!c || !out || !n_out) return SIFT3D_ERR_ARG;
-    std::vector<sift3d_candidate> v;
-    int rc = run_pipeline(c, initial_image_scale, false, 0, 140.0f, 1.0f, &v, nullptr);
-    if (rc) return rc;
-    *n_out = (int64_t)v.size();
-    *out = (sift3d_candidate *)malloc(sizeof(sift3d_candidate) * (v.size() ? v.size() : 1));
-    if (!*out) return set_err(c, SIFT3D_ERR_MEMORY, "out of host memory");
-    if (!v.empty()) memcpy(*out, v.data(), sizeof(sift3d_candidate) * v.size());
-    return SIFT3D_OK;
+    return run_pipeline(c, initial_image_scale, false, 0, 140.0f, 1.0f, out, nullptr, n_out);
+}
+
+extern "C" int sift3d_extract_view(sift3d_ctx *c, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                                   const sift3d_feature **view, int64_t *n_out)
+{
+    if (!c || !view || !n_out) return SIFT3D_ERR_ARG;
+    if (desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) return set_err(c, SIFT3D_ERR_ARG, "bad descriptor mode");
+    sift3d_feature *v = nullptr;
+    int rc = run_pipeline(c, initial_image_scale, true, desc_mode, eig_thres, size_factor, nullptr, &v, n_out);
+    *view = v;
+    return rc;
 }
 
 extern "C" int sift3d_extract(sift3d_ctx *c, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
                               sift3d_feature **out, int64_t *n_out)
 {
     if (!c || !out || !n_out) return SIFT3D_ERR_ARG;
-    if (desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) return set_err(c, SIFT3D_ERR_ARG, "bad descriptor mode");
-    std::vector<sift3d_feature> v;
-    int rc = run_pipeline(c, initial_image_scale, true, desc_mode, eig_thres, size_factor, nullptr, &v);
+    const sift3d_feature *v = nullptr;
+    int rc = sift3d_extract_view(c, initial_image_scale, desc_mode, eig_thres, size_factor, &v, n_out);
     if (rc) return rc;
-    *n_out = (int64_t)v.size();
-    *out = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (v.size() ? v.size() : 1));
+    *out = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(*n_out ? *n_out : 1));
     if (!*out) return set_err(c, SIFT3D_ERR_MEMORY, "out of host memory");
-    if (!v.empty()) memcpy(*out, v.data(), sizeof(sift3d_feature) * v.size());
+    if (*n_out) memcpy(*out, v, sizeof(sift3d_feature) * (size_t)*n_out);
     return SIFT3D_OK;
 }

@@ -133,10 +133,10 @@ int main(int argc, char **argv)
     if (bDoubleImageSize > 0) fSizeFactor /= 2;
     else if (bDoubleImageSize < 0) fSizeFactor *= 2;
 
-    sift3d_feature *feats = NULL;
+    const sift3d_feature *feats = NULL;
     int64_t n = 0;
     int rc = sift3d_set_volume(ctx, vol, PX, PY, PZ);
-    if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
+    if (rc == SIFT3D_OK) rc = sift3d_extract_view(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
     if (rc != SIFT3D_OK) {
         fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
         printf("Error: could not extract features, insufficient memory.\n");
@@ -153,7 +153,6 @@ int main(int argc, char **argv)
         return -1;
     }
     printf("\nDone.\n");
-    sift3d_free(feats);
     free(vol);
     sift3d_destroy(ctx);
     return 0;

@@ -568,42 +568,49 @@ struct kpA_smem {
     float taps[8];
 };
 
-__global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const sift3d_dcand *__restrict__ cands,
-                                                      long long ncand, sift3d_dkp *__restrict__ kps, sift3d_taps taps3)
+__global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
+                                                      const sift3d_cval *__restrict__ vals, long long ncand,
+                                                      sift3d_dkp *__restrict__ kps, int *__restrict__ nrec_out,
+                                                      sift3d_taps taps3)
 {
     __shared__ __attribute__((aligned(16))) kpA_smem sm;
     const long long k = blockIdx.x;
     if (k >= ncand) return;
     const int lane = threadIdx.x;
     if (lane < 3) sm.taps[lane] = taps3.f[lane];
-    const sift3d_dcand cd = cands[k];
+    const unsigned long long key = keys[k];
+    const sift3d_cval cvl = vals[k];
+    const int lvl = (int)(key >> SIFT3D_KEY_LVL_SHIFT);
+    const int is_max = (int)((key >> SIFT3D_KEY_MAX_SHIFT) & 1ull);
+    const long long cidx = (long long)(key & SIFT3D_KEY_IDX_MASK);
+    const sift3d_level lv = p.levels[lvl];
     sift3d_dkp *kp = kps + k;
-    const int X = p.X, Y = p.Y, Z = p.Z;
+    const int X = lv.X, Y = lv.Y, Z = lv.Z;
     const long long XY = (long long)X * Y;
-    const int ix = (int)(cd.idx % X), iy = (int)((cd.idx / X) % Y), iz = (int)(cd.idx / XY);
+    const int ix = (int)(cidx % X), iy = (int)((cidx / X) % Y), iz = (int)(cidx / XY);
 
     /* generateFeatures3D_efficient, R/src_common/MultiScale.cpp:1361-1421 (every lane, identical) */
-    const float *C = p.dogc;
-    const float cv = C[cd.idx];
-    float fx = (float)interp_quadratic(ix - 1, ix, ix + 1, C[cd.idx - 1], cv, C[cd.idx + 1]);
-    float fy = (float)interp_quadratic(iy - 1, iy, iy + 1, C[cd.idx - X], cv, C[cd.idx + X]);
-    float fz = (float)interp_quadratic(iz - 1, iz, iz + 1, C[cd.idx - XY], cv, C[cd.idx + XY]);
-    float scale = (float)(2 * interp_quadratic(p.sigma_h, p.sigma_c, p.sigma_l, cd.h, cv, cd.l));
+    const float *C = lv.dogc;
+    const float cv = C[cidx];
+    float fx = (float)interp_quadratic(ix - 1, ix, ix + 1, C[cidx - 1], cv, C[cidx + 1]);
+    float fy = (float)interp_quadratic(iy - 1, iy, iy + 1, C[cidx - X], cv, C[cidx + X]);
+    float fz = (float)interp_quadratic(iz - 1, iz, iz + 1, C[cidx - XY], cv, C[cidx + XY]);
+    float scale = (float)(2 * interp_quadratic(lv.sigma_h, lv.sigma_c, lv.sigma_l, cvl.h, cv, cvl.l));
     fx += 0.5f; fy += 0.5f; fz += 0.5f;
 
     /* sampleImage3D bounds test, MultiScale.cpp:2630-2643 */
     const float rad = 2.0f * scale;
     const int rmax = (int)(rad + 2);
     if (fx - rmax < 0 || fy - rmax < 0 || fz - rmax < 0 || fx + rmax >= X || fy + rmax >= Y || fz + rmax >= Z) {
-        if (lane == 0) kp->nrec = 0;
+        if (lane == 0) nrec_out[k] = 0;
         return;
     }
     float *patch = sm.A;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    wave_sample_patch(patch, p.img, X, Y, Z, fx, fy, fz, scale, ident);
-    if (p.debug_stop == 1) { if (lane == 0) kp->nrec = 0; return; }
+    wave_sample_patch(patch, lv.img, X, Y, Z, fx, fy, fz, scale, ident);
+    if (p.debug_stop == 1) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_normalize_patch(patch, sm.sc);
-    if (p.debug_stop == 2) { if (lane == 0) kp->nrec = 0; return; }
+    if (p.debug_stop == 2) { if (lane == 0) nrec_out[k] = 0; return; }
     const int nrad = wave_build_radius_list(sm.rlist);
 
     /* determineOrientation3D, MultiScale.cpp:2541-2607: gradients (fioGenerateEdgeImages3D,
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         sm.sc[lane] = acc;
     }
     __syncthreads();
-    if (p.debug_stop == 3) { if (lane == 0) kp->nrec = 0; return; }
+    if (p.debug_stop == 3) { if (lane == 0) nrec_out[k] = 0; return; }
     if (lane == 0) {
         float mat[3][3], w[3], v[3][3];
         for (int i = 0; i < 3; i++)
@@ -649,14 +656,15 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
             kp->eigs[0] = w[0]; kp->eigs[1] = w[1]; kp->eigs[2] = w[2];
             for (int i = 0; i < 3; i++)
                 for (int j = 0; j < 3; j++) kp->ori0[i * 3 + j] = v[i][j];
-            kp->info = cd.is_max ? SIFT3D_INFO_MIN0MAX1 : 0u;
+            kp->info = is_max ? SIFT3D_INFO_MIN0MAX1 : 0u;
+            kp->lvl = lvl;
         } else {
-            kp->nrec = 0;
+            nrec_out[k] = 0;
         }
     }
     __syncthreads();
     if (sm.sc[15] == 0.0f) return;
-    if (p.debug_stop == 4) { if (lane == 0) kp->nrec = 0; return; }
+    if (p.debug_stop == 4) { if (lane == 0) nrec_out[k] = 0; return; }
 
     /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
     float *t0 = sm.B;
@@ -680,13 +688,13 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         sm.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
     }
     __syncthreads();
-    if (p.debug_stop == 5) { if (lane == 0) kp->nrec = 0; return; }
+    if (p.debug_stop == 5) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
-    if (p.debug_stop == 6) { if (lane == 0) kp->nrec = 0; return; }
+    if (p.debug_stop == 6) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_blur_patch(t0, ta, tb, sm.taps, 3);
-    if (p.debug_stop == 7) { if (lane == 0) kp->nrec = 0; return; }
+    if (p.debug_stop == 7) { if (lane == 0) nrec_out[k] = 0; return; }
     const int npk = wave_peaks_sorted(ta, sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
-    if (p.debug_stop == 8) { if (lane == 0) kp->nrec = 0; return; }
+    if (p.debug_stop == 8) { if (lane == 0) nrec_out[k] = 0; return; }
 
     if (lane < npk && lane < PD && lane < 30) {
         float o[3];
@@ -760,7 +768,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     }
     if (lane == 0) {
         kp->nframes = nret;
-        kp->nrec = 1 + nret;
+        nrec_out[k] = 1 + nret;
     }
 }
 
@@ -813,7 +821,8 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
     } else {
         for (int i = 0; i < 9; i++) ori[i] = kp->frames[fr * 9 + i];
     }
-    wave_sample_patch(sm.patch, p.img, p.X, p.Y, p.Z, kp->x, kp->y, kp->z, kp->scale, ori);
+    const sift3d_level lv = p.levels[kp->lvl];
+    wave_sample_patch(sm.patch, lv.img, lv.X, lv.Y, lv.Z, kp->x, kp->y, kp->z, kp->scale, ori);
     /* record 0 was normalised once inside generateFeature3D (MultiScale.cpp:1742) and
      * every record once more in main (featExtract.cpp:480) */
     if (fr < 0) wave_normalize_patch(sm.patch, sm.sc);
@@ -956,7 +965,7 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
     if (lane == 0) {
         /* octave -> image space (MultiScale.cpp:531-543), then fSizeFactor (featExtract.cpp:502-505) */
         float sc = kp->scale, xx = kp->x, yy = kp->y, zz = kp->z;
-        const float fac = p.octave_factor, add = 0;
+        const float fac = lv.octave_factor, add = 0;
         sc *= fac;
         xx = xx * fac + add;
         yy = yy * fac + add;
@@ -972,13 +981,34 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
 /* ---------------------------------------------------------------------- */
 /* launchers                                                               */
 /* ---------------------------------------------------------------------- */
-hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const sift3d_dcand *cands, int64_t ncand,
-                                    sift3d_dkp *kps, const float *taps3)
+/* record r of keypoint k: rec_kp = k, rec_frame = -1 (un-reoriented) or the frame index */
+__global__ void recmap_kernel(const int *__restrict__ nrec, const int *__restrict__ offs, long long ncand,
+                              int *__restrict__ rec_kp, int *__restrict__ rec_frame)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncand) return;
+    const int n = nrec[k], o = offs[k];
+    for (int f = 0; f < n; f++) {
+        rec_kp[o + f] = (int)k;
+        rec_frame[o + f] = f - 1;
+    }
+}
+
+hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const unsigned long long *keys,
+                                    const sift3d_cval *vals, int64_t ncand, sift3d_dkp *kps, int *nrec, const float *taps3)
 {
     if (ncand <= 0) return hipSuccess;
     sift3d_taps t;
     for (int i = 0; i < 17; i++) t.f[i] = i < 3 ? taps3[i] : 0.0f;
-    hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)ncand), dim3(64), 0, s, p, cands, (long long)ncand, kps, t);
+    hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)ncand), dim3(64), 0, s, p, keys, vals, (long long)ncand, kps, nrec, t);
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame)
+{
+    if (ncand <= 0) return hipSuccess;
+    hipLaunchKernelGGL(recmap_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s, nrec, offs, (long long)ncand,
+                       rec_kp, rec_frame);
     return hipGetLastError();
 }
 

@@ -359,8 +359,9 @@ __global__ void halve_size_kernel(const float *__restrict__ in, long long X, lon
 /* the host orders them afterwards (raster order = sort by linear index).    */
 /* ------------------------------------------------------------------------ */
 __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
-                                                      const float *__restrict__ dnext, int X, int Y, int Z,
-                                                      sift3d_dcand *__restrict__ out, unsigned long long *count,
+                                                      const float *__restrict__ dnext, int X, int Y, int Z, int lvl_id,
+                                                      unsigned long long *__restrict__ keys,
+                                                      sift3d_cval *__restrict__ vals, unsigned long long *count,
                                                       long long cap)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -404,13 +405,14 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
     if (mx || mn) {
         unsigned long long slot = atomicAdd(count, 1ull);
         if ((long long)slot < cap) {
-            sift3d_dcand r;
-            r.idx = idx;
+            sift3d_cval r;
             r.value = c;
             r.h = dprev[idx];
             r.l = dnext ? dnext[idx] : 0.0f;
-            r.is_max = mx ? 1 : 0;
-            out[slot] = r;
+            r.pad = 0.0f;
+            keys[slot] = ((unsigned long long)lvl_id << SIFT3D_KEY_LVL_SHIFT) |
+                         ((unsigned long long)(mx ? 1 : 0) << SIFT3D_KEY_MAX_SHIFT) | (unsigned long long)idx;
+            vals[slot] = r;
         }
     }
 }
@@ -595,11 +597,12 @@ hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, i
 }
 
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
-                                 int64_t Y, int64_t Z, sift3d_dcand *out, unsigned long long *count, int64_t cap)
+                                 int64_t Y, int64_t Z, int lvl_id, unsigned long long *keys, sift3d_cval *vals,
+                                 unsigned long long *count, int64_t cap)
 {
     if (X < 3 || Y < 3 || Z < 3) return hipSuccess;
     dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(Z - 2));
-    hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, out, count,
-                       (long long)cap);
+    hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, lvl_id, keys, vals,
+                       count, (long long)cap);
     return hipGetLastError();
 }

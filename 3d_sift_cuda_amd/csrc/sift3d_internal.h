@@ -19,11 +19,24 @@ struct sift3d_taps {
     float f[2 * SIFT3D_FAST_MAX_R + 1];
 };
 
-/* device-side candidate record written by the extrema kernel */
-struct sift3d_dcand {
-    long long idx; /* linear voxel index in the octave volume */
-    float value, h, l;
-    int is_max;
+/* Candidates are kept as (key, value) pairs so that one device radix sort puts them in the
+ * reference's order: key = level id << 40 | is_max << 39 | linear voxel index, with
+ * level id = octave*3 + (DoG level - 1).  Minima sort before maxima, raster order inside. */
+#define SIFT3D_KEY_LVL_SHIFT 40
+#define SIFT3D_KEY_MAX_SHIFT 39
+#define SIFT3D_KEY_IDX_MASK ((1ull << 39) - 1ull)
+struct sift3d_cval {
+    float value, h, l, pad; /* DoG at the extremum, one level below (H), one level above (L) */
+};
+
+/* one detection level of one octave (table in device memory) */
+struct sift3d_level {
+    const float *img;  /* Gaussian level L_k the keypoints are sampled from */
+    const float *dogc; /* DoG level k (centre) */
+    int X, Y, Z;
+    float sigma_h, sigma_c, sigma_l;
+    float octave_factor; /* 2^octave */
+    int pad;
 };
 
 /* ---- kernel launchers (kernels_volume.hip) ---- */
@@ -39,22 +52,18 @@ hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, in
 hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
-                                 int64_t Y, int64_t Z, sift3d_dcand *out, unsigned long long *count, int64_t cap);
+                                 int64_t Y, int64_t Z, int lvl_id, unsigned long long *keys, sift3d_cval *vals,
+                                 unsigned long long *count, int64_t cap);
 
 /* ---- per-keypoint stage (kernels_keypoint.hip) ---- */
 struct sift3d_kp_params {
-    const float *img;  /* Gaussian level L_k of the octave */
-    const float *dogc; /* DoG level k (centre) */
-    int X, Y, Z;
-    float sigma_h, sigma_c, sigma_l;
+    const sift3d_level *levels; /* device table indexed by level id */
     float eig_thres;
-    float octave_factor; /* 2^octave */
     float size_factor;
     int desc_mode;
     int debug_stop; /* development aid: phase A returns after stage N (0 = run everything) */
 };
 #define SIFT3D_MAX_FRAMES 11 /* determineCanonicalOrientation3D stops at FEATURE_3D_DIM frames */
-#define SIFT3D_RECS_PER_KP (1 + SIFT3D_MAX_FRAMES)
 /* phase A result per extremum */
 struct sift3d_dkp {
     float x, y, z, scale; /* octave coordinates, +0.5 applied */
@@ -62,12 +71,20 @@ struct sift3d_dkp {
     float ori0[9]; /* sorted eigenvectors (record 0) */
     int nframes;
     float frames[SIFT3D_MAX_FRAMES * 9];
-    int nrec; /* 0 = rejected, else 1 + nframes */
+    int lvl;
     unsigned info;
 };
-hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const sift3d_dcand *cands, int64_t ncand,
-                                    sift3d_dkp *kps, const float *taps3);
+/* nrec[k] = 0 (rejected) or 1 + number of canonical frames */
+hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const unsigned long long *keys,
+                                    const sift3d_cval *vals, int64_t ncand, sift3d_dkp *kps, int *nrec, const float *taps3);
+hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame);
 hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
                                      const int *rec_frame, int64_t nrec, sift3d_feature *recs, const float *taps5);
+/* device sort / scan (sort_scan.hip, rocPRIM) */
+size_t sift3d_sort_temp_bytes(int64_t n);
+hipError_t sift3d_sort_candidates(hipStream_t s, void *temp, size_t temp_bytes, const unsigned long long *keys_in,
+                                  unsigned long long *keys_out, const sift3d_cval *vals_in, sift3d_cval *vals_out, int64_t n);
+size_t sift3d_scan_temp_bytes(int64_t n);
+hipError_t sift3d_scan_counts(hipStream_t s, void *temp, size_t temp_bytes, const int *in, int *out, int64_t n);
 
 #endif

@@ -147,6 +147,10 @@ int sift3d_detect(sift3d_ctx *ctx, float initial_image_scale, sift3d_candidate *
  * eig_thres: 140 in featExtract.cpp:297.  *out is malloc'ed (sift3d_free). */
 int sift3d_extract(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
                    sift3d_feature **out, int64_t *n_out);
+/* Same, without the final host copy: *view points at the context's pinned download buffer and stays
+ * valid until the next call on this context (or sift3d_destroy).  Do not free it. */
+int sift3d_extract_view(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                        const sift3d_feature **view, int64_t *n_out);
 
 /* ---- measurement ------------------------------------------------------------
  * Device time per stage of the last sift3d_detect/sift3d_extract call, from
