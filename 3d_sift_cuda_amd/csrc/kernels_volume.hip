@@ -17,6 +17,8 @@
  * axis) with 16-byte accesses whenever the row length allows it; nothing here
  * is GEMM-shaped, so no MFMA.
  */
+#include <cstdlib>
+
 #include "sift3d_internal.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -484,14 +486,24 @@ hipError_t sift3d_launch_blur_x(hipStream_t s, const float *in, float *out, int6
 static inline int chunk_len(int R, int64_t L, long long waves_x)
 {
     const int U = 2 * R + 1;
+    static const char *env = getenv("SIFT3D_COL_K"); /* tuning aid: force k groups per chunk */
+    if (env && atoi(env) >= 2) {
+        const int ch = atoi(env) * U - 2 * R;
+        return ch <= L ? ch : 0;
+    }
+    /* cost of a choice = rows streamed (outputs + 2R lead-in rows per chunk + the overlap of the shifted
+     * last chunk), inflated when the grid has fewer than ~2048 wavefronts (8 per CU) to hide latency */
     int best = 0;
-    for (int k = 2; k <= 64; k++) {
+    double best_cost = 0;
+    for (int k = 2; k * U - 2 * R <= L; k++) {
         const int ch = k * U - 2 * R;
-        if (ch > L) break;
         const long long chunks = (L + ch - 1) / ch;
-        best = ch;
-        if (chunks * waves_x < 4096 || ch >= 64) {
-            if (chunks * waves_x >= 2048 || ch >= 128) break;
+        const double waves = (double)chunks * (double)waves_x;
+        double cost = (double)chunks * (ch + 2 * R);
+        if (waves < 2048.0) cost *= 1.0 + 0.6 * (2048.0 - waves) / 2048.0;
+        if (best == 0 || cost < best_cost) {
+            best = ch;
+            best_cost = cost;
         }
     }
     return best; /* 0: the axis is shorter than the smallest full chunk */
