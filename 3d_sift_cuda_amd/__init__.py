@@ -53,6 +53,13 @@ class _Timings(C.Structure):
                 ("n_records", C.c_int64), ("total_ms", C.c_double)]
 
 
+class LevelDesc(C.Structure):
+    """sift3d_level_desc (include/sift3d.h)"""
+    _fields_ = [("img", C.c_void_p), ("dogc", C.c_void_p), ("nx", C.c_int64), ("ny", C.c_int64), ("nz_local", C.c_int64),
+                ("nz_global", C.c_int64), ("z_offset", C.c_int64), ("sigma_h", C.c_float), ("sigma_c", C.c_float),
+                ("sigma_l", C.c_float), ("octave_factor", C.c_float)]
+
+
 LAUNCH_DTYPE = np.dtype([("stage", "<i4"), ("ntaps", "<i4"), ("nvox", "<i8"), ("alg_bytes", "<f8"), ("ms", "<f8")])
 
 
@@ -110,6 +117,10 @@ def hip_lib():
     _sig(L.sift3d_enable_timing, I, P, I)
     _sig(L.sift3d_get_timings, I, P, P)
     _sig(L.sift3d_get_launch_log, I, P, P, I64, P)
+    _sig(L.sift3d_candidates_reset, I, P)
+    _sig(L.sift3d_extrema_append_dev, I, P, P, P, P, I64, I64, I64, I, I64, I64)
+    _sig(L.sift3d_candidates_dev, I, P, P, I, P, P)
+    _sig(L.sift3d_describe_dev, I, P, P, I, I, F, F, P, P, P)
     _hip = L
     return L
 
@@ -293,6 +304,57 @@ class Context:
         self._chk(self._L.sift3d_gauss_blur_dog_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)),
                                                     C.c_void_p(int(d_dog)) if d_dog else None, nx, ny, nz, float(sigma),
                                                     float(min_value)), "sift3d_gauss_blur_dog_dev")
+
+    def gauss_blur_dev(self, d_in, d_out, nx, ny, nz, sigma, min_value=0.01):
+        self._chk(self._L.sift3d_gauss_blur_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)), nx, ny, nz,
+                                                float(sigma), float(min_value)), "sift3d_gauss_blur_dev")
+
+    def dog_dev(self, d_a, d_b, d_out, n):
+        self._chk(self._L.sift3d_dog_dev(self._h, C.c_void_p(int(d_a)), C.c_void_p(int(d_b)), C.c_void_p(int(d_out)), n),
+                  "sift3d_dog_dev")
+
+    def subsample2_dev(self, d_in, nx, ny, nz, d_out):
+        self._chk(self._L.sift3d_subsample2_dev(self._h, C.c_void_p(int(d_in)), nx, ny, nz, C.c_void_p(int(d_out))),
+                  "sift3d_subsample2_dev")
+
+    # ---- Z-slab building blocks ----
+    def candidates_reset(self):
+        self._chk(self._L.sift3d_candidates_reset(self._h), "sift3d_candidates_reset")
+
+    def extrema_append_dev(self, d_prev, d_cur, d_next, nx, ny, nz_local, level_id, z_lo, z_hi):
+        self._chk(self._L.sift3d_extrema_append_dev(self._h, C.c_void_p(int(d_prev)), C.c_void_p(int(d_cur)),
+                                                    C.c_void_p(int(d_next)), nx, ny, nz_local, int(level_id), int(z_lo),
+                                                    int(z_hi)), "sift3d_extrema_append_dev")
+
+    @staticmethod
+    def _level_array(levels):
+        arr = (LevelDesc * len(levels))()
+        for i, lv in enumerate(levels):
+            arr[i] = LevelDesc(int(lv["img"]), int(lv["dogc"]), lv["nx"], lv["ny"], lv["nz_local"], lv["nz_global"],
+                               lv["z_offset"], lv["sigma_h"], lv["sigma_c"], lv["sigma_l"], lv["octave_factor"])
+        return arr
+
+    def candidates_dev(self, levels):
+        arr = self._level_array(levels)
+        out, n = C.c_void_p(), C.c_int64(0)
+        self._chk(self._L.sift3d_candidates_dev(self._h, arr, len(levels), C.byref(out), C.byref(n)), "sift3d_candidates_dev")
+        try:
+            buf = (C.c_char * (n.value * CANDIDATE_DTYPE.itemsize)).from_address(out.value) if n.value else b""
+            return np.frombuffer(buf, CANDIDATE_DTYPE, n.value).copy()
+        finally:
+            self._L.sift3d_free(out)
+
+    def describe_dev(self, levels, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
+        """Returns (records, group) copies; group = level_id*2 + is_max per record."""
+        arr = self._level_array(levels)
+        view, grp, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        self._chk(self._L.sift3d_describe_dev(self._h, arr, len(levels), int(desc_mode), float(eig_thres), float(size_factor),
+                                              C.byref(view), C.byref(grp), C.byref(n)), "sift3d_describe_dev")
+        if n.value == 0:
+            return np.zeros(0, FEATURE_DTYPE), np.zeros(0, np.int32)
+        rb = (C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(view.value)
+        gb = (C.c_char * (n.value * 4)).from_address(grp.value)
+        return np.frombuffer(rb, FEATURE_DTYPE, n.value).copy(), np.frombuffer(gb, np.int32, n.value).copy()
 
     def sync(self):
         self._chk(self._L.sift3d_sync(self._h), "sift3d_sync")

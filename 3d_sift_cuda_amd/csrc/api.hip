@@ -32,6 +32,14 @@ struct timed_launch {
     float ms;
 };
 
+/* One detection level: which buffers, which dims, which slices to keep */
+struct level_job {
+    const float *dp, *dc, *dn;
+    int64_t X, Y, Z;
+    int z_lo, z_hi;
+    int lvl_id;
+};
+
 struct octave_dims {
     int64_t X, Y, Z, off; /* dims and float offset of this octave inside every level buffer */
 };
@@ -64,7 +72,9 @@ struct sift3d_ctx {
     sift3d_feature *recs;
     int64_t recs_cap;
     sift3d_feature *h_recs; /* pinned host mirror of recs: the download target, reused from call to call */
+    int *rec_group, *h_group; /* per record: level id * 2 + is_max (device, pinned host) */
     int64_t h_recs_cap;
+    std::vector<struct level_job> jobs; /* extrema launches since the last reset (replayed if the buffer must grow) */
     int64_t nx, ny, nz;
     bool has_volume;
     bool timing;
@@ -128,7 +138,9 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->rec_kp);
     hipFree(c->rec_frame);
     hipFree(c->recs);
+    hipFree(c->rec_group);
     if (c->h_recs) hipHostFree(c->h_recs);
+    if (c->h_group) hipHostFree(c->h_group);
 }
 
 /* octave list of a volume: halve while every dimension stays above 2 (MultiScale.cpp:359-360,546-556) */
@@ -193,6 +205,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->recs = nullptr;
     c->kps_cap = c->recs_cap = 0;
     c->h_recs = nullptr;
+    c->rec_group = c->h_group = nullptr;
     c->h_recs_cap = 0;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 64 * 34;
@@ -503,31 +516,40 @@ extern "C" int sift3d_halve_size(sift3d_ctx *c, const float *in, int64_t nx, int
     return SIFT3D_OK;
 }
 
-/* One detection level: which buffers, which dims */
-struct level_job {
-    const float *dp, *dc, *dn;
-    int64_t X, Y, Z;
-    int lvl_id;
-};
+/* Extrema of all levels go to one (key, value) buffer: reset, any number of appends (one kernel
+ * launch each, nothing synchronises), then finalize = one host synchronisation for the count, a
+ * replay of the recorded launches into a bigger buffer if it overflowed (the DoG levels stay
+ * resident), and the device radix sort. */
+static int cand_reset(sift3d_ctx *c)
+{
+    c->jobs.clear();
+    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+    return SIFT3D_OK;
+}
 
-/* Runs the extrema kernel for every job into the shared (key, value) buffer, grows the buffer and
- * reruns on overflow (the DoG levels stay resident, so nothing else has to be redone), sorts the
- * pairs on the device and returns the count.  One host synchronisation (the count). */
-static int extrema_sorted(sift3d_ctx *c, const std::vector<level_job> &jobs, int64_t *count_out)
+static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
+{
+    if (record) c->jobs.push_back(j);
+    stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z);
+    HIPCHK(c, sift3d_launch_extrema(c->stream, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
+                                    c->vals_a, c->d_count, c->cand_cap));
+    return SIFT3D_OK;
+}
+
+static int cand_finalize(sift3d_ctx *c, int64_t *count_out)
 {
     for (int attempt = 0; attempt < 3; attempt++) {
-        HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
-        for (const level_job &j : jobs) {
-            stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z);
-            HIPCHK(c, sift3d_launch_extrema(c->stream, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.lvl_id, c->keys_a, c->vals_a,
-                                            c->d_count, c->cand_cap));
-        }
         unsigned long long cnt = 0;
         HIPCHK(c, hipMemcpyAsync(&cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if ((int64_t)cnt > c->cand_cap) {
             if (alloc_cands(c, (int64_t)cnt + (int64_t)cnt / 4 + 4096) != SIFT3D_OK)
                 return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown to %llu entries", cnt);
+            HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+            for (const level_job &j : c->jobs) {
+                int rc = cand_append(c, j, false);
+                if (rc) return rc;
+            }
             continue;
         }
         HIPCHK(c, sift3d_sort_candidates(c->stream, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a,
@@ -551,9 +573,10 @@ extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d
     HIPCHK(c, hipMemcpyAsync(c->D[1], d_cur, b, hipMemcpyHostToDevice, c->stream));
     if (d_next) HIPCHK(c, hipMemcpyAsync(c->D[2], d_next, b, hipMemcpyHostToDevice, c->stream));
     c->has_volume = false;
-    std::vector<level_job> jobs = {{c->D[0], c->D[1], d_next ? c->D[2] : nullptr, nx, ny, nz, 0}};
     int64_t cnt = 0;
-    rc = extrema_sorted(c, jobs, &cnt);
+    rc = cand_reset(c);
+    if (!rc) rc = cand_append(c, {c->D[0], c->D[1], d_next ? c->D[2] : nullptr, nx, ny, nz, 0, (int)nz, 0}, true);
+    if (!rc) rc = cand_finalize(c, &cnt);
     if (rc) return rc;
     std::vector<unsigned long long> keys((size_t)cnt);
     std::vector<sift3d_cval> vals((size_t)cnt);
@@ -634,118 +657,77 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t nrec)
         hipFree(c->recs);
         hipFree(c->rec_kp);
         hipFree(c->rec_frame);
+        hipFree(c->rec_group);
         c->recs = nullptr;
-        c->rec_kp = c->rec_frame = nullptr;
+        c->rec_kp = c->rec_frame = c->rec_group = nullptr;
         c->recs_cap = nrec + nrec / 2 + 1024;
         HIPCHK(c, hipMalloc((void **)&c->recs, sizeof(sift3d_feature) * (size_t)c->recs_cap));
         HIPCHK(c, hipMalloc((void **)&c->rec_kp, sizeof(int) * (size_t)c->recs_cap));
         HIPCHK(c, hipMalloc((void **)&c->rec_frame, sizeof(int) * (size_t)c->recs_cap));
+        HIPCHK(c, hipMalloc((void **)&c->rec_group, sizeof(int) * (size_t)c->recs_cap));
     }
     if (nrec > c->h_recs_cap) {
         if (c->h_recs) hipHostFree(c->h_recs);
+        if (c->h_group) hipHostFree(c->h_group);
         c->h_recs = nullptr;
+        c->h_group = nullptr;
         c->h_recs_cap = nrec + nrec / 2 + 1024;
         HIPCHK(c, hipHostMalloc((void **)&c->h_recs, sizeof(sift3d_feature) * (size_t)c->h_recs_cap, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_group, sizeof(int) * (size_t)c->h_recs_cap, hipHostMallocDefault));
     }
     return SIFT3D_OK;
 }
 
-/* The whole path.  Host synchronisations: the extrema count, the record count, the final
- * download -- everything else is queued on the stream. */
-static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_mode, float eig_thres, float size_factor,
-                        sift3d_candidate **cands_out, sift3d_feature **feats_out, int64_t *n_out)
+/* Sorted candidates -> host list with whole-volume coordinates (sift3d_detect, slab tests). */
+static int candidates_to_host(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand,
+                              sift3d_candidate **cands_out, int64_t *n_out)
 {
-    if (!c) return SIFT3D_ERR_ARG;
-    if (!c->has_volume) return set_err(c, SIFT3D_ERR_ARG, "no volume set (sift3d_set_volume)");
-    HIPCHK(c, hipSetDevice(c->device));
-    timing_begin(c);
-    const std::vector<octave_dims> oct = octave_list(c->nx, c->ny, c->nz);
+    std::vector<unsigned long long> keys((size_t)ncand);
+    std::vector<sift3d_cval> vals((size_t)ncand);
+    if (ncand) {
+        HIPCHK(c, hipMemcpyAsync(keys.data(), c->keys_b, sizeof(unsigned long long) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(vals.data(), c->vals_b, sizeof(sift3d_cval) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
+    }
+    timing_end(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    sift3d_candidate *out = (sift3d_candidate *)malloc(sizeof(sift3d_candidate) * (size_t)(ncand ? ncand : 1));
+    if (!out) return set_err(c, SIFT3D_ERR_MEMORY, "out of host memory");
+    for (int64_t i = 0; i < ncand; i++) {
+        const unsigned long long k = keys[(size_t)i];
+        const int id = (int)(k >> SIFT3D_KEY_LVL_SHIFT);
+        const int64_t idx = (int64_t)(k & SIFT3D_KEY_IDX_MASK);
+        if (id < 0 || id >= (int)levels.size()) {
+            free(out);
+            return set_err(c, SIFT3D_ERR_ARG, "candidate with level id %d outside the level table", id);
+        }
+        const sift3d_level &lv = levels[(size_t)id];
+        sift3d_candidate &o = out[i];
+        o.octave = id / 3;
+        o.level = id % 3 + 1;
+        o.is_max = (int)((k >> SIFT3D_KEY_MAX_SHIFT) & 1ull);
+        o.x = (int32_t)(idx % lv.X);
+        o.y = (int32_t)((idx / lv.X) % lv.Y);
+        o.z = (int32_t)(idx / ((int64_t)lv.X * lv.Y)) + lv.z_off;
+        o.value = vals[(size_t)i].value;
+        o.h_value = vals[(size_t)i].h;
+        o.l_value = vals[(size_t)i].l;
+    }
+    *cands_out = out;
+    *n_out = ncand;
+    return SIFT3D_OK;
+}
 
-    /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
-    float sigma_init = 0.5f;
-    if (init_scale > 0) sigma_init /= init_scale;
-    float sigma = 1.6f;
-    const float factor = (float)pow(2.0, 1.0 / (double)3);
-    const float extra0 = sqrtf(sigma * sigma - sigma_init * sigma_init);
+/* Sorted candidates -> records in the pinned buffer: keypoint launch, scan, record map, descriptor
+ * launch, download.  Two host synchronisations (record total, download). */
+static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode,
+                           float eig_thres, float size_factor, int64_t *n_out)
+{
     float taps3[SIFT3D_MAX_TAPS], taps5[SIFT3D_MAX_TAPS];
     if (sift3d_gauss_taps(0.5f, 0.01f, taps3) != 3 || sift3d_gauss_taps((float)0.95, (float)0.01, taps5) != 5)
         return set_err(c, SIFT3D_ERR_ARG, "unexpected patch tap counts");
-
-    int rc = blur_dev(c, c->vol, c->L[0], nullptr, c->nx, c->ny, c->nz, extra0, 0.01f);
-    if (rc) return rc;
-
-    std::vector<level_job> jobs;
-    std::vector<sift3d_level> levels(oct.size() * 3);
-    float fscale = 1;
-    float sig[7];
-    for (size_t o = 0; o < oct.size(); o++) {
-        const octave_dims &d = oct[o];
-        const double N = (double)d.X * d.Y * d.Z;
-        sigma = 1.6f;
-        sig[0] = sigma;
-        for (int j = 1; j < 6; j++) {
-            const float ex = sigma * sqrtf(factor * factor - 1.0f);
-            /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
-            rc = blur_dev(c, c->L[j - 1] + d.off, c->L[j] + d.off, c->D[j - 1] + d.off, d.X, d.Y, d.Z, ex, 0.01f);
-            if (rc) return rc;
-            if (j == 3 && o + 1 < oct.size()) {
-                stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
-                HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off));
-            }
-            sigma *= factor;
-            sig[j] = sigma;
-        }
-        for (int l = 0; l < 3; l++) {
-            const int id = (int)o * 3 + l;
-            jobs.push_back({c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.X, d.Y, d.Z, id});
-            sift3d_level &lv = levels[(size_t)id];
-            lv.img = c->L[l + 1] + d.off;
-            lv.dogc = c->D[l + 1] + d.off;
-            lv.X = (int)d.X; lv.Y = (int)d.Y; lv.Z = (int)d.Z;
-            lv.sigma_h = sig[l]; lv.sigma_c = sig[l + 1]; lv.sigma_l = sig[l + 2];
-            lv.octave_factor = fscale;
-            lv.pad = 0;
-        }
-        fscale *= 2.0f;
-        c->last.n_octaves++;
-    }
-    int64_t ncand = 0;
-    rc = extrema_sorted(c, jobs, &ncand);
-    if (rc) return rc;
-    c->last.n_extrema = ncand;
-
-    if (!extract) {
-        std::vector<unsigned long long> keys((size_t)ncand);
-        std::vector<sift3d_cval> vals((size_t)ncand);
-        if (ncand) {
-            HIPCHK(c, hipMemcpyAsync(keys.data(), c->keys_b, sizeof(unsigned long long) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(vals.data(), c->vals_b, sizeof(sift3d_cval) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
-        }
-        timing_end(c);
-        sift3d_candidate *out = (sift3d_candidate *)malloc(sizeof(sift3d_candidate) * (size_t)(ncand ? ncand : 1));
-        if (!out) return set_err(c, SIFT3D_ERR_MEMORY, "out of host memory");
-        for (int64_t i = 0; i < ncand; i++) {
-            const unsigned long long k = keys[(size_t)i];
-            const int id = (int)(k >> SIFT3D_KEY_LVL_SHIFT);
-            const int64_t idx = (int64_t)(k & SIFT3D_KEY_IDX_MASK);
-            const octave_dims &d = oct[(size_t)(id / 3)];
-            sift3d_candidate &o = out[i];
-            o.octave = id / 3;
-            o.level = id % 3 + 1;
-            o.is_max = (int)((k >> SIFT3D_KEY_MAX_SHIFT) & 1ull);
-            o.x = (int32_t)(idx % d.X);
-            o.y = (int32_t)((idx / d.X) % d.Y);
-            o.z = (int32_t)(idx / (d.X * d.Y));
-            o.value = vals[(size_t)i].value;
-            o.h_value = vals[(size_t)i].h;
-            o.l_value = vals[(size_t)i].l;
-        }
-        *cands_out = out;
-        *n_out = ncand;
-        return SIFT3D_OK;
-    }
-
+    if (levels.size() > 96) return set_err(c, SIFT3D_ERR_ARG, "too many levels");
     int64_t nrec_total = 0;
+    int rc;
     if (ncand > 0) {
         rc = ensure_kp_buffers(c, ncand, 0);
         if (rc) return rc;
@@ -771,16 +753,163 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             if (rc) return rc;
             HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec, c->offs, ncand, c->rec_kp, c->rec_frame));
             stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nrec_total);
-            HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, c->recs, taps5));
+            HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, c->recs,
+                                                c->rec_group, taps5));
         }
     }
-    if (nrec_total)
+    if (nrec_total) {
         HIPCHK(c, hipMemcpyAsync(c->h_recs, c->recs, sizeof(sift3d_feature) * (size_t)nrec_total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_group, c->rec_group, sizeof(int) * (size_t)nrec_total, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_end(c);
     c->last.n_records = nrec_total;
-    *feats_out = c->h_recs; /* pinned, owned by the context */
     *n_out = nrec_total;
+    return SIFT3D_OK;
+}
+
+/* The whole single-GPU path.  Host synchronisations: the extrema count, the record count, the
+ * final download -- everything else is queued on the stream. */
+static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_mode, float eig_thres, float size_factor,
+                        sift3d_candidate **cands_out, sift3d_feature **feats_out, int64_t *n_out)
+{
+    if (!c) return SIFT3D_ERR_ARG;
+    if (!c->has_volume) return set_err(c, SIFT3D_ERR_ARG, "no volume set (sift3d_set_volume)");
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_begin(c);
+    const std::vector<octave_dims> oct = octave_list(c->nx, c->ny, c->nz);
+
+    /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
+    float sigma_init = 0.5f;
+    if (init_scale > 0) sigma_init /= init_scale;
+    float sigma = 1.6f;
+    const float factor = (float)pow(2.0, 1.0 / (double)3);
+    const float extra0 = sqrtf(sigma * sigma - sigma_init * sigma_init);
+
+    int rc = blur_dev(c, c->vol, c->L[0], nullptr, c->nx, c->ny, c->nz, extra0, 0.01f);
+    if (rc) return rc;
+    rc = cand_reset(c);
+    if (rc) return rc;
+
+    std::vector<sift3d_level> levels(oct.size() * 3);
+    float fscale = 1;
+    float sig[7];
+    for (size_t o = 0; o < oct.size(); o++) {
+        const octave_dims &d = oct[o];
+        const double N = (double)d.X * d.Y * d.Z;
+        sigma = 1.6f;
+        sig[0] = sigma;
+        for (int j = 1; j < 6; j++) {
+            const float ex = sigma * sqrtf(factor * factor - 1.0f);
+            /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
+            rc = blur_dev(c, c->L[j - 1] + d.off, c->L[j] + d.off, c->D[j - 1] + d.off, d.X, d.Y, d.Z, ex, 0.01f);
+            if (rc) return rc;
+            if (j == 3 && o + 1 < oct.size()) {
+                stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
+                HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off));
+            }
+            sigma *= factor;
+            sig[j] = sigma;
+        }
+        for (int l = 0; l < 3; l++) {
+            const int id = (int)o * 3 + l;
+            rc = cand_append(c, {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.X, d.Y, d.Z, 0, (int)d.Z, id}, true);
+            if (rc) return rc;
+            sift3d_level &lv = levels[(size_t)id];
+            lv.img = c->L[l + 1] + d.off;
+            lv.dogc = c->D[l + 1] + d.off;
+            lv.X = (int)d.X; lv.Y = (int)d.Y; lv.Z = (int)d.Z;
+            lv.sigma_h = sig[l]; lv.sigma_c = sig[l + 1]; lv.sigma_l = sig[l + 2];
+            lv.octave_factor = fscale;
+            lv.Zl = (int)d.Z;
+            lv.z_off = 0;
+            lv.pad = 0;
+        }
+        fscale *= 2.0f;
+        c->last.n_octaves++;
+    }
+    int64_t ncand = 0;
+    rc = cand_finalize(c, &ncand);
+    if (rc) return rc;
+    c->last.n_extrema = ncand;
+    if (!extract) return candidates_to_host(c, levels, ncand, cands_out, n_out);
+    rc = describe_sorted(c, levels, ncand, desc_mode, eig_thres, size_factor, n_out);
+    if (rc) return rc;
+    *feats_out = c->h_recs; /* pinned, owned by the context */
+    return SIFT3D_OK;
+}
+
+/* ---- building blocks for Z-slab mode: the caller owns the level buffers (device memory), places
+ * halos, and drives the exchange; the library detects and describes on whatever it is given. ---- */
+extern "C" int sift3d_candidates_reset(sift3d_ctx *c)
+{
+    if (!c) return SIFT3D_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_begin(c);
+    return cand_reset(c);
+}
+
+extern "C" int sift3d_extrema_append_dev(sift3d_ctx *c, const float *d_prev, const float *d_cur, const float *d_next,
+                                         int64_t nx, int64_t ny, int64_t nz_local, int level_id, int64_t z_lo, int64_t z_hi)
+{
+    if (!c || !d_prev || !d_cur || !d_next) return SIFT3D_ERR_ARG;
+    if (nx <= 0 || ny <= 0 || nz_local <= 0 || nx >= (1ll << 31) || ny >= (1ll << 31) || nz_local >= 65538 ||
+        nx * ny * nz_local > (int64_t)SIFT3D_KEY_IDX_MASK || level_id < 0 || level_id >= 96)
+        return set_err(c, SIFT3D_ERR_ARG, "bad extrema_append arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    return cand_append(c, {d_prev, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id}, true);
+}
+
+static int levels_from_desc(sift3d_ctx *c, const sift3d_level_desc *ld, int n, std::vector<sift3d_level> &levels)
+{
+    if (!ld || n <= 0 || n > 96) return set_err(c, SIFT3D_ERR_ARG, "bad level table");
+    levels.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        sift3d_level &lv = levels[(size_t)i];
+        lv.img = ld[i].img;
+        lv.dogc = ld[i].dogc;
+        lv.X = (int)ld[i].nx; lv.Y = (int)ld[i].ny; lv.Z = (int)ld[i].nz_global;
+        lv.Zl = (int)ld[i].nz_local;
+        lv.z_off = (int)ld[i].z_offset;
+        lv.sigma_h = ld[i].sigma_h; lv.sigma_c = ld[i].sigma_c; lv.sigma_l = ld[i].sigma_l;
+        lv.octave_factor = ld[i].octave_factor;
+        lv.pad = 0;
+    }
+    return SIFT3D_OK;
+}
+
+extern "C" int sift3d_candidates_dev(sift3d_ctx *c, const sift3d_level_desc *levels, int n_levels, sift3d_candidate **out,
+                                     int64_t *n_out)
+{
+    if (!c || !out || !n_out) return SIFT3D_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<sift3d_level> lv;
+    int rc = levels_from_desc(c, levels, n_levels, lv);
+    if (rc) return rc;
+    int64_t ncand = 0;
+    rc = cand_finalize(c, &ncand);
+    if (rc) return rc;
+    return candidates_to_host(c, lv, ncand, out, n_out);
+}
+
+extern "C" int sift3d_describe_dev(sift3d_ctx *c, const sift3d_level_desc *levels, int n_levels, int desc_mode,
+                                   float eig_thres, float size_factor, const sift3d_feature **view, const int32_t **group_view,
+                                   int64_t *n_out)
+{
+    if (!c || !view || !n_out) return SIFT3D_ERR_ARG;
+    if (desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) return set_err(c, SIFT3D_ERR_ARG, "bad descriptor mode");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<sift3d_level> lv;
+    int rc = levels_from_desc(c, levels, n_levels, lv);
+    if (rc) return rc;
+    int64_t ncand = 0;
+    rc = cand_finalize(c, &ncand);
+    if (rc) return rc;
+    c->last.n_extrema = ncand;
+    rc = describe_sorted(c, lv, ncand, desc_mode, eig_thres, size_factor, n_out);
+    if (rc) return rc;
+    *view = c->h_recs;
+    if (group_view) *group_view = c->h_group;
     return SIFT3D_OK;
 }
 

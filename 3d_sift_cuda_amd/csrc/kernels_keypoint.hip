@@ -41,13 +41,20 @@ __device__ __forceinline__ void interp_coord(float fX, float fMin, float fMax, i
 }
 
 /* fioGetPixelTrilinearInterp, R/src_common/FeatureIO.cpp:812-850 */
-__device__ __forceinline__ float trilinear(const float *__restrict__ img, int X, int Y, int Z, float x, float y, float z)
+/* (x,y,z) are coordinates in the whole octave volume (Z = its slice count); img holds Zl slices
+ * starting at global slice z_off, so cell and weights are those of the undivided volume and only
+ * the address is shifted.  The clamp is a memory-safety net: with the 32-slice halo of Z-slab
+ * mode (patch reach < 29 slices) it never binds. */
+__device__ __forceinline__ float trilinear(const float *__restrict__ img, int X, int Y, int Z, int Zl, int z_off, float x,
+                                           float y, float z)
 {
     float wx, wy, wz;
     int ix, iy, iz;
     interp_coord(x, 0, (float)X, ix, wx);
     interp_coord(y, 0, (float)Y, iy, wy);
     interp_coord(z, 0, (float)Z, iz, wz);
+    iz -= z_off;
+    iz = iz < 0 ? 0 : (iz > Zl - 2 ? Zl - 2 : iz);
     const long long XY = (long long)X * Y;
     const float *p = img + (long long)iz * XY + (long long)iy * X + ix;
     float f000 = p[0], f100 = p[1], f010 = p[X], f110 = p[X + 1];
@@ -329,31 +336,41 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define NINT 729 /* interior voxels 1..9 in each axis */
 
 /* sampleImage3D, R/src_common/MultiScale.cpp:2614-2714 (bounds test done by the caller) */
-__device__ __forceinline__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, float fx, float fy,
-                                  float fz, float scale, const float *ori9)
+__device__ __forceinline__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, int Zl,
+                                                  int z_off, float fx, float fy, float fz, float scale, const float *ori9)
 {
     float inv[9];
     invert3(ori9, inv);
     const float rad = 2.0f * scale;
     const int sr = PD / 2;
     const float sc = rad / (float)(sr);
-    for (int s = threadIdx.x; s < PV; s += 64) {
-        const int xx = s % PD - sr, yy = (s / PD) % PD - sr, zz = s / (PD * PD) - sr;
-        float in3[3] = {(float)xx, (float)yy, (float)zz};
-        float o[3];
+    /* three samples per lane per trip: the 24 gathers of a trip are issued together */
+    for (int s0 = threadIdx.x; s0 < PV; s0 += 192) {
+        float pix[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            float a = 0;
+        for (int u = 0; u < 3; u++) {
+            const int s = s0 + 64 * u;
+            pix[u] = 0;
+            if (s < PV) {
+                const int xx = s % PD - sr, yy = (s / PD) % PD - sr, zz = s / (PD * PD) - sr;
+                float in3[3] = {(float)xx, (float)yy, (float)zz};
+                float o[3];
 #pragma unroll
-            for (int j = 0; j < 3; j++) a += inv[i * 3 + j] * in3[j];
-            o[i] = a;
+                for (int i = 0; i < 3; i++) {
+                    float a = 0;
+#pragma unroll
+                    for (int j = 0; j < 3; j++) a += inv[i * 3 + j] * in3[j];
+                    o[i] = a;
+                }
+                o[0] *= sc; o[1] *= sc; o[2] *= sc;
+                o[0] += fx; o[1] += fy; o[2] += fz;
+                if (o[0] < 0 || o[0] >= X) pix[u] = 0;
+                else pix[u] = trilinear(img, X, Y, Z, Zl, z_off, o[0], o[1], o[2]);
+            }
         }
-        o[0] *= sc; o[1] *= sc; o[2] *= sc;
-        o[0] += fx; o[1] += fy; o[2] += fz;
-        float pix;
-        if (o[0] < 0 || o[0] >= X) pix = 0;
-        else pix = trilinear(img, X, Y, Z, o[0], o[1], o[2]);
-        patch[s] = pix;
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            if (s0 + 64 * u < PV) patch[s0 + 64 * u] = pix[u];
     }
     __syncthreads();
 }
@@ -363,17 +380,31 @@ __device__ __forceinline__ void wave_sample_patch(float *patch, const float *__r
 template <bool SQUARE>
 __device__ __forceinline__ float serial_sum_patch(const float *d)
 {
+    /* 1331 = 41 blocks of 32 + 19: read a block of 32 values (eight 16-byte LDS reads) while the
+     * previous block is being added, so the LDS latency stays off the add chain */
     float acc = 0;
     const v4f *d4 = reinterpret_cast<const v4f *>(d);
-    for (int i = 0; i < PV / 4; i++) {
-        v4f v = d4[i];
-        if (SQUARE) {
-            acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
-        } else {
-            acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+    v4f cur[8], nxt[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) cur[q] = d4[q];
+    for (int blk = 0; blk < 41; blk++) {
+        if (blk + 1 < 41) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) nxt[q] = d4[(blk + 1) * 8 + q];
         }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const v4f v = cur[q];
+            if (SQUARE) {
+                acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+            } else {
+                acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) cur[q] = nxt[q];
     }
-    for (int i = (PV / 4) * 4; i < PV; i++) acc += SQUARE ? d[i] * d[i] : d[i];
+    for (int i = 41 * 32; i < PV; i++) acc += SQUARE ? d[i] * d[i] : d[i];
     return acc;
 }
 
@@ -587,7 +618,8 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     sift3d_dkp *kp = kps + k;
     const int X = lv.X, Y = lv.Y, Z = lv.Z;
     const long long XY = (long long)X * Y;
-    const int ix = (int)(cidx % X), iy = (int)((cidx / X) % Y), iz = (int)(cidx / XY);
+    /* cidx indexes the local buffer; refinement and all geometry use the global slice number */
+    const int ix = (int)(cidx % X), iy = (int)((cidx / X) % Y), iz = (int)(cidx / XY) + lv.z_off;
 
     /* generateFeatures3D_efficient, R/src_common/MultiScale.cpp:1361-1421 (every lane, identical) */
     const float *C = lv.dogc;
@@ -607,7 +639,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     }
     float *patch = sm.A;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    wave_sample_patch(patch, lv.img, X, Y, Z, fx, fy, fz, scale, ident);
+    wave_sample_patch(patch, lv.img, X, Y, Z, lv.Zl, lv.z_off, fx, fy, fz, scale, ident);
     if (p.debug_stop == 1) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_normalize_patch(patch, sm.sc);
     if (p.debug_stop == 2) { if (lane == 0) nrec_out[k] = 0; return; }
@@ -806,7 +838,7 @@ struct kpB_smem {
 __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
                                                         const int *__restrict__ rec_kp, const int *__restrict__ rec_frame,
                                                         long long nrec, sift3d_feature *__restrict__ recs,
-                                                        sift3d_taps taps5)
+                                                        int *__restrict__ rec_group, sift3d_taps taps5)
 {
     __shared__ __attribute__((aligned(16))) kpB_smem sm;
     const long long r = blockIdx.x;
@@ -822,7 +854,7 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         for (int i = 0; i < 9; i++) ori[i] = kp->frames[fr * 9 + i];
     }
     const sift3d_level lv = p.levels[kp->lvl];
-    wave_sample_patch(sm.patch, lv.img, lv.X, lv.Y, lv.Z, kp->x, kp->y, kp->z, kp->scale, ori);
+    wave_sample_patch(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
     /* record 0 was normalised once inside generateFeature3D (MultiScale.cpp:1742) and
      * every record once more in main (featExtract.cpp:480) */
     if (fr < 0) wave_normalize_patch(sm.patch, sm.sc);
@@ -975,6 +1007,7 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         for (int i = 0; i < 9; i++) out->ori[i] = fr < 0 ? kp->ori0[i] : kp->frames[fr * 9 + i];
         for (int i = 0; i < 3; i++) out->eigs[i] = kp->eigs[i];
         out->info = kp->info | (fr < 0 ? 0u : SIFT3D_INFO_REORIENT);
+        rec_group[r] = kp->lvl * 2 + ((kp->info & SIFT3D_INFO_MIN0MAX1) ? 1 : 0);
     }
 }
 
@@ -1013,12 +1046,13 @@ hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs,
 }
 
 hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
-                                     const int *rec_frame, int64_t nrec, sift3d_feature *recs, const float *taps5)
+                                     const int *rec_frame, int64_t nrec, sift3d_feature *recs, int *rec_group,
+                                     const float *taps5)
 {
     if (nrec <= 0) return hipSuccess;
     sift3d_taps t;
     for (int i = 0; i < 17; i++) t.f[i] = i < 5 ? taps5[i] : 0.0f;
     hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)nrec), dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec,
-                       recs, t);
+                       recs, rec_group, t);
     return hipGetLastError();
 }

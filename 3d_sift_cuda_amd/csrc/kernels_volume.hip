@@ -361,14 +361,15 @@ __global__ void halve_size_kernel(const float *__restrict__ in, long long X, lon
 /* the host orders them afterwards (raster order = sort by linear index).    */
 /* ------------------------------------------------------------------------ */
 __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
-                                                      const float *__restrict__ dnext, int X, int Y, int Z, int lvl_id,
+                                                      const float *__restrict__ dnext, int X, int Y, int Z, int z_first,
+                                                      int lvl_id,
                                                       unsigned long long *__restrict__ keys,
                                                       sift3d_cval *__restrict__ vals, unsigned long long *count,
                                                       long long cap)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z + 1;
+    const int z = blockIdx.z + z_first; /* z_first >= 1; the launcher sizes the grid to the kept planes */
     const bool inside = (x >= 1 && x < X - 1 && y >= 1 && y < Y - 1);
     const long long XY = (long long)X * Y;
     const long long idx = (long long)z * XY + (long long)y * X + x;
@@ -609,12 +610,16 @@ hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, i
 }
 
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
-                                 int64_t Y, int64_t Z, int lvl_id, unsigned long long *keys, sift3d_cval *vals,
-                                 unsigned long long *count, int64_t cap)
+                                 int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
+                                 sift3d_cval *vals, unsigned long long *count, int64_t cap)
 {
     if (X < 3 || Y < 3 || Z < 3) return hipSuccess;
-    dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(Z - 2));
-    hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, lvl_id, keys, vals,
+    /* interior planes 1..Z-2, further restricted to [z_lo, z_hi) (Z-slab mode keeps only its own slices) */
+    const int z0 = z_lo > 1 ? z_lo : 1;
+    const int z1 = z_hi < (int)Z - 1 ? z_hi : (int)Z - 1;
+    if (z1 <= z0) return hipSuccess;
+    dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(z1 - z0));
+    hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0, lvl_id, keys, vals,
                        count, (long long)cap);
     return hipGetLastError();
 }

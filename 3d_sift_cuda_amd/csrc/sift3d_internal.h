@@ -33,9 +33,11 @@ struct sift3d_cval {
 struct sift3d_level {
     const float *img;  /* Gaussian level L_k the keypoints are sampled from */
     const float *dogc; /* DoG level k (centre) */
-    int X, Y, Z;
+    int X, Y, Z;       /* dims of the whole octave volume (Z is the global slice count) */
     float sigma_h, sigma_c, sigma_l;
     float octave_factor; /* 2^octave */
+    int Zl;    /* slices held in img/dogc (== Z on one GPU; slab + halos in Z-slab mode) */
+    int z_off; /* global z of local slice 0 */
     int pad;
 };
 
@@ -52,8 +54,8 @@ hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, in
 hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
-                                 int64_t Y, int64_t Z, int lvl_id, unsigned long long *keys, sift3d_cval *vals,
-                                 unsigned long long *count, int64_t cap);
+                                 int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
+                                 sift3d_cval *vals, unsigned long long *count, int64_t cap);
 
 /* ---- per-keypoint stage (kernels_keypoint.hip) ---- */
 struct sift3d_kp_params {
@@ -79,7 +81,8 @@ hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, co
                                     const sift3d_cval *vals, int64_t ncand, sift3d_dkp *kps, int *nrec, const float *taps3);
 hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame);
 hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
-                                     const int *rec_frame, int64_t nrec, sift3d_feature *recs, const float *taps5);
+                                     const int *rec_frame, int64_t nrec, sift3d_feature *recs, int *rec_group,
+                                     const float *taps5);
 /* device sort / scan (sort_scan.hip, rocPRIM) */
 size_t sift3d_sort_temp_bytes(int64_t n);
 hipError_t sift3d_sort_candidates(hipStream_t s, void *temp, size_t temp_bytes, const unsigned long long *keys_in,

@@ -1,0 +1,357 @@
+"""Z-slab multi-GPU driver of the extraction path (new work, the reference is single-GPU).
+
+One process per GPU; the volume is cut along z (the slowest axis, so a slab is one contiguous block) into one
+slab per rank.  Every level buffer holds the slab plus halos; after each Gaussian level the halo slices are
+refreshed from the two neighbours with point-to-point ``torch.distributed`` sends/receives (backend "nccl" = RCCL
+over xGMI on the GPUs; a slab chain only ever talks to its two neighbours, i.e. 2 of a GPU's 7 links).  There is
+no other data-path collective until the coarse octaves (slab thinner than the halo) are gathered onto rank 0 and
+the records are gathered at the end.
+
+Why the result equals the single-GPU result bit for bit:
+  * a blur output depends on inputs within R <= 8 slices; every level is (re)computed on slab +- 8 slices from an
+    input that is exact there, the rows nearer than R to the artificial edge are overwritten by the neighbour's
+    exact values, and at a face of the whole volume the computed region ends at the face, so the zero border is
+    the reference's;
+  * 2:1 subsampling pairs slices (2k, 2k+1): slab boundaries are multiples of 2^K (K = number of sharded octaves);
+  * extrema are kept only for a rank's own slices (the halo slices are the neighbour's); lists sort by
+    (level, is_max, index) and slabs are in z order, so concatenating ranks per group is the serial raster order;
+  * per-keypoint geometry is computed in whole-volume coordinates (sift3d_level_desc.z_offset).
+
+Halo widths: 8 slices feed the next blur (R <= 8); L1..L3 carry 32 slices because an 11^3 patch reaches
+< 29 slices from its keypoint (|offset| <= 5*sqrt(3) samples * 2*scale/5, scale <= 2*4.04); DoG levels need 1.
+
+The compute backend is pluggable: ``HipBackend`` drives the C-ABI ``*_dev`` operators on torch CUDA tensors;
+the CPU test-suite plugs the oracle in (tests/test_zslab_cpu.py) to check the slab logic with gloo, world size 2.
+"""
+import math
+
+import numpy as np
+
+HALO = 32        # slices of L1..L3 kept around a slab (patch sampling)
+BLUR_HALO = 8    # slices recomputed / exchanged for the next blur (largest half-width in the schedule)
+
+
+def sigma_schedule(initial_image_scale=1.0):
+    """Float32 sigma arithmetic of msGeneratePyramidDOG3D_efficient (MultiScale.cpp:288-294,369,526-527)."""
+    f32 = np.float32
+    sigma_init = f32(0.5)
+    if initial_image_scale > 0:
+        sigma_init = f32(sigma_init / f32(initial_image_scale))
+    s0 = f32(1.6)
+    factor = f32(math.pow(2.0, 1.0 / 3.0))
+    extra0 = f32(np.sqrt(f32(f32(s0 * s0) - f32(sigma_init * sigma_init))))
+    extras, sig = [], [s0]
+    s = s0
+    for _ in range(5):
+        extras.append(f32(s * f32(np.sqrt(f32(f32(factor * factor) - f32(1.0))))))
+        s = f32(s * factor)
+        sig.append(s)
+    return float(extra0), [float(e) for e in extras], [float(v) for v in sig]
+
+
+class SlabPlan:
+    """Pure geometry: octave sizes, slab boundaries, how many octaves are sharded."""
+
+    def __init__(self, nx, ny, nz, nranks):
+        self.nx, self.ny, self.nz, self.nranks = nx, ny, nz, nranks
+        self.octaves = []
+        x, y, z = nx, ny, nz
+        while x > 2 and y > 2 and z > 2 and len(self.octaves) < 32:
+            self.octaves.append((x, y, z))
+            x, y, z = x // 2, y // 2, z // 2
+        # K = number of sharded octaves: boundaries multiples of 2^K, every slab at octave K-1 at least HALO thick
+        self.n_sharded = 0
+        self.bounds = [0, nz]
+        if nranks > 1:
+            for k in range(len(self.octaves), 0, -1):
+                align = 1 << k
+                b = [int(round(r * nz / nranks / align)) * align for r in range(nranks)] + [nz]
+                ok = all(b[r + 1] > b[r] for r in range(nranks))
+                for o in range(k):
+                    zo = self.octaves[o][2]
+                    for r in range(nranks):
+                        lo, hi = b[r] >> o, (zo if r == nranks - 1 else b[r + 1] >> o)
+                        ok = ok and (hi - lo) >= HALO
+                if ok:
+                    self.n_sharded, self.bounds = k, b
+                    break
+            if self.n_sharded == 0:
+                self.bounds = [0] * nranks + [nz]   # too thin to shard: rank nranks-1... (see slab())
+        else:
+            self.n_sharded = 0
+
+    def slab(self, rank, octave):
+        """Global z-range [z0, z1) of `rank` in `octave` (a sharded octave)."""
+        zo = self.octaves[octave][2]
+        z0 = self.bounds[rank] >> octave
+        z1 = zo if rank == self.nranks - 1 else self.bounds[rank + 1] >> octave
+        return z0, z1
+
+    def input_range(self, rank):
+        """Slices of the input volume rank needs: its slab of octave 0 plus BLUR_HALO + the initial blur's reach."""
+        if self.n_sharded == 0:
+            return (0, self.nz)
+        z0, z1 = self.slab(rank, 0)
+        h = 2 * BLUR_HALO
+        return (max(0, z0 - h), min(self.nz, z1 + h))
+
+
+class HipBackend:
+    """Compute on torch CUDA tensors through the C-ABI *_dev operators."""
+
+    def __init__(self, pkg, ctx, torch):
+        self.pkg, self.ctx, self.torch = pkg, ctx, torch
+        # one non-default torch stream carries everything: torch allocations/copies, the library's kernels
+        # (sift3d_set_stream) and the point where NCCL work is ordered against (its current stream)
+        self.stream = torch.cuda.Stream(device=ctx.device)
+        ctx.set_stream(self.stream.cuda_stream)
+
+    def stream_scope(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def empty(self, shape):
+        return self.torch.empty(shape, dtype=self.torch.float32, device="cuda:%d" % self.ctx.device)
+
+    def from_host(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr, np.float32)).to("cuda:%d" % self.ctx.device)
+
+    def blur(self, src, dst, sigma):
+        nz, ny, nx = src.shape
+        self.ctx.gauss_blur_dev(src.data_ptr(), dst.data_ptr(), nx, ny, nz, sigma)
+
+    def blur_dog(self, src, dst, dog, sigma):
+        nz, ny, nx = src.shape
+        self.ctx.gauss_blur_dog_dev(src.data_ptr(), dst.data_ptr(), dog.data_ptr(), nx, ny, nz, sigma)
+
+    def dog(self, a, b, out):
+        self.ctx.dog_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel())
+
+    def subsample(self, src, dst):
+        nz, ny, nx = src.shape
+        self.ctx.subsample2_dev(src.data_ptr(), nx, ny, nz, dst.data_ptr())
+
+    def reset(self):
+        self.ctx.candidates_reset()
+
+    def extrema_append(self, dp, dc, dn, level_id, z_lo, z_hi):
+        nz, ny, nx = dc.shape
+        self.ctx.extrema_append_dev(dp.data_ptr(), dc.data_ptr(), dn.data_ptr(), nx, ny, nz, level_id, z_lo, z_hi)
+
+    def level_entry(self, img, dogc, nz_global, z_offset, sh, sc, sl, factor):
+        nz, ny, nx = img.shape
+        return {"img": img.data_ptr(), "dogc": dogc.data_ptr(), "nx": nx, "ny": ny, "nz_local": nz, "nz_global": nz_global,
+                "z_offset": z_offset, "sigma_h": sh, "sigma_c": sc, "sigma_l": sl, "octave_factor": factor, "_keep": (img, dogc)}
+
+    def candidates(self, levels):
+        return self.ctx.candidates_dev(levels)
+
+    def describe(self, levels, desc_mode, eig_thres, size_factor):
+        return self.ctx.describe_dev(levels, desc_mode, eig_thres, size_factor)
+
+    def before_exchange(self):
+        pass  # the context runs on torch's current stream (ZSlabExtractor sets it), so ordering is the stream's
+
+    def after_exchange(self):
+        pass
+
+
+class ZSlabExtractor:
+    """Runs the pyramid of ONE volume across the ranks of a torch.distributed group."""
+
+    def __init__(self, backend, plan, rank, dist=None, group=None):
+        self.be, self.plan, self.rank, self.dist, self.group = backend, plan, rank, dist, group
+        self.levels = []       # level table entries, index = level id
+        self.level_ids = []
+        self.stats = {"exchanges": 0, "exchange_bytes": 0}
+
+    # ---- halo exchange of one level buffer -------------------------------------------------
+    def _exchange(self, buf, z0, z1, e0, width, has_lo, has_hi):
+        """Refresh [z0-width, z0) from the lower neighbour and [z1, z1+width) from the upper one."""
+        if self.dist is None or (not has_lo and not has_hi):
+            return
+        d, ops, back = self.dist, [], []
+        self.be.before_exchange()
+        # gloo cannot move device memory: stage through the host (the 2-process single-GPU test); with
+        # nccl (= RCCL) the slices go GPU to GPU over xGMI
+        stage = buf.is_cuda and d.get_backend(self.group) == "gloo"
+
+        def snd(t):
+            return t.cpu() if stage else t
+
+        def rcv(t):
+            if not stage:
+                return t
+            h = t.cpu()
+            back.append((t, h))
+            return h
+        if has_lo:
+            ops.append(d.P2POp(d.isend, snd(buf[z0 - e0:z0 - e0 + width]), self.rank - 1, self.group))
+            ops.append(d.P2POp(d.irecv, rcv(buf[z0 - width - e0:z0 - e0]), self.rank - 1, self.group))
+        if has_hi:
+            ops.append(d.P2POp(d.isend, snd(buf[z1 - width - e0:z1 - e0]), self.rank + 1, self.group))
+            ops.append(d.P2POp(d.irecv, rcv(buf[z1 - e0:z1 - e0 + width]), self.rank + 1, self.group))
+        for r in d.batch_isend_irecv(ops):
+            r.wait()
+        for t, h in back:
+            t.copy_(h)
+        self.be.after_exchange()
+        self.stats["exchanges"] += 1
+        self.stats["exchange_bytes"] += 2 * width * buf.shape[1] * buf.shape[2] * 4 * (int(has_lo) + int(has_hi))
+
+    # ---- one octave on one rank ---------------------------------------------------------------
+    def _octave(self, o, L0, z0, z1, e0, e1, zo, has_lo, has_hi, extras, sig, factor, want_next):
+        """L0: level-0 buffer covering global slices [e0, e1), exact on slab +- BLUR_HALO (clipped to the volume).
+        Returns the L3 buffer (exact on its whole extent) for the subsample that seeds the next octave."""
+        be = self.be
+        nzl = e1 - e0
+        shape = (nzl, L0.shape[1], L0.shape[2])
+        L = [L0] + [be.empty(shape) for _ in range(5)]
+        D = [be.empty(shape) for _ in range(5)]
+        # region recomputed per level: slab +- BLUR_HALO, clipped to what the buffer holds (at a face of the
+        # whole volume the buffer ends at the face, which is what makes the zero border exact)
+        c0 = max(e0, z0 - BLUR_HALO) if has_lo else e0
+        c1 = min(e1, z1 + BLUR_HALO) if has_hi else e1
+        a, b = c0 - e0, c1 - e0
+        for j in range(1, 6):
+            be.blur_dog(L[j - 1][a:b], L[j][a:b], D[j - 1][a:b], extras[j - 1])
+            width = HALO if j in (1, 2, 3) else BLUR_HALO
+            self._exchange(L[j], z0, z1, e0, width, has_lo, has_hi)
+            # the fused DoG used the not-yet-exchanged margin of L[j]: redo it on the halo slices
+            if has_lo:
+                be.dog(L[j - 1][a:z0 - e0], L[j][a:z0 - e0], D[j - 1][a:z0 - e0])
+            if has_hi:
+                be.dog(L[j - 1][z1 - e0:b], L[j][z1 - e0:b], D[j - 1][z1 - e0:b])
+        for l in range(3):
+            lid = o * 3 + l
+            be.extrema_append(D[l], D[l + 1], D[l + 2], lid, z0 - e0, z1 - e0)
+            self.levels.append(be.level_entry(L[l + 1], D[l + 1], zo, e0, sig[l], sig[l + 1], sig[l + 2], factor))
+            self.level_ids.append(lid)
+        return L[3] if want_next else None
+
+    # ---- the whole pyramid ----------------------------------------------------------------------
+    def run(self, input_slab, input_z0, initial_image_scale=1.0):
+        """input_slab: this rank's slices [input_z0, input_z0 + n) of the whole volume, as given by
+        SlabPlan.input_range (host array).  Collects the extrema of this rank in the backend."""
+        plan, be, rank, S = self.plan, self.be, self.rank, self.plan.nranks
+        extra0, extras, sig = sigma_schedule(initial_image_scale)
+        K = plan.n_sharded
+        be.reset()
+        self.levels, self.level_ids = [], []
+        factor = 1.0
+        vol = be.from_host(input_slab)
+        nxt = None
+        for o in range(len(plan.octaves)):
+            X, Y, zo = plan.octaves[o]
+            sharded = o < K
+            if sharded:
+                z0, z1 = plan.slab(rank, o)
+                has_lo, has_hi = rank > 0, rank < S - 1
+            else:
+                if rank != 0 and K > 0:
+                    break               # the gathered octaves live on rank 0
+                if K == 0 and rank != 0:
+                    break
+                z0, z1, has_lo, has_hi = 0, zo, False, False
+            e0 = max(0, z0 - HALO) if has_lo else z0
+            e1 = min(zo, z1 + HALO) if has_hi else z1
+            if o == 0:
+                # level 0 = initial blur of the input, computed on slab +- BLUR_HALO from input slab +- 2*BLUR_HALO
+                L0 = be.empty((e1 - e0, Y, X))
+                i0 = input_z0
+                tmp = be.empty(vol.shape)
+                be.blur(vol, tmp, extra0)
+                c0 = max(e0, z0 - BLUR_HALO) if has_lo else e0
+                c1 = min(e1, z1 + BLUR_HALO) if has_hi else e1
+                L0[c0 - e0:c1 - e0].copy_(tmp[c0 - i0:c1 - i0])
+            else:
+                L0 = nxt
+            want_next = o + 1 < len(plan.octaves)
+            L3 = self._octave(o, L0, z0, z1, e0, e1, zo, has_lo, has_hi, extras, sig, factor, want_next)
+            factor *= 2.0
+            if not want_next:
+                break
+            Xn, Yn, zn = plan.octaves[o + 1]
+            if o + 1 < K:
+                # next octave is sharded too: subsample slab +- 2*BLUR_HALO of L3 into next slab +- BLUR_HALO
+                n0, n1 = plan.slab(rank, o + 1)
+                ne0 = max(0, n0 - HALO) if has_lo else n0
+                ne1 = min(zn, n1 + HALO) if has_hi else n1
+                s0 = max(ne0, n0 - BLUR_HALO) if has_lo else ne0
+                s1 = min(ne1, n1 + BLUR_HALO) if has_hi else ne1
+                nxt = be.empty((ne1 - ne0, Yn, Xn))
+                be.subsample(L3[2 * s0 - e0:2 * s1 - e0], nxt[s0 - ne0:s1 - ne0])
+            elif sharded:
+                # last sharded octave: every rank subsamples exactly its slab, rank 0 assembles the whole octave
+                t = (z1 - z0) // 2   # an odd last slice of the whole volume is dropped, as in the serial code
+                part = be.empty((t, Yn, Xn))
+                be.subsample(L3[z0 - e0:z0 - e0 + 2 * t], part)
+                nxt = self._gather_to_root(part, zn, Yn, Xn)
+            else:
+                nxt = be.empty((zn, Yn, Xn))
+                be.subsample(L3, nxt)
+        return self
+
+    def _gather_to_root(self, part, zn, Yn, Xn):
+        """Concatenate the per-rank parts of the first gathered octave on rank 0 (other ranks get None)."""
+        d, S = self.dist, self.plan.nranks
+        if d is None:
+            return part
+        torch = __import__("torch")
+        stage = part.is_cuda and d.get_backend(self.group) == "gloo"
+        dev = "cpu" if stage else part.device
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(S)]
+        self.be.before_exchange()
+        d.all_gather(sizes, torch.tensor([part.shape[0]], dtype=torch.int64, device=dev), group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes)
+        pad = torch.zeros((mx, Yn, Xn), dtype=torch.float32, device=dev)
+        pad[:part.shape[0]].copy_(part)
+        if self.rank == 0:
+            bufs = [torch.zeros((mx, Yn, Xn), dtype=torch.float32, device=dev) for _ in range(S)]
+            d.gather(pad, bufs, dst=0, group=self.group)
+            full = self.be.empty((zn, Yn, Xn))
+            at = 0
+            for r in range(S):
+                n = min(sizes[r], zn - at)
+                full[at:at + n].copy_(bufs[r][:n])
+                at += n
+            assert at == zn, (at, zn, sizes)
+            self.be.after_exchange()
+            return full
+        d.gather(pad, None, dst=0, group=self.group)
+        self.be.after_exchange()
+        return None
+
+    # ---- results ----------------------------------------------------------------------------------
+    def _table(self):
+        n = max(self.level_ids) + 1 if self.level_ids else 0
+        table = [None] * n
+        for lid, lv in zip(self.level_ids, self.levels):
+            table[lid] = lv
+        filler = self.levels[0] if self.levels else None
+        return [t if t is not None else filler for t in table]
+
+    def candidates(self):
+        """This rank's validated extrema (whole-volume coordinates), sorted."""
+        if not self.levels:
+            return np.zeros(0, dtype=[("octave", "<i4"), ("level", "<i4"), ("is_max", "<i4"), ("x", "<i4"), ("y", "<i4"),
+                                      ("z", "<i4"), ("value", "<f4"), ("h_value", "<f4"), ("l_value", "<f4")])
+        return self.be.candidates(self._table())
+
+    def describe(self, desc_mode=0, eig_thres=140.0, size_factor=1.0):
+        """This rank's records and their group ids (level_id*2 + is_max)."""
+        if not self.levels:
+            return None, np.zeros(0, np.int32)
+        return self.be.describe(self._table(), desc_mode, eig_thres, size_factor)
+
+
+def merge_by_group(parts):
+    """parts: per rank (records, group) in rank order -> records in the single-GPU order.
+    Within a group (level, is_max) slabs are in z order, so rank order is raster order."""
+    recs = [p[0] for p in parts if p[0] is not None and len(p[0])]
+    grps = [p[1] for p in parts if p[0] is not None and len(p[0])]
+    if not recs:
+        return None
+    allr, allg = np.concatenate(recs), np.concatenate(grps)
+    order = np.argsort(allg, kind="stable")   # stable: keeps rank order, and raster order inside a rank
+    return allr[order]

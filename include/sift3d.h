@@ -152,6 +152,39 @@ int sift3d_extract(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, fl
 int sift3d_extract_view(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
                         const sift3d_feature **view, int64_t *n_out);
 
+/* ---- Z-slab building blocks (multi-GPU) --------------------------------------
+ * The reference has no multi-GPU code; this is the surface the Z-slab driver
+ * (3d_sift_cuda_amd/zslab.py: one process per GPU, halo exchange with
+ * torch.distributed = RCCL over xGMI) needs on top of the *_dev operators.
+ * The caller owns the level buffers (device memory): each holds nz_local
+ * slices of a level whose whole volume has nz_global slices, starting at
+ * global slice z_offset (slab + halos).  Geometry is always computed in
+ * whole-volume coordinates, so records are those of the undivided volume. */
+typedef struct {
+    const float *img;  /* Gaussian level L_k (device), nx*ny*nz_local */
+    const float *dogc; /* DoG level k (device), same shape */
+    int64_t nx, ny, nz_local, nz_global, z_offset;
+    float sigma_h, sigma_c, sigma_l; /* sigmas of levels k-1, k, k+1 (MultiScale.cpp:463) */
+    float octave_factor;             /* 2^octave (MultiScale.cpp:531-543) */
+} sift3d_level_desc;
+/* Forget the extrema collected so far (also restarts the launch log). */
+int sift3d_candidates_reset(sift3d_ctx *ctx);
+/* Queue one extrema pass over device buffers of nz_local slices and keep the
+ * extrema whose local z lies in [z_lo, z_hi) (and in 1..nz_local-2): a slab
+ * keeps its own slices, the halo slices are the neighbour's.  level_id =
+ * octave*3 + (DoG level - 1) orders the output. Asynchronous. */
+int sift3d_extrema_append_dev(sift3d_ctx *ctx, const float *d_prev, const float *d_cur, const float *d_next, int64_t nx,
+                              int64_t ny, int64_t nz_local, int level_id, int64_t z_lo, int64_t z_hi);
+/* Sort what was collected and return it with whole-volume coordinates (malloc'ed, sift3d_free). */
+int sift3d_candidates_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_levels, sift3d_candidate **out,
+                          int64_t *n_out);
+/* Sort what was collected and run the per-keypoint stage on it.  levels[id]
+ * describes level_id == id.  *view / *group_view (level_id*2 + is_max per
+ * record) point at pinned buffers owned by the context, valid until the next
+ * call. */
+int sift3d_describe_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_levels, int desc_mode, float eig_thres,
+                        float size_factor, const sift3d_feature **view, const int32_t **group_view, int64_t *n_out);
+
 /* ---- measurement ------------------------------------------------------------
  * Device time per stage of the last sift3d_detect/sift3d_extract call, from
  * HIP events recorded on the stream the kernels ran on. */

@@ -1,0 +1,163 @@
+"""CPU suite: the Z-slab driver (3d_sift_cuda_amd/zslab.py) with gloo, world size 2 (and 1 / 3 in-process plans).
+
+The compute backend here is the oracle (test infrastructure); what is under test is the slab logic that the GPU
+path shares: boundaries, halo widths, exchange, DoG halo repair, own-slice filtering, coarse-octave gather, order.
+The sharded run must reproduce the serial oracle's validated extrema exactly.
+"""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleBackend:
+    """numpy/oracle stand-in for HipBackend (CPU tensors; candidates kept as python lists)."""
+
+    def __init__(self, oracle, torch):
+        self.o, self.torch = oracle, torch
+        self.cands = []
+
+    def empty(self, shape):
+        return self.torch.zeros(shape, dtype=self.torch.float32)
+
+    def from_host(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr, np.float32).copy())
+
+    def blur(self, src, dst, sigma):
+        dst.copy_(self.torch.from_numpy(self.o.blur(src.numpy(), sigma)))
+
+    def blur_dog(self, src, dst, dog, sigma):
+        out = self.o.blur(src.numpy(), sigma)
+        dst.copy_(self.torch.from_numpy(out))
+        dog.copy_(self.torch.from_numpy(self.o.dog(src.numpy(), out)))
+
+    def dog(self, a, b, out):
+        if a.numel():
+            out.copy_(self.torch.from_numpy(self.o.dog(a.numpy(), b.numpy())))
+
+    def subsample(self, src, dst):
+        dst.copy_(self.torch.from_numpy(self.o.subsample(src.numpy())))
+
+    def reset(self):
+        self.cands = []
+
+    def extrema_append(self, dp, dc, dn, level_id, z_lo, z_hi):
+        mins, maxs = self.o.detect3(dp.numpy(), dc.numpy(), dn.numpy())
+        for is_max, lst in ((0, mins), (1, maxs)):
+            for e in lst:
+                if z_lo <= e["z"] < z_hi:
+                    h = dp[int(e["z"]), int(e["y"]), int(e["x"])].item()
+                    l = dn[int(e["z"]), int(e["y"]), int(e["x"])].item()
+                    self.cands.append((level_id, is_max, int(e["z"]), int(e["y"]), int(e["x"]), float(e["value"]), h, l))
+
+    def level_entry(self, img, dogc, nz_global, z_offset, sh, sc, sl, factor):
+        return {"z_offset": z_offset, "nz_global": nz_global}
+
+    def candidates(self, table):
+        import _oracle
+        out = np.zeros(len(self.cands), _oracle.CAND)
+        for i, (lid, is_max, z, y, x, v, h, l) in enumerate(sorted(self.cands)):
+            out[i] = (lid // 3, lid % 3 + 1, is_max, x, y, z + table[lid]["z_offset"], v, h, l)
+        return out
+
+    def before_exchange(self):
+        pass
+
+    def after_exchange(self):
+        pass
+
+
+def _same(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    for f in ("octave", "level", "is_max", "x", "y", "z"):
+        assert (got[f] == want[f]).all(), f
+    for f in ("value", "h_value", "l_value"):
+        assert (got[f].view(np.uint32) == want[f].view(np.uint32)).all(), f
+
+
+def test_slab_plan_geometry():
+    zs = importlib.import_module("3d_sift_cuda_amd").__name__ and importlib.import_module("3d_sift_cuda_amd.zslab")
+    p = zs.SlabPlan(512, 512, 512, 8)
+    assert p.n_sharded == 2 and p.bounds == [0, 64, 128, 192, 256, 320, 384, 448, 512]
+    assert p.slab(3, 1) == (96, 128) and p.input_range(0) == (0, 80) and p.input_range(7) == (432, 512)
+    p = zs.SlabPlan(1024, 1024, 512, 4)
+    assert p.n_sharded == 3 and p.slab(1, 2) == (32, 64)
+    p = zs.SlabPlan(2048, 2048, 1024, 8)
+    assert p.n_sharded == 3 and all(b % 8 == 0 for b in p.bounds)
+    p = zs.SlabPlan(64, 64, 64, 8)      # too thin for 32-slice halos: nothing is sharded
+    assert p.n_sharded == 0
+    p = zs.SlabPlan(100, 90, 150, 2)    # odd sizes: boundary aligned to 2^K
+    assert p.n_sharded >= 1 and p.bounds[1] % (1 << p.n_sharded) == 0
+    extra0, extras, sig = zs.sigma_schedule(1.0)
+    assert abs(extra0 - 1.5198684930801392) < 1e-12 and abs(extras[4] - 3.0900158882141113) < 1e-12
+
+
+def _worker(rank, world, port, dims, seed, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    pkg = importlib.import_module("3d_sift_cuda_amd")
+    zs = importlib.import_module("3d_sift_cuda_amd.zslab")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        vol = pkg.synth_blobs(*dims, seed=seed)
+        plan = zs.SlabPlan(dims[0], dims[1], dims[2], world)
+        i0, i1 = plan.input_range(rank)
+        ex = zs.ZSlabExtractor(OracleBackend(_oracle.load(), torch), plan, rank, dist)
+        ex.run(vol[i0:i1], i0)
+        mine = ex.candidates()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if rank == 0:
+            allc = np.concatenate(gathered)
+            key = (allc["octave"].astype(np.int64) * 3 + allc["level"] - 1) * 2 + allc["is_max"]
+            merged = allc[np.argsort(key, kind="stable")]
+            q.put((plan.n_sharded, merged, ex.stats))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("dims,seed", [((40, 36, 160), 3), ((36, 40, 130), 9)])
+def test_two_rank_gloo_matches_serial_oracle(oracle, built, dims, seed):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dims, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n_sharded, merged, stats = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert n_sharded >= 1 and stats["exchanges"] >= 5
+    want = oracle.candidates(built.synth_blobs(*dims, seed=seed))
+    assert len(want) > 20
+    _same(merged, want)
+
+
+def test_single_rank_plan_is_the_serial_path(oracle, built):
+    import torch
+    zs = importlib.import_module("3d_sift_cuda_amd.zslab")
+    dims = (48, 40, 36)
+    vol = built.synth_blobs(*dims, seed=5)
+    plan = zs.SlabPlan(*dims, 1)
+    ex = zs.ZSlabExtractor(OracleBackend(oracle, torch), plan, 0, None)
+    ex.run(vol, 0)
+    _same(ex.candidates(), oracle.candidates(vol))
