@@ -355,3 +355,41 @@ def merge_by_group(parts):
     allr, allg = np.concatenate(recs), np.concatenate(grps)
     order = np.argsort(allg, kind="stable")   # stable: keeps rank order, and raster order inside a rank
     return allr[order]
+
+
+def gather_records(dist, rank, world, recs, grp, device, group=None):
+    """Gather every rank's (records, group) on rank 0 with tensor collectives (sizes first, then padded
+    byte tensors) and merge them into the single-GPU order.  Returns the merged array on rank 0, None elsewhere."""
+    import torch
+    stage = dist.get_backend(group) == "gloo"
+    dev = "cpu" if stage else device
+    n = 0 if recs is None else len(recs)
+    item = 0 if recs is None else recs.dtype.itemsize
+    sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n, item], dtype=torch.int64, device=dev), group=group)
+    counts = [int(t[0].item()) for t in sizes]
+    item = max(int(t[1].item()) for t in sizes)
+    mx = max(counts)
+    if mx == 0:
+        return None
+    rb = torch.zeros(mx * item, dtype=torch.uint8, device=dev)
+    gb = torch.zeros(mx, dtype=torch.int32, device=dev)
+    if n:
+        rb[:n * item].copy_(torch.from_numpy(recs.view(np.uint8).reshape(-1)))
+        gb[:n].copy_(torch.from_numpy(grp.astype(np.int32)))
+    if rank == 0:
+        rbs = [torch.zeros(mx * item, dtype=torch.uint8, device=dev) for _ in range(world)]
+        gbs = [torch.zeros(mx, dtype=torch.int32, device=dev) for _ in range(world)]
+        dist.gather(rb, rbs, dst=0, group=group)
+        dist.gather(gb, gbs, dst=0, group=group)
+        dt = recs.dtype if recs is not None else None
+        parts = []
+        for r in range(world):
+            if counts[r] == 0:
+                continue
+            a = rbs[r][:counts[r] * item].cpu().numpy()
+            parts.append((a.view(dt) if dt is not None else a, gbs[r][:counts[r]].cpu().numpy()))
+        return merge_by_group(parts)
+    dist.gather(rb, None, dst=0, group=group)
+    dist.gather(gb, None, dst=0, group=group)
+    return None

@@ -42,6 +42,58 @@ def kernel_name(stage, ntaps, dog):
     return "blur_col_kernel<%d,4,%s>" % (r, "true" if dog else "false")
 
 
+def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
+    """ONE n^3 volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records."""
+    zs = importlib.import_module("3d_sift_cuda_amd.zslab")
+    n = args.size
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(1, ndev)
+    plan = zs.SlabPlan(n, n, n, world)
+    i0, i1 = plan.input_range(rank)
+    slab = pkg.synth_blobs(n, n, n, seed=12345)[i0:i1].copy()
+    ctx = pkg.Context(n, n, (i1 - i0) + 2 * zs.HALO, device=dev)
+    be = zs.HipBackend(pkg, ctx, torch)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        with be.stream_scope():
+            ex = zs.ZSlabExtractor(be, plan, rank, dist)
+            ex.run(slab, i0)
+            recs, grp = ex.describe(desc_mode=args.desc)
+            merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev)
+        return ex, merged
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ex, merged = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda:%d" % dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ms_per_step = 1e3 * float(el.item()) / args.steps
+    if rank == 0:
+        nrec = 0 if merged is None else len(merged)
+        print(json.dumps({
+            "metric": "keypoints/s (.key records per second)", "value": round(nrec / (ms_per_step * 1e-3), 1),
+            "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ONE %d^3 float32 blob-field volume cut into %d Z-slabs, full featExtract path, all octaves" % (n, world),
+                       "records": nrec, "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
+                       "parallelism": "zslab%d: halo exchange with torch.distributed (%s), coarse octaves on rank 0" % (world, dist.get_backend()),
+                       "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"]}}))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +102,9 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume (512 = the BASELINE metric)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU-baseline sample volume (0 = skip)")
     ap.add_argument("--desc", type=int, default=0, help="0 SIFT-rank, 1 BRIEF, 2 RRIEF, 3 NRRIEF")
+    ap.add_argument("--mode", default="volumes", choices=["volumes", "zslab"],
+                    help="N > 1: 'volumes' = one volume per GPU (default, weak scaling); 'zslab' = ONE volume cut into "
+                         "Z-slabs with halo exchange over torch.distributed (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -59,8 +114,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # (ranks share a GPU only in the gloo rehearsal)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SIFT3D_DIST_BACKEND", "nccl")   # "gloo" only for the single-GPU rehearsal of zslab mode
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
 
@@ -68,6 +128,8 @@ def main():
     if not os.path.exists(pkg.LIB_HIP):
         raise SystemExit("libsift3d_hip.so missing: run python __graft_entry__.py (no CPU fallback)")
     n = args.size
+    if args.mode == "zslab" and world > 1:
+        return zslab_main(args, pkg, torch, dist, rank, world, local_rank)
     vol = pkg.synth_blobs(n, n, n, seed=12345 + rank)
     ctx = pkg.Context(n, n, n, device=local_rank)
     dvol = torch.from_numpy(vol).to("cuda:%d" % local_rank)   # the input lives in HBM before timing starts
