@@ -59,7 +59,11 @@ struct sift3d_ctx {
     unsigned long long *keys_a, *keys_b;
     sift3d_cval *vals_a, *vals_b;
     int64_t cand_cap;
-    unsigned long long *d_count;
+    unsigned long long *d_count; /* [0] validated extrema, [1] own-level survivors of the level in flight, [2] survivor overflow high-water mark */
+    sift3d_survivor *surv;
+    unsigned long long *surv_counts; /* segment counters of the own-level list */
+    int64_t surv_cap;
+    int surv_div; /* own-level extrema expected per level: voxels / surv_div (+ slack); 1 after an overflow */
     void *sort_tmp;
     size_t sort_tmp_bytes;
     void *scan_tmp;
@@ -129,6 +133,8 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->vals_a);
     hipFree(c->vals_b);
     hipFree(c->d_count);
+    hipFree(c->surv);
+    hipFree(c->surv_counts);
     hipFree(c->sort_tmp);
     hipFree(c->scan_tmp);
     hipFree(c->d_levels);
@@ -196,6 +202,10 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->keys_a = c->keys_b = nullptr;
     c->vals_a = c->vals_b = nullptr;
     c->d_count = nullptr;
+    c->surv = nullptr;
+    c->surv_counts = nullptr;
+    c->surv_cap = 0;
+    c->surv_div = 64;
     c->sort_tmp = c->scan_tmp = nullptr;
     c->sort_tmp_bytes = c->scan_tmp_bytes = 0;
     c->d_levels = nullptr;
@@ -220,6 +230,9 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
+    c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
+    ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->surv_counts, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS) == hipSuccess;
     if (!ok) {
         free_dev(c);
         if (c->stream) hipStreamDestroy(c->stream);
@@ -531,33 +544,56 @@ static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
 {
     if (record) c->jobs.push_back(j);
     stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z);
+    /* own-level extrema are ~0.3 % of the voxels on blob fields (7 % on white noise): the list of a level is
+     * sized at 1/surv_div of its voxels; an overflow is flagged on the device and handled in cand_finalize */
+    int64_t cover = j.X * j.Y * j.Z / c->surv_div + 64 * 1024; /* split evenly over 64 segments */
+    if (cover > c->surv_cap) cover = c->surv_cap;
     HIPCHK(c, sift3d_launch_extrema(c->stream, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
-                                    c->vals_a, c->d_count, c->cand_cap));
+                                    c->vals_a, c->d_count, c->cand_cap, c->surv, c->surv_counts, c->d_count + 2, cover));
+    return SIFT3D_OK;
+}
+
+static int cand_replay(sift3d_ctx *c)
+{
+    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+    for (const level_job &j : c->jobs) {
+        int rc = cand_append(c, j, false);
+        if (rc) return rc;
+    }
     return SIFT3D_OK;
 }
 
 static int cand_finalize(sift3d_ctx *c, int64_t *count_out)
 {
-    for (int attempt = 0; attempt < 3; attempt++) {
-        unsigned long long cnt = 0;
-        HIPCHK(c, hipMemcpyAsync(&cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    for (int attempt = 0; attempt < 4; attempt++) {
+        unsigned long long cnt[3] = {0, 0, 0}; /* validated extrema, survivors of the last level, survivor overflow */
+        HIPCHK(c, hipMemcpyAsync(cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((int64_t)cnt > c->cand_cap) {
-            if (alloc_cands(c, (int64_t)cnt + (int64_t)cnt / 4 + 4096) != SIFT3D_OK)
-                return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown to %llu entries", cnt);
-            HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
-            for (const level_job &j : c->jobs) {
-                int rc = cand_append(c, j, false);
-                if (rc) return rc;
+        if (cnt[2] > 0) { /* an own-level list was cut short: make room and redo the extrema launches */
+            c->surv_div = 1;
+            if ((int64_t)cnt[2] > c->surv_cap) {
+                hipFree(c->surv);
+                c->surv = nullptr;
+                c->surv_cap = (int64_t)cnt[2] + (int64_t)cnt[2] / 4 + 4096;
+                HIPCHK(c, hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap));
             }
+            int rc = cand_replay(c);
+            if (rc) return rc;
+            continue;
+        }
+        if ((int64_t)cnt[0] > c->cand_cap) {
+            if (alloc_cands(c, (int64_t)cnt[0] + (int64_t)cnt[0] / 4 + 4096) != SIFT3D_OK)
+                return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown to %llu entries", cnt[0]);
+            int rc = cand_replay(c);
+            if (rc) return rc;
             continue;
         }
         HIPCHK(c, sift3d_sort_candidates(c->stream, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a,
-                                         c->vals_b, (int64_t)cnt));
-        *count_out = (int64_t)cnt;
+                                         c->vals_b, (int64_t)cnt[0]));
+        *count_out = (int64_t)cnt[0];
         return SIFT3D_OK;
     }
-    return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown");
+    return set_err(c, SIFT3D_ERR_MEMORY, "extrema buffers could not be grown");
 }
 
 extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d_cur, const float *d_next, int64_t nx,

@@ -354,22 +354,187 @@ __global__ void halve_size_kernel(const float *__restrict__ in, long long X, lon
 /* Extrema: strict max/min of d_cur over its 26 neighbours, then centre + 26 */
 /* of d_prev and (when present) of d_next: the decision of regFindFEATUREIO  */
 /* + peak/valleyFunction4D (R/src_common/MultiScale.cpp:2260-2524) followed  */
-/* by validateDifferencePeak/Valley3D (:1135-1318).  Lanes along x; a        */
-/* wavefront leaves as soon as none of its 64 voxels can still be an         */
-/* extremum (__any), so the other two levels are touched only around the     */
-/* rare survivors.  Survivors are appended with a wave-aggregated atomic;    */
-/* the host orders them afterwards (raster order = sort by linear index).    */
+/* by validateDifferencePeak/Valley3D (:1135-1318).                          */
+/*                                                                          */
+/* "c > every one of 26 neighbours" == "c > max of the 26", and max/min are  */
+/* exact, so the own-level test is done separably: a workgroup owns 64 x by  */
+/* EX_ROWS y and marches along z; each wavefront owns one row (two extra     */
+/* wavefronts carry the halo rows), gets its x-neighbours with wave-wide DPP */
+/* shifts, publishes the row's 3-max / 3-min through LDS, and keeps the 3x3  */
+/* plane max/min of planes z-1 and z+1 in registers.  Every voxel of d_cur   */
+/* is loaded once; d_prev / d_next are touched only around the rare          */
+/* survivors.  Survivors are appended with a wave-aggregated atomic; the     */
+/* radix sort restores raster order.                                         */
 /* ------------------------------------------------------------------------ */
+#define EX_SEGS 64          /* segments of the own-level extrema list (one atomic counter each) */
+#define EX_SEG_STRIDE 32    /* counters 32 x 8 bytes apart: different cache lines / L2 channels */
+#define EX_ROWS 2          /* output rows per wavefront */
+#define EX_LOAD (EX_ROWS + 2) /* rows loaded per plane (one halo row on each side) */
+#define EX_XOUT 248        /* output voxels per wavefront along x: 64 lanes x float4 minus one halo lane each side */
+
+__device__ __forceinline__ float dpp_from_lower(float v) /* lane l gets lane l-1 (lane 0 keeps its own) */
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper(float v) /* lane l gets lane l+1 (lane 63 keeps its own) */
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+/* max / min over the x-triple of every element of a row: rmax/rmin include the element, l2max/l2min do not */
+__device__ __forceinline__ void row_extrema(v4f a, float (&rmax)[4], float (&rmin)[4], float (&l2max)[4], float (&l2min)[4])
+{
+    const float v[6] = {dpp_from_lower(a.w), a.x, a.y, a.z, a.w, dpp_from_upper(a.x)};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        l2max[e] = fmaxf(v[e], v[e + 2]);
+        l2min[e] = fminf(v[e], v[e + 2]);
+        rmax[e] = fmaxf(l2max[e], v[e + 1]);
+        rmin[e] = fminf(l2min[e], v[e + 1]);
+    }
+}
+
+/* First phase.  One wavefront = 248 output voxels along x (64 lanes x float4; the first and last lane
+ * only supply x-neighbours) by EX_ROWS rows of ONE plane: it loads EX_ROWS+2 rows of the three planes
+ * z-1, z, z+1 as twelve independent 16-byte loads per lane (all in flight together, re-reads are L1/L2
+ * hits), reduces them in registers and hands the own-level extrema to the second phase. */
 __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
                                                       const float *__restrict__ dnext, int X, int Y, int Z, int z_first,
-                                                      int lvl_id,
-                                                      unsigned long long *__restrict__ keys,
+                                                      int z_last, int zchunk, int xtiles,
+                                                      sift3d_survivor *__restrict__ surv, unsigned long long *surv_count,
+                                                      long long surv_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6); /* wavefront index over (x tile, y tile) */
+    const int xt = wv % xtiles, yt = wv / xtiles;
+    const int y0 = 1 + yt * EX_ROWS;                 /* first output row */
+    if (y0 >= Y - 1) return;
+    const int z = z_first + blockIdx.y;
+    if (z >= z_last) return;
+    const int xv = xt * EX_XOUT - 4 + lane * 4;      /* x of this lane's first element (may be -4 or >= X: clamped loads) */
+    const int xld = xv < 0 ? 0 : (xv > X - 4 ? X - 4 : xv);
+    const long long XY = (long long)X * Y;
+    v4f pl[3][EX_LOAD];
+#pragma unroll
+    for (int r = 0; r < EX_LOAD; r++) {
+        int yy = y0 - 1 + r;
+        yy = yy < Y ? yy : Y - 1;
+        const long long off = (long long)yy * X + xld;
+#pragma unroll
+        for (int k = 0; k < 3; k++) pl[k][r] = vload<4>(dcur + (long long)(z - 1 + k) * XY + off);
+    }
+    float p9max[EX_ROWS][4], p9min[EX_ROWS][4]; /* over the 3x3 of planes z-1 and z+1 together */
+    float e8max[EX_ROWS][4], e8min[EX_ROWS][4]; /* over the 8 in-plane neighbours */
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float rmax[EX_LOAD][4], rmin[EX_LOAD][4], l2max[EX_LOAD][4], l2min[EX_LOAD][4];
+#pragma unroll
+        for (int r = 0; r < EX_LOAD; r++) row_extrema(pl[k][r], rmax[r], rmin[r], l2max[r], l2min[r]);
+#pragma unroll
+        for (int r = 0; r < EX_ROWS; r++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (k == 1) {
+                    e8max[r][e] = fmaxf(fmaxf(rmax[r][e], rmax[r + 2][e]), l2max[r + 1][e]);
+                    e8min[r][e] = fminf(fminf(rmin[r][e], rmin[r + 2][e]), l2min[r + 1][e]);
+                } else {
+                    const float m = fmaxf(fmaxf(rmax[r][e], rmax[r + 1][e]), rmax[r + 2][e]);
+                    const float n = fminf(fminf(rmin[r][e], rmin[r + 1][e]), rmin[r + 2][e]);
+                    p9max[r][e] = k == 0 ? m : fmaxf(p9max[r][e], m);
+                    p9min[r][e] = k == 0 ? n : fminf(p9min[r][e], n);
+                }
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < EX_ROWS; r++) {
+        const int y = y0 + r;
+        const v4f cv = pl[1][r + 1];
+        const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float c = cc[e];
+            const bool mx = c > fmaxf(e8max[r][e], p9max[r][e]);
+            const bool mn = c < fminf(e8min[r][e], p9min[r][e]);
+            const int x = xv + e;
+            if ((mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < X - 1 && y < Y - 1) {
+                /* own-level extremum: hand it to the second phase.  One returning atomic on a single word
+                 * saturates near 88 per microsecond chip-wide, so the list is cut into EX_SEGS segments with
+                 * counters 256 bytes apart and a workgroup appends to the segment its index hashes to */
+                const int seg = (int)((blockIdx.x + 7u * blockIdx.y) % EX_SEGS);
+                const unsigned long long slot = atomicAdd(surv_count + seg * EX_SEG_STRIDE, 1ull);
+                if ((long long)slot < surv_cap) {
+                    sift3d_survivor sv;
+                    sv.idx = (long long)z * XY + (long long)y * X + x;
+                    sv.value = c;
+                    sv.is_max = mx ? 1 : 0;
+                    surv[(long long)seg * surv_cap + (long long)slot] = sv;
+                }
+            }
+        }
+    }
+}
+
+/* Second phase: one thread per own-level extremum checks centre + 26 of d_prev and of d_next and
+ * appends the survivors as (key, value) pairs.  The list length lives in device memory, so the grid
+ * is sized for the capacity and surplus threads leave at once (no host round trip). */
+__global__ __launch_bounds__(256) void extrema_validate_kernel(const float *__restrict__ dprev, const float *__restrict__ dnext,
+                                                               int X, int Y, const sift3d_survivor *__restrict__ surv,
+                                                               const unsigned long long *__restrict__ surv_count,
+                                                               long long surv_cap, unsigned long long *surv_overflow,
+                                                               int lvl_id, unsigned long long *__restrict__ keys,
+                                                               sift3d_cval *__restrict__ vals, unsigned long long *count,
+                                                               long long cap)
+{
+    const int seg = blockIdx.y; /* surv_cap is the capacity of one segment */
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n = (long long)surv_count[seg * EX_SEG_STRIDE];
+    if (n > surv_cap) { /* the segment was cut short: tell the host how much room a replay needs */
+        if (i == 0) atomicMax(surv_overflow, (unsigned long long)n * EX_SEGS);
+        n = surv_cap;
+    }
+    if (i >= n) return;
+    const sift3d_survivor sv = surv[(long long)seg * surv_cap + i];
+    const long long XY = (long long)X * Y;
+    const float c = sv.value;
+    const bool mx = sv.is_max != 0;
+    bool ok = true;
+    const float *lv[2] = {dprev, dnext};
+    for (int l = 0; l < 2 && ok; l++) {
+        const float *d = lv[l];
+        if (!d) continue;
+        for (int dz = -1; dz <= 1 && ok; dz++) {
+            float q[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) q[k] = d[sv.idx + dz * XY + (k / 3 - 1) * X + (k % 3 - 1)];
+#pragma unroll
+            for (int k = 0; k < 9; k++) ok = ok && (mx ? (q[k] < c) : (q[k] > c));
+        }
+    }
+    if (!ok) return;
+    const unsigned long long slot = atomicAdd(count, 1ull);
+    if ((long long)slot < cap) {
+        sift3d_cval r;
+        r.value = c;
+        r.h = dprev[sv.idx];
+        r.l = dnext ? dnext[sv.idx] : 0.0f;
+        r.pad = 0.0f;
+        keys[slot] = ((unsigned long long)lvl_id << SIFT3D_KEY_LVL_SHIFT) |
+                     ((unsigned long long)(mx ? 1 : 0) << SIFT3D_KEY_MAX_SHIFT) | (unsigned long long)sv.idx;
+        vals[slot] = r;
+    }
+}
+
+/* Fallback for row lengths that are not a multiple of 4 (no aligned 16-byte rows) and for tiny volumes:
+ * lanes along x, 27 direct loads per voxel, wavefront-wide early-out. */
+__global__ __launch_bounds__(256) void extrema_generic_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
+                                                      const float *__restrict__ dnext, int X, int Y, int Z, int z_first,
+                                                      int lvl_id, unsigned long long *__restrict__ keys,
                                                       sift3d_cval *__restrict__ vals, unsigned long long *count,
                                                       long long cap)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z + z_first; /* z_first >= 1; the launcher sizes the grid to the kept planes */
+    const int z = blockIdx.z + z_first;
     const bool inside = (x >= 1 && x < X - 1 && y >= 1 && y < Y - 1);
     const long long XY = (long long)X * Y;
     const long long idx = (long long)z * XY + (long long)y * X + x;
@@ -419,6 +584,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
         }
     }
 }
+
 
 /* ------------------------------------------------------------------------ */
 /* launchers                                                                */
@@ -611,15 +777,34 @@ hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, i
 
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
                                  int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
-                                 sift3d_cval *vals, unsigned long long *count, int64_t cap)
+                                 sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
+                                 unsigned long long *surv_count, unsigned long long *surv_overflow, int64_t surv_cap)
 {
     if (X < 3 || Y < 3 || Z < 3) return hipSuccess;
     /* interior planes 1..Z-2, further restricted to [z_lo, z_hi) (Z-slab mode keeps only its own slices) */
     const int z0 = z_lo > 1 ? z_lo : 1;
     const int z1 = z_hi < (int)Z - 1 ? z_hi : (int)Z - 1;
     if (z1 <= z0) return hipSuccess;
-    dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(z1 - z0));
-    hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0, lvl_id, keys, vals,
-                       count, (long long)cap);
+    if (X % 4 == 0 && X >= 8 && surv && surv_cap > 0) {
+        const int xtiles = (int)((X - 2 + EX_XOUT - 1) / EX_XOUT);
+        const int ytiles = (int)((Y - 2 + EX_ROWS - 1) / EX_ROWS);
+        const long long waves_xy = (long long)xtiles * ytiles;
+        const int zchunk = 1; /* one output plane per workgroup row */
+        const unsigned nz = (unsigned)(z1 - z0);
+        hipError_t e = hipMemsetAsync(surv_count, 0, sizeof(unsigned long long) * EX_SEGS * EX_SEG_STRIDE, s);
+        if (e != hipSuccess) return e;
+        dim3 grid((unsigned)((waves_xy + 3) / 4), nz);
+        hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0, z1, zchunk,
+                           xtiles, surv, surv_count, (long long)(surv_cap / EX_SEGS));
+        /* the second launch covers the list capacity, reads the true length on the device, and flags an
+         * overflow for cand_finalize to widen the list and replay */
+        const long long segcap = surv_cap / EX_SEGS; /* the caller sized surv_cap: capacity == threads of the second launch */
+        hipLaunchKernelGGL(extrema_validate_kernel, dim3((unsigned)((segcap + 255) / 256), EX_SEGS), dim3(256), 0, s, dprev, dnext,
+                           (int)X, (int)Y, surv, surv_count, segcap, surv_overflow, lvl_id, keys, vals, count, (long long)cap);
+    } else {
+        dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(z1 - z0));
+        hipLaunchKernelGGL(extrema_generic_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0,
+                           lvl_id, keys, vals, count, (long long)cap);
+    }
     return hipGetLastError();
 }

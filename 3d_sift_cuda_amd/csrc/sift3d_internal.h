@@ -25,6 +25,12 @@ struct sift3d_taps {
 #define SIFT3D_KEY_LVL_SHIFT 40
 #define SIFT3D_KEY_MAX_SHIFT 39
 #define SIFT3D_KEY_IDX_MASK ((1ull << 39) - 1ull)
+/* an own-level extremum on its way to the two-level validation */
+struct sift3d_survivor {
+    long long idx;
+    float value;
+    int is_max;
+};
 struct sift3d_cval {
     float value, h, l, pad; /* DoG at the extremum, one level below (H), one level above (L) */
 };
@@ -55,7 +61,10 @@ hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, 
 hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
                                  int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
-                                 sift3d_cval *vals, unsigned long long *count, int64_t cap);
+                                 sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
+                                 unsigned long long *surv_count /* SIFT3D_SURV_COUNTERS words */,
+                                 unsigned long long *surv_overflow, int64_t surv_cap);
+#define SIFT3D_SURV_COUNTERS (64 * 32)
 
 /* ---- per-keypoint stage (kernels_keypoint.hip) ---- */
 struct sift3d_kp_params {
