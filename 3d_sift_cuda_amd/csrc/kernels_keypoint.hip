@@ -15,6 +15,8 @@
  * (9 lanes for the structure tensor, 8 lanes for the 8 corners of a splat, 64
  * lanes for the 64 descriptor bins).  Compiled with -ffp-contract=off.
  */
+#include <type_traits>
+
 #include "sift3d_internal.h"
 
 #define PD SIFT3D_PATCH_DIM
@@ -57,8 +59,13 @@ __device__ __forceinline__ float trilinear(const float *__restrict__ img, int X,
     iz = iz < 0 ? 0 : (iz > Zl - 2 ? Zl - 2 : iz);
     const long long XY = (long long)X * Y;
     const float *p = img + (long long)iz * XY + (long long)iy * X + ix;
-    float f000 = p[0], f100 = p[1], f010 = p[X], f110 = p[X + 1];
-    float f001 = p[XY], f101 = p[XY + 1], f011 = p[XY + X], f111 = p[XY + X + 1];
+    /* the two x-neighbours of a corner pair are adjacent in memory: four 8-byte gathers (dword aligned)
+     * instead of eight 4-byte ones */
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    const f2u q00 = *reinterpret_cast<const f2u *>(p), q10 = *reinterpret_cast<const f2u *>(p + X);
+    const f2u q01 = *reinterpret_cast<const f2u *>(p + XY), q11 = *reinterpret_cast<const f2u *>(p + XY + X);
+    const float f000 = q00.x, f100 = q00.y, f010 = q10.x, f110 = q10.y;
+    const float f001 = q01.x, f101 = q01.y, f011 = q11.x, f111 = q11.y;
     float fn00 = wx * f000 + (1.0f - wx) * f100;
     float fn01 = wx * f001 + (1.0f - wx) * f101;
     float fn10 = wx * f010 + (1.0f - wx) * f110;
@@ -582,6 +589,18 @@ __device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const sh
     __syncthreads();
 }
 
+/* Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, with its private L2), and the
+ * work items arrive sorted by (level, raster index), so neighbours in the list sample neighbouring
+ * image regions: give every XCD one contiguous eighth of the list instead of every eighth item, and
+ * the trilinear gathers of neighbouring keypoints / of the frames of one keypoint meet in one L2.
+ * Placement only changes speed, never results. */
+__device__ __forceinline__ long long xcd_contiguous_item(long long n)
+{
+    const long long b = blockIdx.x;
+    const long long per = (n + 7) / 8;
+    return (b % 8) * per + b / 8;
+}
+
 /* ---------------------------------------------------------------------- */
 /* Phase A: extremum -> keypoint (geometry, eigen test, orientation frames) */
 /* ---------------------------------------------------------------------- */
@@ -817,31 +836,35 @@ __constant__ unsigned char c_brief_y[192] = {
     3,5,4,2,3,6,4,5,6,3,3,5,1,3,1,6,7,4,1,4,3,5,2,4,2,1,2,5,4,5,2,3,3,3,3,4,2,6,3,4,3,3,3,6,1,2,5,4,2,4,1,4,6,7,3,6,2,4,3,6,5,6,4,0,
     6,6,5,1,4,7,2,1,5,3,4,2,2,7,3,3,6,4,2,4,1,9,7,7,5,2,7,1,7,5,5,1,5,4,1,3,3,4,0,5,1,6,3,5,3,2,3,3,7,2,5,1,1,0,4,1,3,1,0,3,1,6,5,9};
 
+struct kpB_sift { /* SIFT-rank: per interior voxel gradient magnitude + orientation octant, bucketed by octant */
+    float mag[NINT + 3];
+    unsigned short order[NINT + 3]; /* interior voxels sorted by (octant, raster); packed x | y<<4 | z<<8 */
+    unsigned char bin[NINT + 3];
+    int start[9];
+};
+struct kpB_brief { /* BRIEF family: blur temporaries */
+    float t1[PV + 1], t2[PV + 1];
+};
+/* LDS of one record: 10.6 KB for the SIFT-rank instantiation (15 wavefronts per CU), 16 KB for BRIEF */
+template <bool SIFT>
 struct kpB_smem {
     float patch[PV + 1];
-    union {
-        struct { /* SIFT-rank: per interior voxel gradient magnitude + orientation octant, bucketed by octant */
-            float mag[NINT + 3];
-            unsigned short order[NINT + 3]; /* interior voxels sorted by (octant, raster); packed x | y<<4 | z<<8 */
-            unsigned char bin[NINT + 3];
-            int start[9];
-        } s;
-        struct { /* BRIEF family: blur temporaries */
-            float t1[PV + 1], t2[PV + 1];
-        } b;
+    struct {
+        typename std::conditional<SIFT, kpB_sift, kpB_brief>::type v;
     } u;
     float sc[16];
     float taps[8];
     float wtab[2][PD + 1];
 };
 
+template <bool SIFT>
 __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
                                                         const int *__restrict__ rec_kp, const int *__restrict__ rec_frame,
                                                         long long nrec, sift3d_feature *__restrict__ recs,
                                                         int *__restrict__ rec_group, sift3d_taps taps5)
 {
-    __shared__ __attribute__((aligned(16))) kpB_smem sm;
-    const long long r = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) kpB_smem<SIFT> sm;
+    const long long r = xcd_contiguous_item(nrec);
     if (r >= nrec) return;
     const int lane = threadIdx.x;
     if (lane < 5) sm.taps[lane] = taps5.f[lane];
@@ -854,14 +877,20 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         for (int i = 0; i < 9; i++) ori[i] = kp->frames[fr * 9 + i];
     }
     const sift3d_level lv = p.levels[kp->lvl];
+    if (p.debug_stop == 21 || p.debug_stop == 22) { /* development aid: every record samples one cache-resident region */
+        wave_sample_patch(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
+        if (p.debug_stop == 21) return;
+    } else
     wave_sample_patch(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
     /* record 0 was normalised once inside generateFeature3D (MultiScale.cpp:1742) and
      * every record once more in main (featExtract.cpp:480) */
+    if (p.debug_stop == 11) return;
     if (fr < 0) wave_normalize_patch(sm.patch, sm.sc);
     wave_normalize_patch(sm.patch, sm.sc);
+    if (p.debug_stop == 12) return;
 
     float myval;
-    if (p.desc_mode == SIFT3D_DESC_SIFT) {
+    if constexpr (SIFT) {
         /* msResampleFeaturesGradientOrientationHistogram, MultiScale.cpp:583-710.  Border voxels
          * have zero gradient (FeatureIO.cpp:2307-2312) and are skipped there, so only the 9^3
          * interior takes part. */
@@ -887,8 +916,8 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
                     }
                 }
             }
-            sm.u.s.mag[q] = mg;
-            sm.u.s.bin[q] = (unsigned char)best;
+            sm.u.v.mag[q] = mg;
+            sm.u.v.bin[q] = (unsigned char)best;
         }
         if (lane < PD) {
             /* spatial coordinate of patch index c in the 2-bin grid (MultiScale.cpp:641-671), then the
@@ -908,53 +937,56 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
             sm.wtab[1][c] = 1.0f - w;
         }
         __syncthreads();
+        if (p.debug_stop == 13) return;
         /* bucket the interior voxels by octant, keeping raster order inside a bucket */
         int cnt[8];
 #pragma unroll
         for (int o = 0; o < 8; o++) cnt[o] = 0;
         for (int base = 0; base < NINT; base += 64) {
             const int q = base + lane;
-            const int b = q < NINT ? sm.u.s.bin[q] : 8;
+            const int b = q < NINT ? sm.u.v.bin[q] : 8;
 #pragma unroll
             for (int o = 0; o < 8; o++) cnt[o] += __popcll(__ballot(b == o));
         }
         if (lane == 0) {
             int acc = 0;
             for (int o = 0; o < 8; o++) {
-                sm.u.s.start[o] = acc;
+                sm.u.v.start[o] = acc;
                 acc += cnt[o];
             }
-            sm.u.s.start[8] = acc;
+            sm.u.v.start[8] = acc;
         }
         __syncthreads();
         int run[8];
 #pragma unroll
-        for (int o = 0; o < 8; o++) run[o] = sm.u.s.start[o];
+        for (int o = 0; o < 8; o++) run[o] = sm.u.v.start[o];
         for (int base = 0; base < NINT; base += 64) {
             const int q = base + lane;
-            const int b = q < NINT ? sm.u.s.bin[q] : 8;
+            const int b = q < NINT ? sm.u.v.bin[q] : 8;
 #pragma unroll
             for (int o = 0; o < 8; o++) {
                 const unsigned long long m = __ballot(b == o);
                 if (b == o) {
                     const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
-                    sm.u.s.order[run[o] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 4) | (z << 8));
+                    sm.u.v.order[run[o] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 4) | (z << 8));
                 }
                 run[o] += __popcll(m);
             }
         }
         __syncthreads();
+        if (p.debug_stop == 14) return;
         /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin over its octant's voxels */
         const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
         const float *wxs = sm.wtab[bx], *wys = sm.wtab[by], *wzs = sm.wtab[bz];
-        const int k0 = sm.u.s.start[o], k1 = sm.u.s.start[o + 1];
+        const int k0 = sm.u.v.start[o], k1 = sm.u.v.start[o + 1];
         float acc = 0;
         for (int kk = k0; kk < k1; kk++) {
-            const unsigned v = sm.u.s.order[kk];
+            const unsigned v = sm.u.v.order[kk];
             const int x = v & 15, y = (v >> 4) & 15, z = v >> 8;
-            const float mg = sm.u.s.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
+            const float mg = sm.u.v.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
             acc += mg * wxs[x] * wys[y] * wzs[z];
         }
+        if (p.debug_stop == 15) return;
         /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 */
         float mn = 100000;
         for (int i = 0; i < 64; i++) {
@@ -971,8 +1003,8 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         myval = v * div;
     } else {
         /* msResampleFeaturesBRIEF, MultiScale.cpp:989-1049 */
-        wave_blur_patch(sm.patch, sm.u.b.t1, sm.u.b.t2, sm.taps, 5);
-        const float *bl = sm.u.b.t1;
+        wave_blur_patch(sm.patch, sm.u.v.t1, sm.u.v.t2, sm.taps, 5);
+        const float *bl = sm.u.v.t1;
         const int x1 = c_brief_x[3 * lane], y1 = c_brief_x[3 * lane + 1], z1 = c_brief_x[3 * lane + 2];
         const int x2 = c_brief_y[3 * lane], y2 = c_brief_y[3 * lane + 1], z2 = c_brief_y[3 * lane + 2];
         float d = bl[x1 + y1 * PD + z1 * PD * PD] - bl[x2 + y2 * PD + z2 * PD * PD];
@@ -1052,7 +1084,12 @@ hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, c
     if (nrec <= 0) return hipSuccess;
     sift3d_taps t;
     for (int i = 0; i < 17; i++) t.f[i] = i < 5 ? taps5[i] : 0.0f;
-    hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)nrec), dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec,
-                       recs, rec_group, t);
+    const dim3 grid((unsigned)(((nrec + 7) / 8) * 8));
+    if (p.desc_mode == SIFT3D_DESC_SIFT)
+        hipLaunchKernelGGL(descriptor_kernel<true>, grid, dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
+                           rec_group, t);
+    else
+        hipLaunchKernelGGL(descriptor_kernel<false>, grid, dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
+                           rec_group, t);
     return hipGetLastError();
 }
