@@ -338,11 +338,18 @@ __device__ __forceinline__ void sort_eig(float w[3], float v[3][3])
 /* wave-cooperative building blocks (block = one wavefront of 64 lanes)    */
 /* ---------------------------------------------------------------------- */
 typedef float v4f __attribute__((ext_vector_type(4)));
+/* One workgroup of KP_NT threads (4 wavefronts) per keypoint / record.  The LDS footprint is per
+ * workgroup, so four wavefronts share what one used to hold alone: four times the wavefronts per CU for
+ * the order-independent phases (gathers, gradients, pre-passes, patch blurs, peak tests), while the
+ * sequential chains run on wavefront 0 and the others wait at the barrier. */
+#define KP_NT 256   /* phase A: four wavefronts per keypoint */
+#define DESC_NT 64  /* phase B: one wavefront per record (15 independent records per CU beat 8 four-wave workgroups) */
 #define NRAD 515 /* voxels of the 11^3 patch with dx^2+dy^2+dz^2 < 25 (all of them interior) */
 #define NRAD_PAD 516
 #define NINT 729 /* interior voxels 1..9 in each axis */
 
 /* sampleImage3D, R/src_common/MultiScale.cpp:2614-2714 (bounds test done by the caller) */
+template <int NT>
 __device__ __forceinline__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, int Zl,
                                                   int z_off, float fx, float fy, float fz, float scale, const float *ori9)
 {
@@ -352,11 +359,11 @@ __device__ __forceinline__ void wave_sample_patch(float *patch, const float *__r
     const int sr = PD / 2;
     const float sc = rad / (float)(sr);
     /* three samples per lane per trip: the 24 gathers of a trip are issued together */
-    for (int s0 = threadIdx.x; s0 < PV; s0 += 192) {
+    for (int s0 = threadIdx.x; s0 < PV; s0 += 3 * NT) {
         float pix[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-            const int s = s0 + 64 * u;
+            const int s = s0 + NT * u;
             pix[u] = 0;
             if (s < PV) {
                 const int xx = s % PD - sr, yy = (s / PD) % PD - sr, zz = s / (PD * PD) - sr;
@@ -377,7 +384,7 @@ __device__ __forceinline__ void wave_sample_patch(float *patch, const float *__r
         }
 #pragma unroll
         for (int u = 0; u < 3; u++)
-            if (s0 + 64 * u < PV) patch[s0 + 64 * u] = pix[u];
+            if (s0 + NT * u < PV) patch[s0 + NT * u] = pix[u];
     }
     __syncthreads();
 }
@@ -417,17 +424,18 @@ __device__ __forceinline__ float serial_sum_patch(const float *d)
 
 /* Feature3D::NormalizeData, R/src_common/MultiScale.cpp:127-205: the two
  * 1331-term sums are single sequential chains (lane 0). */
+template <int NT>
 __device__ __forceinline__ void wave_normalize_patch(float *d, float *scratch2)
 {
     if (threadIdx.x == 0) scratch2[0] = serial_sum_patch<false>(d) / (PD * PD * PD);
     __syncthreads();
     const float mean = scratch2[0];
-    for (int i = threadIdx.x; i < PV; i += 64) d[i] -= mean;
+    for (int i = threadIdx.x; i < PV; i += NT) d[i] -= mean;
     __syncthreads();
     if (threadIdx.x == 0) scratch2[1] = 1.0f / sqrtf(serial_sum_patch<true>(d));
     __syncthreads();
     const float div = scratch2[1];
-    for (int i = threadIdx.x; i < PV; i += 64) d[i] *= div;
+    for (int i = threadIdx.x; i < PV; i += NT) d[i] *= div;
     __syncthreads();
 }
 
@@ -438,26 +446,30 @@ __device__ __forceinline__ bool in_radius(int s)
     return fz * fz + fy * fy + fx * fx < (float)((PD / 2) * (PD / 2));
 }
 
-/* Raster-ordered list of the in-radius voxels (ballot compaction); returns the count (515). */
-__device__ __forceinline__ int wave_build_radius_list(unsigned short *rlist)
+/* Raster-ordered list of the in-radius voxels (ballot compaction by wavefront 0); returns the count (515). */
+__device__ __forceinline__ int wave_build_radius_list(unsigned short *rlist, int *n_lds)
 {
-    int n = 0;
-    for (int base = 0; base < PV; base += 64) {
-        const int s = base + threadIdx.x;
-        const bool in = s < PV && in_radius(s);
-        const unsigned long long m = __ballot(in);
-        if (in) rlist[n + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (unsigned short)s;
-        n += __popcll(m);
+    if (threadIdx.x < 64) {
+        int n = 0;
+        for (int base = 0; base < PV; base += 64) {
+            const int s = base + threadIdx.x;
+            const bool in = s < PV && in_radius(s);
+            const unsigned long long m = __ballot(in);
+            if (in) rlist[n + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (unsigned short)s;
+            n += __popcll(m);
+        }
+        if (threadIdx.x == 0) *n_lds = n;
     }
     __syncthreads();
-    return n;
+    return *n_lds;
 }
 
+template <int NT>
 __device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis, const float *taps, int ntaps)
 {
     const int h = ntaps / 2;
     const int st = axis == 0 ? 1 : (axis == 1 ? PD : PD * PD);
-    for (int s = threadIdx.x; s < PV; s += 64) {
+    for (int s = threadIdx.x; s < PV; s += NT) {
         const int c = axis == 0 ? s % PD : (axis == 1 ? (s / PD) % PD : s / (PD * PD));
         float acc = 0;
         for (int j = 0; j < ntaps; j++) {
@@ -471,50 +483,60 @@ __device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis
 /* 3- or 5-tap separable blur of an 11^3 LDS volume, pass order x,y,z, zero
  * borders (gb3d_blur3d on the patch: R/src_common/MultiScale.cpp:2850,2972,1032).
  * The result lands in tmp_a (in -> tmp_a -> tmp_b -> tmp_a); taps are in LDS. */
+template <int NT>
 __device__ __forceinline__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, const float *taps, int ntaps)
 {
-    blur_pass(in, tmp_a, 0, taps, ntaps);
-    blur_pass(tmp_a, tmp_b, 1, taps, ntaps);
-    blur_pass(tmp_b, tmp_a, 2, taps, ntaps);
+    blur_pass<NT>(in, tmp_a, 0, taps, ntaps);
+    blur_pass<NT>(tmp_a, tmp_b, 1, taps, ntaps);
+    blur_pass<NT>(tmp_b, tmp_a, 2, taps, ntaps);
 }
 
 /* regFindFEATUREIOPeaks without callback (R/src_common/MultiScale.cpp:1987-2121)
- * + lvSortHighLow (R/src_common/LocationValue.cpp:28-56, stable): peaks of g in
- * raster order via ballot compaction, then a stable descending rank by
- * counting.  Returns the count; pk_idx/pk_val hold the sorted list. */
-__device__ __forceinline__ int wave_peaks_sorted(const float *g, short *raw_idx, float *raw_val, short *pk_idx, float *pk_val)
+ * + lvSortHighLow (R/src_common/LocationValue.cpp:28-56, stable): every thread tests its voxels
+ * and leaves a flag, wavefront 0 compacts the flags in raster order (ballot), then a stable
+ * descending rank by counting.  Returns the count; pk_idx/pk_val hold the sorted list.
+ * flags: PV bytes of scratch LDS; n_lds: one LDS int. */
+template <int NT>
+__device__ __forceinline__ int wave_peaks_sorted(const float *g, unsigned char *flags, int *n_lds, short *raw_idx, float *raw_val,
+                                                 short *pk_idx, float *pk_val)
 {
-    int n = 0;
-    for (int base = 0; base < PV; base += 64) {
-        const int s = base + threadIdx.x;
+    for (int s = threadIdx.x; s < PV; s += NT) {
         bool pk = false;
-        float c = 0;
-        if (s < PV) {
-            const int x = s % PD, y = (s / PD) % PD, z = s / (PD * PD);
-            if (x >= 1 && x < PD - 1 && y >= 1 && y < PD - 1 && z >= 1 && z < PD - 1) {
-                c = g[s];
-                pk = true;
+        const int x = s % PD, y = (s / PD) % PD, z = s / (PD * PD);
+        if (x >= 1 && x < PD - 1 && y >= 1 && y < PD - 1 && z >= 1 && z < PD - 1) {
+            const float c = g[s];
+            pk = true;
 #pragma unroll
-                for (int dz = -1; dz <= 1; dz++)
+            for (int dz = -1; dz <= 1; dz++)
 #pragma unroll
-                    for (int dy = -1; dy <= 1; dy++)
+                for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-                        for (int dx = -1; dx <= 1; dx++) {
-                            if (!dz && !dy && !dx) continue;
-                            pk = pk && (g[s + (dz * PD + dy) * PD + dx] < c);
-                        }
-            }
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (!dz && !dy && !dx) continue;
+                        pk = pk && (g[s + (dz * PD + dy) * PD + dx] < c);
+                    }
         }
-        const unsigned long long m = __ballot(pk);
-        if (pk) {
-            const int pos = n + __popcll(m & ((1ull << threadIdx.x) - 1ull));
-            raw_idx[pos] = (short)s;
-            raw_val[pos] = c;
-        }
-        n += __popcll(m);
+        flags[s] = pk ? 1 : 0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 64) {
+    if (threadIdx.x < 64) {
+        int n = 0;
+        for (int base = 0; base < PV; base += 64) {
+            const int s = base + threadIdx.x;
+            const bool pk = s < PV && flags[s] != 0;
+            const unsigned long long m = __ballot(pk);
+            if (pk) {
+                const int pos = n + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+                raw_idx[pos] = (short)s;
+                raw_val[pos] = g[s];
+            }
+            n += __popcll(m);
+        }
+        if (threadIdx.x == 0) *n_lds = n;
+    }
+    __syncthreads();
+    const int n = *n_lds;
+    for (int i = threadIdx.x; i < n; i += NT) {
         const float vi = raw_val[i];
         int rank = 0;
         for (int j = 0; j < n; j++) {
@@ -565,6 +587,7 @@ __device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const sh
     const int slot = lane >> 3;
     const int a = lane & 1, b = (lane >> 1) & 1, c = (lane >> 2) & 1;
     float *g = grid; /* plain LDS accesses: a volatile generic pointer would turn them into system-scope flat ops */
+    if (lane < 64) /* wavefront 0 carries the chain */
     for (int g0 = 0; g0 < n; g0 += 8) {
         const int i = g0 + slot;
         const bool ok = i < n;
@@ -616,9 +639,10 @@ struct kpA_smem {
     float ori_data[PD * 3 + 3];
     float sc[16];
     float taps[8];
+    int cnt[4];
 };
 
-__global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(KP_NT) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
                                                       const sift3d_cval *__restrict__ vals, long long ncand,
                                                       sift3d_dkp *__restrict__ kps, int *__restrict__ nrec_out,
                                                       sift3d_taps taps3)
@@ -658,15 +682,15 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     }
     float *patch = sm.A;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    wave_sample_patch(patch, lv.img, X, Y, Z, lv.Zl, lv.z_off, fx, fy, fz, scale, ident);
+    wave_sample_patch<KP_NT>(patch, lv.img, X, Y, Z, lv.Zl, lv.z_off, fx, fy, fz, scale, ident);
     if (p.debug_stop == 1) { if (lane == 0) nrec_out[k] = 0; return; }
-    wave_normalize_patch(patch, sm.sc);
+    wave_normalize_patch<KP_NT>(patch, sm.sc);
     if (p.debug_stop == 2) { if (lane == 0) nrec_out[k] = 0; return; }
-    const int nrad = wave_build_radius_list(sm.rlist);
+    const int nrad = wave_build_radius_list(sm.rlist, &sm.cnt[0]);
 
     /* determineOrientation3D, MultiScale.cpp:2541-2607: gradients (fioGenerateEdgeImages3D,
      * FeatureIO.cpp:2284-2326) are only ever used inside the radius */
-    for (int i = lane; i < NRAD_PAD; i += 64) {
+    for (int i = lane; i < NRAD_PAD; i += KP_NT) {
         float a = 0, b = 0, c = 0;
         if (i < nrad) {
             const int s = sm.rlist[i];
@@ -723,8 +747,8 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     float *sp_wx = sm.Cc, *sp_wy = sm.Cc + NRAD_PAD; /* live only between the pre-pass and the end of the splat */
     float *sp_wz = sm.A, *sp_mag = sm.A + NRAD_PAD;
     const float radius = (float)(PD / 2);
-    for (int s = lane; s < PV; s += 64) t0[s] = 0;
-    for (int i = lane; i < nrad; i += 64) {
+    for (int s = lane; s < PV; s += KP_NT) t0[s] = 0;
+    for (int i = lane; i < nrad; i += KP_NT) {
         float e[3] = {sm.gx[i], sm.gy[i], sm.gz[i]};
         float m2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
         float mg = 0, wx = 0, wy = 0, wz = 0;
@@ -742,9 +766,9 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
     if (p.debug_stop == 5) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
     if (p.debug_stop == 6) { if (lane == 0) nrec_out[k] = 0; return; }
-    wave_blur_patch(t0, ta, tb, sm.taps, 3);
+    wave_blur_patch<KP_NT>(t0, ta, tb, sm.taps, 3);
     if (p.debug_stop == 7) { if (lane == 0) nrec_out[k] = 0; return; }
-    const int npk = wave_peaks_sorted(ta, sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
+    const int npk = wave_peaks_sorted<KP_NT>(ta, reinterpret_cast<unsigned char *>(tb), &sm.cnt[1], sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
     if (p.debug_stop == 8) { if (lane == 0) nrec_out[k] = 0; return; }
 
     if (lane < npk && lane < PD && lane < 30) {
@@ -764,8 +788,8 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         if ((double)sm.pk_val[i] < 0.8 * (double)pk0) break;
         const float p1[3] = {sm.ori_data[i * 3], sm.ori_data[i * 3 + 1], sm.ori_data[i * 3 + 2]};
         __syncthreads();
-        for (int s = lane; s < PV; s += 64) t0[s] = 0;
-        for (int q = lane; q < nrad; q += 64) {
+        for (int s = lane; s < PV; s += KP_NT) t0[s] = 0;
+        for (int q = lane; q < nrad; q += KP_NT) {
             float e[3] = {sm.gx[q], sm.gy[q], sm.gz[q]};
             float mg = v3_mag(e);
             float wx = 0, wy = 0, wz = 0;
@@ -789,8 +813,8 @@ __global__ __launch_bounds__(64) void keypoint_kernel(sift3d_kp_params p, const 
         }
         __syncthreads();
         wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
-        wave_blur_patch(t0, ta, tb, sm.taps, 3);
-        const int npk2 = wave_peaks_sorted(ta, sm.raw_idx, sm.raw_val, sm.pk2_idx, sm.pk2_val);
+        wave_blur_patch<KP_NT>(t0, ta, tb, sm.taps, 3);
+        const int npk2 = wave_peaks_sorted<KP_NT>(ta, reinterpret_cast<unsigned char *>(tb), &sm.cnt[2], sm.raw_idx, sm.raw_val, sm.pk2_idx, sm.pk2_val);
         const float pk20 = npk2 > 0 ? sm.pk2_val[0] : 0.0f;
         for (int j = 0; j < npk2 && nret < PD && nret < 30; j++) {
             if (sm.pk2_val[j] < 0.5f * pk20) break;
@@ -858,7 +882,7 @@ struct kpB_smem {
 };
 
 template <bool SIFT>
-__global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
+__global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
                                                         const int *__restrict__ rec_kp, const int *__restrict__ rec_frame,
                                                         long long nrec, sift3d_feature *__restrict__ recs,
                                                         int *__restrict__ rec_group, sift3d_taps taps5)
@@ -878,23 +902,24 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
     }
     const sift3d_level lv = p.levels[kp->lvl];
     if (p.debug_stop == 21 || p.debug_stop == 22) { /* development aid: every record samples one cache-resident region */
-        wave_sample_patch(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
+        wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
         if (p.debug_stop == 21) return;
     } else
-    wave_sample_patch(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
+    wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
     /* record 0 was normalised once inside generateFeature3D (MultiScale.cpp:1742) and
      * every record once more in main (featExtract.cpp:480) */
     if (p.debug_stop == 11) return;
-    if (fr < 0) wave_normalize_patch(sm.patch, sm.sc);
-    wave_normalize_patch(sm.patch, sm.sc);
+    if (fr < 0) wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);
+    wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);
     if (p.debug_stop == 12) return;
 
-    float myval;
+    const bool w0 = lane < 64; /* wavefront 0: lane = descriptor bin for everything that follows the parallel pre-pass */
+    float myval = 0.0f;
     if constexpr (SIFT) {
         /* msResampleFeaturesGradientOrientationHistogram, MultiScale.cpp:583-710.  Border voxels
          * have zero gradient (FeatureIO.cpp:2307-2312) and are skipped there, so only the 9^3
          * interior takes part. */
-        for (int q = lane; q < NINT; q += 64) {
+        for (int q = lane; q < NINT; q += DESC_NT) {
             const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
             const int s = (z * PD + y) * PD + x;
             float e[3] = {sm.patch[s + 1] - sm.patch[s - 1], sm.patch[s + PD] - sm.patch[s - PD],
@@ -938,86 +963,89 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
         }
         __syncthreads();
         if (p.debug_stop == 13) return;
-        /* bucket the interior voxels by octant, keeping raster order inside a bucket */
-        int cnt[8];
+        /* bucket the interior voxels by octant, keeping raster order inside a bucket (wavefront 0, ballots) */
+        if (w0) {
+            int cnt[8];
 #pragma unroll
-        for (int o = 0; o < 8; o++) cnt[o] = 0;
-        for (int base = 0; base < NINT; base += 64) {
-            const int q = base + lane;
-            const int b = q < NINT ? sm.u.v.bin[q] : 8;
+            for (int o = 0; o < 8; o++) cnt[o] = 0;
+            for (int base = 0; base < NINT; base += 64) {
+                const int q = base + lane;
+                const int b = q < NINT ? sm.u.v.bin[q] : 8;
 #pragma unroll
-            for (int o = 0; o < 8; o++) cnt[o] += __popcll(__ballot(b == o));
-        }
-        if (lane == 0) {
-            int acc = 0;
-            for (int o = 0; o < 8; o++) {
-                sm.u.v.start[o] = acc;
-                acc += cnt[o];
+                for (int o = 0; o < 8; o++) cnt[o] += __popcll(__ballot(b == o));
             }
-            sm.u.v.start[8] = acc;
-        }
-        __syncthreads();
-        int run[8];
-#pragma unroll
-        for (int o = 0; o < 8; o++) run[o] = sm.u.v.start[o];
-        for (int base = 0; base < NINT; base += 64) {
-            const int q = base + lane;
-            const int b = q < NINT ? sm.u.v.bin[q] : 8;
+            int run[8];
+            int acc0 = 0;
 #pragma unroll
             for (int o = 0; o < 8; o++) {
-                const unsigned long long m = __ballot(b == o);
-                if (b == o) {
-                    const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
-                    sm.u.v.order[run[o] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 4) | (z << 8));
+                run[o] = acc0;
+                if (lane == 0) sm.u.v.start[o] = acc0;
+                acc0 += cnt[o];
+            }
+            if (lane == 0) sm.u.v.start[8] = acc0;
+            for (int base = 0; base < NINT; base += 64) {
+                const int q = base + lane;
+                const int b = q < NINT ? sm.u.v.bin[q] : 8;
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const unsigned long long m = __ballot(b == o);
+                    if (b == o) {
+                        const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
+                        sm.u.v.order[run[o] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 4) | (z << 8));
+                    }
+                    run[o] += __popcll(m);
                 }
-                run[o] += __popcll(m);
             }
         }
         __syncthreads();
         if (p.debug_stop == 14) return;
-        /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin over its octant's voxels */
-        const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
-        const float *wxs = sm.wtab[bx], *wys = sm.wtab[by], *wzs = sm.wtab[bz];
-        const int k0 = sm.u.v.start[o], k1 = sm.u.v.start[o + 1];
-        float acc = 0;
-        for (int kk = k0; kk < k1; kk++) {
-            const unsigned v = sm.u.v.order[kk];
-            const int x = v & 15, y = (v >> 4) & 15, z = v >> 8;
-            const float mg = sm.u.v.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
-            acc += mg * wxs[x] * wys[y] * wzs[z];
+        if (w0) {
+            /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin over its octant's voxels */
+            const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
+            const float *wxs = sm.wtab[bx], *wys = sm.wtab[by], *wzs = sm.wtab[bz];
+            const int k0 = sm.u.v.start[o], k1 = sm.u.v.start[o + 1];
+            float acc = 0;
+            for (int kk = k0; kk < k1; kk++) {
+                const unsigned v = sm.u.v.order[kk];
+                const int x = v & 15, y = (v >> 4) & 15, z = v >> 8;
+                const float mg = sm.u.v.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
+                acc += mg * wxs[x] * wys[y] * wzs[z];
+            }
+            /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 */
+            float mn = 100000;
+            for (int i = 0; i < 64; i++) {
+                float vi = __shfl(acc, i);
+                if (vi < mn) mn = vi;
+            }
+            float v = acc - mn;
+            float ss = 0;
+            for (int i = 0; i < 64; i++) {
+                float vi = __shfl(v, i);
+                ss += vi * vi;
+            }
+            float div = 1.0f / sqrtf(ss);
+            myval = v * div;
         }
-        if (p.debug_stop == 15) return;
-        /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 */
-        float mn = 100000;
-        for (int i = 0; i < 64; i++) {
-            float vi = __shfl(acc, i);
-            if (vi < mn) mn = vi;
-        }
-        float v = acc - mn;
-        float ss = 0;
-        for (int i = 0; i < 64; i++) {
-            float vi = __shfl(v, i);
-            ss += vi * vi;
-        }
-        float div = 1.0f / sqrtf(ss);
-        myval = v * div;
     } else {
         /* msResampleFeaturesBRIEF, MultiScale.cpp:989-1049 */
-        wave_blur_patch(sm.patch, sm.u.v.t1, sm.u.v.t2, sm.taps, 5);
-        const float *bl = sm.u.v.t1;
-        const int x1 = c_brief_x[3 * lane], y1 = c_brief_x[3 * lane + 1], z1 = c_brief_x[3 * lane + 2];
-        const int x2 = c_brief_y[3 * lane], y2 = c_brief_y[3 * lane + 1], z2 = c_brief_y[3 * lane + 2];
-        float d = bl[x1 + y1 * PD + z1 * PD * PD] - bl[x2 + y2 * PD + z2 * PD * PD];
-        if (p.desc_mode == SIFT3D_DESC_BRIEF) {
-            myval = (d < 0) ? 1.0f : 0.0f;
-        } else if (p.desc_mode == SIFT3D_DESC_RRIEF) {
-            myval = d;
-        } else {
-            float fdx = x1 - x2, fdy = y1 - y2, fdz = z1 - z2;
-            int dist = (int)sqrtf(fdx * fdx + fdy * fdy + fdz * fdz);
-            myval = d / dist;
+        wave_blur_patch<DESC_NT>(sm.patch, sm.u.v.t1, sm.u.v.t2, sm.taps, 5);
+        if (w0) {
+            const float *bl = sm.u.v.t1;
+            const int x1 = c_brief_x[3 * lane], y1 = c_brief_x[3 * lane + 1], z1 = c_brief_x[3 * lane + 2];
+            const int x2 = c_brief_y[3 * lane], y2 = c_brief_y[3 * lane + 1], z2 = c_brief_y[3 * lane + 2];
+            float d = bl[x1 + y1 * PD + z1 * PD * PD] - bl[x2 + y2 * PD + z2 * PD * PD];
+            if (p.desc_mode == SIFT3D_DESC_BRIEF) {
+                myval = (d < 0) ? 1.0f : 0.0f;
+            } else if (p.desc_mode == SIFT3D_DESC_RRIEF) {
+                myval = d;
+            } else {
+                float fdx = x1 - x2, fdy = y1 - y2, fdz = z1 - z2;
+                int dist = (int)sqrtf(fdx * fdx + fdy * fdy + fdz * fdz);
+                myval = d / dist;
+            }
         }
     }
+    if (!w0) return;
     /* NormalizeDataRankedPCs, MultiScale.cpp:207-233, order of :3148-3176 */
     int rank = 0;
     for (int j = 0; j < 64; j++) {
@@ -1043,9 +1071,6 @@ __global__ __launch_bounds__(64) void descriptor_kernel(sift3d_kp_params p, cons
     }
 }
 
-/* ---------------------------------------------------------------------- */
-/* launchers                                                               */
-/* ---------------------------------------------------------------------- */
 /* record r of keypoint k: rec_kp = k, rec_frame = -1 (un-reoriented) or the frame index */
 __global__ void recmap_kernel(const int *__restrict__ nrec, const int *__restrict__ offs, long long ncand,
                               int *__restrict__ rec_kp, int *__restrict__ rec_frame)
@@ -1059,13 +1084,16 @@ __global__ void recmap_kernel(const int *__restrict__ nrec, const int *__restric
     }
 }
 
+/* ---------------------------------------------------------------------- */
+/* launchers                                                               */
+/* ---------------------------------------------------------------------- */
 hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const unsigned long long *keys,
                                     const sift3d_cval *vals, int64_t ncand, sift3d_dkp *kps, int *nrec, const float *taps3)
 {
     if (ncand <= 0) return hipSuccess;
     sift3d_taps t;
     for (int i = 0; i < 17; i++) t.f[i] = i < 3 ? taps3[i] : 0.0f;
-    hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)ncand), dim3(64), 0, s, p, keys, vals, (long long)ncand, kps, nrec, t);
+    hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)ncand), dim3(KP_NT), 0, s, p, keys, vals, (long long)ncand, kps, nrec, t);
     return hipGetLastError();
 }
 
@@ -1086,10 +1114,10 @@ hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, c
     for (int i = 0; i < 17; i++) t.f[i] = i < 5 ? taps5[i] : 0.0f;
     const dim3 grid((unsigned)(((nrec + 7) / 8) * 8));
     if (p.desc_mode == SIFT3D_DESC_SIFT)
-        hipLaunchKernelGGL(descriptor_kernel<true>, grid, dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
+        hipLaunchKernelGGL(descriptor_kernel<true>, grid, dim3(DESC_NT), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
                            rec_group, t);
     else
-        hipLaunchKernelGGL(descriptor_kernel<false>, grid, dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
+        hipLaunchKernelGGL(descriptor_kernel<false>, grid, dim3(DESC_NT), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
                            rec_group, t);
     return hipGetLastError();
 }
