@@ -787,19 +787,23 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
         if (nrec_total > 0) {
             rc = ensure_kp_buffers(c, 0, nrec_total);
             if (rc) return rc;
-            HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec, c->offs, ncand, c->rec_kp, c->rec_frame));
+            HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), c->stream));
+            HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec, c->offs, ncand, c->rec_kp, c->rec_frame, c->d_count + 3));
             stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nrec_total);
             HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, c->recs,
                                                 c->rec_group, taps5));
         }
     }
+    unsigned long long nkp = 0;
     if (nrec_total) {
+        HIPCHK(c, hipMemcpyAsync(&nkp, c->d_count + 3, sizeof(nkp), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_recs, c->recs, sizeof(sift3d_feature) * (size_t)nrec_total, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_group, c->rec_group, sizeof(int) * (size_t)nrec_total, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_end(c);
     c->last.n_records = nrec_total;
+    c->last.n_keypoints = (int64_t)nkp;
     *n_out = nrec_total;
     return SIFT3D_OK;
 }

@@ -1073,11 +1073,12 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
 
 /* record r of keypoint k: rec_kp = k, rec_frame = -1 (un-reoriented) or the frame index */
 __global__ void recmap_kernel(const int *__restrict__ nrec, const int *__restrict__ offs, long long ncand,
-                              int *__restrict__ rec_kp, int *__restrict__ rec_frame)
+                              int *__restrict__ rec_kp, int *__restrict__ rec_frame, unsigned long long *kp_count)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncand) return;
     const int n = nrec[k], o = offs[k];
+    if (n > 0) atomicAdd(kp_count, 1ull); /* keypoints that survived the bounds and eigenvalue tests (statistics) */
     for (int f = 0; f < n; f++) {
         rec_kp[o + f] = (int)k;
         rec_frame[o + f] = f - 1;
@@ -1097,11 +1098,12 @@ hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, co
     return hipGetLastError();
 }
 
-hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame)
+hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame,
+                                unsigned long long *kp_count)
 {
     if (ncand <= 0) return hipSuccess;
     hipLaunchKernelGGL(recmap_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s, nrec, offs, (long long)ncand,
-                       rec_kp, rec_frame);
+                       rec_kp, rec_frame, kp_count);
     return hipGetLastError();
 }
 

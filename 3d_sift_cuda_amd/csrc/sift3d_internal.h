@@ -88,7 +88,8 @@ struct sift3d_dkp {
 /* nrec[k] = 0 (rejected) or 1 + number of canonical frames */
 hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const unsigned long long *keys,
                                     const sift3d_cval *vals, int64_t ncand, sift3d_dkp *kps, int *nrec, const float *taps3);
-hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame);
+hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame,
+                                unsigned long long *kp_count);
 hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
                                      const int *rec_frame, int64_t nrec, sift3d_feature *recs, int *rec_group,
                                      const float *taps5);
