@@ -136,6 +136,7 @@ def host_lib():
     P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
     _sig(L.sift3d_synth_blobs, None, P, I64, I64, I64, C.c_uint32)
     _sig(L.nifti_min_write_f32, I, C.c_char_p, P, I, I, I, F, F, F)
+    _sig(L.nifti_min_write_f32_ex, I, C.c_char_p, P, I, I, I, F, F, F, P, P)
     _sig(L.sift3d_write_key, I, C.c_char_p, P, I64, F, I, P)
     _host = L
     return L
@@ -160,10 +161,14 @@ def synth_blobs(nx, ny, nz, seed=12345):
     return v
 
 
-def write_nifti(path, vol, voxel=(1.0, 1.0, 1.0)):
+def write_nifti(path, vol, voxel=(1.0, 1.0, 1.0), qform=None, sform=None):
+    """float32 .nii writer.  qform = (quatern_b, c, d, qoffset_x, y, z, qfac), sform = 12 floats (srow_x, y, z)."""
     vol = np.ascontiguousarray(vol, np.float32)
     nz, ny, nx = vol.shape
-    rc = host_lib().nifti_min_write_f32(os.fsencode(path), vol.ctypes.data, nx, ny, nz, *[float(v) for v in voxel])
+    q = None if qform is None else np.ascontiguousarray(qform, np.float32).reshape(7)
+    s = None if sform is None else np.ascontiguousarray(sform, np.float32).reshape(12)
+    rc = host_lib().nifti_min_write_f32_ex(os.fsencode(path), vol.ctypes.data, nx, ny, nz, *[float(v) for v in voxel],
+                                           None if q is None else q.ctypes.data, None if s is None else s.ctypes.data)
     if rc != 0:
         raise Sift3DError("could not write %s" % path)
 

@@ -9,7 +9,7 @@
  * -d<N> allocates and runs on HIP device N (the reference
  * allocates on device 0 and launches on N); without -d the reference runs its
  * CPU code, this build has no CPU path and runs on device 0 (results are
- * those of the CPU path by construction); -w / -ws are not in this round.
+ * those of the CPU path by construction).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +18,7 @@
 #include "keyfile.h"
 #include "nifti_min.h"
 #include "sift3d.h"
+#include "world.h"
 
 static int print_options(void)
 {
@@ -43,6 +44,7 @@ int main(int argc, char **argv)
     int iArg = 1;
     int bDoubleImageSize = 0;
     int desc_mode = SIFT3D_DESC_SIFT;
+    int bWorldCoordinates = 0;
     const float fEigThres = 140;
     while (iArg < argc && argv[iArg][0] == '-') {
         switch (argv[iArg][1]) {
@@ -66,8 +68,11 @@ int main(int argc, char **argv)
             break;
         case 'w':
         case 'W':
-            printf("Error: world coordinate output (-w) is not available in this build.\n");
-            return -1;
+            /* world coordinates imply isotropic extraction (featExtract.cpp:330-342) */
+            bWorldCoordinates = 1;
+            if (argv[iArg][2] == 's' || argv[iArg][2] == 'S') bWorldCoordinates = 2;
+            iArg++;
+            break;
         default:
             printf("Error: unknown command line argument: %s\n", argv[iArg]);
             print_options();
@@ -82,6 +87,10 @@ int main(int argc, char **argv)
 
     nifti_min_image img;
     if (nifti_min_read(argv[iArg], &img) < 0) {
+        printf("Error: could not read input file: %s\n", argv[iArg]);
+        return -1;
+    }
+    if (bWorldCoordinates && sift3d_world_make_isotropic(&img) < 0) {
         printf("Error: could not read input file: %s\n", argv[iArg]);
         return -1;
     }
@@ -133,10 +142,10 @@ int main(int argc, char **argv)
     if (bDoubleImageSize > 0) fSizeFactor /= 2;
     else if (bDoubleImageSize < 0) fSizeFactor *= 2;
 
-    const sift3d_feature *feats = NULL;
+    sift3d_feature *feats = NULL;
     int64_t n = 0;
     int rc = sift3d_set_volume(ctx, vol, PX, PY, PZ);
-    if (rc == SIFT3D_OK) rc = sift3d_extract_view(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
+    if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
     if (rc != SIFT3D_OK) {
         fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
         printf("Error: could not extract features, insufficient memory.\n");
@@ -146,13 +155,32 @@ int main(int argc, char **argv)
     char c1[200], c2[200], c3[400];
     sprintf(c1, "Extraction Voxel Resolution (ijk) : %d %d %d", (int)PX, (int)PY, (int)PZ);
     sprintf(c2, "Extraction Voxel Size (mm)  (ijk) : %f %f %f", 1.0f * img.dx, 1.0f * img.dy, 1.0f * img.dz);
-    sprintf(c3, "Feature Coordinate Space: voxels: 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0");
+    if (bWorldCoordinates) {
+        /* featExtract.cpp:447-458, 548-564 */
+        float(*m)[4] = img.qto_xyz;
+        const char *name = "qto_xyz";
+        if (bWorldCoordinates == 2) {
+            if (img.sform_code > 0) {
+                m = img.sto_xyz;
+                name = "sto_xyz";
+            } else {
+                printf("Error: sform_code <= 0, output to qto_xyz instead of sto_xyz");
+                name = "sto_xyz"; /* the reference keeps the sto_xyz label while using qto_xyz */
+            }
+        }
+        sift3d_world_transform(feats, n, m);
+        sprintf(c3, "Feature Coordinate Space: millimeters (%s) : %f %f %f %f %f %f %f %f %f %f %f %f 0.0 0.0 0.0 1.0", name,
+                1.0f * m[0][0], 1.0f * m[0][1], 1.0f * m[0][2], 1.0f * m[0][3], 1.0f * m[1][0], 1.0f * m[1][1], 1.0f * m[1][2],
+                1.0f * m[1][3], 1.0f * m[2][0], 1.0f * m[2][1], 1.0f * m[2][2], 1.0f * m[2][3]);
+    } else
+        sprintf(c3, "Feature Coordinate Space: voxels: 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0");
     const char *cm[3] = {c1, c2, c3};
     if (sift3d_write_key(argv[iArg + 1], feats, n, fEigThres, 3, cm) != 0) {
         fprintf(stderr, "Error: could not write %s\n", argv[iArg + 1]);
         return -1;
     }
     printf("\nDone.\n");
+    sift3d_free(feats);
     free(vol);
     sift3d_destroy(ctx);
     return 0;

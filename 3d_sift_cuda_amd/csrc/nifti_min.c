@@ -230,6 +230,12 @@ int nifti_min_read(const char *path, nifti_min_image *img)
 
 int nifti_min_write_f32(const char *path, const float *data, int nx, int ny, int nz, float dx, float dy, float dz)
 {
+    return nifti_min_write_f32_ex(path, data, nx, ny, nz, dx, dy, dz, 0, 0);
+}
+
+int nifti_min_write_f32_ex(const char *path, const float *data, int nx, int ny, int nz, float dx, float dy, float dz,
+                           const float *q, const float *srow)
+{
     unsigned char h[352];
     memset(h, 0, sizeof(h));
     int32_t sz = 348;
@@ -245,6 +251,17 @@ int nifti_min_write_f32(const char *path, const float *data, int nx, int ny, int
     memcpy(h + 108, &vo, 4);
     memcpy(h + 112, &slope, 4);
     h[123] = 2; /* xyzt_units: mm */
+    if (q) {
+        int16_t code = 1;
+        memcpy(h + 252, &code, 2);
+        memcpy(h + 256, q, 24); /* quatern_b,c,d, qoffset_x,y,z */
+        memcpy(h + 76, q + 6, 4); /* pixdim[0] = qfac */
+    }
+    if (srow) {
+        int16_t code = 1;
+        memcpy(h + 254, &code, 2);
+        memcpy(h + 280, srow, 48);
+    }
     memcpy(h + 344, "n+1", 4);
     size_t n = (size_t)nx * ny * nz * 4;
     if (ends_with(path, ".gz")) {

@@ -31,6 +31,10 @@ typedef struct {
 int nifti_min_read(const char *path, nifti_min_image *img);
 /* Writes a float32 single-file .nii (or .nii.gz by extension), voxel size (dx,dy,dz). */
 int nifti_min_write_f32(const char *path, const float *data, int nx, int ny, int nz, float dx, float dy, float dz);
+/* As above with a qform (quaternion b,c,d, offsets, qfac = pixdim[0]) and/or an sform (3 rows of 4):
+ * pass NULL to leave the corresponding code 0.  For tests of the -w / -ws options. */
+int nifti_min_write_f32_ex(const char *path, const float *data, int nx, int ny, int nz, float dx, float dy, float dz,
+                           const float *quatern_bcd_xyz_qfac /* 7 floats */, const float *srow /* 12 floats */);
 void nifti_min_free(nifti_min_image *img);
 
 #ifdef __cplusplus

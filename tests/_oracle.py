@@ -9,6 +9,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ODIR, "_build", "libsift3d_oracle.so")
 CLI = os.path.join(ODIR, "_build", "featExtract_oracle")
+
+# the -w / -ws test case: an anisotropic blob field with a qform (qfac -1) and an sform that differ
+WORLD_CASE = dict(dims=(96, 80, 56), seed=4242, voxel=(1.0, 1.25, 1.5),
+                  qform=(0.1, 0.2, 0.3, -30.0, 20.0, 5.0, -1.0),
+                  sform=(0.9, 0.1, 0.0, -10.0, -0.1, 1.1, 0.05, 7.0, 0.0, -0.05, 1.4, 3.0))
+
+
+def world_case_args(path):
+    """argv of `featExtract_oracle --synth` that writes WORLD_CASE to path."""
+    w = WORLD_CASE
+    return [CLI, "--synth"] + [str(v) for v in w["dims"]] + [str(w["seed"]), path] + \
+        [repr(float(v)) for v in w["voxel"] + w["qform"] + w["sform"]]
 REF = os.path.join(ODIR, "_ref", "libref_partial.so")
 
 EXT = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])

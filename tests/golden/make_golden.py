@@ -10,6 +10,11 @@ generator, so only expected outputs are stored):
       the same pipeline), run here on blob-field volumes written by our NIfTI
       writer.  The binary is executed unprivileged (uid nobody, no new privs)
       through an inherited file descriptor; nothing of it is copied.
+  refbin_aniso_w.key, refbin_aniso_ws.key
+      the same binary with -w / -ws on the anisotropic WORLD_CASE volume of
+      tests/_oracle.py (isotropic resampling + qto_xyz / sto_xyz world coordinates).
+  oracle_aniso_w.key, oracle_aniso_ws.key
+      the oracle CLI's output for the same two runs (regression pins).
   ref_taps.json
       raw Gaussian taps (hex floats) produced by the reference's own
       GaussianMask.cpp (compiled as it lies into oracle/_ref) for every sigma the
@@ -41,11 +46,11 @@ REFBIN = "/root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/bin/Linux/f
 CLI = _oracle.CLI
 
 
-def run_refbin(nii, key, cwd):
+def run_refbin(nii, key, cwd, flags=()):
     with open(REFBIN, "rb") as f:
         fd = f.fileno()
         cmd = ["timeout", "300", "setpriv", "--reuid=65534", "--regid=65534", "--clear-groups", "--no-new-privs",
-               "/lib64/ld-linux-x86-64.so.2", "/dev/fd/%d" % fd, nii, key]
+               "/lib64/ld-linux-x86-64.so.2", "/dev/fd/%d" % fd] + list(flags) + [nii, key]
         subprocess.run(cmd, cwd=cwd, check=True, pass_fds=(fd,), stdout=subprocess.DEVNULL)
 
 
@@ -69,6 +74,15 @@ def main():
     nii = os.path.join(work, "blob80.nii")
     subprocess.run([CLI, "--synth", "80", "64", "48", "777", nii], check=True)
     subprocess.run([CLI, nii, os.path.join(HERE, "oracle_blob80x64x48_sift.key")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    nii = os.path.join(work, "aniso.nii")
+    subprocess.run(_oracle.world_case_args(nii), check=True)
+    os.chmod(nii, 0o644)
+    for flag in ("-w", "-ws"):
+        run_refbin("aniso.nii", "ref_aniso%s.key" % flag, work, [flag])
+        shutil.copy(os.path.join(work, "ref_aniso%s.key" % flag), os.path.join(HERE, "refbin_aniso_%s.key" % flag[1:]))
+        subprocess.run([CLI, flag, nii, os.path.join(HERE, "oracle_aniso_%s.key" % flag[1:])], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
     ref = _oracle.load_ref()
     assert ref is not None, "oracle/_ref missing"

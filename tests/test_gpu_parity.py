@@ -190,6 +190,35 @@ def test_cli_key_file_is_byte_identical(built, oracle, tmp_path):
     assert subprocess.run([built.FEATEXTRACT, "-2+", "-d0", small, k1], capture_output=True).returncode == 0
     assert subprocess.run([_oracle.CLI, "-2+", small, k2], capture_output=True).returncode == 0
     assert open(k1, "rb").read() == open(k2, "rb").read()
+    # -2- likewise
+    assert subprocess.run([built.FEATEXTRACT, "-2-", "-d0", nii, k1], capture_output=True).returncode == 0
+    assert subprocess.run([_oracle.CLI, "-2-", nii, k2], capture_output=True).returncode == 0
+    assert open(k1, "rb").read() == open(k2, "rb").read() and len(open(k1).readlines()) > 8
+
+
+@pytest.mark.parametrize("flag", ["-w", "-ws"])
+def test_cli_world_coordinates(built, tmp_path, flag):
+    """-w / -ws on an anisotropic volume with distinct qform and sform: byte-identical to the oracle's .key."""
+    import _oracle
+    w = _oracle.WORLD_CASE
+    nii, k = str(tmp_path / "aniso.nii"), str(tmp_path / "gpu.key")
+    built.write_nifti(nii, vol_of(built, w["dims"], w["seed"]), w["voxel"], w["qform"], w["sform"])
+    r = subprocess.run([built.FEATEXTRACT, flag, "-d0", nii, k], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Input image: i=96 j=100 k=84" in r.stdout
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_aniso_%s.key" % flag[1:])
+    assert open(k, "rb").read() == open(gold, "rb").read()
+
+
+def test_cli_ws_without_sform_falls_back_to_qform(built, tmp_path):
+    import _oracle
+    w = _oracle.WORLD_CASE
+    nii, k1, k2 = str(tmp_path / "q.nii"), str(tmp_path / "a.key"), str(tmp_path / "b.key")
+    built.write_nifti(nii, vol_of(built, (64, 48, 40), 7), w["voxel"], w["qform"], None)
+    r = subprocess.run([built.FEATEXTRACT, "-ws", "-d0", nii, k1], capture_output=True, text=True)
+    assert r.returncode == 0 and "Error: sform_code <= 0, output to qto_xyz instead of sto_xyz" in r.stdout
+    assert subprocess.run([_oracle.CLI, "-ws", nii, k2], capture_output=True).returncode == 0
+    assert open(k1, "rb").read() == open(k2, "rb").read()
 
 
 def test_full_size_properties(built):
