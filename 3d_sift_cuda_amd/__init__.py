@@ -34,7 +34,7 @@ FEATEXTRACT = os.path.join(CSRC, "_build", "featExtract")
 
 DESC_SIFT, DESC_BRIEF, DESC_RRIEF, DESC_NRRIEF = 0, 1, 2, 3
 INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
-STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor")
+STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused")
 
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),
@@ -48,7 +48,7 @@ class Sift3DError(RuntimeError):
 
 
 class _Timings(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7), ("alg_bytes", C.c_double * 7),
+    _fields_ = [("ms", C.c_double * len(STAGES)), ("launches", C.c_int64 * len(STAGES)), ("alg_bytes", C.c_double * len(STAGES)),
                 ("n_octaves", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
                 ("n_records", C.c_int64), ("total_ms", C.c_double)]
 

@@ -55,6 +55,7 @@ struct sift3d_ctx {
     float *D[5];  /* DoG levels, same layout */
     float *T[2];  /* x- and y-pass intermediates */
     float *d_taps;
+    float *d_zeros; /* 256 bytes of 0.0f: what the fused blur reads outside the volume */
     /* extrema as (key, value) pairs, unsorted (a) and sorted (b) */
     unsigned long long *keys_a, *keys_b;
     sift3d_cval *vals_a, *vals_b;
@@ -128,6 +129,7 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->T[0]);
     hipFree(c->T[1]);
     hipFree(c->d_taps);
+    hipFree(c->d_zeros);
     hipFree(c->keys_a);
     hipFree(c->keys_b);
     hipFree(c->vals_a);
@@ -198,7 +200,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->vol = nullptr;
     for (int i = 0; i < 6; i++) c->L[i] = nullptr;
     for (int i = 0; i < 5; i++) c->D[i] = nullptr;
-    c->T[0] = c->T[1] = c->d_taps = nullptr;
+    c->T[0] = c->T[1] = c->d_taps = c->d_zeros = nullptr;
     c->keys_a = c->keys_b = nullptr;
     c->vals_a = c->vals_b = nullptr;
     c->d_count = nullptr;
@@ -227,6 +229,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_zeros, 256) == hipSuccess && hipMemset(c->d_zeros, 0, 256) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
@@ -306,8 +309,16 @@ struct stage_scope {
             hipEventRecord(e0, c->stream);
         }
     }
+    void cancel() /* the launch did not happen */
+    {
+        c->last.launches[stage] -= 1;
+        c->last.alg_bytes[stage] -= bytes;
+        if (c->timing) c->pool_used -= 2;
+        stage = -1;
+    }
     ~stage_scope()
     {
+        if (stage < 0) return;
         if (c->timing) {
             hipEventRecord(e1, c->stream);
             c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f});
@@ -391,6 +402,17 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     }
     if (n / 2 > SIFT3D_FAST_MAX_R)
         HIPCHK(c, hipMemcpyAsync(c->d_taps, taps, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    /* One fused launch per level where the volume fills the chip (it marches along z with few, fat workgroups);
+     * coarse octaves keep the three-pass path.  SIFT3D_BLUR_FUSED = 0 never / 2 always (tests, A/B timing). */
+    const char *fenv = getenv("SIFT3D_BLUR_FUSED");
+    const int fmode = fenv ? atoi(fenv) : 1;
+    if (fmode == 2 || (fmode == 1 && N >= (double)(1 << 22))) {
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog ? 12.0 : 8.0) * N, n, (int64_t)N);
+        hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, c->d_zeros, X, Y, Z, taps, n);
+        if (e == hipSuccess) return SIFT3D_OK;
+        if (e != hipErrorNotSupported) HIPCHK(c, e);
+        sc.cancel();
+    }
     {
         stage_scope sc(c, SIFT3D_STAGE_BLUR_X, 8.0 * N, n, (int64_t)N);
         HIPCHK(c, sift3d_launch_blur_x(c->stream, in, c->T[0], X, Y, Z, taps, n, c->d_taps));

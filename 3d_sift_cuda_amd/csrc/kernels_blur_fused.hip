@@ -1,0 +1,297 @@
+/*
+ * kernels_blur_fused.hip -- the three separable Gaussian passes and the DoG
+ * subtraction of one pyramid level in ONE kernel for gfx950 (MI355X).
+ *
+ * The three-launch path (kernels_volume.hip) moves 32 bytes per voxel and level
+ * through HBM (x: 4+4, y: 4+4, z+DoG: 4+4+4+4).  This kernel reads the level's
+ * input once and writes the blurred level and the DoG once: 12 bytes per voxel
+ * (8 when one of the two outputs is not needed) plus the halo, which neighbouring
+ * workgroups share through L2 / Infinity Cache.
+ *
+ * A workgroup (256 threads) owns a 64 x 16 (x, y) tile and marches along z:
+ *   A  x pass    every thread keeps an aligned window of one input row in
+ *                registers (loaded one plane ahead) and produces 8 outputs of
+ *                that row; the 16 + 2R rows of the tile and its y halo go to LDS;
+ *   B  y pass    every thread produces a 2 x 2 block (two rows of one column
+ *                pair) from LDS and appends it to a ring of the last 2R+1
+ *                xy-blurred planes, also in LDS;
+ *   C  z pass    every thread sums its own ring entries for the plane R steps
+ *                back, loads the input voxel of that plane (the "previous level"
+ *                of the DoG) and stores the level and input - level.
+ * The z range is cut into chunks (grid y) that recompute 2R lead-in planes.
+ *
+ * Arithmetic contract: identical to kernels_volume.hip (and to the reference's
+ * CPU path, R/src_common/GaussBlur3D.cpp:43-61,329-479): every pass is
+ *   acc = 0; for j ascending: acc = acc + f[j]*v[j]
+ * with separately rounded multiply and add (-ffp-contract=off; the packed
+ * v_pk_mul_f32 / v_pk_add_f32 forms are the same IEEE operations on two lanes),
+ * zeros outside the volume, float32 between the passes.  A zero tap adds +0 to an
+ * accumulator that is never -0, so zero rows / planes and skipped taps agree.
+ */
+#include <cstdlib>
+#include <type_traits>
+
+#include "sift3d_internal.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global
+ * load (s_waitcnt vmcnt(0)), which would expose the full HBM latency of the next plane's window once per
+ * plane; the only data workgroups exchange here lives in LDS. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#define FB_TX 64
+#define FB_TY 16
+#define FB_P1_ROWS 32 /* FB_TY + 2 * SIFT3D_FAST_MAX_R */
+
+struct fb_taps2 {
+    v2f f[2 * SIFT3D_FAST_MAX_R + 1]; /* (f[j], f[j]): a 64-bit scalar operand of the packed multiply */
+};
+
+template <int R>
+__global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                         float *__restrict__ dog, const float *__restrict__ zeros, int X,
+                                                         int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total,
+                                                         fb_taps2 t)
+{
+    constexpr int U = 2 * R + 1;
+    constexpr int NR = FB_TY + 2 * R;        /* rows of the x pass */
+    constexpr int H4 = ((R + 3) / 4) * 4;    /* window halo, whole 16-byte vectors */
+    constexpr int WIN = 8 + 2 * H4;          /* floats per window */
+    constexpr int NV = WIN / 4;              /* vectors per window */
+    __shared__ __attribute__((aligned(16))) float P1[FB_P1_ROWS * FB_TX];
+    __shared__ __attribute__((aligned(16))) float RING[U * FB_TY * FB_TX];
+
+    /* workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of tiles (y fastest,
+     * then x, then z chunk) so that the y halo of a tile is fetched by the L2 that holds its neighbour */
+    const long long lin = blockIdx.x;
+    const long long per = (total + 7) / 8;
+    const long long w = (lin % 8) * per + lin / 8;
+    if (w >= total) return;
+    const int ty = (int)(w % tiles_y);
+    const int tx = (int)((w / tiles_y) % tiles_x);
+    const int chunk = (int)(w / ((long long)tiles_y * tiles_x));
+    const int x0 = tx * FB_TX, y0 = ty * FB_TY;
+    const int zc0 = chunk * zlen;
+    const int zc1 = zc0 + zlen < Z ? zc0 + zlen : Z;
+    const int tid = threadIdx.x;
+    const long long XY = (long long)X * Y;
+    const int zfirst = zc0 - R, zlast = zc1 - 1 + R;
+
+    /* stage A role: row ar of the x pass, outputs x0 + axs .. + 7.  Every vector of the window has its own
+     * pointer that advances one plane per step; a vector outside the volume points at a zero page and does
+     * not advance, so the loop needs no masks. */
+    const int ar = tid >> 3, axs = (tid & 7) * 8;
+    const int agy = y0 - R + ar;
+    const bool arow = ar < NR && agy >= 0 && agy < Y;
+    const float *wp[NV]; /* this lane's vector k in the plane being loaded (kept in the global address space) */
+    unsigned wstep[NV];  /* floats to the same vector of the next plane (0 on the zero page) */
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int gx = x0 + axs - H4 + 4 * k;
+        const bool ok = arow && gx >= 0 && gx < X;
+        const long long e = (long long)zfirst * XY + (long long)agy * X + gx; /* negative before plane 0: not loaded */
+        wp[k] = ok ? in + e : zeros;
+        wstep[k] = ok ? (unsigned)XY : 0u;
+    }
+    /* stage B/C role: column pair bcp, rows 2*brs and 2*brs+1 of the tile */
+    const int bcp = tid & 31, brs = tid >> 5;
+    const int bx = x0 + 2 * bcp;
+    const int by = y0 + 2 * brs;
+    const bool st0 = bx < X && by < Y, st1 = bx < X && by + 1 < Y;
+    const long long boff0 = st0 ? (long long)by * X + bx : 0;
+    const long long boff1 = st1 ? (long long)(by + 1) * X + bx : 0;
+
+    v4f winA[NV]; /* window of the next plane: loaded one step before its x pass */
+    /* x pass of the plane whose window is in win[]: 8 outputs (4 pairs) to P1.  Output pair e, tap j reads the
+     * window floats s, s+1 with s = H4 - R + 2e + j: an aligned register pair when s is even, one of the
+     * WIN/2 - 1 odd pairs (built once per plane) when it is odd. */
+    auto x_pass = [&](const v4f(&win)[NV]) {
+        v2f ev[WIN / 2], od[WIN / 2 - 1];
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            ev[2 * k].x = win[k].x; ev[2 * k].y = win[k].y;
+            ev[2 * k + 1].x = win[k].z; ev[2 * k + 1].y = win[k].w;
+        }
+#pragma unroll
+        for (int m = 0; m < WIN / 2 - 1; m++) {
+            od[m].x = ev[m].y; od[m].y = ev[m + 1].x;
+        }
+        v2f o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v2f acc = v2f(0.0f);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                constexpr int base = H4 - R;
+                const int sidx = base + 2 * e + j;
+                const v2f p = (sidx & 1) ? od[(sidx - 1) / 2] : ev[sidx / 2];
+                acc = acc + t.f[j] * p;
+            }
+            o[e] = acc;
+        }
+        v4f r0, r1;
+        r0.x = o[0].x; r0.y = o[0].y; r0.z = o[1].x; r0.w = o[1].y;
+        r1.x = o[2].x; r1.y = o[2].y; r1.z = o[3].x; r1.w = o[3].y;
+        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs]) = r0;
+        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs + 4]) = r1;
+    };
+    /* loads the window of plane z (if it exists) and moves the pointers on to plane z + 1: called for
+     * consecutive planes */
+    auto load_window = [&](v4f(&win)[NV], int z) {
+        if (z >= 0 && z < Z && z <= zlast) {
+#pragma unroll
+            for (int k = 0; k < NV; k++) win[k] = *reinterpret_cast<const v4f *>(wp[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; k++) wp[k] += wstep[k];
+    };
+    load_window(winA, zfirst);
+    if (zfirst >= 0 && ar < NR) x_pass(winA); /* zfirst < Z always */
+    load_window(winA, zfirst + 1);
+
+    float *ring_me = RING + (2 * brs) * FB_TX + 2 * bcp;
+    int slot = 0; /* ring slot of the plane being produced */
+    /* the input voxels of the output plane (the previous level of the DoG), loaded one step ahead */
+    v2f pv0 = v2f(0.0f), pv1 = v2f(0.0f);
+    auto load_prev = [&](int z) {
+        if (z < zc1) {
+            const float *src = in + (long long)z * XY;
+            pv0 = *reinterpret_cast<const v2f *>(src + boff0);
+            pv1 = *reinterpret_cast<const v2f *>(src + boff1);
+        }
+    };
+    if (dog) load_prev(zc0);
+    /* One plane step; `win` holds plane zin + 1.  During the 2R lead-in steps of a chunk the
+     * ring is not full yet: the z pass then runs on stale LDS contents and its result is not stored (cheaper
+     * than a second copy of the loop body).  A plane outside the volume contributes zeros to the ring. */
+    auto step = [&](int zin, v4f(&win)[NV]) {
+        const bool plane = zin >= 0 && zin < Z;
+        const int zo = zin - R;
+        const bool emit = zo >= zc0; /* zo < zc1 by construction of zlast */
+        lds_barrier(); /* P1 holds the x pass of plane zin */
+        v2f p[U + 1];
+#pragma unroll
+        for (int q = 0; q < U + 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(2 * brs + q) * FB_TX + 2 * bcp]);
+        lds_barrier(); /* every wavefront has its rows of P1 in registers: P1 may be overwritten */
+        /* this thread's ring entries of the 2R older planes (thread-private data: no synchronisation) */
+        v2f q0[U - 1], q1[U - 1];
+        {
+            int s = slot + 1 == U ? 0 : slot + 1; /* slot of plane zin - 2R */
+#pragma unroll
+            for (int j = 0; j < U - 1; j++) {
+                const float *rp = ring_me + s * (FB_TY * FB_TX);
+                q0[j] = *reinterpret_cast<const v2f *>(rp);
+                q1[j] = *reinterpret_cast<const v2f *>(rp + FB_TX);
+                s = s + 1 == U ? 0 : s + 1;
+            }
+        }
+        /* ---- A: x pass of plane zin + 1, then reuse its buffer for the window of plane zin + 2 ---- */
+        if (zin + 1 >= 0 && zin + 1 < Z && zin + 1 <= zlast && ar < NR) x_pass(win);
+        load_window(win, zin + 2);
+        /* ---- B: y pass of plane zin, 2 rows x 2 columns per thread ---- */
+        v2f g0 = v2f(0.0f), g1 = v2f(0.0f);
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            g0 = g0 + t.f[j] * p[j];
+            g1 = g1 + t.f[j] * p[j + 1];
+        }
+        if (!plane) g0 = g1 = v2f(0.0f); /* P1 was stale */
+        *reinterpret_cast<v2f *>(ring_me + slot * (FB_TY * FB_TX)) = g0;
+        *reinterpret_cast<v2f *>(ring_me + slot * (FB_TY * FB_TX) + FB_TX) = g1;
+        /* ---- C: z pass for plane zo ---- */
+        v2f a0 = v2f(0.0f), a1 = v2f(0.0f);
+#pragma unroll
+        for (int j = 0; j < U - 1; j++) {
+            a0 = a0 + t.f[j] * q0[j];
+            a1 = a1 + t.f[j] * q1[j];
+        }
+        a0 = a0 + t.f[U - 1] * g0;
+        a1 = a1 + t.f[U - 1] * g1;
+        if (emit) {
+            const long long zoff = (long long)zo * XY;
+            if (out) {
+                if (st0) *reinterpret_cast<v2f *>(out + zoff + boff0) = a0;
+                if (st1) *reinterpret_cast<v2f *>(out + zoff + boff1) = a1;
+            }
+            if (dog) {
+                if (st0) *reinterpret_cast<v2f *>(dog + zoff + boff0) = pv0 - a0;
+                if (st1) *reinterpret_cast<v2f *>(dog + zoff + boff1) = pv1 - a1;
+                load_prev(zo + 1); /* for the next step */
+            }
+        }
+        slot = slot + 1 == U ? 0 : slot + 1;
+    };
+    for (int zin = zfirst; zin <= zlast; zin++) step(zin, winA);
+}
+
+/* chunks along z: enough workgroups to fill every CU's resident slots while the 2R lead-in planes stay cheap */
+static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
+{
+    const char *env = getenv("SIFT3D_FUSED_CHUNKS"); /* tuning / test aid: force the number of z chunks */
+    if (env && atoi(env) >= 1) return atoi(env);
+    /* time ~ rounds of resident workgroups x planes marched per workgroup */
+    const double slots = 256.0 * resident;
+    int best = 1;
+    double best_cost = 0;
+    for (int n = 1; n <= 256; n++) {
+        const int64_t zlen = (Z + n - 1) / n;
+        if (n > 1 && zlen < 4 * R) break;
+        const double wgs = (double)tiles * (double)((Z + zlen - 1) / zlen);
+        const double cost = (wgs <= slots ? 1.0 : wgs / slots) * (double)(zlen + 2 * R);
+        if (n == 1 || cost < best_cost) {
+            best = n;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+template <int R>
+static void launch_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
+                         int64_t Z, const fb_taps2 &t)
+{
+    static int resident = 0; /* workgroups of this instantiation one CU holds (LDS ring and registers) */
+    if (resident == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<R>, 256, 0) != hipSuccess || n < 1) n = 2;
+        resident = n;
+    }
+    const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + FB_TY - 1) / FB_TY);
+    const long long tiles = (long long)tiles_x * tiles_y;
+    const int n = fused_chunks(R, Z, tiles, resident);
+    const int zlen = (int)((Z + n - 1) / n);
+    const int nch = (int)((Z + zlen - 1) / zlen);
+    const long long total = tiles * nch;
+    const long long per = (total + 7) / 8;
+    hipLaunchKernelGGL((blur_fused_kernel<R>), dim3((unsigned)(8 * per)), dim3(256), 0, s, in, out, dog, zeros, (int)X, (int)Y,
+                       (int)Z, zlen, tiles_x, tiles_y, total, t);
+}
+
+/* Returns hipErrorNotSupported when the shape is outside this kernel (the caller then runs the three-pass
+ * path): rows must be whole 16-byte vectors and the filter at most 17 taps.  out or dog may be NULL.
+ * zeros: at least 16 bytes of device memory holding 0.0f. */
+hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X,
+                                    int64_t Y, int64_t Z, const float *taps, int ntaps)
+{
+    const int R = ntaps / 2;
+    if (R < 1 || R > SIFT3D_FAST_MAX_R || X % 4 != 0 || X * Y >= (1ll << 29) || (!out && !dog) || !zeros)
+        return hipErrorNotSupported;
+    fb_taps2 t;
+    for (int i = 0; i < 2 * SIFT3D_FAST_MAX_R + 1; i++) t.f[i] = v2f(i < ntaps ? taps[i] : 0.0f);
+    switch (R) {
+    case 1: launch_fused<1>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    case 2: launch_fused<2>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    case 3: launch_fused<3>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    case 4: launch_fused<4>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    case 5: launch_fused<5>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    case 6: launch_fused<6>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    case 7: launch_fused<7>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    default: launch_fused<8>(s, in, out, dog, zeros, X, Y, Z, t); break;
+    }
+    return hipGetLastError();
+}

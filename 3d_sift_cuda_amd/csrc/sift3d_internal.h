@@ -55,6 +55,9 @@ hipError_t sift3d_launch_blur_y(hipStream_t s, const float *in, float *out, int6
 /* prev/dog may be NULL (no DoG epilogue) */
 hipError_t sift3d_launch_blur_z(hipStream_t s, const float *in, float *out, const float *prev, float *dog, int64_t X,
                                 int64_t Y, int64_t Z, const float *taps, int ntaps, const float *d_taps);
+/* all three passes and the DoG in one kernel; hipErrorNotSupported when the shape is outside it */
+hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X,
+                                    int64_t Y, int64_t Z, const float *taps, int ntaps);
 hipError_t sift3d_launch_dog(hipStream_t s, const float *a, const float *b, float *out, int64_t n);
 hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);

@@ -196,6 +196,7 @@ typedef enum {
     SIFT3D_STAGE_EXTREMA,
     SIFT3D_STAGE_KEYPOINT,   /* refinement, patch, orientation frames */
     SIFT3D_STAGE_DESCRIPTOR,
+    SIFT3D_STAGE_BLUR_FUSED, /* x, y, z passes and the DoG store in one kernel */
     SIFT3D_STAGE_COUNT
 } sift3d_stage;
 typedef struct {

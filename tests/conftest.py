@@ -11,6 +11,10 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime: when a test process uses both torch and libsift3d_hip.so (device buffers for
+# the *_dev entry points), torch has to be loaded first so that the process ends up with ONE runtime.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

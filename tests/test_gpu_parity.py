@@ -39,6 +39,38 @@ def test_blur_bit_exact(built, oracle, dims):
             assert (bits(got) == bits(want)).all(), (dims, s, np.abs(got - want).max())
 
 
+FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37, 45), (68, 17, 3), (128, 64, 70)]
+
+
+@pytest.mark.parametrize("dims", FUSED_SHAPES)
+@pytest.mark.parametrize("chunks", [0, 3])
+def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, monkeypatch):
+    """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up), partial tiles
+    in x and y, volumes thinner than the filter, several z chunks: level and DoG bit-identical to the oracle."""
+    import torch
+    monkeypatch.setenv("SIFT3D_BLUR_FUSED", "2")
+    if chunks:
+        monkeypatch.setenv("SIFT3D_FUSED_CHUNKS", str(chunks))
+    vol = vol_of(built, dims, 5) - np.float32(1.5)
+    nx, ny, nz = dims
+    with built.Context(*dims) as ctx:
+        d_in = torch.from_numpy(vol).cuda()
+        d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
+        ctx.enable_timing(True)
+        for s in SIGMAS[1:]:
+            want = oracle.blur(vol, s)
+            ctx.gauss_blur_dog_dev(d_in.data_ptr(), d_out.data_ptr(), d_dog.data_ptr(), nx, ny, nz, s)
+            ctx.sync()
+            assert (bits(d_out.cpu().numpy()) == bits(want)).all(), (dims, s)
+            assert (bits(d_dog.cpu().numpy()) == bits(oracle.dog(vol, want))).all(), (dims, s)
+            d_out.zero_()
+            ctx.gauss_blur_dev(d_in.data_ptr(), d_out.data_ptr(), nx, ny, nz, s)   # no DoG output
+            ctx.sync()
+            assert (bits(d_out.cpu().numpy()) == bits(want)).all(), (dims, s)
+        log = ctx.launch_log()
+        assert (log["stage"] == built.STAGES.index("blur_fused")).all()   # the fused kernel is what ran
+
+
 def test_blur_generic_tap_counts(built, oracle):
     """sigmas outside the templated 3..17-tap range take the generic kernel."""
     dims = (40, 24, 20)

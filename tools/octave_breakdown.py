@@ -17,11 +17,12 @@ print("records %d  wall %.2f ms  stream first->last %.2f ms  sum of kernels %.2f
 ctx.enable_timing(False)
 t0 = time.perf_counter(); f = ctx.extract(); wall2 = time.perf_counter() - t0
 print("wall without event timing %.2f ms" % (wall2 * 1e3))
-sizes = sorted(set(int(v) for v in log["nvox"][log["stage"] <= 4]), reverse=True)
-print("%-12s" % "nvox" + "".join("%12s" % s for s in pkg.STAGES[:5]))
+vol_stages = (0, 1, 2, 7, 3, 4)
+sizes = sorted(set(int(v) for v in log["nvox"][np.isin(log["stage"], vol_stages)]), reverse=True)
+print("%-12s" % "nvox" + "".join("%12s" % pkg.STAGES[s] for s in vol_stages))
 for nv in sizes:
     row = []
-    for st in range(5):
+    for st in vol_stages:
         sel = log[(log["stage"] == st) & (log["nvox"] == nv)]
         row.append("%7.3f(%2d)" % (sel["ms"].sum(), len(sel)))
     print("%-12d" % nv + "".join("%12s" % r for r in row))
