@@ -343,7 +343,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
  * the order-independent phases (gathers, gradients, pre-passes, patch blurs, peak tests), while the
  * sequential chains run on wavefront 0 and the others wait at the barrier. */
 #define KP_NT 256   /* phase A: four wavefronts per keypoint */
-#define DESC_NT 64  /* phase B: one wavefront per record (15 independent records per CU beat 8 four-wave workgroups) */
+#define DESC_NT 128  /* phase B: one wavefront per record (15 independent records per CU beat 8 four-wave workgroups) */
 #define NRAD 515 /* voxels of the 11^3 patch with dx^2+dy^2+dz^2 < 25 (all of them interior) */
 #define NRAD_PAD 516
 #define NINT 729 /* interior voxels 1..9 in each axis */
@@ -642,7 +642,7 @@ struct kpA_smem {
     int cnt[4];
 };
 
-__global__ __launch_bounds__(KP_NT) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
                                                       const sift3d_cval *__restrict__ vals, long long ncand,
                                                       sift3d_dkp *__restrict__ kps, int *__restrict__ nrec_out,
                                                       sift3d_taps taps3)
