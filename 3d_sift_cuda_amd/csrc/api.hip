@@ -47,6 +47,8 @@ struct octave_dims {
 struct sift3d_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t copy_stream;   /* record download, overlapped with the descriptor launches */
+    hipEvent_t ev_chunk[4];
     bool own_stream;
     int64_t capN;   /* voxels of the largest volume */
     int64_t capTot; /* floats per level buffer: all octaves of a capN volume back to back */
@@ -222,6 +224,10 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 64 * 34;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    c->copy_stream = nullptr;
+    for (int i = 0; i < 4; i++) c->ev_chunk[i] = nullptr;
+    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
     const size_t vb = sizeof(float) * (size_t)c->capN;
     const size_t tb = sizeof(float) * (size_t)c->capTot;
     ok = ok && hipMalloc((void **)&c->vol, vb) == hipSuccess;
@@ -239,6 +245,9 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     if (!ok) {
         free_dev(c);
         if (c->stream) hipStreamDestroy(c->stream);
+        if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+        for (int i = 0; i < 4; i++)
+            if (c->ev_chunk[i]) hipEventDestroy(c->ev_chunk[i]);
         delete c;
         return nullptr;
     }
@@ -252,6 +261,9 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
     hipStreamSynchronize(c->stream);
     free_dev(c);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
+    hipStreamSynchronize(c->copy_stream);
+    hipStreamDestroy(c->copy_stream);
+    for (int i = 0; i < 4; i++) hipEventDestroy(c->ev_chunk[i]);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -811,18 +823,27 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
             if (rc) return rc;
             HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), c->stream));
             HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec, c->offs, ncand, c->rec_kp, c->rec_frame, c->d_count + 3));
+            /* The records are 324 bytes each: their download is a millisecond at 512^3.  Describe them in up to four
+             * slices and copy each slice on a second stream while the next one is being computed. */
             stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nrec_total);
-            HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, c->recs,
-                                                c->rec_group, taps5));
+            const int nslice = nrec_total >= 32768 ? 4 : 1;
+            const int64_t per = (nrec_total + nslice - 1) / nslice;
+            for (int k = 0; k < nslice; k++) {
+                const int64_t o = k * per, m = std::min<int64_t>(per, nrec_total - o);
+                if (m <= 0) break;
+                HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp + o, c->rec_frame + o, m, c->recs + o,
+                                                    c->rec_group + o, taps5));
+                HIPCHK(c, hipEventRecord(c->ev_chunk[k], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_chunk[k], 0));
+                HIPCHK(c, hipMemcpyAsync(c->h_recs + o, c->recs + o, sizeof(sift3d_feature) * (size_t)m, hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(c->h_group + o, c->rec_group + o, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->copy_stream));
+            }
         }
     }
     unsigned long long nkp = 0;
-    if (nrec_total) {
-        HIPCHK(c, hipMemcpyAsync(&nkp, c->d_count + 3, sizeof(nkp), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_recs, c->recs, sizeof(sift3d_feature) * (size_t)nrec_total, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_group, c->rec_group, sizeof(int) * (size_t)nrec_total, hipMemcpyDeviceToHost, c->stream));
-    }
+    if (nrec_total) HIPCHK(c, hipMemcpyAsync(&nkp, c->d_count + 3, sizeof(nkp), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nrec_total) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     timing_end(c);
     c->last.n_records = nrec_total;
     c->last.n_keypoints = (int64_t)nkp;

@@ -474,6 +474,121 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
     }
 }
 
+/* First phase, marching form (used when the volume has enough planes): the same wavefront tile, but the
+ * wavefront walks a chunk of planes and keeps, for the three planes around the output plane, what the test
+ * needs -- the 3x3 max/min around every voxel, the 8-neighbour max/min and the centre values -- so every
+ * plane is loaded and reduced once instead of three times.  The decisions are the same max/min/compare
+ * operations on the same values as extrema_kernel. */
+struct ex_plane {
+    float m[EX_ROWS][4], n[EX_ROWS][4];       /* 3x3 max / min around the voxel, centre included */
+    float e8max[EX_ROWS][4], e8min[EX_ROWS][4]; /* the 8 in-plane neighbours */
+    float c[EX_ROWS][4];
+};
+
+__device__ __forceinline__ void ex_reduce_plane(const v4f (&raw)[EX_LOAD], ex_plane &o)
+{
+    float rmax[EX_LOAD][4], rmin[EX_LOAD][4], l2max[EX_LOAD][4], l2min[EX_LOAD][4];
+#pragma unroll
+    for (int r = 0; r < EX_LOAD; r++) row_extrema(raw[r], rmax[r], rmin[r], l2max[r], l2min[r]);
+#pragma unroll
+    for (int r = 0; r < EX_ROWS; r++) {
+        const v4f cv = raw[r + 1];
+        o.c[r][0] = cv.x; o.c[r][1] = cv.y; o.c[r][2] = cv.z; o.c[r][3] = cv.w;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            o.e8max[r][e] = fmaxf(fmaxf(rmax[r][e], rmax[r + 2][e]), l2max[r + 1][e]);
+            o.e8min[r][e] = fminf(fminf(rmin[r][e], rmin[r + 2][e]), l2min[r + 1][e]);
+            o.m[r][e] = fmaxf(fmaxf(rmax[r][e], rmax[r + 1][e]), rmax[r + 2][e]);
+            o.n[r][e] = fminf(fminf(rmin[r][e], rmin[r + 1][e]), rmin[r + 2][e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restrict__ dcur, int X, int Y, int Z, int z_first,
+                                                            int z_last, int zchunk, int xtiles,
+                                                            sift3d_survivor *__restrict__ surv, unsigned long long *surv_count,
+                                                            long long surv_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6); /* wavefront index over (x tile, y tile) */
+    const int xt = wv % xtiles, yt = wv / xtiles;
+    const int y0 = 1 + yt * EX_ROWS;                 /* first output row */
+    if (y0 >= Y - 1) return;
+    const int za = z_first + blockIdx.y * zchunk;
+    if (za >= z_last) return;
+    const int zb = za + zchunk < z_last ? za + zchunk : z_last;
+    const int xv = xt * EX_XOUT - 4 + lane * 4;
+    const int xld = xv < 0 ? 0 : (xv > X - 4 ? X - 4 : xv);
+    const long long XY = (long long)X * Y;
+    long long roff[EX_LOAD];
+#pragma unroll
+    for (int r = 0; r < EX_LOAD; r++) {
+        int yy = y0 - 1 + r;
+        yy = yy < Y ? yy : Y - 1;
+        roff[r] = (long long)yy * X + xld;
+    }
+    const int seg = (int)((blockIdx.x + 7u * blockIdx.y) % EX_SEGS);
+    auto load_plane = [&](v4f(&raw)[EX_LOAD], int z) { /* z <= Z - 1 always: z_last <= Z - 1 */
+#pragma unroll
+        for (int r = 0; r < EX_LOAD; r++) raw[r] = vload<4>(dcur + (long long)z * XY + roff[r]);
+    };
+    auto emit = [&](const ex_plane &lo, const ex_plane &ce, const ex_plane &hi, int z) {
+#pragma unroll
+        for (int r = 0; r < EX_ROWS; r++) {
+            const int y = y0 + r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float c = ce.c[r][e];
+                const bool mx = c > fmaxf(ce.e8max[r][e], fmaxf(lo.m[r][e], hi.m[r][e]));
+                const bool mn = c < fminf(ce.e8min[r][e], fminf(lo.n[r][e], hi.n[r][e]));
+                const int x = xv + e;
+                if ((mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < X - 1 && y < Y - 1) {
+                    const unsigned long long slot = atomicAdd(surv_count + seg * EX_SEG_STRIDE, 1ull);
+                    if ((long long)slot < surv_cap) {
+                        sift3d_survivor sv;
+                        sv.idx = (long long)z * XY + (long long)y * X + x;
+                        sv.value = c;
+                        sv.is_max = mx ? 1 : 0;
+                        surv[(long long)seg * surv_cap + (long long)slot] = sv;
+                    }
+                }
+            }
+        }
+    };
+    ex_plane A, B, C;
+    v4f raw[EX_LOAD], nxt[EX_LOAD];
+    load_plane(raw, za - 1);
+    load_plane(nxt, za);
+    ex_reduce_plane(raw, A);
+    load_plane(raw, za + 1);
+    ex_reduce_plane(nxt, B);
+    /* invariant at the top of a step for output plane z: A = plane z-1, B = plane z, raw = plane z+1 (in flight) */
+    int z = za;
+    for (; z + 2 < zb; z += 3) {
+        load_plane(nxt, z + 2);
+        ex_reduce_plane(raw, C);
+        emit(A, B, C, z);
+        load_plane(raw, z + 3 <= Z - 1 ? z + 3 : Z - 1);
+        ex_reduce_plane(nxt, A);
+        emit(B, C, A, z + 1);
+        load_plane(nxt, z + 4 <= Z - 1 ? z + 4 : Z - 1);
+        ex_reduce_plane(raw, B);
+        emit(C, A, B, z + 2);
+#pragma unroll
+        for (int r = 0; r < EX_LOAD; r++) raw[r] = nxt[r];
+        /* now A = plane z+2, B = plane z+3, raw = plane z+4: the invariant for output plane z+3 */
+    }
+    if (z < zb) {
+        if (z + 1 < zb) load_plane(nxt, z + 2);
+        ex_reduce_plane(raw, C);
+        emit(A, B, C, z);
+        if (z + 1 < zb) {
+            ex_reduce_plane(nxt, A);
+            emit(B, C, A, z + 1);
+        }
+    }
+}
+
 /* Second phase: one thread per own-level extremum checks centre + 26 of d_prev and of d_next and
  * appends the survivors as (key, value) pairs.  The list length lives in device memory, so the grid
  * is sized for the capacity and surplus threads leave at once (no host round trip). */
@@ -789,13 +904,25 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
         const int xtiles = (int)((X - 2 + EX_XOUT - 1) / EX_XOUT);
         const int ytiles = (int)((Y - 2 + EX_ROWS - 1) / EX_ROWS);
         const long long waves_xy = (long long)xtiles * ytiles;
-        const int zchunk = 1; /* one output plane per workgroup row */
-        const unsigned nz = (unsigned)(z1 - z0);
         hipError_t e = hipMemsetAsync(surv_count, 0, sizeof(unsigned long long) * EX_SEGS * EX_SEG_STRIDE, s);
         if (e != hipSuccess) return e;
+        /* marching form when chunks of >= 8 planes still give the chip a few thousand wavefronts */
+        int zchunk = 1;
+        for (int zc = 32; zc >= 8; zc /= 2)
+            if (waves_xy * ((z1 - z0 + zc - 1) / zc) >= 4096) {
+                zchunk = zc;
+                break;
+            }
+        static const char *env = getenv("SIFT3D_EX_ZCHUNK"); /* tuning aid */
+        if (env) zchunk = atoi(env) >= 1 ? atoi(env) : 1;
+        const unsigned nz = (unsigned)((z1 - z0 + zchunk - 1) / zchunk);
         dim3 grid((unsigned)((waves_xy + 3) / 4), nz);
-        hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0, z1, zchunk,
-                           xtiles, surv, surv_count, (long long)(surv_cap / EX_SEGS));
+        if (zchunk >= 2)
+            hipLaunchKernelGGL(extrema_march_kernel, grid, dim3(256), 0, s, dcur, (int)X, (int)Y, (int)Z, z0, z1, zchunk, xtiles,
+                               surv, surv_count, (long long)(surv_cap / EX_SEGS));
+        else
+            hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0, z1, zchunk,
+                               xtiles, surv, surv_count, (long long)(surv_cap / EX_SEGS));
         /* the second launch covers the list capacity, reads the true length on the device, and flags an
          * overflow for cand_finalize to widen the list and replay */
         const long long segcap = surv_cap / EX_SEGS; /* the caller sized surv_cap: capacity == threads of the second launch */
