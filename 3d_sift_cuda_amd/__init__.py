@@ -109,6 +109,7 @@ def hip_lib():
     _sig(L.sift3d_extrema, I, P, P, P, P, I64, I64, I64, P, I64, P, P, I64, P)
     _sig(L.sift3d_double_size, I, P, P, I64, I64, I64, P)
     _sig(L.sift3d_halve_size, I, P, P, I64, I64, I64, P)
+    _sig(L.sift3d_selftest_lds_add, I, P, P, P, I64, P, P)
     _sig(L.sift3d_set_volume, I, P, P, I64, I64, I64)
     _sig(L.sift3d_set_volume_dev, I, P, P, I64, I64, I64)
     _sig(L.sift3d_detect, I, P, F, P, P)
@@ -258,6 +259,14 @@ class Context:
         out = np.empty((nz // 2, ny // 2, nx // 2), np.float32)
         self._chk(self._L.sift3d_halve_size(self._h, vol.ctypes.data, nx, ny, nz, out.ctypes.data), "sift3d_halve_size")
         return out
+
+    def selftest_lds_add(self, a, b):
+        """(a + b on the vector ALU, a + b through ds_add_f32), both computed on the device."""
+        a, b = _f32(a).ravel(), _f32(b).ravel()
+        valu, lds = np.empty_like(a), np.empty_like(a)
+        self._chk(self._L.sift3d_selftest_lds_add(self._h, a.ctypes.data, b.ctypes.data, a.size, valu.ctypes.data,
+                                                  lds.ctypes.data), "sift3d_selftest_lds_add")
+        return valu, lds
 
     def extrema(self, d_prev, d_cur, d_next=None, capacity=None):
         """Returns (minima, maxima) structured arrays in raster order."""

@@ -292,6 +292,39 @@ extern "C" int sift3d_sync(sift3d_ctx *c)
     return SIFT3D_OK;
 }
 
+/* ---- self-test: LDS float atomic add == vector ALU add ------------------- */
+__global__ void selftest_lds_add_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n,
+                                        float *__restrict__ valu, float *__restrict__ lds)
+{
+    __shared__ float cell[256];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float x = i < n ? a[i] : 0.0f, y = i < n ? b[i] : 0.0f;
+    cell[threadIdx.x] = x;
+    __syncthreads();
+    __hip_atomic_fetch_add(&cell[threadIdx.x], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    if (i < n) {
+        valu[i] = x + y;
+        lds[i] = cell[threadIdx.x];
+    }
+}
+
+extern "C" int sift3d_selftest_lds_add(sift3d_ctx *c, const float *a, const float *b, int64_t n, float *valu, float *lds)
+{
+    if (!c || !a || !b || !valu || !lds || n <= 0 || 4 * n > c->capTot) return c ? set_err(c, SIFT3D_ERR_ARG, "bad self-test arguments") : SIFT3D_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *da = c->L[0], *db = c->L[0] + n, *dv = c->L[0] + 2 * n, *dl = c->L[0] + 3 * n;
+    HIPCHK(c, hipMemcpyAsync(da, a, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, b, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(selftest_lds_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, (long long)n, dv, dl);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(valu, dv, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(lds, dl, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->has_volume = false;
+    return SIFT3D_OK;
+}
+
 /* ---- timing ------------------------------------------------------------ */
 static hipEvent_t get_event(sift3d_ctx *c)
 {

@@ -587,26 +587,36 @@ __device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const sh
     const int slot = lane >> 3;
     const int a = lane & 1, b = (lane >> 1) & 1, c = (lane >> 2) & 1;
     float *g = grid; /* plain LDS accesses: a volatile generic pointer would turn them into system-scope flat ops */
-    if (lane < 64) /* wavefront 0 carries the chain */
-    for (int g0 = 0; g0 < n; g0 += 8) {
-        const int i = g0 + slot;
-        const bool ok = i < n;
-        int cell = 0;
-        float contrib = 0.0f;
-        if (ok) {
-            const int packed = sp_base[i];
-            const float wx = sp_wx[i], wy = sp_wy[i], wz = sp_wz[i], v = sp_mag[i];
+    if (lane < 64) { /* wavefront 0 carries the chain */
+        /* parameters of the group after the current one are read while the current one is being applied */
+        int packed = 0;
+        float wx = 0, wy = 0, wz = 0, v = 0;
+        if (slot < n) {
+            packed = sp_base[slot];
+            wx = sp_wx[slot]; wy = sp_wy[slot]; wz = sp_wz[slot]; v = sp_mag[slot];
+        }
+        for (int g0 = 0; g0 < n; g0 += 8) {
+            const int i = g0 + slot;
+            const bool ok = i < n;
             const int ix = packed & 15, iy = (packed >> 4) & 15, iz = packed >> 8;
-            cell = ((iz + c) * PD + (iy + b)) * PD + (ix + a);
+            const int cell = ((iz + c) * PD + (iy + b)) * PD + (ix + a);
             const float ux = a ? (1.0f - wx) : wx;
             const float uy = b ? (1.0f - wy) : wy;
             const float uz = c ? (1.0f - wz) : wz;
-            contrib = v * ux * uy * uz;
-        }
+            const float contrib = v * ux * uy * uz;
+            const int in = i + 8;
+            if (in < n) {
+                packed = sp_base[in];
+                wx = sp_wx[in]; wy = sp_wy[in]; wz = sp_wz[in]; v = sp_mag[in];
+            }
+            /* ds_add_f32 without return: the LDS unit performs the IEEE single-precision add (round to nearest
+             * even, denormals kept: the same operation as v_add_f32, checked by sift3d_selftest_lds_add) in the
+             * order the instructions were issued, and the wavefront does not wait for any of them */
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (slot == j && ok) g[cell] = g[cell] + contrib;
-            __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < 8; j++) {
+                if (slot == j && ok) __hip_atomic_fetch_add(&g[cell], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     __syncthreads();
@@ -704,8 +714,18 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
     if (lane < 9) {
         const float *ei = lane / 3 == 0 ? sm.gx : (lane / 3 == 1 ? sm.gy : sm.gz);
         const float *ej = lane % 3 == 0 ? sm.gx : (lane % 3 == 1 ? sm.gy : sm.gz);
+        /* one sequential chain per matrix entry; the LDS reads of a block of 16 terms are issued together so
+         * that their latency stays off the add chain */
         float acc = 0;
-        for (int i = 0; i < nrad; i++) acc += ei[i] * ej[i];
+        int i = 0;
+        for (; i + 16 <= nrad; i += 16) {
+            float a[16], b[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) { a[q] = ei[i + q]; b[q] = ej[i + q]; }
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += a[q] * b[q];
+        }
+        for (; i < nrad; i++) acc += ei[i] * ej[i];
         sm.sc[lane] = acc;
     }
     __syncthreads();

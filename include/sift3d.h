@@ -132,6 +132,12 @@ int sift3d_extrema(sift3d_ctx *ctx, const float *d_prev, const float *d_cur, con
  * fioSubSample2DCenterPixel (:1670-1714), out is (nx/2)*(ny/2)*(nz/2): the -2+ / -2- options. */
 int sift3d_double_size(sift3d_ctx *ctx, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out);
 int sift3d_halve_size(sift3d_ctx *ctx, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out);
+/* Hardware self-test behind one implementation choice (no reference counterpart): the orientation-histogram
+ * splat accumulates with LDS float atomics (ds_add_f32), which is only a drop-in for the reference's float
+ * additions if the LDS unit rounds exactly like the vector ALU.  For i < n: valu[i] = a[i] + b[i] on the vector
+ * ALU, lds[i] = the same sum through ds_add_f32 (host arrays).  tests/ compare the two bit for bit on random,
+ * denormal, signed-zero, infinite and NaN operands. */
+int sift3d_selftest_lds_add(sift3d_ctx *ctx, const float *a, const float *b, int64_t n, float *valu, float *lds);
 
 /* ---- pipeline level: msGeneratePyramidDOG3D_efficient + the descriptor loop --
  * (R/src_common/MultiScale.cpp:236-570, R/featExtract/featExtract.cpp:409,474-505).

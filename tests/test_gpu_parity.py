@@ -71,6 +71,29 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, monkeypatch):
         assert (log["stage"] == built.STAGES.index("blur_fused")).all()   # the fused kernel is what ran
 
 
+def test_lds_float_atomic_add_rounds_like_the_alu(built):
+    """The orientation-histogram splat adds with ds_add_f32: it must be the IEEE add the reference's CPU performs."""
+    rng = np.random.default_rng(7)
+    n = 1 << 16
+    a = (rng.standard_normal(n) * 10.0 ** rng.integers(-42, 30, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.integers(-42, 30, n)).astype(np.float32)
+    b[:n // 4] = -a[:n // 4] * np.float32(1.0000001)                      # cancellation
+    a[n // 4:n // 2] = a[n // 4:n // 2] * np.float32(1e-39) / np.float32(1e-3)  # denormal operands and results
+    b[n // 4:n // 2] = b[n // 4:n // 2] * np.float32(1e-39) / np.float32(1e-3)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, 1.0, -1.0, 0.5 ** 24],
+                       np.float32)
+    aa, bb = np.meshgrid(special, special)
+    a[-aa.size:], b[-bb.size:] = aa.ravel(), bb.ravel()
+    with built.Context(64, 64, 64) as ctx:
+        valu, lds = ctx.selftest_lds_add(a, b)
+    with np.errstate(all="ignore"):
+        want = a + b
+    same = lambda p, q: ((bits(p) == bits(q)) | (np.isnan(p) & np.isnan(q))).all()
+    assert same(valu, want) and same(lds, want)
+    fin = ~np.isnan(want)
+    assert (bits(lds[fin]) == bits(valu[fin])).all()
+
+
 def test_blur_generic_tap_counts(built, oracle):
     """sigmas outside the templated 3..17-tap range take the generic kernel."""
     dims = (40, 24, 20)
