@@ -215,12 +215,12 @@ __global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restr
         if (emit) {
             const long long zoff = (long long)zo * XY;
             if (out) {
-                if (st0) *reinterpret_cast<v2f *>(out + zoff + boff0) = a0;
-                if (st1) *reinterpret_cast<v2f *>(out + zoff + boff1) = a1;
+                if (st0) __builtin_nontemporal_store(a0, reinterpret_cast<v2f *>(out + zoff + boff0));
+                if (st1) __builtin_nontemporal_store(a1, reinterpret_cast<v2f *>(out + zoff + boff1));
             }
             if (dog) {
-                if (st0) *reinterpret_cast<v2f *>(dog + zoff + boff0) = pv0 - a0;
-                if (st1) *reinterpret_cast<v2f *>(dog + zoff + boff1) = pv1 - a1;
+                if (st0) __builtin_nontemporal_store(pv0 - a0, reinterpret_cast<v2f *>(dog + zoff + boff0));
+                if (st1) __builtin_nontemporal_store(pv1 - a1, reinterpret_cast<v2f *>(dog + zoff + boff1));
                 load_prev(zo + 1); /* for the next step */
             }
         }

@@ -194,7 +194,7 @@ def main():
         big_ms, big_bytes = float(sel["ms"].sum()), float(sel["alg_bytes"].sum())
         achieved = big_bytes / (big_ms * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
         if os.path.exists(pmc) and n == 512:
             try:
                 traffic = json.load(open(pmc)).get(kernel_name(dom_key[0], dom_key[1], dom_key[2]), {}).get("hbm_bytes_per_launch_512")
@@ -215,7 +215,7 @@ def main():
                     "all_launches": {"launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                                      "achieved": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
                                      "note": "every octave down to 4^3; compare with the per-kernel average of rocprofv3 --stats"},
-                    "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)" if traffic else None}
+                    "traffic_source": "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md)" if traffic else None}
         pyr_ms = sum(v["ms"] for v in blur_groups.values())
         pyr_bytes = sum(v["bytes"] for v in blur_groups.values())
         pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
