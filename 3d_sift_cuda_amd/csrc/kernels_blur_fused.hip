@@ -11,14 +11,18 @@
  * A workgroup (256 threads) owns a 64 x 16 (x, y) tile and marches along z:
  *   A  x pass    every thread keeps an aligned window of one input row in
  *                registers (loaded one plane ahead) and produces 8 outputs of
- *                that row; the 16 + 2R rows of the tile and its y halo go to LDS;
+ *                that row; the 16 + 2R rows of the tile and its y halo go to one
+ *                of two LDS buffers (one barrier per plane);
  *   B  y pass    every thread produces a 2 x 2 block (two rows of one column
- *                pair) from LDS and appends it to a ring of the last 2R+1
- *                xy-blurred planes, also in LDS;
- *   C  z pass    every thread sums its own ring entries for the plane R steps
- *                back, loads the input voxel of that plane (the "previous level"
- *                of the DoG) and stores the level and input - level.
- * The z range is cut into chunks (grid y) that recompute 2R lead-in planes.
+ *                pair) from LDS;
+ *   C  z pass    the block feeds the thread's 2R+1 partial sums of the output
+ *                planes it touches, all in registers (a switch on the plane's
+ *                phase makes every slot a compile-time register); the finished
+ *                plane is stored together with input - level, the input voxel
+ *                (the "previous level" of the DoG) having been loaded a step ahead.
+ * The z range is cut into chunks that recompute 2R lead-in planes.  The register
+ * file (512 KB per CU) holds what an LDS ring of 2R+1 planes (78 KB per tile for
+ * 17 taps) held in the first version of this kernel.
  *
  * Arithmetic contract: identical to kernels_volume.hip (and to the reference's
  * CPU path, R/src_common/GaussBlur3D.cpp:43-61,329-479): every pass is
@@ -53,7 +57,7 @@ struct fb_taps2 {
 };
 
 template <int R>
-__global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restrict__ in, float *__restrict__ out,
+__global__ __launch_bounds__(256, (R >= 6 ? 2 : (R >= 4 ? 3 : 4))) void blur_fused_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                          float *__restrict__ dog, const float *__restrict__ zeros, int X,
                                                          int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total,
                                                          fb_taps2 t)
@@ -63,8 +67,7 @@ __global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restr
     constexpr int H4 = ((R + 3) / 4) * 4;    /* window halo, whole 16-byte vectors */
     constexpr int WIN = 8 + 2 * H4;          /* floats per window */
     constexpr int NV = WIN / 4;              /* vectors per window */
-    __shared__ __attribute__((aligned(16))) float P1[FB_P1_ROWS * FB_TX];
-    __shared__ __attribute__((aligned(16))) float RING[U * FB_TY * FB_TX];
+    __shared__ __attribute__((aligned(16))) float P1buf[2][FB_P1_ROWS * FB_TX]; /* double-buffered: one barrier per plane */
 
     /* workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of tiles (y fastest,
      * then x, then z chunk) so that the y halo of a tile is fetched by the L2 that holds its neighbour */
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restr
     /* x pass of the plane whose window is in win[]: 8 outputs (4 pairs) to P1.  Output pair e, tap j reads the
      * window floats s, s+1 with s = H4 - R + 2e + j: an aligned register pair when s is even, one of the
      * WIN/2 - 1 odd pairs (built once per plane) when it is odd. */
-    auto x_pass = [&](const v4f(&win)[NV]) {
+    auto x_pass = [&](const v4f(&win)[NV], float *P1) {
         v2f ev[WIN / 2], od[WIN / 2 - 1];
 #pragma unroll
         for (int k = 0; k < NV; k++) {
@@ -151,11 +154,15 @@ __global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restr
         for (int k = 0; k < NV; k++) wp[k] += wstep[k];
     };
     load_window(winA, zfirst);
-    if (zfirst >= 0 && ar < NR) x_pass(winA); /* zfirst < Z always */
+    if (zfirst >= 0 && ar < NR) x_pass(winA, P1buf[0]); /* zfirst < Z always */
     load_window(winA, zfirst + 1);
 
-    float *ring_me = RING + (2 * brs) * FB_TX + 2 * bcp;
-    int slot = 0; /* ring slot of the plane being produced */
+    /* z pass in registers: slot i of acc0/acc1 (rows 2*brs, 2*brs+1) is the output plane that started with the
+     * plane of phase i; at phase s the new plane feeds tap (s - i) mod U of slot i, and slot (s + 1) mod U has just
+     * received its last tap.  The switch makes every slot index a compile-time register. */
+    v2f acc0[U], acc1[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) acc0[i] = acc1[i] = v2f(0.0f);
     /* the input voxels of the output plane (the previous level of the DoG), loaded one step ahead */
     v2f pv0 = v2f(0.0f), pv1 = v2f(0.0f);
     auto load_prev = [&](int z) {
@@ -166,33 +173,19 @@ __global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restr
         }
     };
     if (dog) load_prev(zc0);
-    /* One plane step; `win` holds plane zin + 1.  During the 2R lead-in steps of a chunk the
-     * ring is not full yet: the z pass then runs on stale LDS contents and its result is not stored (cheaper
-     * than a second copy of the loop body).  A plane outside the volume contributes zeros to the ring. */
-    auto step = [&](int zin, v4f(&win)[NV]) {
+    int phase = 0, cur = 0;
+    lds_barrier(); /* P1buf[0] holds the x pass of plane zfirst */
+    for (int zin = zfirst; zin <= zlast; zin++) {
         const bool plane = zin >= 0 && zin < Z;
         const int zo = zin - R;
         const bool emit = zo >= zc0; /* zo < zc1 by construction of zlast */
-        lds_barrier(); /* P1 holds the x pass of plane zin */
+        const float *P1 = P1buf[cur];
         v2f p[U + 1];
 #pragma unroll
         for (int q = 0; q < U + 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(2 * brs + q) * FB_TX + 2 * bcp]);
-        lds_barrier(); /* every wavefront has its rows of P1 in registers: P1 may be overwritten */
-        /* this thread's ring entries of the 2R older planes (thread-private data: no synchronisation) */
-        v2f q0[U - 1], q1[U - 1];
-        {
-            int s = slot + 1 == U ? 0 : slot + 1; /* slot of plane zin - 2R */
-#pragma unroll
-            for (int j = 0; j < U - 1; j++) {
-                const float *rp = ring_me + s * (FB_TY * FB_TX);
-                q0[j] = *reinterpret_cast<const v2f *>(rp);
-                q1[j] = *reinterpret_cast<const v2f *>(rp + FB_TX);
-                s = s + 1 == U ? 0 : s + 1;
-            }
-        }
-        /* ---- A: x pass of plane zin + 1, then reuse its buffer for the window of plane zin + 2 ---- */
-        if (zin + 1 >= 0 && zin + 1 < Z && zin + 1 <= zlast && ar < NR) x_pass(win);
-        load_window(win, zin + 2);
+        /* ---- A: x pass of plane zin + 1 into the other buffer, then the window of plane zin + 2 ---- */
+        if (zin + 1 >= 0 && zin + 1 < Z && zin + 1 <= zlast && ar < NR) x_pass(winA, P1buf[cur ^ 1]);
+        load_window(winA, zin + 2);
         /* ---- B: y pass of plane zin, 2 rows x 2 columns per thread ---- */
         v2f g0 = v2f(0.0f), g1 = v2f(0.0f);
 #pragma unroll
@@ -201,17 +194,32 @@ __global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restr
             g1 = g1 + t.f[j] * p[j + 1];
         }
         if (!plane) g0 = g1 = v2f(0.0f); /* P1 was stale */
-        *reinterpret_cast<v2f *>(ring_me + slot * (FB_TY * FB_TX)) = g0;
-        *reinterpret_cast<v2f *>(ring_me + slot * (FB_TY * FB_TX) + FB_TX) = g1;
-        /* ---- C: z pass for plane zo ---- */
+        /* ---- C: z pass ---- */
         v2f a0 = v2f(0.0f), a1 = v2f(0.0f);
-#pragma unroll
-        for (int j = 0; j < U - 1; j++) {
-            a0 = a0 + t.f[j] * q0[j];
-            a1 = a1 + t.f[j] * q1[j];
+        switch (phase) {
+#define FB_PHASE(S)                                                              \
+    case S:                                                                      \
+        if constexpr (S < U) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < U; i++) {                      \
+                constexpr int dummy = 0; (void)dummy;                            \
+                const int j = (S - i + U) % U;                                   \
+                if (j == 0) {                                                    \
+                    acc0[i] = v2f(0.0f) + t.f[0] * g0;                           \
+                    acc1[i] = v2f(0.0f) + t.f[0] * g1;                           \
+                } else {                                                         \
+                    acc0[i] = acc0[i] + t.f[j] * g0;                             \
+                    acc1[i] = acc1[i] + t.f[j] * g1;                             \
+                }                                                                \
+            }                                                                    \
+            a0 = acc0[(S + 1) % U];                                              \
+            a1 = acc1[(S + 1) % U];                                              \
+        }                                                                        \
+        break;
+            FB_PHASE(0) FB_PHASE(1) FB_PHASE(2) FB_PHASE(3) FB_PHASE(4) FB_PHASE(5) FB_PHASE(6) FB_PHASE(7) FB_PHASE(8)
+            FB_PHASE(9) FB_PHASE(10) FB_PHASE(11) FB_PHASE(12) FB_PHASE(13) FB_PHASE(14) FB_PHASE(15) FB_PHASE(16)
+#undef FB_PHASE
+        default: break;
         }
-        a0 = a0 + t.f[U - 1] * g0;
-        a1 = a1 + t.f[U - 1] * g1;
         if (emit) {
             const long long zoff = (long long)zo * XY;
             if (out) {
@@ -224,9 +232,10 @@ __global__ __launch_bounds__(256, 2) void blur_fused_kernel(const float *__restr
                 load_prev(zo + 1); /* for the next step */
             }
         }
-        slot = slot + 1 == U ? 0 : slot + 1;
-    };
-    for (int zin = zfirst; zin <= zlast; zin++) step(zin, winA);
+        phase = phase + 1 == U ? 0 : phase + 1;
+        cur ^= 1;
+        lds_barrier(); /* the other buffer is complete, and every wavefront has read this one */
+    }
 }
 
 /* chunks along z: enough workgroups to fill every CU's resident slots while the 2R lead-in planes stay cheap */
@@ -255,7 +264,7 @@ template <int R>
 static void launch_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
                          int64_t Z, const fb_taps2 &t)
 {
-    static int resident = 0; /* workgroups of this instantiation one CU holds (LDS ring and registers) */
+    static int resident = 0; /* workgroups of this instantiation one CU holds (registers) */
     if (resident == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<R>, 256, 0) != hipSuccess || n < 1) n = 2;
