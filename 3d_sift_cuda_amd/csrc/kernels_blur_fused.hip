@@ -8,10 +8,10 @@
  * (8 when one of the two outputs is not needed) plus the halo, which neighbouring
  * workgroups share through L2 / Infinity Cache.
  *
- * A workgroup (256 threads) owns a 64 x 16 (x, y) tile and marches along z:
+ * A workgroup (512 threads, or 256) owns a 64 x 32 (or 64 x 16) (x, y) tile and marches along z:
  *   A  x pass    every thread keeps an aligned window of one input row in
  *                registers (loaded one plane ahead) and produces 8 outputs of
- *                that row; the 16 + 2R rows of the tile and its y halo go to one
+ *                that row; the TY + 2R rows of the tile and its y halo go to one
  *                of two LDS buffers (one barrier per plane);
  *   B  y pass    every thread produces a 2 x 2 block (two rows of one column
  *                pair) from LDS;
@@ -49,20 +49,23 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 #define FB_TX 64
-#define FB_TY 16
-#define FB_P1_ROWS 32 /* FB_TY + 2 * SIFT3D_FAST_MAX_R */
 
 struct fb_taps2 {
     v2f f[2 * SIFT3D_FAST_MAX_R + 1]; /* (f[j], f[j]): a 64-bit scalar operand of the packed multiply */
 };
 
-template <int R>
-__global__ __launch_bounds__(256, (R >= 6 ? 2 : (R >= 4 ? 3 : 4))) void blur_fused_kernel(const float *__restrict__ in, float *__restrict__ out,
+/* TY = rows of the tile (16 or 32), 16 * TY threads: 8 threads per row for the x pass of the TY + 2R rows, a 2 x 2
+ * block per thread for the y and z passes.  The taller tile halves the relative cost of the y halo (x pass work and
+ * halo traffic) and is used whenever the volume has enough rows. */
+template <int R, int TY>
+__global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 : (R >= 4 ? 3 : 4))))) void blur_fused_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                          float *__restrict__ dog, const float *__restrict__ zeros, int X,
                                                          int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total,
                                                          fb_taps2 t)
 {
     constexpr int U = 2 * R + 1;
+    constexpr int FB_TY = TY;
+    constexpr int FB_P1_ROWS = TY + 2 * SIFT3D_FAST_MAX_R;
     constexpr int NR = FB_TY + 2 * R;        /* rows of the x pass */
     constexpr int H4 = ((R + 3) / 4) * 4;    /* window halo, whole 16-byte vectors */
     constexpr int WIN = 8 + 2 * H4;          /* floats per window */
@@ -260,25 +263,37 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
     return best;
 }
 
-template <int R>
-static void launch_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
-                         int64_t Z, const fb_taps2 &t)
+template <int R, int TY>
+static void launch_fused_ty(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
+                            int64_t Z, const fb_taps2 &t)
 {
     static int resident = 0; /* workgroups of this instantiation one CU holds (registers) */
     if (resident == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<R>, 256, 0) != hipSuccess || n < 1) n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<R, TY>, 16 * TY, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
-    const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + FB_TY - 1) / FB_TY);
+    const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + TY - 1) / TY);
     const long long tiles = (long long)tiles_x * tiles_y;
     const int n = fused_chunks(R, Z, tiles, resident);
     const int zlen = (int)((Z + n - 1) / n);
     const int nch = (int)((Z + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
-    hipLaunchKernelGGL((blur_fused_kernel<R>), dim3((unsigned)(8 * per)), dim3(256), 0, s, in, out, dog, zeros, (int)X, (int)Y,
-                       (int)Z, zlen, tiles_x, tiles_y, total, t);
+    hipLaunchKernelGGL((blur_fused_kernel<R, TY>), dim3((unsigned)(8 * per)), dim3(16 * TY), 0, s, in, out, dog, zeros, (int)X,
+                       (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
+}
+
+template <int R>
+static void launch_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
+                         int64_t Z, const fb_taps2 &t)
+{
+    const char *env = getenv("SIFT3D_FUSED_TY"); /* tuning / test aid: 16 or 32 */
+    /* 11 taps: the 512-thread workgroup would need 160 registers per thread at three wavefronts per SIMD, i.e. one
+     * workgroup per CU; two 256-thread ones do better there */
+    const int ty = env ? atoi(env) : ((Y >= 64 && R != 5) ? 32 : 16);
+    if (ty == 32) launch_fused_ty<R, 32>(s, in, out, dog, zeros, X, Y, Z, t);
+    else launch_fused_ty<R, 16>(s, in, out, dog, zeros, X, Y, Z, t);
 }
 
 /* Returns hipErrorNotSupported when the shape is outside this kernel (the caller then runs the three-pass

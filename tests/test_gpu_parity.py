@@ -43,14 +43,16 @@ FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37
 
 
 @pytest.mark.parametrize("dims", FUSED_SHAPES)
-@pytest.mark.parametrize("chunks", [0, 3])
-def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, monkeypatch):
+@pytest.mark.parametrize("chunks,tile_rows", [(0, 0), (3, 16), (2, 32)])
+def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, monkeypatch):
     """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up), partial tiles
     in x and y, volumes thinner than the filter, several z chunks: level and DoG bit-identical to the oracle."""
     import torch
     monkeypatch.setenv("SIFT3D_BLUR_FUSED", "2")
     if chunks:
         monkeypatch.setenv("SIFT3D_FUSED_CHUNKS", str(chunks))
+    if tile_rows:
+        monkeypatch.setenv("SIFT3D_FUSED_TY", str(tile_rows))   # both tile heights on every shape
     vol = vol_of(built, dims, 5) - np.float32(1.5)
     nx, ny, nz = dims
     with built.Context(*dims) as ctx:

@@ -29,3 +29,5 @@ for nv in sizes:
 for st in (5, 6):
     sel = log[log["stage"] == st]
     print(pkg.STAGES[st], "launches", len(sel), "items", sel["nvox"].tolist(), "ms", np.round(sel["ms"], 3).tolist())
+sel = log[log["stage"] == 7]
+print("fused launches (voxels, taps, ms):", [(int(r["nvox"]), int(r["ntaps"]), round(float(r["ms"]), 3)) for r in sel])
