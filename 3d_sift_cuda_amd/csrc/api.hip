@@ -73,6 +73,7 @@ struct sift3d_ctx {
     size_t scan_tmp_bytes;
     sift3d_level *d_levels;
     sift3d_dkp *kps;
+    float *patch0; /* identity-frame patches of the extrema, kps_cap x 1331 floats */
     int *nrec, *offs; /* per-candidate record count and exclusive prefix */
     int64_t kps_cap;
     int *rec_kp, *rec_frame;
@@ -143,6 +144,7 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->scan_tmp);
     hipFree(c->d_levels);
     hipFree(c->kps);
+    hipFree(c->patch0);
     hipFree(c->nrec);
     hipFree(c->offs);
     hipFree(c->rec_kp);
@@ -214,6 +216,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->sort_tmp_bytes = c->scan_tmp_bytes = 0;
     c->d_levels = nullptr;
     c->kps = nullptr;
+    c->patch0 = nullptr;
     c->nrec = c->offs = nullptr;
     c->rec_kp = c->rec_frame = nullptr;
     c->recs = nullptr;
@@ -744,13 +747,15 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t nrec)
 {
     if (ncand > c->kps_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->kps); hipFree(c->nrec); hipFree(c->offs); hipFree(c->scan_tmp);
+        hipFree(c->kps); hipFree(c->nrec); hipFree(c->offs); hipFree(c->scan_tmp); hipFree(c->patch0);
         c->kps = nullptr;
+        c->patch0 = nullptr;
         c->nrec = c->offs = nullptr;
         c->scan_tmp = nullptr;
         c->kps_cap = ncand + ncand / 2 + 1024;
         c->scan_tmp_bytes = sift3d_scan_temp_bytes(c->kps_cap) + 256;
         HIPCHK(c, hipMalloc((void **)&c->kps, sizeof(sift3d_dkp) * (size_t)c->kps_cap));
+        HIPCHK(c, hipMalloc((void **)&c->patch0, sizeof(float) * SIFT3D_PATCH_VOX * (size_t)c->kps_cap));
         HIPCHK(c, hipMalloc((void **)&c->nrec, sizeof(int) * (size_t)c->kps_cap));
         HIPCHK(c, hipMalloc((void **)&c->offs, sizeof(int) * (size_t)c->kps_cap));
         HIPCHK(c, hipMalloc(&c->scan_tmp, c->scan_tmp_bytes));
@@ -841,6 +846,7 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
         p.size_factor = size_factor;
         p.desc_mode = desc_mode;
         p.debug_stop = getenv("SIFT3D_KP_STOP") ? atoi(getenv("SIFT3D_KP_STOP")) : 0;
+        p.patch0 = c->patch0;
         {
             stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, ncand);
             HIPCHK(c, sift3d_launch_keypointsA(c->stream, p, c->keys_b, c->vals_b, ncand, c->kps, c->nrec, taps3));

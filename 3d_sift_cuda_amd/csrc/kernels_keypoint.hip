@@ -760,6 +760,10 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
     __syncthreads();
     if (sm.sc[15] == 0.0f) return;
     if (p.debug_stop == 4) { if (lane == 0) nrec_out[k] = 0; return; }
+    /* the un-reoriented record is described from exactly this patch (identity frame, normalised once): hand it to
+     * phase B instead of having it gathered from the image a second time */
+    for (int s = lane; s < PV; s += KP_NT) p.patch0[(long long)k * PV + s] = patch[s];
+    __syncthreads(); /* the splat parameters below overwrite the patch */
 
     /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
     float *t0 = sm.B;
@@ -924,12 +928,16 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
     if (p.debug_stop == 21 || p.debug_stop == 22) { /* development aid: every record samples one cache-resident region */
         wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
         if (p.debug_stop == 21) return;
+    } else if (fr < 0) {
+        /* record 0 is sampled with the identity frame and normalised once inside generateFeature3D
+         * (MultiScale.cpp:1742): phase A did exactly that and left the result in patch0 */
+        const float *src = p.patch0 + (long long)rec_kp[r] * PV;
+        for (int s = lane; s < PV; s += DESC_NT) sm.patch[s] = src[s];
+        __syncthreads();
     } else
     wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
-    /* record 0 was normalised once inside generateFeature3D (MultiScale.cpp:1742) and
-     * every record once more in main (featExtract.cpp:480) */
+    /* ... and every record is normalised once more in main (featExtract.cpp:480) */
     if (p.debug_stop == 11) return;
-    if (fr < 0) wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);
     wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);
     if (p.debug_stop == 12) return;
 

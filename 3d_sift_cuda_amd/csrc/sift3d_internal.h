@@ -76,6 +76,8 @@ struct sift3d_kp_params {
     float size_factor;
     int desc_mode;
     int debug_stop; /* development aid: phase A returns after stage N (0 = run everything) */
+    float *patch0;  /* per extremum: the identity-frame patch (1331 floats, normalised once) that phase A sampled anyway;
+                     * phase B reads it for the un-reoriented record instead of sampling it again */
 };
 #define SIFT3D_MAX_FRAMES 11 /* determineCanonicalOrientation3D stops at FEATURE_3D_DIM frames */
 /* phase A result per extremum */
