@@ -435,7 +435,7 @@ extern "C" int sift3d_get_launch_log(const sift3d_ctx *c, sift3d_launch_record *
 }
 
 /* ---- device-level building blocks -------------------------------------- */
-/* out = blur(in); if dog != NULL also dog = in - out.  Uses T[0], T[1]. */
+/* out = blur(in); if dog != NULL also dog = in - out.  out may be NULL when only the DoG is wanted.  Uses T[0], T[1]. */
 static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma,
                     float min_value)
 {
@@ -444,7 +444,7 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     if (n < 0) return set_err(c, SIFT3D_ERR_ARG, "bad blur parameters sigma=%g min=%g", sigma, min_value);
     const double N = (double)X * Y * Z;
     if (n == 1) { /* delta filter: out = 1*in */
-        HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, c->stream));
+        if (out) HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, c->stream));
         if (dog) HIPCHK(c, hipMemsetAsync(dog, 0, sizeof(float) * (size_t)N, c->stream));
         return SIFT3D_OK;
     }
@@ -455,7 +455,7 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     const char *fenv = getenv("SIFT3D_BLUR_FUSED");
     const int fmode = fenv ? atoi(fenv) : 1;
     if (fmode == 2 || (fmode == 1 && N >= (double)(1 << 22))) {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog ? 12.0 : 8.0) * N, n, (int64_t)N);
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N);
         hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, c->d_zeros, X, Y, Z, taps, n);
         if (e == hipSuccess) return SIFT3D_OK;
         if (e != hipErrorNotSupported) HIPCHK(c, e);
@@ -471,7 +471,7 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     }
     {
         stage_scope sc(c, SIFT3D_STAGE_BLUR_Z_DOG, (dog ? 16.0 : 8.0) * N, n, (int64_t)N);
-        HIPCHK(c, sift3d_launch_blur_z(c->stream, c->T[1], out, dog ? in : nullptr, dog, X, Y, Z, taps, n, c->d_taps));
+        HIPCHK(c, sift3d_launch_blur_z(c->stream, c->T[1], out ? out : c->T[0], dog ? in : nullptr, dog, X, Y, Z, taps, n, c->d_taps));
     }
     return SIFT3D_OK;
 }
@@ -924,7 +924,8 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         for (int j = 1; j < 6; j++) {
             const float ex = sigma * sqrtf(factor * factor - 1.0f);
             /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
-            rc = blur_dev(c, c->L[j - 1] + d.off, c->L[j] + d.off, c->D[j - 1] + d.off, d.X, d.Y, d.Z, ex, 0.01f);
+            /* nothing reads L_5: only D_4 = L_4 - L_5 is needed, so the last level is not stored */
+            rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, c->D[j - 1] + d.off, d.X, d.Y, d.Z, ex, 0.01f);
             if (rc) return rc;
             if (j == 3 && o + 1 < oct.size()) {
                 stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
