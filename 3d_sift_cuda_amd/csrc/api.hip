@@ -48,6 +48,9 @@ struct sift3d_ctx {
     int device;
     hipStream_t stream;
     hipStream_t copy_stream;   /* record download, overlapped with the descriptor launches */
+    hipStream_t ex_stream;     /* extrema detection of an octave, overlapped with the blurs of the coarser octaves */
+    hipStream_t cand_stream;   /* where cand_append launches: stream, or ex_stream inside run_pipeline */
+    hipEvent_t ev_oct[2];      /* octave's DoG levels complete / extrema launches complete */
     hipEvent_t ev_chunk[4];
     bool own_stream;
     int64_t capN;   /* voxels of the largest volume */
@@ -230,6 +233,10 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->copy_stream = nullptr;
     for (int i = 0; i < 4; i++) c->ev_chunk[i] = nullptr;
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    c->ex_stream = c->cand_stream = nullptr;
+    c->ev_oct[0] = c->ev_oct[1] = nullptr;
+    ok = ok && hipStreamCreateWithFlags(&c->ex_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_oct[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
     const size_t vb = sizeof(float) * (size_t)c->capN;
     const size_t tb = sizeof(float) * (size_t)c->capTot;
@@ -249,8 +256,11 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
         free_dev(c);
         if (c->stream) hipStreamDestroy(c->stream);
         if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+        if (c->ex_stream) hipStreamDestroy(c->ex_stream);
         for (int i = 0; i < 4; i++)
             if (c->ev_chunk[i]) hipEventDestroy(c->ev_chunk[i]);
+        for (int i = 0; i < 2; i++)
+            if (c->ev_oct[i]) hipEventDestroy(c->ev_oct[i]);
         delete c;
         return nullptr;
     }
@@ -266,7 +276,10 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     hipStreamSynchronize(c->copy_stream);
     hipStreamDestroy(c->copy_stream);
+    hipStreamSynchronize(c->ex_stream);
+    hipStreamDestroy(c->ex_stream);
     for (int i = 0; i < 4; i++) hipEventDestroy(c->ev_chunk[i]);
+    for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_oct[i]);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -346,15 +359,16 @@ struct stage_scope {
     int ntaps;
     int64_t nvox;
     double bytes;
-    stage_scope(sift3d_ctx *c_, int stage_, double bytes_, int ntaps_ = 0, int64_t nvox_ = 0)
-        : c(c_), stage(stage_), e0(nullptr), e1(nullptr), ntaps(ntaps_), nvox(nvox_), bytes(bytes_)
+    hipStream_t st;
+    stage_scope(sift3d_ctx *c_, int stage_, double bytes_, int ntaps_ = 0, int64_t nvox_ = 0, hipStream_t st_ = nullptr)
+        : c(c_), stage(stage_), e0(nullptr), e1(nullptr), ntaps(ntaps_), nvox(nvox_), bytes(bytes_), st(st_ ? st_ : c_->stream)
     {
         c->last.launches[stage] += 1;
         c->last.alg_bytes[stage] += bytes;
         if (c->timing) {
             e0 = get_event(c);
             e1 = get_event(c);
-            hipEventRecord(e0, c->stream);
+            hipEventRecord(e0, st);
         }
     }
     void cancel() /* the launch did not happen */
@@ -368,7 +382,7 @@ struct stage_scope {
     {
         if (stage < 0) return;
         if (c->timing) {
-            hipEventRecord(e1, c->stream);
+            hipEventRecord(e1, st);
             c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f});
         }
     }
@@ -613,12 +627,13 @@ static int cand_reset(sift3d_ctx *c)
 static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
 {
     if (record) c->jobs.push_back(j);
-    stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z);
+    hipStream_t st = c->cand_stream ? c->cand_stream : c->stream;
+    stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z, st);
     /* own-level extrema are ~0.3 % of the voxels on blob fields (7 % on white noise): the list of a level is
      * sized at 1/surv_div of its voxels; an overflow is flagged on the device and handled in cand_finalize */
     int64_t cover = j.X * j.Y * j.Z / c->surv_div + 64 * 1024; /* split evenly over 64 segments */
     if (cover > c->surv_cap) cover = c->surv_cap;
-    HIPCHK(c, sift3d_launch_extrema(c->stream, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
+    HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
                                     c->vals_a, c->d_count, c->cand_cap, c->surv, c->surv_counts, c->d_count + 2, cover));
     return SIFT3D_OK;
 }
@@ -934,10 +949,15 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             sigma *= factor;
             sig[j] = sigma;
         }
+        /* the extrema of this octave go to a second stream: they run beside the blurs of the coarser octaves, which are
+         * launch-latency-bound and leave most of the chip idle */
+        HIPCHK(c, hipEventRecord(c->ev_oct[0], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->ex_stream, c->ev_oct[0], 0));
+        c->cand_stream = c->ex_stream;
         for (int l = 0; l < 3; l++) {
             const int id = (int)o * 3 + l;
             rc = cand_append(c, {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.X, d.Y, d.Z, 0, (int)d.Z, id}, true);
-            if (rc) return rc;
+            if (rc) { c->cand_stream = nullptr; return rc; }
             sift3d_level &lv = levels[(size_t)id];
             lv.img = c->L[l + 1] + d.off;
             lv.dogc = c->D[l + 1] + d.off;
@@ -948,9 +968,12 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             lv.z_off = 0;
             lv.pad = 0;
         }
+        c->cand_stream = nullptr;
         fscale *= 2.0f;
         c->last.n_octaves++;
     }
+    HIPCHK(c, hipEventRecord(c->ev_oct[1], c->ex_stream)); /* the candidate counts are read on the main stream */
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_oct[1], 0));
     int64_t ncand = 0;
     rc = cand_finalize(c, &ncand);
     if (rc) return rc;
