@@ -315,7 +315,7 @@ class Context:
 
     # ---- device-pointer forms (bench) ----
     def gauss_blur_dog_dev(self, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value=0.01):
-        self._chk(self._L.sift3d_gauss_blur_dog_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)),
+        self._chk(self._L.sift3d_gauss_blur_dog_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)) if d_out else None,
                                                     C.c_void_p(int(d_dog)) if d_dog else None, nx, ny, nz, float(sigma),
                                                     float(min_value)), "sift3d_gauss_blur_dog_dev")
 

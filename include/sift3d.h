@@ -107,7 +107,8 @@ int sift3d_gauss_blur(sift3d_ctx *ctx, const float *in, float *out, int64_t nx, 
                       float min_value);
 int sift3d_gauss_blur_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, int64_t nx, int64_t ny, int64_t nz,
                           float sigma, float min_value);
-/* Fused form used by the pyramid: out = blur(in), dog = in - out. */
+/* Fused form used by the pyramid: out = blur(in), dog = in - out.  d_out may be NULL when only the DoG is wanted
+ * (the pyramid does that for its sixth level); d_dog may be NULL. */
 int sift3d_gauss_blur_dog_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, float *d_dog, int64_t nx, int64_t ny,
                               int64_t nz, float sigma, float min_value);
 /* fioMultSum_interleave(a, b, out, -1.0f) -> fioCudaMultSum
