@@ -139,6 +139,10 @@ def host_lib():
     _sig(L.nifti_min_write_f32, I, C.c_char_p, P, I, I, I, F, F, F)
     _sig(L.nifti_min_write_f32_ex, I, C.c_char_p, P, I, I, I, F, F, F, P, P)
     _sig(L.sift3d_write_key, I, C.c_char_p, P, I64, F, I, P)
+    _sig(L.sift3d_write_key_bin, I, C.c_char_p, P, I64, F)
+    _sig(L.sift3d_read_key, I, C.c_char_p, P, P)
+    L.free_ptr = C.CDLL(None).free
+    L.free_ptr.argtypes = [C.c_void_p]
     _host = L
     return L
 
@@ -181,6 +185,25 @@ def write_key(path, feats, eig_thres=140.0, comments=()):
                                      C.cast(arr, C.c_void_p))
     if rc != 0:
         raise Sift3DError("could not write %s" % path)
+
+
+def write_key_bin(path, feats, eig_thres=140.0):
+    """msFeature3DVectorOutputBin: header lines as text, then fixed-size binary records."""
+    feats = np.ascontiguousarray(feats, FEATURE_DTYPE)
+    if host_lib().sift3d_write_key_bin(os.fsencode(path), feats.ctypes.data, len(feats), float(eig_thres)) != 0:
+        raise Sift3DError("could not write %s" % path)
+
+
+def read_key(path):
+    """msFeature3DVectorInputText: the records of a text .key file as a FEATURE_DTYPE array."""
+    L = host_lib()
+    ptr, n = C.c_void_p(), C.c_int64(0)
+    rc = L.sift3d_read_key(os.fsencode(path), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise Sift3DError("could not read %s (%d)" % (path, rc))
+    out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n.value * FEATURE_DTYPE.itemsize,)).view(FEATURE_DTYPE).copy()
+    L.free_ptr(ptr)
+    return out
 
 
 def _f32(a):

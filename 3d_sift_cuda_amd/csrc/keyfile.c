@@ -2,6 +2,8 @@
 #include "keyfile.h"
 
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 static int keep(const sift3d_feature *r, float eig_thres)
 {
@@ -35,5 +37,80 @@ int sift3d_write_key(const char *path, const sift3d_feature *recs, int64_t n, fl
         fprintf(f, "\n");
     }
     fclose(f);
+    return 0;
+}
+
+int sift3d_write_key_bin(const char *path, const sift3d_feature *recs, int64_t n, float eig_thres)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    int count = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (keep(&recs[i], eig_thres)) count++;
+    fprintf(f, "# featExtract %s\n", "1.1");
+    fprintf(f, "Features: %d\n", count);
+    for (int64_t i = 0; i < n; i++) {
+        const sift3d_feature *r = &recs[i];
+        if (!keep(r, eig_thres)) continue;
+        fwrite(&r->x, sizeof(float), 1, f);
+        fwrite(&r->y, sizeof(float), 1, f);
+        fwrite(&r->z, sizeof(float), 1, f);
+        fwrite(&r->scale, sizeof(float), 1, f);
+        fwrite(r->ori, sizeof(float), 9, f);
+        fwrite(r->eigs, sizeof(float), 3, f);
+        fwrite(&r->info, sizeof(unsigned int), 1, f);
+        unsigned char pc[SIFT3D_DESC_LEN];
+        for (int j = 0; j < SIFT3D_DESC_LEN; j++) pc[j] = (unsigned char)(r->desc[j]);
+        fwrite(pc, 1, SIFT3D_DESC_LEN, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+int sift3d_read_key(const char *path, sift3d_feature **recs, int64_t *n)
+{
+    if (!recs || !n) return -1;
+    *recs = NULL;
+    *n = 0;
+    FILE *f = fopen(path, "rt");
+    if (!f) return -1;
+    char buff[400];
+    buff[0] = '#';
+    while (buff[0] == '#') /* read past comments */
+        if (!fgets(buff, sizeof(buff), f)) {
+            fclose(f);
+            return -1;
+        }
+    int count = 0;
+    if (sscanf(buff, "Features: %d\n", &count) <= 0 || count <= 0) {
+        fclose(f);
+        return -1;
+    }
+    if (!fgets(buff, sizeof(buff), f) || !strstr(buff, "Scale-space location[x y z scale]")) {
+        fclose(f);
+        return -1;
+    }
+    sift3d_feature *r = (sift3d_feature *)calloc((size_t)count, sizeof(sift3d_feature));
+    if (!r) {
+        fclose(f);
+        return -1;
+    }
+    for (int i = 0; i < count; i++) {
+        int ok = fscanf(f, "%f\t%f\t%f\t%f\t", &r[i].x, &r[i].y, &r[i].z, &r[i].scale) == 4;
+        for (int j = 0; j < 9 && ok; j++) ok = fscanf(f, "%f\t", &r[i].ori[j]) == 1;
+        for (int j = 0; j < 3 && ok; j++) ok = fscanf(f, "%f\t", &r[i].eigs[j]) == 1;
+        int info = 0;
+        if (ok) ok = fscanf(f, "%d\t", &info) == 1;
+        r[i].info = (unsigned int)info;
+        for (int j = 0; j < SIFT3D_DESC_LEN && ok; j++) ok = fscanf(f, "%f\t", &r[i].desc[j]) == 1;
+        if (!ok) { /* the reference asserts here */
+            free(r);
+            fclose(f);
+            return -2;
+        }
+    }
+    fclose(f);
+    *recs = r;
+    *n = count;
     return 0;
 }

@@ -13,6 +13,14 @@ extern "C" {
 /* Returns 0, or -1 if the file cannot be opened.  eig_thres < 0 keeps every record. */
 int sift3d_write_key(const char *path, const sift3d_feature *recs, int64_t n, float eig_thres, int n_comments,
                      const char *const *comments);
+/* The binary flavour, msFeature3DVectorOutputBin (MultiScale.h:228-303): the same two header lines as text
+ * ("# featExtract 1.1", "Features: N"), then per kept record 4+9+3 floats, the info word and the 64 descriptor
+ * values as unsigned char. */
+int sift3d_write_key_bin(const char *path, const sift3d_feature *recs, int64_t n, float eig_thres);
+/* Reader of the text format, msFeature3DVectorInputText (MultiScale.h:305-384): skips the '#' lines, needs the
+ * "Features: N" and the column line, reads N records.  *recs is malloc'ed (release with free()).  Returns 0, -1 if
+ * the file cannot be opened or has no valid header, -2 if a record is incomplete. */
+int sift3d_read_key(const char *path, sift3d_feature **recs, int64_t *n);
 #ifdef __cplusplus
 }
 #endif

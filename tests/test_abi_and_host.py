@@ -7,6 +7,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from keyio import read_key
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -99,3 +101,36 @@ def test_key_writer_matches_oracle_writer(built, oracle, tmp_path):
     oracle.write_key(p1, recs, comments=cm)
     built.write_key(p2, recs.astype(built.FEATURE_DTYPE), comments=cm)
     assert open(p1, "rb").read() == open(p2, "rb").read()
+
+
+def test_key_reader_and_binary_writer(built, oracle, tmp_path):
+    """msFeature3DVectorInputText / msFeature3DVectorOutputBin (MultiScale.h:228-384) on the host side."""
+    import struct
+    gold = os.path.join(ROOT, "tests", "golden", "refbin_blob64.key")   # written by the reference's shipped binary
+    recs = built.read_key(gold)
+    ref = read_key(gold)
+    assert len(recs) == ref["count"] == 74
+    assert np.allclose(recs["x"], ref["rows"][:, 0]) and np.allclose(recs["scale"], ref["rows"][:, 3])
+    assert (recs["ori"] == ref["rows"][:, 4:13].astype(np.float32)).all()
+    assert (recs["info"] == ref["rows"][:, 16].astype(np.uint32)).all()
+    assert (recs["desc"] == ref["rows"][:, 17:].astype(np.float32)).all()
+    # text round trip: what the reader returns writes back to the same file body
+    p = str(tmp_path / "again.key")
+    built.write_key(p, recs, comments=[h[2:] for h in ref["header"][1:4]])
+    assert open(p).read() == open(gold).read()
+    # binary flavour: two text header lines, then 4+9+3 floats, the info word and 64 unsigned chars per record
+    b = str(tmp_path / "out.bin")
+    built.write_key_bin(b, recs)
+    raw = open(b, "rb").read()
+    head = b"# featExtract 1.1\nFeatures: 74\n"
+    assert raw.startswith(head) and len(raw) == len(head) + 74 * (16 * 4 + 4 + 64)
+    first = struct.unpack_from("<16fI64B", raw, len(head))
+    assert np.float32(first[0]) == recs["x"][0] and first[16] == recs["info"][0]
+    assert list(first[17:]) == [int(v) for v in recs["desc"][0]]
+    # errors: missing file, no header
+    with pytest.raises(built.Sift3DError):
+        built.read_key(str(tmp_path / "missing.key"))
+    bad = str(tmp_path / "bad.key")
+    open(bad, "w").write("# featExtract 1.1\nnothing here\n")
+    with pytest.raises(built.Sift3DError):
+        built.read_key(bad)
