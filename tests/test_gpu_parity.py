@@ -205,6 +205,50 @@ def test_pipeline_records(built, oracle, dims, seed, mode):
     assert exact, "float fields are within 1e-4 but not bit-identical"
 
 
+@pytest.mark.parametrize("dims,seed,mode", [((67, 45, 38), 5, 0), ((67, 45, 38), 5, 1), ((73, 90, 51), 21, 3)])
+def test_pipeline_records_odd_dims(built, oracle, dims, seed, mode):
+    """Rows that are not whole 16-byte vectors: every octave takes the scalar-per-lane kernels."""
+    vol = vol_of(built, dims, seed)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        got = ctx.extract(desc_mode=mode)
+    want, _ = oracle.extract(vol, desc_mode=mode)
+    assert len(want) > 5 and _compare_records(got, want)
+
+
+def test_pipeline_records_through_the_fused_blur(built, oracle):
+    """A volume of more than 2^22 voxels: its finest octave is built by the one-launch blur kernel (both tile
+    heights: 11 taps use the 64x16 tile), the coarser ones by the three-pass kernels; records against the oracle."""
+    dims = (168, 164, 160)
+    vol = vol_of(built, dims, 9)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        ctx.enable_timing(True)
+        got = ctx.extract()
+        log = ctx.launch_log()
+    assert (log["stage"] == built.STAGES.index("blur_fused")).sum() == 6       # initial blur + five levels of octave 0
+    want, _ = oracle.extract(vol)
+    assert len(want) > 200 and _compare_records(got, want)
+
+
+def test_pipeline_empty_volume(built, oracle, tmp_path):
+    """No extremum anywhere: zero records, and the CLI still writes a well-formed .key."""
+    dims = (48, 40, 36)
+    vol = np.zeros(dims[::-1], np.float32)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        assert len(ctx.detect()) == 0
+        assert len(ctx.extract()) == 0
+    want, _ = oracle.extract(vol)
+    assert len(want) == 0
+    nii, k = str(tmp_path / "zero.nii"), str(tmp_path / "zero.key")
+    built.write_nifti(nii, vol)
+    r = subprocess.run([built.FEATEXTRACT, "-d0", nii, k], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(k).read().splitlines()
+    assert lines[0] == "# featExtract 1.1" and "Features: 0" in lines and len(lines) == 6
+
+
 def test_pipeline_double_and_halve(built, oracle):
     dims = (40, 36, 32)
     vol = vol_of(built, dims, 99)
