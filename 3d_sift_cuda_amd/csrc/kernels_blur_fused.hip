@@ -49,6 +49,9 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 #define FB_TX 64
+/* planes of window prefetch: two where the registers are there without spilling (13 taps: 243 VGPRs at two wavefronts
+ * per SIMD; 17 taps would spill) */
+#define FB_PF(R) (((R) == 6 || (R) == 7) ? 2 : 1)
 
 struct fb_taps2 {
     v2f f[2 * SIFT3D_FAST_MAX_R + 1]; /* (f[j], f[j]): a 64-bit scalar operand of the packed multiply */
@@ -57,7 +60,7 @@ struct fb_taps2 {
 /* TY = rows of the tile (16 or 32), 16 * TY threads: 8 threads per row for the x pass of the TY + 2R rows, a 2 x 2
  * block per thread for the y and z passes.  The taller tile halves the relative cost of the y halo (x pass work and
  * halo traffic) and is used whenever the volume has enough rows. */
-template <int R, int TY>
+template <int R, int TY, int PF>
 __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 : (R >= 4 ? 3 : 4))))) void blur_fused_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                          float *__restrict__ dog, const float *__restrict__ zeros, int X,
                                                          int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total,
@@ -112,7 +115,10 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
     const long long boff0 = st0 ? (long long)by * X + bx : 0;
     const long long boff1 = st1 ? (long long)(by + 1) * X + bx : 0;
 
-    v4f winA[NV]; /* window of the next plane: loaded one step before its x pass */
+    /* PF = 2: two window buffers; plane z lives in buffer (z - zfirst) & 1 and is loaded two steps before its x pass,
+     * so that every wavefront has the loads of two planes in flight (worth its 24 registers where they are free).
+     * PF = 1: one buffer, loaded one step ahead. */
+    v4f winA[NV], winB[PF == 2 ? NV : 1];
     /* x pass of the plane whose window is in win[]: 8 outputs (4 pairs) to P1.  Output pair e, tap j reads the
      * window floats s, s+1 with s = H4 - R + 2e + j: an aligned register pair when s is even, one of the
      * WIN/2 - 1 odd pairs (built once per plane) when it is odd. */
@@ -158,7 +164,12 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
     };
     load_window(winA, zfirst);
     if (zfirst >= 0 && ar < NR) x_pass(winA, P1buf[0]); /* zfirst < Z always */
-    load_window(winA, zfirst + 1);
+    if constexpr (PF == 2) {
+        load_window(winB, zfirst + 1);
+        load_window(winA, zfirst + 2);
+    } else {
+        load_window(winA, zfirst + 1);
+    }
 
     /* z pass in registers: slot i of acc0/acc1 (rows 2*brs, 2*brs+1) is the output plane that started with the
      * plane of phase i; at phase s the new plane feeds tap (s - i) mod U of slot i, and slot (s + 1) mod U has just
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
     if (dog) load_prev(zc0);
     int phase = 0, cur = 0;
     lds_barrier(); /* P1buf[0] holds the x pass of plane zfirst */
-    for (int zin = zfirst; zin <= zlast; zin++) {
+    auto step = [&](int zin, v4f(&win)[NV]) { /* win holds plane zin + 1 */
         const bool plane = zin >= 0 && zin < Z;
         const int zo = zin - R;
         const bool emit = zo >= zc0; /* zo < zc1 by construction of zlast */
@@ -186,9 +197,6 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
         v2f p[U + 1];
 #pragma unroll
         for (int q = 0; q < U + 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(2 * brs + q) * FB_TX + 2 * bcp]);
-        /* ---- A: x pass of plane zin + 1 into the other buffer, then the window of plane zin + 2 ---- */
-        if (zin + 1 >= 0 && zin + 1 < Z && zin + 1 <= zlast && ar < NR) x_pass(winA, P1buf[cur ^ 1]);
-        load_window(winA, zin + 2);
         /* ---- B: y pass of plane zin, 2 rows x 2 columns per thread ---- */
         v2f g0 = v2f(0.0f), g1 = v2f(0.0f);
 #pragma unroll
@@ -197,6 +205,9 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
             g1 = g1 + t.f[j] * p[j + 1];
         }
         if (!plane) g0 = g1 = v2f(0.0f); /* P1 was stale */
+        /* ---- A: x pass of plane zin + 1 into the other buffer, then the next window for this register buffer ---- */
+        if (zin + 1 >= 0 && zin + 1 < Z && zin + 1 <= zlast && ar < NR) x_pass(win, P1buf[cur ^ 1]);
+        load_window(win, zin + 1 + PF); /* the buffer is free again */
         /* ---- C: z pass ---- */
         v2f a0 = v2f(0.0f), a1 = v2f(0.0f);
         switch (phase) {
@@ -238,6 +249,16 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
         phase = phase + 1 == U ? 0 : phase + 1;
         cur ^= 1;
         lds_barrier(); /* the other buffer is complete, and every wavefront has read this one */
+    };
+    if constexpr (PF == 2) {
+        int zin = zfirst;
+        for (; zin + 1 <= zlast; zin += 2) {
+            step(zin, winB);
+            step(zin + 1, winA);
+        }
+        if (zin <= zlast) step(zin, winB);
+    } else {
+        for (int zin = zfirst; zin <= zlast; zin++) step(zin, winA);
     }
 }
 
@@ -270,7 +291,7 @@ static void launch_fused_ty(hipStream_t s, const float *in, float *out, float *d
     static int resident = 0; /* workgroups of this instantiation one CU holds (registers) */
     if (resident == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<R, TY>, 16 * TY, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<R, TY, FB_PF(R)>, 16 * TY, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + TY - 1) / TY);
@@ -280,7 +301,7 @@ static void launch_fused_ty(hipStream_t s, const float *in, float *out, float *d
     const int nch = (int)((Z + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
-    hipLaunchKernelGGL((blur_fused_kernel<R, TY>), dim3((unsigned)(8 * per)), dim3(16 * TY), 0, s, in, out, dog, zeros, (int)X,
+    hipLaunchKernelGGL((blur_fused_kernel<R, TY, FB_PF(R)>), dim3((unsigned)(8 * per)), dim3(16 * TY), 0, s, in, out, dog, zeros, (int)X,
                        (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
 }
 

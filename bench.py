@@ -14,10 +14,11 @@ GPUs is described in DESIGN.md and is not what this line measures.
 
 Rank 0 prints ONE JSON line: metric = keypoints/s (.key records per second,
 whole job), plus
-  roofline     the dominant pyramid kernel (the fused x+y+z+DoG blur of one level):
-               algorithmic = compulsory bytes (12 B/voxel/launch)
-               / its launch time, measured here with HIP events on the stream the
-               kernels run on
+  roofline     the dominant pyramid kernel (the fused x+y+z+DoG blur, one launch per
+               level): algorithmic = compulsory bytes (12 B/voxel,
+               8 where only the level or only the DoG is kept) / launch time over its
+               512^3 launches, measured here with HIP events on the stream the kernels
+               run on; per tap count in `per_instantiation`
   pyramid      Gauss-pyramid + DoG GB/s over all blur launches of a step
   cpu_baseline the CPU restatement (oracle/, single thread like the reference's
                extractor) timed on this box on a 256^3 sample, N = 1 only
@@ -36,13 +37,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def kernel_name(stage, ntaps, dog):
+def kernel_name(stage, ntaps, dog, vec=4):
     r = ntaps // 2
     if stage == "blur_fused":
         return "blur_fused_kernel<%d>" % r
     if stage == "blur_x":
-        return "blur_x_kernel<%d,4>" % r
-    return "blur_col_kernel<%d,4,%s>" % (r, "true" if dog else "false")
+        return "blur_x_kernel<%d,%d>" % (r, vec)
+    return "blur_col_kernel<%d,%d,%s>" % (r, vec, "true" if dog else "false")
 
 
 def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
@@ -182,51 +183,74 @@ def main():
             g = groups.setdefault(key, {"ms": 0.0, "bytes": 0.0, "launches": 0})
             g["ms"] += float(r["ms"]); g["bytes"] += float(r["alg_bytes"]); g["launches"] += 1
         blur_groups = {k: v for k, v in groups.items() if k[0].startswith("blur")}
-        # dominant = the blur instantiation with the largest total time over the n^3 (octave-0) launches, which run
-        # before anything shares the chip with them (the extrema of an octave overlap the blurs of the coarser ones)
-        big = {}
-        for r in log[log["nvox"] == n ** 3]:
-            st = stage_names[r["stage"]]
-            if st.startswith("blur"):
-                key = (st, int(r["ntaps"]), bool(st in ("blur_z_dog", "blur_fused") and r["alg_bytes"] > 8.5 * r["nvox"]))
-                big[key] = big.get(key, 0.0) + float(r["ms"])
-        dom_key = max(big, key=big.get) if big else max(blur_groups, key=lambda k: blur_groups[k]["ms"])
-        dom = blur_groups[dom_key]
-        # The roofline figure is for the octave-0 launches of the dominant instantiation (the n^3 volume:
-        # 7/8 of the bytes of the pyramid); the same instantiation also runs once per coarser octave, down to
-        # 4^3, where launch latency dominates -- that aggregate is reported next to it and is what the
-        # per-kernel average of `rocprofv3 --stats` shows.
-        sel = log[(log["stage"] == stage_names.index(dom_key[0])) & (log["ntaps"] == dom_key[1]) & (log["nvox"] == n ** 3)]
-        if dom_key[0] in ("blur_z_dog", "blur_fused"):
-            sel = sel[(sel["alg_bytes"] > 8.5 * sel["nvox"]) == dom_key[2]]
+        # The dominant kernel of the pyramid is the fused blur (one template, one instantiation per tap count); its
+        # roofline figure is taken over its n^3 (octave-0) launches -- 7/8 of the pyramid's bytes, and they run before
+        # anything shares the chip with them (the extrema of an octave overlap the blurs of the coarser ones).  The
+        # same kernels also run on the coarser octaves; that aggregate is what `rocprofv3 --stats` averages.
+        fused_id = stage_names.index("blur_fused") if "blur_fused" in stage_names else -1
+        sel = log[(log["stage"] == fused_id) & (log["nvox"] == n ** 3)]
+        if len(sel):
+            dom_name = "blur_fused_kernel<R, tile rows, prefetch> (the %d launches per volume at %d^3: initial blur + five levels)" % (len(sel) // args.steps, n)
+            dom_all = log[log["stage"] == fused_id]
+            per_inst = []
+            for taps in sorted(set(int(t) for t in sel["ntaps"])):
+                for dogflag in (False, True):
+                    q = sel[(sel["ntaps"] == taps) & ((sel["alg_bytes"] > 8.5 * sel["nvox"]) == dogflag)]
+                    if len(q):
+                        per_inst.append({"taps": taps, "alg_bytes_per_voxel": round(float(q["alg_bytes"][0]) / n ** 3, 1),
+                                         "launches": int(len(q)), "avg_launch_ms": round(float(q["ms"].mean()), 4),
+                                         "GBs": round(float(q["alg_bytes"].sum()) / (float(q["ms"].sum()) * 1e-3) / 1e9, 1)})
+            accounting = ("fused x+y+z+DoG launches: compulsory bytes only -- read the level once, write what is kept (level and "
+                          "DoG: 12 B/voxel; initial blur: level only, sixth level: DoG only: 8 B/voxel); the three-pass form of "
+                          "the same work is credited 32 (24) B/voxel")
+        else:   # rows that are not whole 16-byte vectors: three-pass kernels; dominant = slowest instantiation at n^3
+            big = {}
+            for r in log[log["nvox"] == n ** 3]:
+                st = stage_names[r["stage"]]
+                if st.startswith("blur"):
+                    key = (st, int(r["ntaps"]), bool(st == "blur_z_dog" and r["alg_bytes"] > 8.5 * r["nvox"]))
+                    big[key] = big.get(key, 0.0) + float(r["ms"])
+            dom_key = max(big, key=big.get)
+            sel = log[(log["stage"] == stage_names.index(dom_key[0])) & (log["ntaps"] == dom_key[1]) & (log["nvox"] == n ** 3)]
+            if dom_key[0] == "blur_z_dog":
+                sel = sel[(sel["alg_bytes"] > 8.5 * sel["nvox"]) == dom_key[2]]
+            dom_name = kernel_name(dom_key[0], dom_key[1], dom_key[2], 4 if n % 4 == 0 else 1)
+            dom_all = log[(log["stage"] == stage_names.index(dom_key[0])) & (log["ntaps"] == dom_key[1])]
+            per_inst = None
+            accounting = "8 B/voxel per x or y pass, 16 B/voxel for the z pass with fused DoG store"
         big_ms, big_bytes = float(sel["ms"].sum()), float(sel["alg_bytes"].sum())
         achieved = big_bytes / (big_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
-        if os.path.exists(pmc) and n == 512:
-            try:
-                name = kernel_name(dom_key[0], dom_key[1], dom_key[2])
+        if os.path.exists(pmc) and n == 512 and per_inst:
+            try:   # PMC bytes of every instantiation (keys "blur_fused_kernel<R, ...>"), averaged over the launches
                 tab = json.load(open(pmc))
-                hit = [k for k in tab if k == name or k.startswith(name[:-1] + ",")]   # "<R>" or "<R, tile rows>"
-                traffic = tab[hit[0]].get("hbm_bytes_per_launch_512") if hit else None
+                tot, cnt = 0.0, 0
+                for pi in per_inst:
+                    hit = [k for k in tab if k.startswith("blur_fused_kernel<%d," % (pi["taps"] // 2))]
+                    if not hit:
+                        raise KeyError(pi["taps"])
+                    v = tab[hit[0]]
+                    # the PMC pass stores level and DoG except for the sixth level; a launch that keeps only the level
+                    # (initial blur) writes 4 B/voxel less than its PMC twin
+                    w = v["hbm_bytes_per_launch_512"] - (4.0 * n ** 3 if (pi["alg_bytes_per_voxel"] < 9 and pi["taps"] != 17) else 0.0)
+                    tot += w * pi["launches"]; cnt += pi["launches"]
+                traffic = tot / cnt
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": kernel_name(dom_key[0], dom_key[1], dom_key[2]),
+                    "kernel": dom_name,
                     "launch": "%d^3 volume (octave 0)" % n, "launches": int(len(sel)),
                     "avg_launch_ms": round(big_ms / max(1, len(sel)), 4),
                     "alg_bytes_per_launch": big_bytes / max(1, len(sel)),
                     "alg_bytes_per_voxel": round(big_bytes / max(1, len(sel)) / n ** 3, 2),
-                    "accounting": ("fused x+y+z+DoG launch: compulsory bytes only -- read the level once, write the blurred level "
-                                   "and the DoG once = 12 B/voxel (8 without DoG); the three-pass form of the same work moves 32 "
-                                   "(24) B/voxel, i.e. this launch equals %.0f GB/s of three-pass traffic"
-                                   % (achieved * 32.0 / 12.0)) if dom_key[0] == "blur_fused" else
-                                  "8 B/voxel per x or y pass, 16 B/voxel for the z pass with fused DoG store",
-                    "all_launches": {"launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                                     "achieved": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
-                                     "note": "every octave down to 4^3; compare with the per-kernel average of rocprofv3 --stats"},
-                    "traffic_source": "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md)" if traffic else None}
+                    "accounting": accounting,
+                    "per_instantiation": per_inst,
+                    "all_launches": {"launches": int(len(dom_all)), "avg_launch_ms": round(float(dom_all["ms"].mean()), 4),
+                                     "achieved": round(float(dom_all["alg_bytes"].sum()) / (float(dom_all["ms"].sum()) * 1e-3) / 1e9, 1),
+                                     "note": "every octave the kernel runs on; compare with the per-kernel averages of rocprofv3 --stats"},
+                    "traffic_source": "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md), averaged over the launches" if traffic else None}
         pyr_ms = sum(v["ms"] for v in blur_groups.values())
         pyr_bytes = sum(v["bytes"] for v in blur_groups.values())
         pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
