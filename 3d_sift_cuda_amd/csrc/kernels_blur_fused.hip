@@ -75,14 +75,15 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
     constexpr int NV = WIN / 4;              /* vectors per window */
     __shared__ __attribute__((aligned(16))) float P1buf[2][FB_P1_ROWS * FB_TX]; /* double-buffered: one barrier per plane */
 
-    /* workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of tiles (y fastest,
-     * then x, then z chunk) so that the y halo of a tile is fetched by the L2 that holds its neighbour */
+    /* workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of tiles (x fastest, then y,
+     * then z chunk), i.e. a band of whole rows: the x halos of its tiles and all but the band's two outer y halos
+     * are fetched by the L2 that holds the neighbouring tile */
     const long long lin = blockIdx.x;
     const long long per = (total + 7) / 8;
     const long long w = (lin % 8) * per + lin / 8;
     if (w >= total) return;
-    const int ty = (int)(w % tiles_y);
-    const int tx = (int)((w / tiles_y) % tiles_x);
+    const int tx = (int)(w % tiles_x);
+    const int ty = (int)((w / tiles_x) % tiles_y);
     const int chunk = (int)(w / ((long long)tiles_y * tiles_x));
     const int x0 = tx * FB_TX, y0 = ty * FB_TY;
     const int zc0 = chunk * zlen;
