@@ -67,7 +67,8 @@ struct sift3d_ctx {
     int64_t cand_cap;
     unsigned long long *d_count; /* [0] validated extrema, [1] own-level survivors of the level in flight, [2] survivor overflow high-water mark */
     sift3d_survivor *surv;
-    unsigned long long *surv_counts; /* segment counters of the own-level list */
+    unsigned long long *surv_counts; /* segment counters of the own-level list: SIFT3D_SURV_SETS sets */
+    int surv_set;                    /* next unused set since the last reset */
     int64_t surv_cap;
     int surv_div; /* own-level extrema expected per level: voxels / surv_div (+ slack); 1 after an overflow */
     void *sort_tmp;
@@ -251,7 +252,8 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
     c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
     ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->surv_counts, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->surv_counts, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
+    c->surv_set = 0;
     if (!ok) {
         free_dev(c);
         if (c->stream) hipStreamDestroy(c->stream);
@@ -621,6 +623,9 @@ static int cand_reset(sift3d_ctx *c)
 {
     c->jobs.clear();
     HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+    /* every extrema pass of the run gets its own counter set: one memset here instead of one per pass */
+    HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, c->stream));
+    c->surv_set = 0;
     return SIFT3D_OK;
 }
 
@@ -633,14 +638,18 @@ static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
      * sized at 1/surv_div of its voxels; an overflow is flagged on the device and handled in cand_finalize */
     int64_t cover = j.X * j.Y * j.Z / c->surv_div + 64 * 1024; /* split evenly over 64 segments */
     if (cover > c->surv_cap) cover = c->surv_cap;
+    const bool fresh = c->surv_set < SIFT3D_SURV_SETS;
+    unsigned long long *counters = c->surv_counts + (size_t)(fresh ? c->surv_set++ : SIFT3D_SURV_SETS - 1) * SIFT3D_SURV_COUNTERS;
     HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
-                                    c->vals_a, c->d_count, c->cand_cap, c->surv, c->surv_counts, c->d_count + 2, cover));
+                                    c->vals_a, c->d_count, c->cand_cap, c->surv, counters, c->d_count + 2, cover, !fresh));
     return SIFT3D_OK;
 }
 
 static int cand_replay(sift3d_ctx *c)
 {
     HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, c->stream));
+    c->surv_set = 0;
     for (const level_job &j : c->jobs) {
         int rc = cand_append(c, j, false);
         if (rc) return rc;

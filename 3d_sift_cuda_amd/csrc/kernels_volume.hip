@@ -893,7 +893,8 @@ hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, i
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
                                  int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
                                  sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
-                                 unsigned long long *surv_count, unsigned long long *surv_overflow, int64_t surv_cap)
+                                 unsigned long long *surv_count, unsigned long long *surv_overflow, int64_t surv_cap,
+                                 bool zero_counters)
 {
     if (X < 3 || Y < 3 || Z < 3) return hipSuccess;
     /* interior planes 1..Z-2, further restricted to [z_lo, z_hi) (Z-slab mode keeps only its own slices) */
@@ -904,8 +905,10 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
         const int xtiles = (int)((X - 2 + EX_XOUT - 1) / EX_XOUT);
         const int ytiles = (int)((Y - 2 + EX_ROWS - 1) / EX_ROWS);
         const long long waves_xy = (long long)xtiles * ytiles;
-        hipError_t e = hipMemsetAsync(surv_count, 0, sizeof(unsigned long long) * EX_SEGS * EX_SEG_STRIDE, s);
-        if (e != hipSuccess) return e;
+        if (zero_counters) { /* the pipeline hands every level its own, already zeroed, counter set instead */
+            hipError_t e = hipMemsetAsync(surv_count, 0, sizeof(unsigned long long) * EX_SEGS * EX_SEG_STRIDE, s);
+            if (e != hipSuccess) return e;
+        }
         /* marching form when chunks of >= 8 planes still give the chip a few thousand wavefronts */
         int zchunk = 1;
         for (int zc = 32; zc >= 8; zc /= 2)

@@ -66,7 +66,8 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
                                  int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
                                  sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
                                  unsigned long long *surv_count /* SIFT3D_SURV_COUNTERS words */,
-                                 unsigned long long *surv_overflow, int64_t surv_cap);
+                                 unsigned long long *surv_overflow, int64_t surv_cap, bool zero_counters);
+#define SIFT3D_SURV_SETS 96 /* one counter set per extrema pass of a pipeline run, zeroed together */
 #define SIFT3D_SURV_COUNTERS (64 * 32)
 
 /* ---- per-keypoint stage (kernels_keypoint.hip) ---- */
