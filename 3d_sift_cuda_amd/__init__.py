@@ -400,7 +400,8 @@ class Context:
         self._chk(self._L.sift3d_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None), "sift3d_set_stream")
 
     def enable_timing(self, on=True):
-        self._chk(self._L.sift3d_enable_timing(self._h, 1 if on else 0), "sift3d_enable_timing")
+        """False / 0 off, True / 1 every launch, 2 only the blur launches on the full-size volume."""
+        self._chk(self._L.sift3d_enable_timing(self._h, int(on)), "sift3d_enable_timing")
 
     def launch_log(self):
         """Per-launch records (stage, ntaps, nvox, alg_bytes, ms) of the last pipeline/blur call."""

@@ -89,7 +89,7 @@ struct sift3d_ctx {
     std::vector<struct level_job> jobs; /* extrema launches since the last reset (replayed if the buffer must grow) */
     int64_t nx, ny, nz;
     bool has_volume;
-    bool timing;
+    int timing; /* 0 off; 1 every launch bracketed by events; 2 only the blur launches of the finest octave */
     std::vector<timed_launch> launches;
     std::vector<hipEvent_t> pool;
     size_t pool_used;
@@ -199,7 +199,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->own_stream = true;
     c->capN = nx * ny * nz;
     c->err[0] = 0;
-    c->timing = false;
+    c->timing = 0;
     c->pool_used = 0;
     c->resolved = 0;
     c->has_volume = false;
@@ -362,12 +362,19 @@ struct stage_scope {
     int64_t nvox;
     double bytes;
     hipStream_t st;
+    bool timed;
     stage_scope(sift3d_ctx *c_, int stage_, double bytes_, int ntaps_ = 0, int64_t nvox_ = 0, hipStream_t st_ = nullptr)
         : c(c_), stage(stage_), e0(nullptr), e1(nullptr), ntaps(ntaps_), nvox(nvox_), bytes(bytes_), st(st_ ? st_ : c_->stream)
     {
         c->last.launches[stage] += 1;
         c->last.alg_bytes[stage] += bytes;
-        if (c->timing) {
+        /* events cost a few microseconds each (two per launch, ~170 launches: 1 ms of a 13 ms run at 512^3): mode 2
+         * keeps them to the dominant kernels, the blur launches on the full-size volume */
+        timed = c->timing == 1 ||
+                (c->timing == 2 && nvox == c->nx * c->ny * c->nz &&
+                 (stage == SIFT3D_STAGE_BLUR_FUSED || stage == SIFT3D_STAGE_BLUR_X || stage == SIFT3D_STAGE_BLUR_Y ||
+                  stage == SIFT3D_STAGE_BLUR_Z_DOG));
+        if (timed) {
             e0 = get_event(c);
             e1 = get_event(c);
             hipEventRecord(e0, st);
@@ -377,13 +384,13 @@ struct stage_scope {
     {
         c->last.launches[stage] -= 1;
         c->last.alg_bytes[stage] -= bytes;
-        if (c->timing) c->pool_used -= 2;
+        if (timed) c->pool_used -= 2;
         stage = -1;
     }
     ~stage_scope()
     {
         if (stage < 0) return;
-        if (c->timing) {
+        if (timed) {
             hipEventRecord(e1, st);
             c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f});
         }
@@ -421,7 +428,7 @@ extern "C" int sift3d_enable_timing(sift3d_ctx *c, int on)
     if (!c) return SIFT3D_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->timing = on != 0;
+    c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
     timing_begin(c); /* operator-level *_dev calls accumulate from here until the log is read */
     return SIFT3D_OK;
 }

@@ -213,6 +213,8 @@ typedef struct {
     int64_t n_octaves, n_extrema, n_keypoints, n_records;
     double total_ms;                      /* first kernel to last, on the stream */
 } sift3d_timings;
+/* on: 0 off; 1 every launch bracketed by two events (full per-stage breakdown; costs about 1 ms per 512^3 run);
+ * 2 only the blur launches on the full-size volume (the dominant kernels: what a benchmark can leave on). */
 int sift3d_enable_timing(sift3d_ctx *ctx, int on);
 int sift3d_get_timings(const sift3d_ctx *ctx, sift3d_timings *t);
 /* Per-launch log of the same call (needs timing enabled): one entry per kernel
