@@ -35,13 +35,15 @@ struct timed_launch {
 /* One detection level: which buffers, which dims, which slices to keep */
 struct level_job {
     const float *dp, *dc, *dn;
-    int64_t X, Y, Z;
+    int64_t X, Y, Z; /* X is the row pitch of the buffers */
     int z_lo, z_hi;
     int lvl_id;
+    int64_t Xl;      /* logical row length (0: same as X) */
 };
 
 struct octave_dims {
     int64_t X, Y, Z, off; /* dims and float offset of this octave inside every level buffer */
+    int64_t XP;           /* row pitch: X rounded up to whole 16-byte vectors (the pad columns stay zero) */
 };
 
 struct sift3d_ctx {
@@ -88,6 +90,7 @@ struct sift3d_ctx {
     int64_t h_recs_cap;
     std::vector<struct level_job> jobs; /* extrema launches since the last reset (replayed if the buffer must grow) */
     int64_t nx, ny, nz;
+    int64_t pad_nx, pad_ny, pad_nz; /* geometry the pad columns of the level buffers were last cleared for */
     bool has_volume;
     int timing; /* 0 off; 1 every launch bracketed by events; 2 only the blur launches of the finest octave */
     std::vector<timed_launch> launches;
@@ -160,13 +163,18 @@ static void free_dev(sift3d_ctx *c)
 }
 
 /* octave list of a volume: halve while every dimension stays above 2 (MultiScale.cpp:359-360,546-556) */
+static inline int64_t pitch_of(int64_t X) { return (X + 3) / 4 * 4; }
+
+/* Inside the pipeline every octave is stored with rows padded to whole 16-byte vectors; the pad columns hold zeros
+ * (what the blur reads outside the volume), so the vector kernels serve any row length. */
 static std::vector<octave_dims> octave_list(int64_t X, int64_t Y, int64_t Z)
 {
     std::vector<octave_dims> v;
     int64_t off = 0;
     while (X > 2 && Y > 2 && Z > 2 && v.size() < 32) {
-        v.push_back({X, Y, Z, off});
-        off += ((X * Y * Z + 63) / 64) * 64; /* keep every octave 256-byte aligned */
+        const int64_t XP = pitch_of(X);
+        v.push_back({X, Y, Z, off, XP});
+        off += ((XP * Y * Z + 63) / 64) * 64; /* keep every octave 256-byte aligned */
         X /= 2; Y /= 2; Z /= 2;
     }
     return v;
@@ -197,12 +205,14 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     sift3d_ctx *c = new sift3d_ctx();
     c->device = device;
     c->own_stream = true;
-    c->capN = nx * ny * nz;
+    c->capN = pitch_of(nx) * ny * nz; /* floats of the largest volume, rows padded to whole vectors */
     c->err[0] = 0;
     c->timing = 0;
+    c->pad_nx = c->pad_ny = c->pad_nz = 0;
     c->pool_used = 0;
     c->resolved = 0;
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     c->nx = c->ny = c->nz = 0;
     memset(&c->last, 0, sizeof(c->last));
     c->vol = nullptr;
@@ -229,7 +239,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->rec_group = c->h_group = nullptr;
     c->h_recs_cap = 0;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
-    c->capTot = c->capN + c->capN / 7 + 64 * 34;
+    c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     c->copy_stream = nullptr;
     for (int i = 0; i < 4; i++) c->ev_chunk[i] = nullptr;
@@ -340,6 +350,7 @@ extern "C" int sift3d_selftest_lds_add(sift3d_ctx *c, const float *a, const floa
     HIPCHK(c, hipMemcpyAsync(lds, dl, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     return SIFT3D_OK;
 }
 
@@ -371,7 +382,7 @@ struct stage_scope {
         /* events cost a few microseconds each (two per launch, ~170 launches: 1 ms of a 13 ms run at 512^3): mode 2
          * keeps them to the dominant kernels, the blur launches on the full-size volume */
         timed = c->timing == 1 ||
-                (c->timing == 2 && nvox == c->nx * c->ny * c->nz &&
+                (c->timing == 2 && nvox == pitch_of(c->nx) * c->ny * c->nz &&
                  (stage == SIFT3D_STAGE_BLUR_FUSED || stage == SIFT3D_STAGE_BLUR_X || stage == SIFT3D_STAGE_BLUR_Y ||
                   stage == SIFT3D_STAGE_BLUR_Z_DOG));
         if (timed) {
@@ -502,7 +513,7 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
 static int check_shape(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    if (nx <= 0 || ny <= 0 || nz <= 0 || nx * ny * nz > c->capN)
+    if (nx <= 0 || ny <= 0 || nz <= 0 || pitch_of(nx) * ny * nz > c->capN)
         return set_err(c, SIFT3D_ERR_ARG, "volume %lldx%lldx%lld does not fit the context (%lld voxels)", (long long)nx,
                        (long long)ny, (long long)nz, (long long)c->capN);
     if (nx >= (1ll << 31) || ny >= (1ll << 31) || nz >= 65536 + 2) return set_err(c, SIFT3D_ERR_ARG, "dimension too large");
@@ -544,6 +555,7 @@ extern "C" int sift3d_gauss_blur(sift3d_ctx *c, const float *in, float *out, int
     HIPCHK(c, hipMemcpyAsync(out, c->L[0], b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     return SIFT3D_OK;
 }
 
@@ -567,6 +579,7 @@ extern "C" int sift3d_dog(sift3d_ctx *c, const float *a, const float *b, float *
     HIPCHK(c, hipMemcpyAsync(out, c->D[0], by, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     return SIFT3D_OK;
 }
 
@@ -574,7 +587,7 @@ extern "C" int sift3d_subsample2_dev(sift3d_ctx *c, const float *d_in, int64_t n
 {
     if (!c || nx < 2 || ny < 2 || nz < 2) return set_err(c, SIFT3D_ERR_ARG, "subsample needs every dimension >= 2");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, sift3d_launch_subsample(c->stream, d_in, nx, ny, nz, d_out));
+    HIPCHK(c, sift3d_launch_subsample(c->stream, d_in, nx, nx, ny, nz, d_out, nx / 2));
     return SIFT3D_OK;
 }
 
@@ -591,6 +604,7 @@ extern "C" int sift3d_subsample2(sift3d_ctx *c, const float *in, int64_t nx, int
     HIPCHK(c, hipMemcpyAsync(out, c->L[1], ob, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     return SIFT3D_OK;
 }
 
@@ -604,6 +618,7 @@ extern "C" int sift3d_double_size(sift3d_ctx *c, const float *in, int64_t nx, in
     HIPCHK(c, hipMemcpyAsync(out, c->L[1], sizeof(float) * (size_t)(8 * nx * ny * nz), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     return SIFT3D_OK;
 }
 
@@ -619,6 +634,7 @@ extern "C" int sift3d_halve_size(sift3d_ctx *c, const float *in, int64_t nx, int
     HIPCHK(c, hipMemcpyAsync(out, c->L[1], ob, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     return SIFT3D_OK;
 }
 
@@ -647,7 +663,7 @@ static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
     if (cover > c->surv_cap) cover = c->surv_cap;
     const bool fresh = c->surv_set < SIFT3D_SURV_SETS;
     unsigned long long *counters = c->surv_counts + (size_t)(fresh ? c->surv_set++ : SIFT3D_SURV_SETS - 1) * SIFT3D_SURV_COUNTERS;
-    HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
+    HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Xl ? j.Xl : j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
                                     c->vals_a, c->d_count, c->cand_cap, c->surv, counters, c->d_count + 2, cover, !fresh));
     return SIFT3D_OK;
 }
@@ -710,6 +726,7 @@ extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d
     HIPCHK(c, hipMemcpyAsync(c->D[1], d_cur, b, hipMemcpyHostToDevice, c->stream));
     if (d_next) HIPCHK(c, hipMemcpyAsync(c->D[2], d_next, b, hipMemcpyHostToDevice, c->stream));
     c->has_volume = false;
+    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
     int64_t cnt = 0;
     rc = cand_reset(c);
     if (!rc) rc = cand_append(c, {c->D[0], c->D[1], d_next ? c->D[2] : nullptr, nx, ny, nz, 0, (int)nz, 0}, true);
@@ -746,6 +763,29 @@ extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d
 }
 
 /* ---- pipeline ------------------------------------------------------------ */
+/* The pipeline's copy of the volume has its rows padded to whole 16-byte vectors (octave_list).  When the padded
+ * geometry changes, every level buffer is cleared once: the pad columns are never written afterwards. */
+static int load_volume(sift3d_ctx *c, const float *src, bool from_host, int64_t nx, int64_t ny, int64_t nz)
+{
+    const int64_t xp = pitch_of(nx);
+    if (xp != nx && (c->pad_nx != nx || c->pad_ny != ny || c->pad_nz != nz)) {
+        for (int i = 0; i < 6; i++) HIPCHK(c, hipMemsetAsync(c->L[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
+        for (int i = 0; i < 5; i++) HIPCHK(c, hipMemsetAsync(c->D[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->vol, 0, sizeof(float) * (size_t)c->capN, c->stream));
+        c->pad_nx = nx; c->pad_ny = ny; c->pad_nz = nz;
+    }
+    if (xp == nx) {
+        c->pad_nx = 0; /* dense rows overwrite what would be pad columns of another geometry */
+        if (src != c->vol)
+            HIPCHK(c, hipMemcpyAsync(c->vol, src, sizeof(float) * (size_t)(nx * ny * nz), from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if (src == c->vol) return set_err(c, SIFT3D_ERR_ARG, "in-place set_volume needs rows of whole 16-byte vectors");
+        HIPCHK(c, hipMemcpy2DAsync(c->vol, sizeof(float) * (size_t)xp, src, sizeof(float) * (size_t)nx, sizeof(float) * (size_t)nx,
+                                   (size_t)(ny * nz), from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    }
+    return SIFT3D_OK;
+}
+
 extern "C" int sift3d_set_volume(sift3d_ctx *c, const float *vol, int64_t nx, int64_t ny, int64_t nz)
 {
     int rc = check_shape(c, nx, ny, nz);
@@ -753,7 +793,8 @@ extern "C" int sift3d_set_volume(sift3d_ctx *c, const float *vol, int64_t nx, in
     if (!vol) return set_err(c, SIFT3D_ERR_ARG, "null volume");
     if (nz <= 1) return set_err(c, SIFT3D_ERR_ARG, "Could not read volume (z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->vol, vol, sizeof(float) * (size_t)(nx * ny * nz), hipMemcpyHostToDevice, c->stream));
+    rc = load_volume(c, vol, true, nx, ny, nz);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nx = nx; c->ny = ny; c->nz = nz;
     c->has_volume = true;
@@ -767,8 +808,8 @@ extern "C" int sift3d_set_volume_dev(sift3d_ctx *c, const float *d_vol, int64_t 
     if (!d_vol) return set_err(c, SIFT3D_ERR_ARG, "null volume");
     if (nz <= 1) return set_err(c, SIFT3D_ERR_ARG, "Could not read volume (z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
-    if (d_vol != c->vol)
-        HIPCHK(c, hipMemcpyAsync(c->vol, d_vol, sizeof(float) * (size_t)(nx * ny * nz), hipMemcpyDeviceToDevice, c->stream));
+    rc = load_volume(c, d_vol, false, nx, ny, nz);
+    if (rc) return rc;
     c->nx = nx; c->ny = ny; c->nz = nz;
     c->has_volume = true;
     return SIFT3D_OK;
@@ -844,9 +885,9 @@ static int candidates_to_host(sift3d_ctx *c, const std::vector<sift3d_level> &le
         o.octave = id / 3;
         o.level = id % 3 + 1;
         o.is_max = (int)((k >> SIFT3D_KEY_MAX_SHIFT) & 1ull);
-        o.x = (int32_t)(idx % lv.X);
-        o.y = (int32_t)((idx / lv.X) % lv.Y);
-        o.z = (int32_t)(idx / ((int64_t)lv.X * lv.Y)) + lv.z_off;
+        o.x = (int32_t)(idx % lv.XP);
+        o.y = (int32_t)((idx / lv.XP) % lv.Y);
+        o.z = (int32_t)(idx / ((int64_t)lv.XP * lv.Y)) + lv.z_off;
         o.value = vals[(size_t)i].value;
         o.h_value = vals[(size_t)i].h;
         o.l_value = vals[(size_t)i].l;
@@ -939,8 +980,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     const float factor = (float)pow(2.0, 1.0 / (double)3);
     const float extra0 = sqrtf(sigma * sigma - sigma_init * sigma_init);
 
-    int rc = blur_dev(c, c->vol, c->L[0], nullptr, c->nx, c->ny, c->nz, extra0, 0.01f);
+    const int64_t xp0 = pitch_of(c->nx);
+    int rc = blur_dev(c, c->vol, c->L[0], nullptr, xp0, c->ny, c->nz, extra0, 0.01f);
     if (rc) return rc;
+    if (xp0 != c->nx) HIPCHK(c, sift3d_launch_zero_pad(c->stream, c->L[0], nullptr, xp0, c->nx, c->ny * c->nz));
     rc = cand_reset(c);
     if (rc) return rc;
 
@@ -956,11 +999,13 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             const float ex = sigma * sqrtf(factor * factor - 1.0f);
             /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
             /* nothing reads L_5: only D_4 = L_4 - L_5 is needed, so the last level is not stored */
-            rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, c->D[j - 1] + d.off, d.X, d.Y, d.Z, ex, 0.01f);
+            rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, c->D[j - 1] + d.off, d.XP, d.Y, d.Z, ex, 0.01f);
             if (rc) return rc;
+            if (d.XP != d.X) /* the blur ran over the pitched width: its pad columns go back to zero */
+                HIPCHK(c, sift3d_launch_zero_pad(c->stream, j < 5 ? c->L[j] + d.off : nullptr, c->D[j - 1] + d.off, d.XP, d.X, d.Y * d.Z));
             if (j == 3 && o + 1 < oct.size()) {
                 stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
-                HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off));
+                HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
             }
             sigma *= factor;
             sig[j] = sigma;
@@ -972,12 +1017,13 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         c->cand_stream = c->ex_stream;
         for (int l = 0; l < 3; l++) {
             const int id = (int)o * 3 + l;
-            rc = cand_append(c, {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.X, d.Y, d.Z, 0, (int)d.Z, id}, true);
+            rc = cand_append(c, {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X}, true);
             if (rc) { c->cand_stream = nullptr; return rc; }
             sift3d_level &lv = levels[(size_t)id];
             lv.img = c->L[l + 1] + d.off;
             lv.dogc = c->D[l + 1] + d.off;
             lv.X = (int)d.X; lv.Y = (int)d.Y; lv.Z = (int)d.Z;
+            lv.XP = (int)d.XP;
             lv.sigma_h = sig[l]; lv.sigma_c = sig[l + 1]; lv.sigma_l = sig[l + 2];
             lv.octave_factor = fscale;
             lv.Zl = (int)d.Z;
@@ -1029,6 +1075,7 @@ static int levels_from_desc(sift3d_ctx *c, const sift3d_level_desc *ld, int n, s
     for (int i = 0; i < n; i++) {
         sift3d_level &lv = levels[(size_t)i];
         lv.img = ld[i].img;
+        lv.XP = (int)ld[i].nx;
         lv.dogc = ld[i].dogc;
         lv.X = (int)ld[i].nx; lv.Y = (int)ld[i].ny; lv.Z = (int)ld[i].nz_global;
         lv.Zl = (int)ld[i].nz_local;

@@ -47,8 +47,8 @@ __device__ __forceinline__ void interp_coord(float fX, float fMin, float fMax, i
  * starting at global slice z_off, so cell and weights are those of the undivided volume and only
  * the address is shifted.  The clamp is a memory-safety net: with the 32-slice halo of Z-slab
  * mode (patch reach < 29 slices) it never binds. */
-__device__ __forceinline__ float trilinear(const float *__restrict__ img, int X, int Y, int Z, int Zl, int z_off, float x,
-                                           float y, float z)
+__device__ __forceinline__ float trilinear(const float *__restrict__ img, int X, int XP, int Y, int Z, int Zl, int z_off,
+                                           float x, float y, float z)
 {
     float wx, wy, wz;
     int ix, iy, iz;
@@ -57,13 +57,13 @@ __device__ __forceinline__ float trilinear(const float *__restrict__ img, int X,
     interp_coord(z, 0, (float)Z, iz, wz);
     iz -= z_off;
     iz = iz < 0 ? 0 : (iz > Zl - 2 ? Zl - 2 : iz);
-    const long long XY = (long long)X * Y;
-    const float *p = img + (long long)iz * XY + (long long)iy * X + ix;
+    const long long XY = (long long)XP * Y; /* XP: row pitch; X only bounds the coordinates */
+    const float *p = img + (long long)iz * XY + (long long)iy * XP + ix;
     /* the two x-neighbours of a corner pair are adjacent in memory: four 8-byte gathers (dword aligned)
      * instead of eight 4-byte ones */
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    const f2u q00 = *reinterpret_cast<const f2u *>(p), q10 = *reinterpret_cast<const f2u *>(p + X);
-    const f2u q01 = *reinterpret_cast<const f2u *>(p + XY), q11 = *reinterpret_cast<const f2u *>(p + XY + X);
+    const f2u q00 = *reinterpret_cast<const f2u *>(p), q10 = *reinterpret_cast<const f2u *>(p + XP);
+    const f2u q01 = *reinterpret_cast<const f2u *>(p + XY), q11 = *reinterpret_cast<const f2u *>(p + XY + XP);
     const float f000 = q00.x, f100 = q00.y, f010 = q10.x, f110 = q10.y;
     const float f001 = q01.x, f101 = q01.y, f011 = q11.x, f111 = q11.y;
     float fn00 = wx * f000 + (1.0f - wx) * f100;
@@ -350,7 +350,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 /* sampleImage3D, R/src_common/MultiScale.cpp:2614-2714 (bounds test done by the caller) */
 template <int NT>
-__device__ __forceinline__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int Y, int Z, int Zl,
+__device__ __forceinline__ void wave_sample_patch(float *patch, const float *__restrict__ img, int X, int XP, int Y, int Z, int Zl,
                                                   int z_off, float fx, float fy, float fz, float scale, const float *ori9)
 {
     float inv[9];
@@ -379,7 +379,7 @@ __device__ __forceinline__ void wave_sample_patch(float *patch, const float *__r
                 o[0] *= sc; o[1] *= sc; o[2] *= sc;
                 o[0] += fx; o[1] += fy; o[2] += fz;
                 if (o[0] < 0 || o[0] >= X) pix[u] = 0;
-                else pix[u] = trilinear(img, X, Y, Z, Zl, z_off, o[0], o[1], o[2]);
+                else pix[u] = trilinear(img, X, XP, Y, Z, Zl, z_off, o[0], o[1], o[2]);
             }
         }
 #pragma unroll
@@ -669,16 +669,16 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
     const long long cidx = (long long)(key & SIFT3D_KEY_IDX_MASK);
     const sift3d_level lv = p.levels[lvl];
     sift3d_dkp *kp = kps + k;
-    const int X = lv.X, Y = lv.Y, Z = lv.Z;
-    const long long XY = (long long)X * Y;
+    const int X = lv.X, Y = lv.Y, Z = lv.Z, XP = lv.XP;
+    const long long XY = (long long)XP * Y;
     /* cidx indexes the local buffer; refinement and all geometry use the global slice number */
-    const int ix = (int)(cidx % X), iy = (int)((cidx / X) % Y), iz = (int)(cidx / XY) + lv.z_off;
+    const int ix = (int)(cidx % XP), iy = (int)((cidx / XP) % Y), iz = (int)(cidx / XY) + lv.z_off;
 
     /* generateFeatures3D_efficient, R/src_common/MultiScale.cpp:1361-1421 (every lane, identical) */
     const float *C = lv.dogc;
     const float cv = C[cidx];
     float fx = (float)interp_quadratic(ix - 1, ix, ix + 1, C[cidx - 1], cv, C[cidx + 1]);
-    float fy = (float)interp_quadratic(iy - 1, iy, iy + 1, C[cidx - X], cv, C[cidx + X]);
+    float fy = (float)interp_quadratic(iy - 1, iy, iy + 1, C[cidx - XP], cv, C[cidx + XP]);
     float fz = (float)interp_quadratic(iz - 1, iz, iz + 1, C[cidx - XY], cv, C[cidx + XY]);
     float scale = (float)(2 * interp_quadratic(lv.sigma_h, lv.sigma_c, lv.sigma_l, cvl.h, cv, cvl.l));
     fx += 0.5f; fy += 0.5f; fz += 0.5f;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
     }
     float *patch = sm.A;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    wave_sample_patch<KP_NT>(patch, lv.img, X, Y, Z, lv.Zl, lv.z_off, fx, fy, fz, scale, ident);
+    wave_sample_patch<KP_NT>(patch, lv.img, X, lv.XP, Y, Z, lv.Zl, lv.z_off, fx, fy, fz, scale, ident);
     if (p.debug_stop == 1) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_normalize_patch<KP_NT>(patch, sm.sc);
     if (p.debug_stop == 2) { if (lane == 0) nrec_out[k] = 0; return; }
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
     }
     const sift3d_level lv = p.levels[kp->lvl];
     if (p.debug_stop == 21 || p.debug_stop == 22) { /* development aid: every record samples one cache-resident region */
-        wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
+        wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
         if (p.debug_stop == 21) return;
     } else if (fr < 0) {
         /* record 0 is sampled with the identity frame and normalised once inside generateFeature3D
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         for (int s = lane; s < PV; s += DESC_NT) sm.patch[s] = src[s];
         __syncthreads();
     } else
-    wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
+    wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
     /* ... and every record is normalised once more in main (featExtract.cpp:480) */
     if (p.debug_stop == 11) return;
     wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);

@@ -262,10 +262,11 @@ __global__ void dog_kernel(const float *__restrict__ a, const float *__restrict_
 
 /* 2x2x2 mean, association of R/src_common/FeatureIO.cpp:1532-1538:
  * ((p000+p010)+p100)+p110, then + (((p001+p011)+p101)+p111), times 0.125 */
-__global__ void subsample_kernel(const float *__restrict__ in, long long X, long long Y, long long Z,
-                                 float *__restrict__ out)
+__global__ void subsample_kernel(const float *__restrict__ in, long long X, long long Xl, long long Y, long long Z,
+                                 float *__restrict__ out, long long XPout)
 {
-    const long long ox = X / 2, oy = Y / 2, oz = Z / 2;
+    /* X: row pitch of in, Xl: its logical row length; XPout: row pitch of out (== Xl / 2 when dense) */
+    const long long ox = Xl / 2, oy = Y / 2, oz = Z / 2;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ox * oy * oz) return;
     const long long x = i % ox, y = (i / ox) % oy, z = i / (ox * oy);
@@ -284,7 +285,19 @@ __global__ void subsample_kernel(const float *__restrict__ in, long long X, long
     float s = 0.0f;
     s = s + (((a00 + a01) + a10) + a11);
     s = s + (((b00 + b01) + b10) + b11);
-    out[i] = s * 0.125f;
+    out[(z * oy + y) * XPout + x] = s * 0.125f;
+}
+
+/* Columns [Xl, X) of a pitched volume back to zero (a blur over the pitched width also writes them; "outside the
+ * volume" has to read as zero for the next level). */
+__global__ void zero_pad_kernel(float *__restrict__ a, float *__restrict__ b, long long X, long long Xl, long long rows)
+{
+    const long long w = X - Xl;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const long long r = i / w, x = Xl + i % w;
+    if (a) a[r * X + x] = 0.0f;
+    if (b) b[r * X + x] = 0.0f;
 }
 
 /* fioDoubleSize, R/src_common/FeatureIO.cpp:2452-2548: one thread per output
@@ -399,7 +412,7 @@ __device__ __forceinline__ void row_extrema(v4f a, float (&rmax)[4], float (&rmi
  * z-1, z, z+1 as twelve independent 16-byte loads per lane (all in flight together, re-reads are L1/L2
  * hits), reduces them in registers and hands the own-level extrema to the second phase. */
 __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
-                                                      const float *__restrict__ dnext, int X, int Y, int Z, int z_first,
+                                                      const float *__restrict__ dnext, int X, int Xl, int Y, int Z, int z_first,
                                                       int z_last, int zchunk, int xtiles,
                                                       sift3d_survivor *__restrict__ surv, unsigned long long *surv_count,
                                                       long long surv_cap)
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
             const bool mx = c > fmaxf(e8max[r][e], p9max[r][e]);
             const bool mn = c < fminf(e8min[r][e], p9min[r][e]);
             const int x = xv + e;
-            if ((mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < X - 1 && y < Y - 1) {
+            if ((mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < Xl - 1 && y < Y - 1) {
                 /* own-level extremum: hand it to the second phase.  One returning atomic on a single word
                  * saturates near 88 per microsecond chip-wide, so the list is cut into EX_SEGS segments with
                  * counters 256 bytes apart and a workgroup appends to the segment its index hashes to */
@@ -504,7 +517,7 @@ __device__ __forceinline__ void ex_reduce_plane(const v4f (&raw)[EX_LOAD], ex_pl
     }
 }
 
-__global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restrict__ dcur, int X, int Y, int Z, int z_first,
+__global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restrict__ dcur, int X, int Xl, int Y, int Z, int z_first,
                                                             int z_last, int zchunk, int xtiles,
                                                             sift3d_survivor *__restrict__ surv, unsigned long long *surv_count,
                                                             long long surv_cap)
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
                 const bool mx = c > fmaxf(ce.e8max[r][e], fmaxf(lo.m[r][e], hi.m[r][e]));
                 const bool mn = c < fminf(ce.e8min[r][e], fminf(lo.n[r][e], hi.n[r][e]));
                 const int x = xv + e;
-                if ((mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < X - 1 && y < Y - 1) {
+                if ((mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < Xl - 1 && y < Y - 1) {
                     const unsigned long long slot = atomicAdd(surv_count + seg * EX_SEG_STRIDE, 1ull);
                     if ((long long)slot < surv_cap) {
                         sift3d_survivor sv;
@@ -642,7 +655,7 @@ __global__ __launch_bounds__(256) void extrema_validate_kernel(const float *__re
 /* Fallback for row lengths that are not a multiple of 4 (no aligned 16-byte rows) and for tiny volumes:
  * lanes along x, 27 direct loads per voxel, wavefront-wide early-out. */
 __global__ __launch_bounds__(256) void extrema_generic_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
-                                                      const float *__restrict__ dnext, int X, int Y, int Z, int z_first,
+                                                      const float *__restrict__ dnext, int X, int Xl, int Y, int Z, int z_first,
                                                       int lvl_id, unsigned long long *__restrict__ keys,
                                                       sift3d_cval *__restrict__ vals, unsigned long long *count,
                                                       long long cap)
@@ -650,7 +663,7 @@ __global__ __launch_bounds__(256) void extrema_generic_kernel(const float *__res
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int z = blockIdx.z + z_first;
-    const bool inside = (x >= 1 && x < X - 1 && y >= 1 && y < Y - 1);
+    const bool inside = (x >= 1 && x < Xl - 1 && y >= 1 && y < Y - 1);
     const long long XY = (long long)X * Y;
     const long long idx = (long long)z * XY + (long long)y * X + x;
     bool mx = inside, mn = inside;
@@ -864,12 +877,22 @@ hipError_t sift3d_launch_dog(hipStream_t s, const float *a, const float *b, floa
     return hipGetLastError();
 }
 
-hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out)
+hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Xl, int64_t Y, int64_t Z, float *out,
+                                   int64_t XPout)
 {
-    const long long n = (X / 2) * (Y / 2) * (Z / 2);
+    const long long n = (Xl / 2) * (Y / 2) * (Z / 2);
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, (long long)X, (long long)Y,
-                       (long long)Z, out);
+    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, (long long)X, (long long)Xl,
+                       (long long)Y, (long long)Z, out, (long long)XPout);
+    return hipGetLastError();
+}
+
+hipError_t sift3d_launch_zero_pad(hipStream_t s, float *a, float *b, int64_t X, int64_t Xl, int64_t rows)
+{
+    const long long n = rows * (X - Xl);
+    if (n <= 0 || (!a && !b)) return hipSuccess;
+    hipLaunchKernelGGL(zero_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, (long long)X, (long long)Xl,
+                       (long long)rows);
     return hipGetLastError();
 }
 
@@ -891,13 +914,13 @@ hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, i
 }
 
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
-                                 int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
+                                 int64_t Xl, int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
                                  sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
                                  unsigned long long *surv_count, unsigned long long *surv_overflow, int64_t surv_cap,
                                  bool zero_counters)
 {
-    if (X < 3 || Y < 3 || Z < 3) return hipSuccess;
-    /* interior planes 1..Z-2, further restricted to [z_lo, z_hi) (Z-slab mode keeps only its own slices) */
+    if (Xl < 3 || Y < 3 || Z < 3) return hipSuccess;
+    /* X: row pitch (== Xl for a dense volume), Xl: logical row length; interior planes 1..Z-2, further restricted to [z_lo, z_hi) (Z-slab mode keeps only its own slices) */
     const int z0 = z_lo > 1 ? z_lo : 1;
     const int z1 = z_hi < (int)Z - 1 ? z_hi : (int)Z - 1;
     if (z1 <= z0) return hipSuccess;
@@ -921,10 +944,10 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
         const unsigned nz = (unsigned)((z1 - z0 + zchunk - 1) / zchunk);
         dim3 grid((unsigned)((waves_xy + 3) / 4), nz);
         if (zchunk >= 2)
-            hipLaunchKernelGGL(extrema_march_kernel, grid, dim3(256), 0, s, dcur, (int)X, (int)Y, (int)Z, z0, z1, zchunk, xtiles,
+            hipLaunchKernelGGL(extrema_march_kernel, grid, dim3(256), 0, s, dcur, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk, xtiles,
                                surv, surv_count, (long long)(surv_cap / EX_SEGS));
         else
-            hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0, z1, zchunk,
+            hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk,
                                xtiles, surv, surv_count, (long long)(surv_cap / EX_SEGS));
         /* the second launch covers the list capacity, reads the true length on the device, and flags an
          * overflow for cand_finalize to widen the list and replay */
@@ -933,7 +956,7 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
                            (int)X, (int)Y, surv, surv_count, segcap, surv_overflow, lvl_id, keys, vals, count, (long long)cap);
     } else {
         dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(z1 - z0));
-        hipLaunchKernelGGL(extrema_generic_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Y, (int)Z, z0,
+        hipLaunchKernelGGL(extrema_generic_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Xl, (int)Y, (int)Z, z0,
                            lvl_id, keys, vals, count, (long long)cap);
     }
     return hipGetLastError();

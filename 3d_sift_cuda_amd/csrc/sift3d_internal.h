@@ -40,6 +40,7 @@ struct sift3d_level {
     const float *img;  /* Gaussian level L_k the keypoints are sampled from */
     const float *dogc; /* DoG level k (centre) */
     int X, Y, Z;       /* dims of the whole octave volume (Z is the global slice count) */
+    int XP;            /* row pitch of img/dogc in floats (== X for a dense volume) */
     float sigma_h, sigma_c, sigma_l;
     float octave_factor; /* 2^octave */
     int Zl;    /* slices held in img/dogc (== Z on one GPU; slab + halos in Z-slab mode) */
@@ -59,11 +60,14 @@ hipError_t sift3d_launch_blur_z(hipStream_t s, const float *in, float *out, cons
 hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X,
                                     int64_t Y, int64_t Z, const float *taps, int ntaps);
 hipError_t sift3d_launch_dog(hipStream_t s, const float *a, const float *b, float *out, int64_t n);
-hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
+hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Xl, int64_t Y, int64_t Z, float *out,
+                                   int64_t XPout);
+hipError_t sift3d_launch_zero_pad(hipStream_t s, float *a, float *b, int64_t X, int64_t Xl, int64_t rows);
 hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
+/* X: row pitch, Xl: logical row length (Xl == X for a dense volume) */
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
-                                 int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
+                                 int64_t Xl, int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
                                  sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
                                  unsigned long long *surv_count /* SIFT3D_SURV_COUNTERS words */,
                                  unsigned long long *surv_overflow, int64_t surv_cap, bool zero_counters);

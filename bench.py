@@ -183,6 +183,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
 
     if rank == 0:
+        nfullvox = ((n + 3) // 4 * 4) * n * n   # rows are padded to whole 16-byte vectors inside the pipeline
         log = np.concatenate(logs)            # timed region: the blur launches on the n^3 volume
         full = np.concatenate(full_logs)      # two extra steps with every launch bracketed (per-stage breakdown)
         nfull = len(full_logs)
@@ -200,7 +201,7 @@ def main():
         # anything shares the chip with them (the extrema of an octave overlap the blurs of the coarser ones).  The
         # same kernels also run on the coarser octaves; that aggregate is what `rocprofv3 --stats` averages.
         fused_id = stage_names.index("blur_fused") if "blur_fused" in stage_names else -1
-        sel = log[(log["stage"] == fused_id) & (log["nvox"] == n ** 3)]
+        sel = log[(log["stage"] == fused_id) & (log["nvox"] == nfullvox)]
         if len(sel):
             dom_name = "blur_fused_kernel<R, tile rows, prefetch> (the %d launches per volume at %d^3: initial blur + five levels)" % (len(sel) // args.steps, n)
             dom_all = full[full["stage"] == fused_id]
@@ -217,13 +218,13 @@ def main():
                           "the same work is credited 32 (24) B/voxel")
         else:   # rows that are not whole 16-byte vectors: three-pass kernels; dominant = slowest instantiation at n^3
             big = {}
-            for r in log[log["nvox"] == n ** 3]:
+            for r in log[log["nvox"] == nfullvox]:
                 st = stage_names[r["stage"]]
                 if st.startswith("blur"):
                     key = (st, int(r["ntaps"]), bool(st == "blur_z_dog" and r["alg_bytes"] > 8.5 * r["nvox"]))
                     big[key] = big.get(key, 0.0) + float(r["ms"])
             dom_key = max(big, key=big.get)
-            sel = log[(log["stage"] == stage_names.index(dom_key[0])) & (log["ntaps"] == dom_key[1]) & (log["nvox"] == n ** 3)]
+            sel = log[(log["stage"] == stage_names.index(dom_key[0])) & (log["ntaps"] == dom_key[1]) & (log["nvox"] == nfullvox)]
             if dom_key[0] == "blur_z_dog":
                 sel = sel[(sel["alg_bytes"] > 8.5 * sel["nvox"]) == dom_key[2]]
             dom_name = kernel_name(dom_key[0], dom_key[1], dom_key[2], 4 if n % 4 == 0 else 1)

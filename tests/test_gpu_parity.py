@@ -207,13 +207,34 @@ def test_pipeline_records(built, oracle, dims, seed, mode):
 
 @pytest.mark.parametrize("dims,seed,mode", [((67, 45, 38), 5, 0), ((67, 45, 38), 5, 1), ((73, 90, 51), 21, 3)])
 def test_pipeline_records_odd_dims(built, oracle, dims, seed, mode):
-    """Rows that are not whole 16-byte vectors: every octave takes the scalar-per-lane kernels."""
+    """Rows that are not whole 16-byte vectors: padded to a pitch inside the pipeline, pad columns kept at zero."""
     vol = vol_of(built, dims, seed)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)
         got = ctx.extract(desc_mode=mode)
     want, _ = oracle.extract(vol, desc_mode=mode)
     assert len(want) > 5 and _compare_records(got, want)
+
+
+def test_context_reuse_across_row_lengths(built, oracle):
+    """Inside the pipeline rows are padded to whole 16-byte vectors and the pad columns must read as zero: reuse one
+    context for an odd row length, a dense one, an operator-level call (which uses the level buffers as dense
+    scratch) and the odd one again."""
+    a_dims, b_dims = (67, 45, 38), (64, 48, 40)
+    va, vb = vol_of(built, a_dims, 5), vol_of(built, b_dims, 12345)
+    wa, _ = oracle.extract(va)
+    wb, _ = oracle.extract(vb)
+    with built.Context(68, 48, 40) as ctx:
+        for vol, want in ((va, wa), (vb, wb), (va, wa)):
+            ctx.set_volume(vol)
+            assert _compare_records(ctx.extract(), want)
+        junk = ctx.gauss_blur(vb + np.float32(100.0), 1.5450079441070557)   # dense scratch use of the level buffers
+        assert (bits(junk) == bits(oracle.blur(vb + np.float32(100.0), 1.5450079441070557))).all()
+        ctx.set_volume(va)
+        assert _compare_records(ctx.extract(), wa)
+        got = ctx.detect()
+        want = oracle.candidates(va)
+        assert len(got) == len(want) and (got["x"] == want["x"]).all() and (got["z"] == want["z"]).all()
 
 
 def test_pipeline_records_through_the_fused_blur(built, oracle):
