@@ -730,7 +730,37 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
     }
     __syncthreads();
     if (p.debug_stop == 3) { if (lane == 0) nrec_out[k] = 0; return; }
-    if (lane == 0) {
+    /* The SVD + eigen test (one lane, double-precision internals) and the first orientation-histogram splat (one
+     * wavefront, a chain of LDS atomics) do not depend on each other: the splat runs on wavefront 0 while lane 0 of
+     * the last wavefront does the SVD.  For the ~15 % of the extrema the eigen test rejects the splat was wasted. */
+    /* the un-reoriented record is described from exactly this patch (identity frame, normalised once): hand it to
+     * phase B instead of having it gathered from the image a second time (unused if the eigen test rejects) */
+    for (int s = lane; s < PV; s += KP_NT) p.patch0[(long long)k * PV + s] = patch[s];
+    __syncthreads(); /* the splat parameters below overwrite the patch */
+
+    /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
+    float *t0 = sm.B;
+    float *ta = sm.A, *tb = sm.Cc;           /* blur: t0 -> ta -> tb -> ta */
+    float *sp_wx = sm.Cc, *sp_wy = sm.Cc + NRAD_PAD; /* live only between the pre-pass and the end of the splat */
+    float *sp_wz = sm.A, *sp_mag = sm.A + NRAD_PAD;
+    const float radius = (float)(PD / 2);
+    for (int s = lane; s < PV; s += KP_NT) t0[s] = 0;
+    for (int i = lane; i < nrad; i += KP_NT) {
+        float e[3] = {sm.gx[i], sm.gy[i], sm.gz[i]};
+        float m2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        float mg = 0, wx = 0, wy = 0, wz = 0;
+        short base = 0;
+        if (m2 != 0) {
+            mg = sqrtf(m2);
+            float u[3];
+            for (int q = 0; q < 3; q++) u[q] = e[q] * radius / mg;
+            for (int q = 0; q < 3; q++) u[q] += radius;
+            splat_params((float)(u[0] + 0.5), (float)(u[1] + 0.5), (float)(u[2] + 0.5), base, wx, wy, wz);
+        }
+        sm.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
+    }
+    __syncthreads();
+    if (lane == KP_NT - 64) {
         float mat[3][3], w[3], v[3][3];
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) {
@@ -757,38 +787,9 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
             nrec_out[k] = 0;
         }
     }
-    __syncthreads();
+    wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag); /* wavefront 0; ends with a barrier */
     if (sm.sc[15] == 0.0f) return;
-    if (p.debug_stop == 4) { if (lane == 0) nrec_out[k] = 0; return; }
-    /* the un-reoriented record is described from exactly this patch (identity frame, normalised once): hand it to
-     * phase B instead of having it gathered from the image a second time */
-    for (int s = lane; s < PV; s += KP_NT) p.patch0[(long long)k * PV + s] = patch[s];
-    __syncthreads(); /* the splat parameters below overwrite the patch */
-
-    /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
-    float *t0 = sm.B;
-    float *ta = sm.A, *tb = sm.Cc;           /* blur: t0 -> ta -> tb -> ta */
-    float *sp_wx = sm.Cc, *sp_wy = sm.Cc + NRAD_PAD; /* live only between the pre-pass and the end of the splat */
-    float *sp_wz = sm.A, *sp_mag = sm.A + NRAD_PAD;
-    const float radius = (float)(PD / 2);
-    for (int s = lane; s < PV; s += KP_NT) t0[s] = 0;
-    for (int i = lane; i < nrad; i += KP_NT) {
-        float e[3] = {sm.gx[i], sm.gy[i], sm.gz[i]};
-        float m2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
-        float mg = 0, wx = 0, wy = 0, wz = 0;
-        short base = 0;
-        if (m2 != 0) {
-            mg = sqrtf(m2);
-            float u[3];
-            for (int q = 0; q < 3; q++) u[q] = e[q] * radius / mg;
-            for (int q = 0; q < 3; q++) u[q] += radius;
-            splat_params((float)(u[0] + 0.5), (float)(u[1] + 0.5), (float)(u[2] + 0.5), base, wx, wy, wz);
-        }
-        sm.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
-    }
-    __syncthreads();
-    if (p.debug_stop == 5) { if (lane == 0) nrec_out[k] = 0; return; }
-    wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
+    if (p.debug_stop == 4 || p.debug_stop == 5) { if (lane == 0) nrec_out[k] = 0; return; }
     if (p.debug_stop == 6) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_blur_patch<KP_NT>(t0, ta, tb, sm.taps, 3);
     if (p.debug_stop == 7) { if (lane == 0) nrec_out[k] = 0; return; }
