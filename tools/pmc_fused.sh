@@ -7,7 +7,7 @@ ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for grp in "$@"; do
   tag=$(echo "$grp" | tr ' ,' '__')
-  rocprofv3 --kernel-trace --pmc $grp -d $ROOT/gpurun_out/$OUT/$tag -o pmc --output-format csv -- python3 $ROOT/tools/bench_blur.py $N 2 > $ROOT/gpurun_out/$OUT/$tag.log 2>&1 || { tail -5 $ROOT/gpurun_out/$OUT/$tag.log; exit 1; }
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp -d $ROOT/gpurun_out/$OUT/$tag -o pmc --output-format csv -- python3 $ROOT/tools/bench_blur.py $N 2 > $ROOT/gpurun_out/$OUT/$tag.log 2>&1 || { tail -5 $ROOT/gpurun_out/$OUT/$tag.log; exit 1; }
 done
 cd $ROOT
 python3 - "$OUT" <<'PY'

@@ -8,7 +8,7 @@ mkdir -p $ROOT/gpurun_out/$OUT
 cd /tmp && export TMPDIR=/tmp
 for grp in "$@"; do
   tag=$(echo "$grp" | tr ' ,' '__')
-  rocprofv3 --kernel-trace --pmc $grp -d $ROOT/gpurun_out/$OUT/$tag -o pmc --output-format csv -- python3 $ROOT/tools/octave_breakdown.py $N > $ROOT/gpurun_out/$OUT/$tag.log 2>&1 || { tail -5 $ROOT/gpurun_out/$OUT/$tag.log; exit 1; }
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp -d $ROOT/gpurun_out/$OUT/$tag -o pmc --output-format csv -- python3 $ROOT/tools/octave_breakdown.py $N > $ROOT/gpurun_out/$OUT/$tag.log 2>&1 || { tail -5 $ROOT/gpurun_out/$OUT/$tag.log; exit 1; }
 done
 cd $ROOT
 python3 - "$OUT" "$PAT" <<'PY'
