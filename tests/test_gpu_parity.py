@@ -375,6 +375,23 @@ def test_full_size_properties(built):
         assert (again.view(np.uint8) == feats.view(np.uint8)).all()
 
 
+def test_volume_beyond_32_bit_indices(built):
+    """Maximum sizes: 1280 x 1280 x 1408 = 2.3e9 voxels (linear indices beyond 2^31, byte offsets beyond 2^33), which
+    the reference's int arithmetic cannot address.  Translation property instead of an oracle run:
+    a blob block near the far corner gives the candidates of the same block in a small volume, shifted, with
+    bit-identical DoG values; see tools/big_volume_check.py."""
+    import importlib.util
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip("needs about 160 GB of free HBM")
+    spec = importlib.util.spec_from_file_location(
+        "big_volume_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "big_volume_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check()
+
+
 # ---------------------------------------------------------------------------------------------------
 # Z-slab mode on the GPU: two processes share the one GPU of the test box and exchange halos through gloo
 # (staged through the host); on a multi-GPU node the same driver runs with backend "nccl" (RCCL).
