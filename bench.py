@@ -9,8 +9,11 @@ A step = one full sift3d_extract (Gaussian pyramid + DoG + extrema + keypoints +
 SIFT-rank descriptors, all octaves, records copied back to the host) of one
 512^3 float32 blob-field volume that is already resident in HBM.  With N > 1
 every rank extracts its own 512^3 volume on its own GPU (independent volumes,
-no data-path collective: weak scaling); the Z-slab split of ONE volume across
-GPUs is described in DESIGN.md and is not what this line measures.
+no data-path collective: weak scaling) -- that is `value`.  The Z-slab split of
+ONE 512^3 volume across the same ranks (halo exchange over RCCL, DESIGN.md
+section 6) then runs under a watchdog and is attached to the line as `zslab`
+(strong scaling: its own ms_per_step and records/s, and whether the merged
+records are the bytes of the single-GPU run).
 
 Rank 0 prints ONE JSON line: metric = keypoints/s (.key records per second,
 whole job), plus
@@ -46,8 +49,10 @@ def kernel_name(stage, ntaps, dog, vec=4):
     return "blur_col_kernel<%d,%d,%s>" % (r, vec, "true" if dog else "false")
 
 
-def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
-    """ONE n^3 volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records."""
+def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
+    """ONE n^3 volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records on rank 0.
+    Returns the result object on rank 0 (None elsewhere).  expect: the single-GPU records of the same volume, if the
+    caller has them (rank 0), to state whether the merged records are the same bytes."""
     zs = importlib.import_module("3d_sift_cuda_amd.zslab")
     n = args.size
     ndev = torch.cuda.device_count()
@@ -71,7 +76,7 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
             merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev)
         return ex, merged
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         step()
     barrier()
     t0 = time.perf_counter()
@@ -82,20 +87,64 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
     el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda:%d" % dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ms_per_step = 1e3 * float(el.item()) / args.steps
+    res = None
     if rank == 0:
         nrec = 0 if merged is None else len(merged)
+        res = {"value": round(nrec / (ms_per_step * 1e-3), 1), "unit": "keypoints/s", "ms_per_step": round(ms_per_step, 3),
+               "scaling": "strong", "records": nrec,
+               "workload": "ONE %d^3 float32 blob-field volume cut into %d Z-slabs, full featExtract path, all octaves" % (n, world),
+               "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
+               "parallelism": "zslab%d: halo exchange with torch.distributed (%s), coarse octaves on rank 0" % (world, dist.get_backend()),
+               "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"]}
+        if expect is not None:
+            res["same_bytes_as_single_gpu"] = bool(merged is not None and len(merged) == len(expect)
+                                                   and (merged.view(np.uint8) == expect.view(np.uint8)).all())
+    ctx.close()
+    return res
+
+
+def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
+    res = zslab_measure(args, pkg, torch, dist, rank, world, local_rank)
+    if rank == 0:
         print(json.dumps({
-            "metric": "keypoints/s (.key records per second)", "value": round(nrec / (ms_per_step * 1e-3), 1),
+            "metric": "keypoints/s (.key records per second)", "value": res["value"],
             "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ONE %d^3 float32 blob-field volume cut into %d Z-slabs, full featExtract path, all octaves" % (n, world),
-                       "records": nrec, "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
-                       "parallelism": "zslab%d: halo exchange with torch.distributed (%s), coarse octaves on rank 0" % (world, dist.get_backend()),
-                       "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"]}}))
+            "config": {k: res[k] for k in ("workload", "records", "sharded_octaves", "slab_bounds", "parallelism",
+                                           "halo_exchanges_per_step", "halo_bytes_per_rank_per_step")}}))
     dist.barrier()
     dist.destroy_process_group()
-    ctx.close()
+
+
+def zslab_beside(out, args, pkg, torch, dist, rank, world, local_rank, expect, limit_s):
+    """N > 1, default mode: after the per-GPU-volume measurement, also run the Z-slab split of ONE volume over the same
+    ranks and attach it to the line as `zslab`.  It is the only place this path meets RCCL on real links (the
+    development box has one GPU), so it runs under a watchdog: if a rank fails or the exchange stalls, rank 0 prints
+    the line without it and every rank leaves."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(limit_s):
+            if rank == 0:
+                out["zslab"] = {"status": "no result within %d s (a rank failed or the exchange stalled)" % limit_s}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        res = zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect)
+        if rank == 0:
+            res["status"] = "ok"
+            out["zslab"] = res
+    except Exception as e:   # the other ranks are released by their own watchdogs
+        sys.stderr.write("bench.py: rank %d: zslab run failed: %r\n" % (rank, e))
+        if rank != 0:
+            done.wait(limit_s + 5)   # never returns normally: the watchdog ends this process
+        out["zslab"] = {"status": "failed on rank 0: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+        os._exit(0)
+    done.set()
 
 
 def main():
@@ -107,8 +156,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU-baseline sample volume (0 = skip)")
     ap.add_argument("--desc", type=int, default=0, help="0 SIFT-rank, 1 BRIEF, 2 RRIEF, 3 NRRIEF")
     ap.add_argument("--mode", default="volumes", choices=["volumes", "zslab"],
-                    help="N > 1: 'volumes' = one volume per GPU (default, weak scaling); 'zslab' = ONE volume cut into "
-                         "Z-slabs with halo exchange over torch.distributed (strong scaling)")
+                    help="N > 1: 'volumes' = one volume per GPU (default, weak scaling; the Z-slab run of ONE volume is "
+                         "attached as `zslab`); 'zslab' = only the Z-slab run (strong scaling)")
+    ap.add_argument("--zslab-limit", type=int, default=240,
+                    help="N > 1, mode volumes: seconds the attached Z-slab run may take (0 = do not attach it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -305,11 +356,16 @@ def main():
             out["cpu_baseline"] = {"value": round(len(recs) / cdt, 1), "unit": "keypoints/s", "cores": 1, "kind": "port",
                                    "sample": "oracle o3_extract (C restatement of the reference CPU path, gcc -O2 -ffp-contract=off, 1 thread) on a %d^3 blob-field volume: %d records in %.2f s (blur %.2f s, DoG %.2f s, detect %.2f s, keypoints %.2f s, descriptors %.2f s)"
                                              % (m, len(recs), cdt, st.t_blur, st.t_dog, st.t_detect, st.t_features, st.t_desc)}
-        print(json.dumps(out))
+    expect = feats.copy() if (rank == 0 and world > 1) else None
+    ctx.close()
+    del dvol
+    if dist is not None and args.zslab_limit > 0:
+        zslab_beside(out if rank == 0 else None, args, pkg, torch, dist, rank, world, local_rank, expect, args.zslab_limit)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":
