@@ -375,21 +375,31 @@ def test_full_size_properties(built):
         assert (again.view(np.uint8) == feats.view(np.uint8)).all()
 
 
+def _tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        name, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_randomized_parity_sweep(built, oracle):
+    """40 random (shape, seed, noise, descriptor mode, initial scale, blur path) cases, records bit-identical to the
+    oracle's (tools/fuzz_parity.py; 500 cases of the same sweep ran clean during development)."""
+    assert _tool("fuzz_parity").sweep(40, 11, 112) == 0
+
+
 def test_volume_beyond_32_bit_indices(built):
     """Maximum sizes: 1280 x 1280 x 1408 = 2.3e9 voxels (linear indices beyond 2^31, byte offsets beyond 2^33), which
     the reference's int arithmetic cannot address.  Translation property instead of an oracle run:
     a blob block near the far corner gives the candidates of the same block in a small volume, shifted, with
     bit-identical DoG values; see tools/big_volume_check.py."""
-    import importlib.util
     import torch
     free, _ = torch.cuda.mem_get_info()
     if free < 200 * 2 ** 30:
         pytest.skip("needs about 160 GB of free HBM")
-    spec = importlib.util.spec_from_file_location(
-        "big_volume_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "big_volume_check.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    assert mod.check()
+    assert _tool("big_volume_check").check()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""GPU box: randomized parity sweep of the extraction path against the CPU oracle.
+
+Random volume shapes (including rows that are not whole 16-byte vectors and volumes large enough for the fused
+blur), blob-field seeds, noise levels, descriptor modes and initial scales; every record is compared bit for bit.
+usage: python tools/fuzz_parity.py [cases=60] [seed=1] [max_edge=112]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401  (one HIP runtime in the process)
+pkg = importlib.import_module("3d_sift_cuda_amd")
+import _oracle
+
+
+def sweep(cases=60, seed=1, max_edge=112):
+    """Returns the number of cases whose records differ from the oracle's."""
+    rng = np.random.default_rng(seed)
+    orc = _oracle.load()
+    saved = os.environ.get("SIFT3D_BLUR_FUSED")
+    bad = 0
+    t0 = time.time()
+    fields = ("x", "y", "z", "scale", "ori", "eigs", "info", "desc")
+    for i in range(cases):
+        dims = tuple(int(v) for v in rng.integers(12, max_edge + 1, 3))
+        if i % 7 == 3:
+            dims = (168, 164, 160)[i % 3:] + (168, 164, 160)[:i % 3]   # >= 2^22 voxels: the fused blur
+        vseed = int(rng.integers(1, 1 << 30))
+        mode = int(rng.integers(0, 4))
+        init_scale = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
+        noise = float(rng.choice([0.0, 0.0, 1.0, 8.0]))
+        os.environ["SIFT3D_BLUR_FUSED"] = str(int(rng.choice([1, 1, 2, 0])))   # 2: fused on every octave it supports
+        vol = pkg.synth_blobs(*dims, seed=vseed)
+        if noise:
+            vol = vol + (rng.standard_normal(vol.shape) * noise).astype(np.float32)
+        with pkg.Context(*dims) as ctx:
+            ctx.set_volume(vol)
+            got = ctx.extract(initial_image_scale=init_scale, desc_mode=mode)
+        want, _ = orc.extract(vol, init_scale=init_scale, desc_mode=mode)
+        ok = len(got) == len(want) and all((got[f].view(np.uint32) == want[f].view(np.uint32)).all() for f in fields)
+        if not ok:
+            bad += 1
+            where = "count" if len(got) != len(want) else ",".join(
+                f for f in fields if not (got[f].view(np.uint32) == want[f].view(np.uint32)).all())
+            print("MISMATCH case %d dims %s seed %d mode %d init %.1f noise %.1f fused %s: %d / %d records, differs in %s"
+                  % (i, dims, vseed, mode, init_scale, noise, os.environ["SIFT3D_BLUR_FUSED"], len(got), len(want), where), flush=True)
+        elif i % 10 == 0:
+            print("case %d dims %s mode %d: %d records identical (%.0f s)" % (i, dims, mode, len(got), time.time() - t0), flush=True)
+    if saved is None:
+        os.environ.pop("SIFT3D_BLUR_FUSED", None)
+    else:
+        os.environ["SIFT3D_BLUR_FUSED"] = saved
+    print("%d cases, %d mismatches, %.0f s" % (cases, bad, time.time() - t0))
+    return bad
+
+
+if __name__ == "__main__":
+    a = [int(v) for v in sys.argv[1:4]]
+    sys.exit(1 if sweep(*a) else 0)
