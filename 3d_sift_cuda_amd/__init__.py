@@ -112,6 +112,7 @@ def hip_lib():
     _sig(L.sift3d_selftest_lds_add, I, P, P, P, I64, P, P)
     _sig(L.sift3d_set_volume, I, P, P, I64, I64, I64)
     _sig(L.sift3d_set_volume_dev, I, P, P, I64, I64, I64)
+    _sig(L.sift3d_set_volume_resized, I, P, P, I64, I64, I64, I)
     _sig(L.sift3d_detect, I, P, F, P, P)
     _sig(L.sift3d_extract, I, P, F, I, F, F, P, P)
     _sig(L.sift3d_extract_view, I, P, F, I, F, F, P, P)
@@ -307,10 +308,11 @@ class Context:
         return mins[:nmin.value].copy(), maxs[:nmax.value].copy()
 
     # ---- pipeline level ----
-    def set_volume(self, vol):
+    def set_volume(self, vol, resize=0):
+        """resize: +1 / -1 = the -2+ / -2- options (doubled / halved on the device after the upload)."""
         vol = _f32(vol)
         nz, ny, nx = vol.shape
-        self._chk(self._L.sift3d_set_volume(self._h, vol.ctypes.data, nx, ny, nz), "sift3d_set_volume")
+        self._chk(self._L.sift3d_set_volume_resized(self._h, vol.ctypes.data, nx, ny, nz, int(resize)), "sift3d_set_volume_resized")
 
     def set_volume_dev(self, dev_ptr, nx, ny, nz):
         self._chk(self._L.sift3d_set_volume_dev(self._h, C.c_void_p(int(dev_ptr)), nx, ny, nz), "sift3d_set_volume_dev")

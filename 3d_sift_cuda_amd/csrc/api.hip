@@ -815,6 +815,28 @@ extern "C" int sift3d_set_volume_dev(sift3d_ctx *c, const float *d_vol, int64_t 
     return SIFT3D_OK;
 }
 
+extern "C" int sift3d_set_volume_resized(sift3d_ctx *c, const float *vol, int64_t nx, int64_t ny, int64_t nz, int resize)
+{
+    if (resize == 0) return sift3d_set_volume(c, vol, nx, ny, nz);
+    if (!c || !vol || nx < 2 || ny < 2 || nz < 2 || nx * ny * nz > c->capN)
+        return set_err(c, SIFT3D_ERR_ARG, "set_volume_resized: bad shape or null volume");
+    const int64_t ox = resize > 0 ? 2 * nx : nx / 2, oy = resize > 0 ? 2 * ny : ny / 2, oz = resize > 0 ? 2 * nz : nz / 2;
+    int rc = check_shape(c, ox, oy, oz); /* the doubled volume must fit the context */
+    if (rc) return rc;
+    if (oz <= 1) return set_err(c, SIFT3D_ERR_ARG, "Could not read volume (z <= 1)");
+    HIPCHK(c, hipSetDevice(c->device));
+    /* T[0], T[1]: the dense scratch volumes of the three-pass blur, free until the pyramid runs */
+    HIPCHK(c, hipMemcpyAsync(c->T[0], vol, sizeof(float) * (size_t)(nx * ny * nz), hipMemcpyHostToDevice, c->stream));
+    if (resize > 0) HIPCHK(c, sift3d_launch_double_size(c->stream, c->T[0], nx, ny, nz, c->T[1]));
+    else HIPCHK(c, sift3d_launch_halve_size(c->stream, c->T[0], nx, ny, nz, c->T[1]));
+    rc = load_volume(c, c->T[1], false, ox, oy, oz);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller may free vol */
+    c->nx = ox; c->ny = oy; c->nz = oz;
+    c->has_volume = true;
+    return SIFT3D_OK;
+}
+
 static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t nrec)
 {
     if (ncand > c->kps_cap) {

@@ -117,25 +117,8 @@ int main(int argc, char **argv)
         printf("Error: could not extract features, insufficient memory.\n");
         return -1;
     }
-    float *vol = img.data;
-    if (bDoubleImageSize == 1) {
-        float *d = (float *)malloc(sizeof(float) * (size_t)(PX * PY * PZ));
-        if (!d || sift3d_double_size(ctx, vol, X, Y, Z, d) != SIFT3D_OK) {
-            printf("Error: could not extract features, insufficient memory.\n");
-            return -1;
-        }
-        free(vol);
-        vol = d;
-        fInitialBlurScale *= 0.5;
-    } else if (bDoubleImageSize == -1) {
-        float *d = (float *)malloc(sizeof(float) * (size_t)(PX * PY * PZ));
-        if (!d || sift3d_halve_size(ctx, vol, X, Y, Z, d) != SIFT3D_OK) {
-            printf("Error: could not extract features, insufficient memory.\n");
-            return -1;
-        }
-        free(vol);
-        vol = d;
-    }
+    /* -2+ / -2-: the resize happens on the device, between the upload and the pyramid */
+    if (bDoubleImageSize == 1) fInitialBlurScale *= 0.5;
     printf("Input image: i=%d j=%d k=%d\n", (int)PX, (int)PY, (int)PZ);
 
     float fSizeFactor = 1;
@@ -144,7 +127,7 @@ int main(int argc, char **argv)
 
     sift3d_feature *feats = NULL;
     int64_t n = 0;
-    int rc = sift3d_set_volume(ctx, vol, PX, PY, PZ);
+    int rc = sift3d_set_volume_resized(ctx, img.data, X, Y, Z, bDoubleImageSize);
     if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
     if (rc != SIFT3D_OK) {
         fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
@@ -181,7 +164,7 @@ int main(int argc, char **argv)
     }
     printf("\nDone.\n");
     sift3d_free(feats);
-    free(vol);
+    free(img.data);
     sift3d_destroy(ctx);
     return 0;
 }

@@ -146,6 +146,11 @@ int sift3d_selftest_lds_add(sift3d_ctx *ctx, const float *a, const float *b, int
  * download of the records. */
 int sift3d_set_volume(sift3d_ctx *ctx, const float *vol, int64_t nx, int64_t ny, int64_t nz);
 int sift3d_set_volume_dev(sift3d_ctx *ctx, const float *d_vol, int64_t nx, int64_t ny, int64_t nz);
+/* The -2+ / -2- options without a round trip through the host (R/featExtract/featExtract.cpp:409-421 calls
+ * fioDoubleSize / fioSubSample2DCenterPixel on the host image): upload vol (nx*ny*nz), resize it on the device
+ * (resize = +1: doubled to 2nx*2ny*2nz, -1: halved to (nx/2)*(ny/2)*(nz/2), 0: as it is) and make the result the
+ * context's volume.  The context must have been created for the larger of the two sizes. */
+int sift3d_set_volume_resized(sift3d_ctx *ctx, const float *vol, int64_t nx, int64_t ny, int64_t nz, int resize);
 /* Scale-space + detection only: validated extrema of every octave/level in the
  * reference's order.  *out is malloc'ed (sift3d_free). */
 int sift3d_detect(sift3d_ctx *ctx, float initial_image_scale, sift3d_candidate **out, int64_t *n_out);

@@ -280,6 +280,9 @@ def test_pipeline_double_and_halve(built, oracle):
         got = ctx.extract(initial_image_scale=0.5, size_factor=0.5)
         want, _ = oracle.extract(big, init_scale=0.5, size_factor=0.5)
         assert len(want) > 5 and _compare_records(got, want)
+        ctx.set_volume(vol, resize=+1)
+        again = ctx.extract(initial_image_scale=0.5, size_factor=0.5)
+        assert (again.view(np.uint8) == got.view(np.uint8)).all()
     big_dims = (96, 80, 72)
     vol = vol_of(built, big_dims, 5)
     with built.Context(*big_dims) as ctx:
@@ -288,6 +291,10 @@ def test_pipeline_double_and_halve(built, oracle):
         got = ctx.extract(size_factor=2.0)
         want, _ = oracle.extract(oracle.halve(vol), size_factor=2.0)
         assert len(want) > 5 and _compare_records(got, want)
+        # the same resize between the upload and the pyramid, without the trip through the host (what the CLI uses)
+        ctx.set_volume(vol, resize=-1)
+        again = ctx.extract(size_factor=2.0)
+        assert (again.view(np.uint8) == got.view(np.uint8)).all()
 
 
 def test_cli_key_file_is_byte_identical(built, oracle, tmp_path):
