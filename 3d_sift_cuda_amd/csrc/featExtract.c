@@ -14,11 +14,20 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "keyfile.h"
 #include "nifti_min.h"
 #include "sift3d.h"
 #include "world.h"
+
+/* SIFT3D_CLI_TIMES=1: wall time of every phase on stderr (the reference prints its "#us" lines the same way) */
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 static int print_options(void)
 {
@@ -84,6 +93,8 @@ int main(int argc, char **argv)
         return -1;
     }
     printf("Extracting features: %s\n", argv[iArg]);
+    const int times = getenv("SIFT3D_CLI_TIMES") != NULL;
+    double t0 = now_s(), t1;
 
     nifti_min_image img;
     if (nifti_min_read(argv[iArg], &img) < 0) {
@@ -94,6 +105,9 @@ int main(int argc, char **argv)
         printf("Error: could not read input file: %s\n", argv[iArg]);
         return -1;
     }
+    t1 = now_s();
+    if (times) fprintf(stderr, "# read image: %.3f s\n", t1 - t0);
+    t0 = t1;
     if (device < 0) device = 0; /* no CPU path in this build */
     if (sift3d_device_count() <= 0 || device >= sift3d_device_count()) {
         fprintf(stderr, "Error: no usable HIP device %d (this build has no CPU fallback).\n", device);
@@ -117,6 +131,9 @@ int main(int argc, char **argv)
         printf("Error: could not extract features, insufficient memory.\n");
         return -1;
     }
+    t1 = now_s();
+    if (times) fprintf(stderr, "# device context: %.3f s\n", t1 - t0);
+    t0 = t1;
     /* -2+ / -2-: the resize happens on the device, between the upload and the pyramid */
     if (bDoubleImageSize == 1) fInitialBlurScale *= 0.5;
     printf("Input image: i=%d j=%d k=%d\n", (int)PX, (int)PY, (int)PZ);
@@ -128,12 +145,19 @@ int main(int argc, char **argv)
     sift3d_feature *feats = NULL;
     int64_t n = 0;
     int rc = sift3d_set_volume_resized(ctx, img.data, X, Y, Z, bDoubleImageSize);
+    t1 = now_s();
+    if (times) fprintf(stderr, "# upload: %.3f s\n", t1 - t0);
+    t0 = t1;
     if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
     if (rc != SIFT3D_OK) {
         fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
         printf("Error: could not extract features, insufficient memory.\n");
         return -1;
     }
+
+    t1 = now_s();
+    if (times) fprintf(stderr, "# extraction: %.3f s (%lld records)\n", t1 - t0, (long long)n);
+    t0 = t1;
 
     char c1[200], c2[200], c3[400];
     sprintf(c1, "Extraction Voxel Resolution (ijk) : %d %d %d", (int)PX, (int)PY, (int)PZ);
@@ -162,6 +186,8 @@ int main(int argc, char **argv)
         fprintf(stderr, "Error: could not write %s\n", argv[iArg + 1]);
         return -1;
     }
+    t1 = now_s();
+    if (times) fprintf(stderr, "# write features: %.3f s\n", t1 - t0);
     printf("\nDone.\n");
     sift3d_free(feats);
     free(img.data);

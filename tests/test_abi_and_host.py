@@ -103,6 +103,35 @@ def test_key_writer_matches_oracle_writer(built, oracle, tmp_path):
     assert open(p1, "rb").read() == open(p2, "rb").read()
 
 
+def test_key_writer_number_formatting(built, oracle, tmp_path):
+    """The product's writer formats "%f" / "%d" itself (keyfile.c); the oracle's uses fprintf.  Random bit patterns,
+    ties at the sixth decimal, signed zeros, denormals, huge values, infinities and NaNs must give the same bytes."""
+    rng = np.random.default_rng(3)
+    n = 4000
+    recs = np.zeros(n, built.FEATURE_DTYPE)
+    special = np.array([0.0, -0.0, 0.0078125, -0.0078125, 0.5 ** 7 * 3, 1e-7, -4.9e-7, 5e-7, 0.9999995, 0.99999949, 1.5e-45,
+                        -1.5e-45, 3.4e38, -3.4e38, 4.0e9, 3.9999998e9, 4.1e9, np.inf, -np.inf, np.nan, 123456.789, 2.0 ** 31,
+                        16777216.0, 0.1, 0.2, 0.3], np.float32)
+    for f, k in (("x", 1), ("y", 1), ("z", 1), ("scale", 1), ("ori", 9), ("eigs", 3)):
+        bits = rng.integers(0, 1 << 32, n * k, dtype=np.uint64).astype(np.uint32)
+        vals = bits.view(np.float32).copy()
+        pick = rng.random(n * k) < 0.5                     # half of them ordinary magnitudes
+        vals[pick] = ((rng.random(pick.sum()) - 0.5) * 10.0 ** rng.integers(-7, 8, pick.sum())).astype(np.float32)
+        tie = rng.random(n * k) < 0.1                      # exact ties: odd multiples of 2^-7 scaled by powers of two
+        vals[tie] = ((2 * rng.integers(0, 5000, tie.sum()) + 1) * 0.5 ** rng.integers(7, 12, tie.sum())).astype(np.float32)
+        sp = rng.random(n * k) < 0.05
+        vals[sp] = special[rng.integers(0, len(special), sp.sum())]
+        recs[f] = vals.reshape(recs[f].shape)
+    recs["info"] = rng.integers(0, 1 << 31, n).astype(np.uint32)
+    recs["desc"] = rng.integers(-128, 128, (n, 64)).astype(np.float32)
+    p1, p2 = str(tmp_path / "a.key"), str(tmp_path / "b.key")
+    oracle.write_key(p1, recs, eig_thres=-1.0, comments=["a", "b", "c"])
+    built.write_key(p2, recs, eig_thres=-1.0, comments=["a", "b", "c"])
+    a, b = open(p1, "rb").read(), open(p2, "rb").read()
+    assert a.count(b"\n") == n + 6
+    assert a == b
+
+
 def test_key_reader_and_binary_writer(built, oracle, tmp_path):
     """msFeature3DVectorInputText / msFeature3DVectorOutputBin (MultiScale.h:228-384) on the host side."""
     import struct
