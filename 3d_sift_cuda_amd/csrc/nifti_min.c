@@ -189,10 +189,12 @@ int nifti_min_read(const char *path, nifti_min_image *img)
         if (!df) return -2;
         if (vox_offset > 0) gzseek(df, (long)vox_offset, SEEK_SET);
     }
-    unsigned char *raw = (unsigned char *)malloc(nvox * es);
+    /* float32 voxels are read straight into the result; every other type goes through a raw buffer and a cast */
+    const int direct = img->datatype == 16;
     img->data = (float *)malloc(nvox * sizeof(float));
+    unsigned char *raw = direct ? (unsigned char *)img->data : (unsigned char *)malloc(nvox * es);
     if (!raw || !img->data) {
-        free(raw);
+        if (!direct) free(raw);
         free(img->data);
         img->data = 0;
         gzclose(df);
@@ -207,7 +209,7 @@ int nifti_min_read(const char *path, nifti_min_image *img)
     }
     gzclose(df);
     if (got != want) {
-        free(raw);
+        if (!direct) free(raw);
         free(img->data);
         img->data = 0;
         return -2;
@@ -221,10 +223,10 @@ int nifti_min_read(const char *path, nifti_min_image *img)
     case 4: for (size_t i = 0; i < nvox; i++) o[i] = (float)((short *)raw)[i]; break;
     case 768: for (size_t i = 0; i < nvox; i++) o[i] = (float)((unsigned int *)raw)[i]; break;
     case 8: for (size_t i = 0; i < nvox; i++) o[i] = (float)((int *)raw)[i]; break;
-    case 16: memcpy(o, raw, nvox * 4); break;
+    case 16: break; /* already in place */
     case 64: for (size_t i = 0; i < nvox; i++) o[i] = (float)((double *)raw)[i]; break;
     }
-    free(raw);
+    if (!direct) free(raw);
     return 0;
 }
 
