@@ -926,7 +926,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         for (int i = 0; i < 9; i++) ori[i] = kp->frames[fr * 9 + i];
     }
     const sift3d_level lv = p.levels[kp->lvl];
-    if (p.debug_stop == 21 || p.debug_stop == 22) { /* development aid: every record samples one cache-resident region */
+    if (p.debug_stop >= 21 && p.debug_stop <= 25) { /* development aid: every record samples one cache-resident region (22: and runs to the end, 23/24/25: stops where 12/13/14 do) */
         wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
         if (p.debug_stop == 21) return;
     } else if (fr < 0) {
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
     /* ... and every record is normalised once more in main (featExtract.cpp:480) */
     if (p.debug_stop == 11) return;
     wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);
-    if (p.debug_stop == 12) return;
+    if (p.debug_stop == 12 || p.debug_stop == 23) return;
 
     const bool w0 = lane < 64; /* wavefront 0: lane = descriptor bin for everything that follows the parallel pre-pass */
     float myval = 0.0f;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
             sm.wtab[1][c] = 1.0f - w;
         }
         __syncthreads();
-        if (p.debug_stop == 13) return;
+        if (p.debug_stop == 13 || p.debug_stop == 24) return;
         /* bucket the interior voxels by octant, keeping raster order inside a bucket (wavefront 0, ballots) */
         if (w0) {
             int cnt[8];
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
             }
         }
         __syncthreads();
-        if (p.debug_stop == 14) return;
+        if (p.debug_stop == 14 || p.debug_stop == 25) return;
         if (w0) {
             /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin over its octant's voxels */
             const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
