@@ -62,7 +62,7 @@ struct sift3d_ctx {
     float *D[5];  /* DoG levels, same layout */
     float *T[2];  /* x- and y-pass intermediates */
     float *d_taps;
-    float *d_zeros; /* 256 bytes of 0.0f: what the fused blur reads outside the volume */
+    float *d_zeros; /* 512 bytes: 256 of 0.0f (what the fused blur reads outside the volume), then 256 it may write (store sink) */
     /* extrema as (key, value) pairs, unsorted (a) and sorted (b) */
     unsigned long long *keys_a, *keys_b;
     sift3d_cval *vals_a, *vals_b;
@@ -256,7 +256,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_zeros, 256) == hipSuccess && hipMemset(c->d_zeros, 0, 256) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_zeros, 512) == hipSuccess && hipMemset(c->d_zeros, 0, 512) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;

@@ -263,6 +263,246 @@ __global__ __launch_bounds__(16 * TY, (R >= 6 ? 2 : (R == 5 ? 3 : (TY == 32 ? 4 
     }
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * 11 to 17 taps: the same march with the input planes brought in by LDS-DMA (global_load_lds_dwordx4: global -> LDS, no
+ * register destination).  With the window in registers these instantiations have room for one or two planes of prefetch
+ * at two wavefronts per SIMD, and the x pass waits for HBM every plane (without its window loads the 13-tap launch takes
+ * 0.40 ms instead of 0.59).  Here a ring of NBUF raw planes (the tile's TY + 2R rows of 64 + 16 floats) lives in LDS,
+ * two planes in flight, at the cost of no registers (which lets two workgroups share a CU); the input voxel of the DoG comes the same way (so that no ordinary
+ * global load is left in the loop: beside LDS-DMA the compiler would wait for vmcnt(0) at each use of one).
+ *
+ * LDS-DMA writes base + lane * 16 bytes: a plane is dealt to the wavefronts in groups of 64 consecutive 16-byte vectors
+ * (row-major, 20 vectors per row), GPW groups per wavefront; lanes past the last vector and vectors outside the volume
+ * read a zero page.  Ordering: a wavefront's DMA is covered by its own counted s_waitcnt vmcnt(N) (vector memory
+ * operations retire in issue order) and, for the other wavefronts' reads, by the barrier that ends the step; every step
+ * issues the same number of DMA operations so that N is a constant.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef __attribute__((address_space(1))) const void fb_gptr;
+typedef __attribute__((address_space(3))) void fb_lptr;
+
+/* NBUF: raw planes in the ring, one being read and NBUF - 1 in flight.  3: 80 KB of LDS, two workgroups per CU where the
+ * kernel stays within 128 registers; 4: 110 KB, one workgroup per CU with a deeper prefetch. */
+template <int R, int TY, int NBUF>
+__global__ __launch_bounds__(16 * TY, (NBUF == 3 ? 4 : 2)) void blur_fused_dma_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                                    float *__restrict__ dog, const float *__restrict__ zeros,
+                                                                    float *__restrict__ sink, int X, int Y, int Z, int zlen,
+                                                                    int tiles_x, int tiles_y, long long total, fb_taps2 t)
+{
+    static_assert(R >= 5 && R <= 8 && TY == 32, "window halo of 8 floats, eight wavefronts");
+    constexpr int PD = NBUF - 2;  /* steps between the issue of a DMA and the wait that covers it */
+    constexpr int NPV = PD + 1;   /* DoG-input planes in LDS: issued PD steps before their use */
+    constexpr int U = 2 * R + 1;
+    constexpr int NR = TY + 2 * R;           /* rows of the x pass */
+    constexpr int H4 = 8;                    /* window halo, whole 16-byte vectors */
+    constexpr int ROWF = FB_TX + 2 * H4;     /* floats of a raw row */
+    constexpr int ROWV = ROWF / 4;           /* vectors of a raw row */
+    constexpr int NVEC = NR * ROWV;          /* vectors of a raw plane */
+    constexpr int NW = TY / 4;               /* wavefronts */
+    constexpr int GR = (NVEC + 63) / 64;     /* DMA groups of a plane: wavefront w takes group w and, if it exists, w + NW */
+    static_assert(GR > NW && GR <= 2 * NW, "one or two groups per wavefront");
+    constexpr int PLANE = GR * 256;          /* floats of a ring slot */
+    constexpr int PVPL = TY * FB_TX;         /* floats of a DoG-input plane: exactly one DMA group per wavefront */
+    constexpr int P1PL = NR * FB_TX;
+    constexpr int WIN = 8 + 2 * H4, NV = WIN / 4;
+    /* one array: a second __shared__ object beside an LDS-DMA target makes the compiler drain vmcnt before LDS reads */
+    __shared__ __attribute__((aligned(1024))) float lds[NBUF * PLANE + NPV * PVPL + 2 * P1PL];
+    float *const raw = lds;
+    float *const pvb = lds + NBUF * PLANE;
+    float *const P1b = pvb + NPV * PVPL;
+
+    const long long lin = blockIdx.x;
+    const long long per = (total + 7) / 8;
+    const long long wi = (lin % 8) * per + lin / 8;
+    if (wi >= total) return;
+    const int tx = (int)(wi % tiles_x);
+    const int ty = (int)((wi / tiles_x) % tiles_y);
+    const int chunk = (int)(wi / ((long long)tiles_y * tiles_x));
+    const int x0 = tx * FB_TX, y0 = ty * TY;
+    const int zc0 = chunk * zlen;
+    const int zc1 = zc0 + zlen < Z ? zc0 + zlen : Z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long XY = (long long)X * Y;
+    const int zfirst = zc0 - R, zlast = zc1 - 1 + R;
+
+    /* DMA roles.  Raw plane: vector v = 64 * (wv + NW * k) + lane -> row v / ROWV, vector v % ROWV of the row. */
+    constexpr int GPW = 2;
+    const int ngr = wv + NW < GR ? 2 : 1; /* groups of this wavefront */
+    const float *rp[GPW]; /* this lane's vector k in plane 0 (never dereferenced when the plane is outside the volume) */
+    bool rok[GPW];
+#pragma unroll
+    for (int k = 0; k < GPW; k++) {
+        const int v = 64 * (wv + NW * k) + lane;
+        const int row = v / ROWV, col = v - row * ROWV;
+        const int gy = y0 - R + row, gx = x0 - H4 + 4 * col;
+        rok[k] = v < NVEC && gy >= 0 && gy < Y && gx >= 0 && gx < X;
+        rp[k] = rok[k] ? in + (long long)gy * X + gx : zeros;
+    }
+    /* DoG input plane: vector 64 * wv + lane -> row (64 * wv + lane) / 16: the rows this wavefront's own threads take */
+    const int pvr = (64 * wv + lane) >> 4, pvc = (64 * wv + lane) & 15;
+    const bool pok = y0 + pvr < Y && x0 + 4 * pvc < X;
+    const float *const pp = pok ? in + (long long)(y0 + pvr) * X + x0 + 4 * pvc : zeros;
+    auto issue_raw = [&](int z, int slot) { /* plane z -> ring slot; wave-uniform z */
+        const bool zin_vol = z >= 0 && z < Z && z <= zlast;
+#pragma unroll
+        for (int k = 0; k < GPW; k++) {
+            if (k < ngr) { /* wave-uniform */
+                const float *src = (zin_vol && rok[k]) ? rp[k] + (long long)z * XY : zeros;
+                __builtin_amdgcn_global_load_lds((fb_gptr *)src, (fb_lptr *)(raw + slot * PLANE + (wv + NW * k) * 256), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_prev = [&](int z, int slot) {
+        const float *src = (z >= zc0 && z < zc1 && pok && dog) ? pp + (long long)z * XY : zeros;
+        __builtin_amdgcn_global_load_lds((fb_gptr *)src, (fb_lptr *)(pvb + slot * PVPL + wv * 256), 16, 0, 0);
+    };
+
+    /* stage A role: row ar of the x pass, outputs x0 + axs .. + 7, window = floats axs .. axs + 23 of the raw row */
+    const int ar = tid >> 3, axs = (tid & 7) * 8;
+    auto x_pass = [&](const float *slotp, float *P1) {
+        v4f win[NV];
+        const v4f *rw = reinterpret_cast<const v4f *>(slotp + ar * ROWF + axs);
+#pragma unroll
+        for (int k = 0; k < NV; k++) win[k] = rw[k];
+        v2f ev[WIN / 2], od[WIN / 2 - 1];
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            ev[2 * k].x = win[k].x; ev[2 * k].y = win[k].y;
+            ev[2 * k + 1].x = win[k].z; ev[2 * k + 1].y = win[k].w;
+        }
+#pragma unroll
+        for (int m = 0; m < WIN / 2 - 1; m++) {
+            od[m].x = ev[m].y; od[m].y = ev[m + 1].x;
+        }
+        v2f o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v2f acc = v2f(0.0f);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                constexpr int base = H4 - R;
+                const int sidx = base + 2 * e + j;
+                const v2f p = (sidx & 1) ? od[(sidx - 1) / 2] : ev[sidx / 2];
+                acc = acc + t.f[j] * p;
+            }
+            o[e] = acc;
+        }
+        v4f r0, r1;
+        r0.x = o[0].x; r0.y = o[0].y; r0.z = o[1].x; r0.w = o[1].y;
+        r1.x = o[2].x; r1.y = o[2].y; r1.z = o[3].x; r1.w = o[3].y;
+        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs]) = r0;
+        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs + 4]) = r1;
+    };
+    /* stage B/C role: column pair bcp, rows 2*brs and 2*brs+1 of the tile */
+    const int bcp = tid & 31, brs = tid >> 5;
+    const int bx = x0 + 2 * bcp;
+    const int by = y0 + 2 * brs;
+    const bool st0 = bx < X && by < Y, st1 = bx < X && by + 1 < Y;
+    const long long boff0 = st0 ? (long long)by * X + bx : 0;
+    const long long boff1 = st1 ? (long long)(by + 1) * X + bx : 0;
+
+    /* prologue: planes zfirst .. zfirst + NBUF - 1 into slots 0 .. NBUF - 1, x pass of plane zfirst */
+#pragma unroll
+    for (int b = 0; b < NBUF; b++) issue_raw(zfirst + b, b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (zfirst >= 0 && ar < NR) x_pass(raw, P1b); /* zfirst < Z always */
+    v2f acc0[U], acc1[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) acc0[i] = acc1[i] = v2f(0.0f);
+    int phase = 0, cur = 0;
+    int xslot = 1;  /* ring slot of plane zin + 1 */
+    const int ns = (out ? 2 : 0) + (dog ? 2 : 0); /* stores per storing step */
+    int pslot_w = 0, pslot_r = 0; /* DoG-input ring: slot filled this step (plane zin + PD - R), slot read (plane zin - R) */
+    lds_barrier(); /* P1b[0] holds the x pass of plane zfirst, and every wavefront has read slot 0 */
+    for (int zin = zfirst; zin <= zlast; zin++) {
+        const bool plane = zin >= 0 && zin < Z;
+        const int zo = zin - R;
+        const bool emit = zo >= zc0; /* zo < zc1 by construction of zlast */
+        const float *P1 = P1b + cur * P1PL;
+        v2f p[U + 1];
+#pragma unroll
+        for (int q = 0; q < U + 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(2 * brs + q) * FB_TX + 2 * bcp]);
+        /* ---- B: y pass of plane zin ---- */
+        v2f g0 = v2f(0.0f), g1 = v2f(0.0f);
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            g0 = g0 + t.f[j] * p[j];
+            g1 = g1 + t.f[j] * p[j + 1];
+        }
+        if (!plane) g0 = g1 = v2f(0.0f); /* P1 was stale */
+        /* ---- A: x pass of plane zin + 1 from its ring slot into the other P1 buffer ---- */
+        if (zin + 1 >= 0 && zin + 1 < Z && zin + 1 <= zlast && ar < NR) x_pass(raw + xslot * PLANE, P1b + (cur ^ 1) * P1PL);
+        /* ---- DMA: the DoG input of the plane stored two steps from now, then plane zin + NBUF into the slot plane
+         * zin left (every wavefront passed the barrier after reading it).  Always issued (a zero page when there is
+         * nothing to fetch), so that the count below is exact. ---- */
+        issue_prev(zo + PD, pslot_w);
+        issue_raw(zin + NBUF, xslot == 0 ? NBUF - 1 : xslot - 1);
+        /* Wait for the DMA issued PD steps ago: plane zin + 2 (read next step) and the DoG input read below.  Younger
+         * than those are the 1 + ngr DMA operations of each step since and the stores of the last PD steps: exactly `ns`
+         * per step once the march stores (lanes outside the volume store to a sink instead of being skipped).  Vector
+         * memory operations retire in issue order, so "all but the N youngest are done" covers them. */
+        {
+            int nyoung = PD * (1 + ngr);
+#pragma unroll
+            for (int k = 1; k <= PD; k++) nyoung += (zo - k >= zc0) ? ns : 0;
+            switch (nyoung) {
+#define FB_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+                FB_WAIT(2) FB_WAIT(3) FB_WAIT(4) FB_WAIT(5) FB_WAIT(6) FB_WAIT(7) FB_WAIT(8) FB_WAIT(9) FB_WAIT(10)
+                FB_WAIT(11) FB_WAIT(12) FB_WAIT(13) FB_WAIT(14)
+#undef FB_WAIT
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        }
+        /* ---- C: z pass ---- */
+        v2f a0 = v2f(0.0f), a1 = v2f(0.0f);
+        switch (phase) {
+#define FB_PHASE(S)                                                              \
+    case S:                                                                      \
+        if constexpr (S < U) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < U; i++) {                      \
+                const int j = (S - i + U) % U;                                   \
+                if (j == 0) {                                                    \
+                    acc0[i] = v2f(0.0f) + t.f[0] * g0;                           \
+                    acc1[i] = v2f(0.0f) + t.f[0] * g1;                           \
+                } else {                                                         \
+                    acc0[i] = acc0[i] + t.f[j] * g0;                             \
+                    acc1[i] = acc1[i] + t.f[j] * g1;                             \
+                }                                                                \
+            }                                                                    \
+            a0 = acc0[(S + 1) % U];                                              \
+            a1 = acc1[(S + 1) % U];                                              \
+        }                                                                        \
+        break;
+            FB_PHASE(0) FB_PHASE(1) FB_PHASE(2) FB_PHASE(3) FB_PHASE(4) FB_PHASE(5) FB_PHASE(6) FB_PHASE(7) FB_PHASE(8)
+            FB_PHASE(9) FB_PHASE(10) FB_PHASE(11) FB_PHASE(12) FB_PHASE(13) FB_PHASE(14) FB_PHASE(15) FB_PHASE(16)
+#undef FB_PHASE
+        default: break;
+        }
+        if (emit) { /* wave-uniform; every lane stores (see the wait above) */
+            const long long zoff = (long long)zo * XY;
+            if (out) {
+                __builtin_nontemporal_store(a0, reinterpret_cast<v2f *>(st0 ? out + zoff + boff0 : sink));
+                __builtin_nontemporal_store(a1, reinterpret_cast<v2f *>(st1 ? out + zoff + boff1 : sink));
+            }
+            if (dog) {
+                const float *pvp = pvb + pslot_r * PVPL + (2 * brs) * FB_TX + 2 * bcp;
+                const v2f pv0 = *reinterpret_cast<const v2f *>(pvp);
+                const v2f pv1 = *reinterpret_cast<const v2f *>(pvp + FB_TX);
+                __builtin_nontemporal_store(pv0 - a0, reinterpret_cast<v2f *>(st0 ? dog + zoff + boff0 : sink));
+                __builtin_nontemporal_store(pv1 - a1, reinterpret_cast<v2f *>(st1 ? dog + zoff + boff1 : sink));
+            }
+        }
+        phase = phase + 1 == U ? 0 : phase + 1;
+        cur ^= 1;
+        xslot = xslot + 1 == NBUF ? 0 : xslot + 1;
+        pslot_w = pslot_w + 1 == NPV ? 0 : pslot_w + 1;
+        if (zin - zfirst >= PD) pslot_r = pslot_r + 1 == NPV ? 0 : pslot_r + 1; /* read slot = written PD steps before */
+        lds_barrier(); /* the other P1 buffer is complete, every wavefront has read this one and its ring slot */
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* no DMA may land after the workgroup has released its LDS */
+}
+
 /* chunks along z: enough workgroups to fill every CU's resident slots while the 2R lead-in planes stay cheap */
 static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
 {
@@ -283,6 +523,39 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
         }
     }
     return best;
+}
+
+template <int R, int NBUF>
+static void launch_fused_dma_n(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
+                               int64_t Z, const fb_taps2 &t)
+{
+    constexpr int TY = 32;
+    static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
+    if (resident == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_dma_kernel<R, TY, NBUF>, 16 * TY, 0) != hipSuccess || n < 1) n = 1;
+        resident = n;
+    }
+    const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + TY - 1) / TY);
+    const long long tiles = (long long)tiles_x * tiles_y;
+    const int n = fused_chunks(R, Z, tiles, resident);
+    const int zlen = (int)((Z + n - 1) / n);
+    const int nch = (int)((Z + zlen - 1) / zlen);
+    const long long total = tiles * nch;
+    const long long per = (total + 7) / 8;
+    /* the second half of the zero page's 512 bytes is the write sink of lanes outside the volume */
+    hipLaunchKernelGGL((blur_fused_dma_kernel<R, TY, NBUF>), dim3((unsigned)(8 * per)), dim3(16 * TY), 0, s, in, out, dog, zeros,
+                       const_cast<float *>(zeros) + 64, (int)X, (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
+}
+
+template <int R>
+static void launch_fused_dma(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
+                             int64_t Z, const fb_taps2 &t)
+{
+    const char *env = getenv("SIFT3D_FUSED_NBUF"); /* tuning / test aid: ring depth 3 or 4 */
+    const int nbuf = env ? atoi(env) : (R == 5 ? 3 : 4); /* by measurement at 512^3 */
+    if (nbuf == 3) launch_fused_dma_n<R, 3>(s, in, out, dog, zeros, X, Y, Z, t);
+    else launch_fused_dma_n<R, 4>(s, in, out, dog, zeros, X, Y, Z, t);
 }
 
 template <int R, int TY>
@@ -310,6 +583,10 @@ template <int R>
 static void launch_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
                          int64_t Z, const fb_taps2 &t)
 {
+    if constexpr (R >= 5 && R <= 7) { /* 17 taps: arithmetic-bound, the register window is faster */
+        const char *dma = getenv("SIFT3D_FUSED_DMA"); /* A/B aid: 0 = the register-window kernel */
+        if (!dma || atoi(dma) != 0) return launch_fused_dma<R>(s, in, out, dog, zeros, X, Y, Z, t);
+    }
     const char *env = getenv("SIFT3D_FUSED_TY"); /* tuning / test aid: 16 or 32 */
     /* 11 taps: the 512-thread workgroup would need 160 registers per thread at three wavefronts per SIMD, i.e. one
      * workgroup per CU; two 256-thread ones do better there */
@@ -320,7 +597,7 @@ static void launch_fused(hipStream_t s, const float *in, float *out, float *dog,
 
 /* Returns hipErrorNotSupported when the shape is outside this kernel (the caller then runs the three-pass
  * path): rows must be whole 16-byte vectors and the filter at most 17 taps.  out or dog may be NULL.
- * zeros: at least 16 bytes of device memory holding 0.0f. */
+ * zeros: 512 bytes of device memory: the first 256 hold 0.0f and are only read, the second 256 are a write sink. */
 hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X,
                                     int64_t Y, int64_t Z, const float *taps, int ntaps)
 {
