@@ -38,6 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_TABLE = "r01_d_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
 
 
 def kernel_name(stage, ntaps, dog, vec=4):
@@ -254,7 +255,7 @@ def main():
         fused_id = stage_names.index("blur_fused") if "blur_fused" in stage_names else -1
         sel = log[(log["stage"] == fused_id) & (log["nvox"] == nfullvox)]
         if len(sel):
-            dom_name = "blur_fused_kernel<R, tile rows, prefetch> (the %d launches per volume at %d^3: initial blur + five levels)" % (len(sel) // args.steps, n)
+            dom_name = "blur_fused_kernel<R, tile rows, prefetch> / blur_fused_dma_kernel<R, 32, ring> for 11 and 13 taps (the %d launches per volume at %d^3: initial blur + five levels)" % (len(sel) // args.steps, n)
             dom_all = full[full["stage"] == fused_id]
             per_inst = []
             for taps in sorted(set(int(t) for t in sel["ntaps"])):
@@ -285,13 +286,15 @@ def main():
         big_ms, big_bytes = float(sel["ms"].sum()), float(sel["alg_bytes"].sum())
         achieved = big_bytes / (big_ms * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", PMC_TABLE)
         if os.path.exists(pmc) and n == 512 and per_inst:
             try:   # PMC bytes of every instantiation (keys "blur_fused_kernel<R, ...>"), averaged over the launches
                 tab = json.load(open(pmc))
                 tot, cnt = 0.0, 0
                 for pi in per_inst:
-                    hit = [k for k in tab if k.startswith("blur_fused_kernel<%d," % (pi["taps"] // 2))]
+                    hit = [k for k in tab if k.startswith("blur_fused_kernel<%d," % (pi["taps"] // 2))
+                           or k.startswith("blur_fused_dma_kernel<%d," % (pi["taps"] // 2))]
+                    hit.sort(key=lambda k: "dma" not in k)   # 11 and 13 taps run the LDS-DMA instantiation
                     if not hit:
                         raise KeyError(pi["taps"])
                     v = tab[hit[0]]
@@ -314,7 +317,7 @@ def main():
                     "all_launches": {"launches": int(len(dom_all)), "avg_launch_ms": round(float(dom_all["ms"].mean()), 4),
                                      "achieved": round(float(dom_all["alg_bytes"].sum()) / (float(dom_all["ms"].sum()) * 1e-3) / 1e9, 1),
                                      "note": "every octave the kernel runs on, from the two breakdown steps after the timed region; compare with the per-kernel averages of rocprofv3 --stats"},
-                    "traffic_source": "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md), averaged over the launches" if traffic else None}
+                    "traffic_source": "profiles/" + PMC_TABLE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md), averaged over the launches" if traffic else None}
         pyr_ms = sum(v["ms"] for v in blur_groups.values())
         pyr_bytes = sum(v["bytes"] for v in blur_groups.values())
         pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

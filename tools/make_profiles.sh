@@ -32,10 +32,11 @@ if tr:
         if "blur" not in k and "extrema" not in k: continue
         k = k.split("(")[0].replace("void ", "")
         g[(k, r.get("Grid_Size") or r.get("Grid_Size_X"), r.get("Workgroup_Size") or r.get("Workgroup_Size_X"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    with open(out + "/%s_blur_dispatches.csv" % tag, "w") as f:
-        f.write("kernel,grid,workgroup,calls,min_us,avg_us,max_us\n")
+    with open(out + "/%s_blur_dispatches.csv" % tag, "w", newline="") as f:
+        w = csv.writer(f)   # kernel names hold commas
+        w.writerow(["kernel", "grid", "workgroup", "calls", "min_us", "avg_us", "max_us"])
         for (k, gs, ws), v in sorted(g.items()):
-            f.write("%s,%s,%s,%d,%.1f,%.1f,%.1f\n" % (k, gs, ws, len(v), min(v), sum(v) / len(v), max(v)))
+            w.writerow([k, gs, ws, len(v), "%.1f" % min(v), "%.1f" % (sum(v) / len(v)), "%.1f" % max(v)])
 # PMC traffic per blur kernel at 512^3
 res = {"_about": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python3 tools/bench_blur.py 512 3` on MI355X; medians per launch at 512^3 (134 217 728 voxels). FETCH_SIZE (KB, TCC_EA0_RDREQ x 64 B) is doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950; WRITE_SIZE (KB) is taken as is."}
 vals = collections.defaultdict(dict)
