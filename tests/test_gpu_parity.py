@@ -43,12 +43,16 @@ FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37
 
 
 @pytest.mark.parametrize("dims", FUSED_SHAPES)
-@pytest.mark.parametrize("chunks,tile_rows", [(0, 0), (3, 16), (2, 32)])
-def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, monkeypatch):
+@pytest.mark.parametrize("chunks,tile_rows,variant", [(0, 0, ""), (3, 16, "SIFT3D_FUSED_DMA=0"), (2, 32, "SIFT3D_FUSED_NBUF=3"),
+                                                      (3, 0, "SIFT3D_FUSED_NBUF=4")])
+def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, variant, monkeypatch):
     """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up), partial tiles
-    in x and y, volumes thinner than the filter, several z chunks: level and DoG bit-identical to the oracle."""
+    in x and y, volumes thinner than the filter, several z chunks, the register-window form and the LDS-DMA form
+    (11 and 13 taps) with both ring depths: level and DoG bit-identical to the oracle."""
     import torch
     monkeypatch.setenv("SIFT3D_BLUR_FUSED", "2")
+    if variant:
+        monkeypatch.setenv(*variant.split("="))
     if chunks:
         monkeypatch.setenv("SIFT3D_FUSED_CHUNKS", str(chunks))
     if tile_rows:
@@ -58,6 +62,7 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, monkey
     with built.Context(*dims) as ctx:
         d_in = torch.from_numpy(vol).cuda()
         d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
+        torch.cuda.synchronize()
         ctx.enable_timing(True)
         for s in SIGMAS[1:]:
             want = oracle.blur(vol, s)
@@ -66,9 +71,15 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, monkey
             assert (bits(d_out.cpu().numpy()) == bits(want)).all(), (dims, s)
             assert (bits(d_dog.cpu().numpy()) == bits(oracle.dog(vol, want))).all(), (dims, s)
             d_out.zero_()
+            torch.cuda.synchronize()   # torch's stream and the context's stream are not ordered with each other
             ctx.gauss_blur_dev(d_in.data_ptr(), d_out.data_ptr(), nx, ny, nz, s)   # no DoG output
             ctx.sync()
             assert (bits(d_out.cpu().numpy()) == bits(want)).all(), (dims, s)
+            d_dog.zero_()
+            torch.cuda.synchronize()
+            ctx.gauss_blur_dog_dev(d_in.data_ptr(), 0, d_dog.data_ptr(), nx, ny, nz, s)   # DoG only (the sixth level)
+            ctx.sync()
+            assert (bits(d_dog.cpu().numpy()) == bits(oracle.dog(vol, want))).all(), (dims, s)
         log = ctx.launch_log()
         assert (log["stage"] == built.STAGES.index("blur_fused")).all()   # the fused kernel is what ran
 
