@@ -83,7 +83,9 @@ sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz);
 void sift3d_destroy(sift3d_ctx *ctx);
 const char *sift3d_last_error(const sift3d_ctx *ctx);
 /* Optional: run on a caller-owned hipStream_t (e.g. torch's); NULL = the
- * context's own stream. */
+ * context's own stream.  The context's own stream is created non-blocking: it is
+ * not ordered with the legacy default stream, so device buffers handed to the
+ * *_dev entry points must be complete (or this call must put both on one stream). */
 int sift3d_set_stream(sift3d_ctx *ctx, void *hip_stream);
 int sift3d_sync(sift3d_ctx *ctx);
 void sift3d_free(void *p);
