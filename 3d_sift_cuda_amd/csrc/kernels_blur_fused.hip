@@ -328,32 +328,29 @@ __global__ __launch_bounds__(16 * TY, (NBUF == 3 ? 4 : 2)) void blur_fused_dma_k
     /* DMA roles.  Raw plane: vector v = 64 * (wv + NW * k) + lane -> row v / ROWV, vector v % ROWV of the row. */
     constexpr int GPW = 2;
     const int ngr = wv + NW < GR ? 2 : 1; /* groups of this wavefront */
-    const float *rp[GPW]; /* this lane's vector k in plane 0 (never dereferenced when the plane is outside the volume) */
-    bool rok[GPW];
+    int roff[GPW]; /* this lane's vector k: element offset inside a plane (X * Y < 2^29), -1 = outside the volume */
 #pragma unroll
     for (int k = 0; k < GPW; k++) {
         const int v = 64 * (wv + NW * k) + lane;
         const int row = v / ROWV, col = v - row * ROWV;
         const int gy = y0 - R + row, gx = x0 - H4 + 4 * col;
-        rok[k] = v < NVEC && gy >= 0 && gy < Y && gx >= 0 && gx < X;
-        rp[k] = rok[k] ? in + (long long)gy * X + gx : zeros;
+        roff[k] = (v < NVEC && gy >= 0 && gy < Y && gx >= 0 && gx < X) ? gy * X + gx : -1;
     }
     /* DoG input plane: vector 64 * wv + lane -> row (64 * wv + lane) / 16: the rows this wavefront's own threads take */
     const int pvr = (64 * wv + lane) >> 4, pvc = (64 * wv + lane) & 15;
-    const bool pok = y0 + pvr < Y && x0 + 4 * pvc < X;
-    const float *const pp = pok ? in + (long long)(y0 + pvr) * X + x0 + 4 * pvc : zeros;
+    const int poff = (y0 + pvr < Y && x0 + 4 * pvc < X) ? (y0 + pvr) * X + x0 + 4 * pvc : -1;
     auto issue_raw = [&](int z, int slot) { /* plane z -> ring slot; wave-uniform z */
         const bool zin_vol = z >= 0 && z < Z && z <= zlast;
 #pragma unroll
         for (int k = 0; k < GPW; k++) {
             if (k < ngr) { /* wave-uniform */
-                const float *src = (zin_vol && rok[k]) ? rp[k] + (long long)z * XY : zeros;
+                const float *src = (zin_vol && roff[k] >= 0) ? in + ((long long)z * XY + roff[k]) : zeros;
                 __builtin_amdgcn_global_load_lds((fb_gptr *)src, (fb_lptr *)(raw + slot * PLANE + (wv + NW * k) * 256), 16, 0, 0);
             }
         }
     };
     auto issue_prev = [&](int z, int slot) {
-        const float *src = (z >= zc0 && z < zc1 && pok && dog) ? pp + (long long)z * XY : zeros;
+        const float *src = (z >= zc0 && z < zc1 && poff >= 0 && dog) ? in + ((long long)z * XY + poff) : zeros;
         __builtin_amdgcn_global_load_lds((fb_gptr *)src, (fb_lptr *)(pvb + slot * PVPL + wv * 256), 16, 0, 0);
     };
 
@@ -397,9 +394,8 @@ __global__ __launch_bounds__(16 * TY, (NBUF == 3 ? 4 : 2)) void blur_fused_dma_k
     const int bcp = tid & 31, brs = tid >> 5;
     const int bx = x0 + 2 * bcp;
     const int by = y0 + 2 * brs;
-    const bool st0 = bx < X && by < Y, st1 = bx < X && by + 1 < Y;
-    const long long boff0 = st0 ? (long long)by * X + bx : 0;
-    const long long boff1 = st1 ? (long long)(by + 1) * X + bx : 0;
+    const int boff0 = (bx < X && by < Y) ? by * X + bx : -1;         /* element offset inside a plane, -1: store to the sink */
+    const int boff1 = (bx < X && by + 1 < Y) ? (by + 1) * X + bx : -1;
 
     /* prologue: planes zfirst .. zfirst + NBUF - 1 into slots 0 .. NBUF - 1, x pass of plane zfirst */
 #pragma unroll
@@ -482,15 +478,15 @@ __global__ __launch_bounds__(16 * TY, (NBUF == 3 ? 4 : 2)) void blur_fused_dma_k
         if (emit) { /* wave-uniform; every lane stores (see the wait above) */
             const long long zoff = (long long)zo * XY;
             if (out) {
-                __builtin_nontemporal_store(a0, reinterpret_cast<v2f *>(st0 ? out + zoff + boff0 : sink));
-                __builtin_nontemporal_store(a1, reinterpret_cast<v2f *>(st1 ? out + zoff + boff1 : sink));
+                __builtin_nontemporal_store(a0, reinterpret_cast<v2f *>(boff0 >= 0 ? out + (zoff + boff0) : sink));
+                __builtin_nontemporal_store(a1, reinterpret_cast<v2f *>(boff1 >= 0 ? out + (zoff + boff1) : sink));
             }
             if (dog) {
                 const float *pvp = pvb + pslot_r * PVPL + (2 * brs) * FB_TX + 2 * bcp;
                 const v2f pv0 = *reinterpret_cast<const v2f *>(pvp);
                 const v2f pv1 = *reinterpret_cast<const v2f *>(pvp + FB_TX);
-                __builtin_nontemporal_store(pv0 - a0, reinterpret_cast<v2f *>(st0 ? dog + zoff + boff0 : sink));
-                __builtin_nontemporal_store(pv1 - a1, reinterpret_cast<v2f *>(st1 ? dog + zoff + boff1 : sink));
+                __builtin_nontemporal_store(pv0 - a0, reinterpret_cast<v2f *>(boff0 >= 0 ? dog + (zoff + boff0) : sink));
+                __builtin_nontemporal_store(pv1 - a1, reinterpret_cast<v2f *>(boff1 >= 0 ? dog + (zoff + boff1) : sink));
             }
         }
         phase = phase + 1 == U ? 0 : phase + 1;
