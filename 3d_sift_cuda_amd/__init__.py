@@ -383,8 +383,9 @@ class Context:
         finally:
             self._L.sift3d_free(out)
 
-    def describe_dev(self, levels, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
-        """Returns (records, group) copies; group = level_id*2 + is_max per record."""
+    def describe_dev(self, levels, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0, copy=True):
+        """Returns (records, group); group = level_id*2 + is_max per record.  copy=False returns views of the
+        context's pinned download buffers, valid until the next call on this context."""
         arr = self._level_array(levels)
         view, grp, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
         self._chk(self._L.sift3d_describe_dev(self._h, arr, len(levels), int(desc_mode), float(eig_thres), float(size_factor),
@@ -393,7 +394,8 @@ class Context:
             return np.zeros(0, FEATURE_DTYPE), np.zeros(0, np.int32)
         rb = (C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(view.value)
         gb = (C.c_char * (n.value * 4)).from_address(grp.value)
-        return np.frombuffer(rb, FEATURE_DTYPE, n.value).copy(), np.frombuffer(gb, np.int32, n.value).copy()
+        recs, grp = np.frombuffer(rb, FEATURE_DTYPE, n.value), np.frombuffer(gb, np.int32, n.value)
+        return (recs.copy(), grp.copy()) if copy else (recs, grp)
 
     def sync(self):
         self._chk(self._L.sift3d_sync(self._h), "sift3d_sync")

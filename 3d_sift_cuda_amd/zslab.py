@@ -113,6 +113,8 @@ class HipBackend:
         return self.torch.empty(shape, dtype=self.torch.float32, device="cuda:%d" % self.ctx.device)
 
     def from_host(self, arr):
+        if self.torch.is_tensor(arr):   # already resident on the device (the benchmark keeps its slab in HBM)
+            return arr
         return self.torch.from_numpy(np.ascontiguousarray(arr, np.float32)).to("cuda:%d" % self.ctx.device)
 
     def blur(self, src, dst, sigma):
@@ -145,8 +147,8 @@ class HipBackend:
     def candidates(self, levels):
         return self.ctx.candidates_dev(levels)
 
-    def describe(self, levels, desc_mode, eig_thres, size_factor):
-        return self.ctx.describe_dev(levels, desc_mode, eig_thres, size_factor)
+    def describe(self, levels, desc_mode, eig_thres, size_factor, copy=True):
+        return self.ctx.describe_dev(levels, desc_mode, eig_thres, size_factor, copy=copy)
 
     def before_exchange(self):
         pass  # the context runs on torch's current stream (ZSlabExtractor sets it), so ordering is the stream's
@@ -338,11 +340,14 @@ class ZSlabExtractor:
                                       ("z", "<i4"), ("value", "<f4"), ("h_value", "<f4"), ("l_value", "<f4")])
         return self.be.candidates(self._table())
 
-    def describe(self, desc_mode=0, eig_thres=140.0, size_factor=1.0):
-        """This rank's records and their group ids (level_id*2 + is_max)."""
+    def describe(self, desc_mode=0, eig_thres=140.0, size_factor=1.0, copy=True):
+        """This rank's records and their group ids (level_id*2 + is_max).  copy=False: views of the context's
+        download buffers (HIP backend), valid until the next call on the context."""
         if not self.levels:
             return None, np.zeros(0, np.int32)
-        return self.be.describe(self._table(), desc_mode, eig_thres, size_factor)
+        if copy:
+            return self.be.describe(self._table(), desc_mode, eig_thres, size_factor)
+        return self.be.describe(self._table(), desc_mode, eig_thres, size_factor, copy=False)
 
 
 def merge_by_group(parts):

@@ -60,9 +60,11 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
     dev = local_rank % max(1, ndev)
     plan = zs.SlabPlan(n, n, n, world)
     i0, i1 = plan.input_range(rank)
-    slab = pkg.synth_blobs(n, n, n, seed=12345)[i0:i1].copy()
     ctx = pkg.Context(n, n, (i1 - i0) + 2 * zs.HALO, device=dev)
     be = zs.HipBackend(pkg, ctx, torch)
+    # the rank's input slices live in HBM before timing starts, as the volume of the per-GPU run does
+    slab = torch.from_numpy(pkg.synth_blobs(n, n, n, seed=12345)[i0:i1].copy()).to("cuda:%d" % dev)
+    torch.cuda.synchronize(dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -73,7 +75,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
         with be.stream_scope():
             ex = zs.ZSlabExtractor(be, plan, rank, dist)
             ex.run(slab, i0)
-            recs, grp = ex.describe(desc_mode=args.desc)
+            recs, grp = ex.describe(desc_mode=args.desc, copy=False)   # views of the pinned download buffers
             merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev)
         return ex, merged
 

@@ -4,7 +4,7 @@ import importlib, os, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     pkg = importlib.import_module("3d_sift_cuda_amd")
-    n = 256
+    n = int(os.environ.get("ABL_N", "256"))
     ctx = pkg.Context(n, n, n); ctx.set_volume(pkg.synth_blobs(n, n, n))
     ctx.extract(); ctx.enable_timing(True); ctx.extract()
     log = ctx.launch_log(); sel = log[log["stage"] == 5]
