@@ -482,9 +482,9 @@ __device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis
 }
 /* 3- or 5-tap separable blur of an 11^3 LDS volume, pass order x,y,z, zero
  * borders (gb3d_blur3d on the patch: R/src_common/MultiScale.cpp:2850,2972,1032).
- * The result lands in tmp_a (in -> tmp_a -> tmp_b -> tmp_a); taps are in LDS. */
+ * The result lands in tmp_a (in -> tmp_a -> tmp_b -> tmp_a; tmp_b may be the input buffer); taps are in LDS. */
 template <int NT>
-__device__ __forceinline__ void wave_blur_patch(const float *in, float *tmp_a, float *tmp_b, const float *taps, int ntaps)
+__device__ __forceinline__ void wave_blur_patch(float *in, float *tmp_a, float *tmp_b, const float *taps, int ntaps)
 {
     blur_pass<NT>(in, tmp_a, 0, taps, ntaps);
     blur_pass<NT>(tmp_a, tmp_b, 1, taps, ntaps);
@@ -637,22 +637,36 @@ __device__ __forceinline__ long long xcd_contiguous_item(long long n)
 /* ---------------------------------------------------------------------- */
 /* Phase A: extremum -> keypoint (geometry, eigen test, orientation frames) */
 /* ---------------------------------------------------------------------- */
+/* 23 032 bytes: seven workgroups per CU (the kernel is latency-bound; its throughput follows the number of resident
+ * workgroups).  Buffers are shared between phases that never overlap:
+ *   A   patch -> splat wz, mag -> blurred grid           B   splat grid t0 / middle pass of the blur
+ *   C   splat wx, wy -> scratch of the peak search       r   in-radius list -> splat base cells */
 struct kpA_smem {
-    float A[PV + 1];  /* patch, then blur output / splat wz,mag */
-    float B[PV + 1];  /* splat grid t0 */
-    float Cc[PV + 1]; /* blur temporary / splat wx,wy */
+    float A[PV + 1];
+    float B[PV + 1];
+    union {
+        float sp_wxy[2 * NRAD_PAD]; /* live from the splat pre-pass to the end of the splat */
+        struct {                    /* live from the peak search to the end of the frame loop body */
+            unsigned char flags[PV + 13];
+            short raw_idx[128], pk2_idx[128];
+            float raw_val[128], pk2_val[128];
+        } pk;
+    } C;
     float gx[NRAD_PAD], gy[NRAD_PAD], gz[NRAD_PAD]; /* gradients of the in-radius voxels */
-    short sp_base[NRAD_PAD];
-    unsigned short rlist[NRAD_PAD];
-    short raw_idx[128], pk_idx[128], pk2_idx[128];
-    float raw_val[128], pk_val[128], pk2_val[128];
+    union {
+        unsigned short rlist[NRAD_PAD]; /* until the gradients are taken */
+        short sp_base[NRAD_PAD];        /* from the first splat pre-pass on */
+    } r;
+    short pk_idx[128];
+    float pk_val[128];
     float ori_data[PD * 3 + 3];
     float sc[16];
     float taps[8];
     int cnt[4];
 };
+static_assert(sizeof(kpA_smem) * 7 <= 160 * 1024, "seven workgroups per CU");
 
-__global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
                                                       const sift3d_cval *__restrict__ vals, long long ncand,
                                                       sift3d_dkp *__restrict__ kps, int *__restrict__ nrec_out,
                                                       sift3d_taps taps3)
@@ -696,14 +710,14 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
     if (p.debug_stop == 1) { if (lane == 0) nrec_out[k] = 0; return; }
     wave_normalize_patch<KP_NT>(patch, sm.sc);
     if (p.debug_stop == 2) { if (lane == 0) nrec_out[k] = 0; return; }
-    const int nrad = wave_build_radius_list(sm.rlist, &sm.cnt[0]);
+    const int nrad = wave_build_radius_list(sm.r.rlist, &sm.cnt[0]);
 
     /* determineOrientation3D, MultiScale.cpp:2541-2607: gradients (fioGenerateEdgeImages3D,
      * FeatureIO.cpp:2284-2326) are only ever used inside the radius */
     for (int i = lane; i < NRAD_PAD; i += KP_NT) {
         float a = 0, b = 0, c = 0;
         if (i < nrad) {
-            const int s = sm.rlist[i];
+            const int s = sm.r.rlist[i];
             a = patch[s + 1] - patch[s - 1];
             b = patch[s + PD] - patch[s - PD];
             c = patch[s + PD * PD] - patch[s - PD * PD];
@@ -740,8 +754,8 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
 
     /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
     float *t0 = sm.B;
-    float *ta = sm.A, *tb = sm.Cc;           /* blur: t0 -> ta -> tb -> ta */
-    float *sp_wx = sm.Cc, *sp_wy = sm.Cc + NRAD_PAD; /* live only between the pre-pass and the end of the splat */
+    float *ta = sm.A;                        /* blur: t0 -> ta -> t0 -> ta */
+    float *sp_wx = sm.C.sp_wxy, *sp_wy = sm.C.sp_wxy + NRAD_PAD; /* live only between the pre-pass and the end of the splat */
     float *sp_wz = sm.A, *sp_mag = sm.A + NRAD_PAD;
     const float radius = (float)(PD / 2);
     for (int s = lane; s < PV; s += KP_NT) t0[s] = 0;
@@ -757,7 +771,7 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
             for (int q = 0; q < 3; q++) u[q] += radius;
             splat_params((float)(u[0] + 0.5), (float)(u[1] + 0.5), (float)(u[2] + 0.5), base, wx, wy, wz);
         }
-        sm.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
+        sm.r.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
     }
     __syncthreads();
     if (lane == KP_NT - 64) {
@@ -787,13 +801,13 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
             nrec_out[k] = 0;
         }
     }
-    wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag); /* wavefront 0; ends with a barrier */
+    wave_splat_sequence(t0, nrad, sm.r.sp_base, sp_wx, sp_wy, sp_wz, sp_mag); /* wavefront 0; ends with a barrier */
     if (sm.sc[15] == 0.0f) return;
     if (p.debug_stop == 4 || p.debug_stop == 5) { if (lane == 0) nrec_out[k] = 0; return; }
     if (p.debug_stop == 6) { if (lane == 0) nrec_out[k] = 0; return; }
-    wave_blur_patch<KP_NT>(t0, ta, tb, sm.taps, 3);
+    wave_blur_patch<KP_NT>(t0, ta, t0, sm.taps, 3);
     if (p.debug_stop == 7) { if (lane == 0) nrec_out[k] = 0; return; }
-    const int npk = wave_peaks_sorted<KP_NT>(ta, reinterpret_cast<unsigned char *>(tb), &sm.cnt[1], sm.raw_idx, sm.raw_val, sm.pk_idx, sm.pk_val);
+    const int npk = wave_peaks_sorted<KP_NT>(ta, sm.C.pk.flags, &sm.cnt[1], sm.C.pk.raw_idx, sm.C.pk.raw_val, sm.pk_idx, sm.pk_val);
     if (p.debug_stop == 8) { if (lane == 0) nrec_out[k] = 0; return; }
 
     if (lane < npk && lane < PD && lane < 30) {
@@ -834,18 +848,22 @@ __global__ __launch_bounds__(KP_NT, 6) void keypoint_kernel(sift3d_kp_params p, 
                 }
                 splat_params((float)(pp[0] + 0.5), (float)(pp[1] + 0.5), (float)(pp[2] + 0.5), base, wx, wy, wz);
             }
-            sm.sp_base[q] = base; sp_wx[q] = wx; sp_wy[q] = wy; sp_wz[q] = wz; sp_mag[q] = mg;
+            sm.r.sp_base[q] = base; sp_wx[q] = wx; sp_wy[q] = wy; sp_wz[q] = wz; sp_mag[q] = mg;
         }
         __syncthreads();
-        wave_splat_sequence(t0, nrad, sm.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
-        wave_blur_patch<KP_NT>(t0, ta, tb, sm.taps, 3);
-        const int npk2 = wave_peaks_sorted<KP_NT>(ta, reinterpret_cast<unsigned char *>(tb), &sm.cnt[2], sm.raw_idx, sm.raw_val, sm.pk2_idx, sm.pk2_val);
-        const float pk20 = npk2 > 0 ? sm.pk2_val[0] : 0.0f;
+        if (p.debug_stop == 31) { if (lane == 0) nrec_out[k] = 0; return; }
+        wave_splat_sequence(t0, nrad, sm.r.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
+        if (p.debug_stop == 32) { if (lane == 0) nrec_out[k] = 0; return; }
+        wave_blur_patch<KP_NT>(t0, ta, t0, sm.taps, 3);
+        if (p.debug_stop == 33) { if (lane == 0) nrec_out[k] = 0; return; }
+        const int npk2 = wave_peaks_sorted<KP_NT>(ta, sm.C.pk.flags, &sm.cnt[2], sm.C.pk.raw_idx, sm.C.pk.raw_val, sm.C.pk.pk2_idx, sm.C.pk.pk2_val);
+        if (p.debug_stop == 34) { if (lane == 0) nrec_out[k] = 0; return; }
+        const float pk20 = npk2 > 0 ? sm.C.pk.pk2_val[0] : 0.0f;
         for (int j = 0; j < npk2 && nret < PD && nret < 30; j++) {
-            if (sm.pk2_val[j] < 0.5f * pk20) break;
+            if (sm.C.pk.pk2_val[j] < 0.5f * pk20) break;
             if (lane == 0) {
                 float p2[3], p3[3];
-                interp_point_patch(ta, sm.pk2_idx[j], p2);
+                interp_point_patch(ta, sm.C.pk.pk2_idx[j], p2);
                 p2[0] -= radius; p2[1] -= radius; p2[2] -= radius;
                 v3_norm(p2);
                 float par = v3_dot(p1, p2);

@@ -10,6 +10,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     log = ctx.launch_log(); sel = log[log["stage"] == 5]
     print("stop=%s keypoint ms: first3 %s  total %.3f  (items %s)" % (os.environ.get("SIFT3D_KP_STOP", "0"), [round(float(x), 3) for x in sel["ms"][:3]], sel["ms"].sum(), sel["nvox"][:3].tolist()))
 else:
-    for stop in (1, 2, 3, 4, 5, 6, 7, 8, 0):
+    for stop in [int(v) for v in os.environ.get("ABL_STOPS", "1,2,3,4,7,8,31,32,33,34,0").split(",")]:
         env = dict(os.environ, SIFT3D_KP_STOP=str(stop))
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env)
