@@ -909,10 +909,10 @@ struct kpB_sift { /* SIFT-rank: per interior voxel gradient magnitude + orientat
     unsigned char bin[NINT + 3];
     int start[9];
 };
-struct kpB_brief { /* BRIEF family: blur temporaries */
-    float t1[PV + 1], t2[PV + 1];
+struct kpB_brief { /* BRIEF family: blur output (the middle pass goes back into the patch) */
+    float t1[PV + 1];
 };
-/* LDS of one record: 10.6 KB for the SIFT-rank instantiation (15 wavefronts per CU), 16 KB for BRIEF */
+/* LDS of one record: 10.6 KB for both instantiations */
 template <bool SIFT>
 struct kpB_smem {
     float patch[PV + 1];
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         }
     } else {
         /* msResampleFeaturesBRIEF, MultiScale.cpp:989-1049 */
-        wave_blur_patch<DESC_NT>(sm.patch, sm.u.v.t1, sm.u.v.t2, sm.taps, 5);
+        wave_blur_patch<DESC_NT>(sm.patch, sm.u.v.t1, sm.patch, sm.taps, 5);
         if (w0) {
             const float *bl = sm.u.v.t1;
             const int x1 = c_brief_x[3 * lane], y1 = c_brief_x[3 * lane + 1], z1 = c_brief_x[3 * lane + 2];
