@@ -454,14 +454,15 @@ def _zslab_worker(rank, world, port, dims, seed, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims,seed,mode", [((96, 80, 160), 7, 0), ((64, 72, 136), 11, 2)])
-def test_zslab_two_processes_match_single_gpu(built, dims, seed, mode):
+@pytest.mark.parametrize("dims,seed,mode,world", [((96, 80, 160), 7, 0, 2), ((64, 72, 136), 11, 2, 2), ((72, 64, 232), 4, 0, 3)])
+def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
+    """Two ranks, and three (the middle one exchanges on both sides, as every interior rank of an 8-GPU run does)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_zslab_worker, args=(r, 2, port, dims, seed, mode, q)) for r in range(2)]
+    procs = [mpc.Process(target=_zslab_worker, args=(r, world, port, dims, seed, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
     n_sharded, merged, stats = q.get(timeout=300)

@@ -1,4 +1,4 @@
-"""CPU suite: the Z-slab driver (3d_sift_cuda_amd/zslab.py) with gloo, world size 2 (and 1 / 3 in-process plans).
+"""CPU suite: the Z-slab driver (3d_sift_cuda_amd/zslab.py) with gloo, world size 2 and 3 (and 1 / 3 in-process plans).
 
 The compute backend here is the oracle (test infrastructure); what is under test is the slab logic that the GPU
 path shares: boundaries, halo widths, exchange, DoG halo repair, own-slice filtering, coarse-octave gather, order.
@@ -133,13 +133,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("dims,seed", [((40, 36, 160), 3), ((36, 40, 130), 9)])
-def test_two_rank_gloo_matches_serial_oracle(oracle, built, dims, seed):
+@pytest.mark.parametrize("dims,seed,world", [((40, 36, 160), 3, 2), ((36, 40, 130), 9, 2), ((28, 24, 208), 5, 3)])
+def test_gloo_ranks_match_serial_oracle(oracle, built, dims, seed, world):
+    """World size 2, and 3: the middle rank has a neighbour on both sides (what every interior rank of an 8-GPU run is)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dims, seed, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, seed, q)) for r in range(world)]
     for p in procs:
         p.start()
     n_sharded, merged, stats = q.get(timeout=600)
