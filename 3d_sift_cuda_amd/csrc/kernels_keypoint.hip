@@ -15,6 +15,7 @@
  * (9 lanes for the structure tensor, 8 lanes for the 8 corners of a splat, 64
  * lanes for the 64 descriptor bins).  Compiled with -ffp-contract=off.
  */
+#include <cstddef>
 #include <type_traits>
 
 #include "sift3d_internal.h"
@@ -580,8 +581,7 @@ __device__ __forceinline__ void splat_params(float x, float y, float z, short &b
  * of a wavefront execute in issue order, so every cell sees its updates in
  * voxel order, which is the reference's.  A voxel the reference skips has
  * mag == 0 and adds +0, which leaves a cell unchanged. */
-__device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const short *sp_base, const float *sp_wx, const float *sp_wy,
-                                                    const float *sp_wz, const float *sp_mag)
+__device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const short *sp_base, const v4f *sp4)
 {
     const int lane = threadIdx.x;
     const int slot = lane >> 3;
@@ -591,9 +591,10 @@ __device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const sh
         /* parameters of the group after the current one are read while the current one is being applied */
         int packed = 0;
         float wx = 0, wy = 0, wz = 0, v = 0;
-        if (slot < n) {
+        if (slot < n) { /* (wx, wy, wz, magnitude) of a voxel in one 16-byte read */
             packed = sp_base[slot];
-            wx = sp_wx[slot]; wy = sp_wy[slot]; wz = sp_wz[slot]; v = sp_mag[slot];
+            const v4f q = sp4[slot];
+            wx = q.x; wy = q.y; wz = q.z; v = q.w;
         }
         for (int g0 = 0; g0 < n; g0 += 8) {
             const int i = g0 + slot;
@@ -607,7 +608,8 @@ __device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const sh
             const int in = i + 8;
             if (in < n) {
                 packed = sp_base[in];
-                wx = sp_wx[in]; wy = sp_wy[in]; wz = sp_wz[in]; v = sp_mag[in];
+                const v4f q = sp4[in];
+                wx = q.x; wy = q.y; wz = q.z; v = q.w;
             }
             /* ds_add_f32 without return: the LDS unit performs the IEEE single-precision add (round to nearest
              * even, denormals kept: the same operation as v_add_f32, checked by sift3d_selftest_lds_add) in the
@@ -639,19 +641,20 @@ __device__ __forceinline__ long long xcd_contiguous_item(long long n)
 /* ---------------------------------------------------------------------- */
 /* 23 032 bytes: seven workgroups per CU (the kernel is latency-bound; its throughput follows the number of resident
  * workgroups).  Buffers are shared between phases that never overlap:
- *   A   patch -> splat wz, mag -> blurred grid           B   splat grid t0 / middle pass of the blur
- *   C   splat wx, wy -> scratch of the peak search       r   in-radius list -> splat base cells */
+ *   A   patch -> blurred grid                            B   splat grid t0 / middle pass of the blur
+ *   A+C (contiguous) splat parameters (wx, wy, wz, magnitude) of the in-radius voxels, one 16-byte vector each
+ *   C   scratch of the peak search                       r   in-radius list -> splat base cells */
 struct kpA_smem {
     float A[PV + 1];
-    float B[PV + 1];
-    union {
-        float sp_wxy[2 * NRAD_PAD]; /* live from the splat pre-pass to the end of the splat */
+    union { /* directly behind A */
+        float sp_tail[2 * NRAD_PAD]; /* the splat parameters run from A into here: live from the pre-pass to the end of the splat */
         struct {                    /* live from the peak search to the end of the frame loop body */
             unsigned char flags[PV + 13];
             short raw_idx[128], pk2_idx[128];
             float raw_val[128], pk2_val[128];
         } pk;
     } C;
+    float B[PV + 1];
     float gx[NRAD_PAD], gy[NRAD_PAD], gz[NRAD_PAD]; /* gradients of the in-radius voxels */
     union {
         unsigned short rlist[NRAD_PAD]; /* until the gradients are taken */
@@ -665,6 +668,8 @@ struct kpA_smem {
     int cnt[4];
 };
 static_assert(sizeof(kpA_smem) * 7 <= 160 * 1024, "seven workgroups per CU");
+static_assert(offsetof(kpA_smem, C) == sizeof(float) * (PV + 1) && sizeof(float) * (PV + 1) + sizeof(float) * 2 * NRAD_PAD >= 16 * NRAD_PAD,
+              "the splat parameters span A and C");
 
 __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, const unsigned long long *__restrict__ keys,
                                                       const sift3d_cval *__restrict__ vals, long long ncand,
@@ -732,12 +737,17 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
          * that their latency stays off the add chain */
         float acc = 0;
         int i = 0;
-        for (; i + 16 <= nrad; i += 16) {
-            float a[16], b[16];
+        for (; i + 16 <= nrad; i += 16) { /* 16-byte LDS reads: the kernel is bound by its LDS unit */
+            v4f a[4], b[4];
 #pragma unroll
-            for (int q = 0; q < 16; q++) { a[q] = ei[i + q]; b[q] = ej[i + q]; }
+            for (int q = 0; q < 4; q++) {
+                a[q] = *reinterpret_cast<const v4f *>(ei + i + 4 * q);
+                b[q] = *reinterpret_cast<const v4f *>(ej + i + 4 * q);
+            }
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc += a[q] * b[q];
+            for (int q = 0; q < 4; q++) {
+                acc += a[q].x * b[q].x; acc += a[q].y * b[q].y; acc += a[q].z * b[q].z; acc += a[q].w * b[q].w;
+            }
         }
         for (; i < nrad; i++) acc += ei[i] * ej[i];
         sm.sc[lane] = acc;
@@ -755,8 +765,7 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
     /* determineCanonicalOrientation3D, MultiScale.cpp:2722-3037.  The patch (A) is dead from here on. */
     float *t0 = sm.B;
     float *ta = sm.A;                        /* blur: t0 -> ta -> t0 -> ta */
-    float *sp_wx = sm.C.sp_wxy, *sp_wy = sm.C.sp_wxy + NRAD_PAD; /* live only between the pre-pass and the end of the splat */
-    float *sp_wz = sm.A, *sp_mag = sm.A + NRAD_PAD;
+    v4f *sp4 = reinterpret_cast<v4f *>(sm.A); /* live only between the pre-pass and the end of the splat */
     const float radius = (float)(PD / 2);
     for (int s = lane; s < PV; s += KP_NT) t0[s] = 0;
     for (int i = lane; i < nrad; i += KP_NT) {
@@ -771,7 +780,9 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
             for (int q = 0; q < 3; q++) u[q] += radius;
             splat_params((float)(u[0] + 0.5), (float)(u[1] + 0.5), (float)(u[2] + 0.5), base, wx, wy, wz);
         }
-        sm.r.sp_base[i] = base; sp_wx[i] = wx; sp_wy[i] = wy; sp_wz[i] = wz; sp_mag[i] = mg;
+        sm.r.sp_base[i] = base;
+        v4f q; q.x = wx; q.y = wy; q.z = wz; q.w = mg;
+        sp4[i] = q;
     }
     __syncthreads();
     if (lane == KP_NT - 64) {
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
             nrec_out[k] = 0;
         }
     }
-    wave_splat_sequence(t0, nrad, sm.r.sp_base, sp_wx, sp_wy, sp_wz, sp_mag); /* wavefront 0; ends with a barrier */
+    wave_splat_sequence(t0, nrad, sm.r.sp_base, sp4); /* wavefront 0; ends with a barrier */
     if (sm.sc[15] == 0.0f) return;
     if (p.debug_stop == 4 || p.debug_stop == 5) { if (lane == 0) nrec_out[k] = 0; return; }
     if (p.debug_stop == 6) { if (lane == 0) nrec_out[k] = 0; return; }
@@ -848,11 +859,13 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
                 }
                 splat_params((float)(pp[0] + 0.5), (float)(pp[1] + 0.5), (float)(pp[2] + 0.5), base, wx, wy, wz);
             }
-            sm.r.sp_base[q] = base; sp_wx[q] = wx; sp_wy[q] = wy; sp_wz[q] = wz; sp_mag[q] = mg;
+            sm.r.sp_base[q] = base;
+            v4f pq; pq.x = wx; pq.y = wy; pq.z = wz; pq.w = mg;
+            sp4[q] = pq;
         }
         __syncthreads();
         if (p.debug_stop == 31) { if (lane == 0) nrec_out[k] = 0; return; }
-        wave_splat_sequence(t0, nrad, sm.r.sp_base, sp_wx, sp_wy, sp_wz, sp_mag);
+        wave_splat_sequence(t0, nrad, sm.r.sp_base, sp4);
         if (p.debug_stop == 32) { if (lane == 0) nrec_out[k] = 0; return; }
         wave_blur_patch<KP_NT>(t0, ta, t0, sm.taps, 3);
         if (p.debug_stop == 33) { if (lane == 0) nrec_out[k] = 0; return; }
