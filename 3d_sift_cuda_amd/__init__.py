@@ -34,7 +34,7 @@ FEATEXTRACT = os.path.join(CSRC, "_build", "featExtract")
 
 DESC_SIFT, DESC_BRIEF, DESC_RRIEF, DESC_NRRIEF = 0, 1, 2, 3
 INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
-STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused")
+STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),

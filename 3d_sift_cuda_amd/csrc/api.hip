@@ -1017,7 +1017,42 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         const double N = (double)d.X * d.Y * d.Z;
         sigma = 1.6f;
         sig[0] = sigma;
+        /* an octave of at most 4096 voxels: all five levels in one single-workgroup launch instead of fifteen */
+        static const char *tenv = getenv("SIFT3D_TINY_OCTAVE"); /* A/B aid: 0 = the per-level launches */
+        bool tiny_done = false;
+        if (d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && !(tenv && atoi(tenv) == 0)) {
+            sift3d_octave_taps ot;
+            sift3d_octave_out oo;
+            float sg = sigma;
+            bool ok = true;
+            for (int j = 1; j < 6 && ok; j++) {
+                float taps[SIFT3D_MAX_TAPS];
+                const int n = sift3d_gauss_taps(sg * sqrtf(factor * factor - 1.0f), 0.01f, taps);
+                ok = n >= 3 && n <= 2 * SIFT3D_FAST_MAX_R + 1;
+                for (int q = 0; ok && q < n; q++) ot.f[j - 1][q] = taps[q];
+                ot.n[j - 1] = n;
+                oo.L[j - 1] = j < 5 ? c->L[j] + d.off : nullptr;
+                oo.D[j - 1] = c->D[j - 1] + d.off;
+                sg *= factor;
+            }
+            if (ok) {
+                stage_scope sc(c, SIFT3D_STAGE_OCTAVE_TINY, 40.0 * N, 0, (int64_t)N);
+                hipError_t e = sift3d_launch_tiny_octave(c->stream, c->L[0] + d.off, oo, d.X, d.XP, d.Y, d.Z, ot);
+                if (e == hipSuccess) tiny_done = true;
+                else if (e != hipErrorNotSupported) HIPCHK(c, e);
+                else sc.cancel();
+            }
+        }
         for (int j = 1; j < 6; j++) {
+            if (tiny_done) {
+                if (j == 3 && o + 1 < oct.size()) {
+                    stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
+                    HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
+                }
+                sigma *= factor;
+                sig[j] = sigma;
+                continue;
+            }
             const float ex = sigma * sqrtf(factor * factor - 1.0f);
             /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
             /* nothing reads L_5: only D_4 = L_4 - L_5 is needed, so the last level is not stored */

@@ -887,6 +887,65 @@ hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, in
     return hipGetLastError();
 }
 
+/* The coarsest octaves (at most 4096 voxels: 16^3 and below) are launch latency and nothing else: fifteen blur launches
+ * for a few microseconds of work.  One 1024-thread workgroup keeps the octave in LDS and produces its five levels and
+ * five DoGs: per level x, y, z pass (the arithmetic of filter_1d as everywhere: ascending taps, separate multiply and
+ * add, taps outside the volume skipped = adding the +0 the zero border contributes), then D = L_prev - L_new. */
+template <int AXIS>
+__device__ __forceinline__ void tiny_pass(const float *src, float *dst, int X, int Y, int Z, int N, const float *f, int nt)
+{
+    const int R = nt / 2;
+    const int len = AXIS == 0 ? X : (AXIS == 1 ? Y : Z);
+    const int st = AXIS == 0 ? 1 : (AXIS == 1 ? X : X * Y);
+    for (int s = threadIdx.x; s < N; s += 1024) {
+        const int c = AXIS == 0 ? s % X : (AXIS == 1 ? (s / X) % Y : s / (X * Y));
+        float acc = 0;
+        for (int j = 0; j < nt; j++) {
+            const int cc = c + j - R;
+            if (cc >= 0 && cc < len) acc = acc + f[j] * src[s + (cc - c) * st];
+        }
+        dst[s] = acc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void tiny_octave_kernel(const float *__restrict__ L0, sift3d_octave_out o, int X, int XP, int Y, int Z,
+                                                           sift3d_octave_taps t)
+{
+    __shared__ float buf[3][SIFT3D_TINY_VOX];
+    __shared__ float taps[2 * SIFT3D_FAST_MAX_R + 1];
+    const int N = X * Y * Z;
+    float *cur = buf[0], *a = buf[1], *b = buf[2];
+    for (int s = threadIdx.x; s < N; s += 1024) cur[s] = L0[(long long)(s / X) * XP + s % X];
+    __syncthreads();
+    for (int lvl = 0; lvl < 5; lvl++) {
+        const int nt = t.n[lvl];
+        if (threadIdx.x < nt) taps[threadIdx.x] = t.f[lvl][threadIdx.x];
+        __syncthreads();
+        tiny_pass<0>(cur, a, X, Y, Z, N, taps, nt);
+        tiny_pass<1>(a, b, X, Y, Z, N, taps, nt);
+        tiny_pass<2>(b, a, X, Y, Z, N, taps, nt);
+        for (int s = threadIdx.x; s < N; s += 1024) {
+            const long long g = (long long)(s / X) * XP + s % X; /* pad columns stay zero */
+            const float v = a[s];
+            if (o.L[lvl]) o.L[lvl][g] = v;
+            o.D[lvl][g] = cur[s] - v;
+        }
+        __syncthreads();
+        float *tmp = cur; cur = a; a = tmp;
+    }
+}
+
+hipError_t sift3d_launch_tiny_octave(hipStream_t s, const float *L0, const sift3d_octave_out &o, int64_t X, int64_t XP, int64_t Y,
+                                     int64_t Z, const sift3d_octave_taps &t)
+{
+    if (X * Y * Z > SIFT3D_TINY_VOX) return hipErrorNotSupported;
+    for (int l = 0; l < 5; l++)
+        if (t.n[l] < 1 || t.n[l] > 2 * SIFT3D_FAST_MAX_R + 1 || (t.n[l] & 1) == 0 || !o.D[l]) return hipErrorNotSupported;
+    hipLaunchKernelGGL(tiny_octave_kernel, dim3(1), dim3(1024), 0, s, L0, o, (int)X, (int)XP, (int)Y, (int)Z, t);
+    return hipGetLastError();
+}
+
 hipError_t sift3d_launch_zero_pad(hipStream_t s, float *a, float *b, int64_t X, int64_t Xl, int64_t rows)
 {
     const long long n = rows * (X - Xl);

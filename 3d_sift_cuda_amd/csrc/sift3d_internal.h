@@ -63,6 +63,19 @@ hipError_t sift3d_launch_dog(hipStream_t s, const float *a, const float *b, floa
 hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Xl, int64_t Y, int64_t Z, float *out,
                                    int64_t XPout);
 hipError_t sift3d_launch_zero_pad(hipStream_t s, float *a, float *b, int64_t X, int64_t Xl, int64_t rows);
+/* levels 1..5 (L[4] may be NULL) and DoGs 0..4 of an octave of at most SIFT3D_TINY_VOX voxels from its level 0, rows of
+ * pitch XP; hipErrorNotSupported outside that */
+#define SIFT3D_TINY_VOX 4096
+struct sift3d_octave_out {
+    float *L[5];
+    float *D[5];
+};
+struct sift3d_octave_taps {
+    float f[5][2 * SIFT3D_FAST_MAX_R + 1];
+    int n[5];
+};
+hipError_t sift3d_launch_tiny_octave(hipStream_t s, const float *L0, const sift3d_octave_out &o, int64_t X, int64_t XP, int64_t Y,
+                                     int64_t Z, const sift3d_octave_taps &t);
 hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 /* X: row pitch, Xl: logical row length (Xl == X for a dense volume) */

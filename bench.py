@@ -249,7 +249,7 @@ def main():
             key = (st, int(r["ntaps"]), bool(st in ("blur_z_dog", "blur_fused") and r["alg_bytes"] > 8.5 * r["nvox"]))
             g = groups.setdefault(key, {"ms": 0.0, "bytes": 0.0, "launches": 0})
             g["ms"] += float(r["ms"]); g["bytes"] += float(r["alg_bytes"]); g["launches"] += 1
-        blur_groups = {k: v for k, v in groups.items() if k[0].startswith("blur")}
+        blur_groups = {k: v for k, v in groups.items() if k[0].startswith("blur") or k[0] == "octave_tiny"}
         # The dominant kernel of the pyramid is the fused blur (one template, one instantiation per tap count); its
         # roofline figure is taken over its n^3 (octave-0) launches -- 7/8 of the pyramid's bytes, and they run before
         # anything shares the chip with them (the extrema of an octave overlap the blurs of the coarser ones).  The
@@ -325,7 +325,8 @@ def main():
         pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "ms_per_step": round(pyr_ms / nfull, 3), "alg_bytes_per_step": pyr_bytes / nfull,
                    "accounting": "fused launches (volumes >= 2^22 voxels): 12 B/voxel with DoG, 8 without; three-pass launches "
-                                 "(coarse octaves): 8 B/voxel per x or y pass, 16 for the z pass with fused DoG"}
+                                 "(coarse octaves): 8 B/voxel per x or y pass, 16 for the z pass with fused DoG; octaves of at "
+                                 "most 4096 voxels: one launch, 40 B/voxel (level 0 in, four levels and five DoGs out)"}
         stages = {}
         for i, s in enumerate(stage_names):
             sel = full[full["stage"] == i]

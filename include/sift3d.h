@@ -211,6 +211,7 @@ typedef enum {
     SIFT3D_STAGE_KEYPOINT,   /* refinement, patch, orientation frames */
     SIFT3D_STAGE_DESCRIPTOR,
     SIFT3D_STAGE_BLUR_FUSED, /* x, y, z passes and the DoG store in one kernel */
+    SIFT3D_STAGE_OCTAVE_TINY, /* all five levels and DoGs of an octave of at most 4096 voxels in one workgroup */
     SIFT3D_STAGE_COUNT
 } sift3d_stage;
 typedef struct {
