@@ -248,10 +248,11 @@ def test_context_reuse_across_row_lengths(built, oracle):
         assert len(got) == len(want) and (got["x"] == want["x"]).all() and (got["z"] == want["z"]).all()
 
 
-def test_pipeline_records_through_the_fused_blur(built, oracle):
-    """A volume of more than 2^22 voxels: its finest octave is built by the one-launch blur kernel (both tile
-    heights: 11 taps use the 64x16 tile), the coarser ones by the three-pass kernels; records against the oracle."""
-    dims = (168, 164, 160)
+@pytest.mark.parametrize("dims", [(168, 164, 160), (166, 165, 161)])
+def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
+    """A volume of more than 2^22 voxels: its finest octave is built by the one-launch blur kernels (register window
+    for 7, 9 and 17 taps, LDS-DMA ring for 11 and 13), the coarser ones by the three-pass kernels and the single-workgroup
+    octave kernel; the second shape has rows that are not whole 16-byte vectors (pitched rows).  Records against the oracle."""
     vol = vol_of(built, dims, 9)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)
