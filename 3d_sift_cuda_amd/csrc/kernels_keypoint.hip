@@ -501,23 +501,47 @@ template <int NT>
 __device__ __forceinline__ int wave_peaks_sorted(const float *g, unsigned char *flags, int *n_lds, short *raw_idx, float *raw_val,
                                                  short *pk_idx, float *pk_val)
 {
-    for (int s = threadIdx.x; s < PV; s += NT) {
-        bool pk = false;
-        const int x = s % PD, y = (s / PD) % PD, z = s / (PD * PD);
-        if (x >= 1 && x < PD - 1 && y >= 1 && y < PD - 1 && z >= 1 && z < PD - 1) {
-            const float c = g[s];
-            pk = true;
+    /* One thread per interior row (y, z in 1..9) slides a 3-column window of the nine neighbouring rows along x: nine
+     * LDS reads per voxel instead of twenty-seven (the kernel is bound by its LDS unit); the comparisons are the same. */
+    static_assert(NT >= 81 + PD * PD, "one thread per interior row plus one per row for the border flags");
+    const int t = threadIdx.x;
+    if (t < 81) {
+        const int y = t % 9 + 1, z = t / 9 + 1;
+        const int rb = (z * PD + y) * PD; /* the row's first voxel */
+        float a[9], b[9];
 #pragma unroll
-            for (int dz = -1; dz <= 1; dz++)
-#pragma unroll
-                for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; dx++) {
-                        if (!dz && !dy && !dx) continue;
-                        pk = pk && (g[s + (dz * PD + dy) * PD + dx] < c);
-                    }
+        for (int k = 0; k < 9; k++) {
+            const int off = rb + ((k / 3 - 1) * PD + (k % 3 - 1)) * PD;
+            a[k] = g[off];
+            b[k] = g[off + 1];
         }
-        flags[s] = pk ? 1 : 0;
+        flags[rb] = 0;
+#pragma unroll
+        for (int x = 1; x < PD - 1; x++) {
+            float n[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) n[k] = g[rb + ((k / 3 - 1) * PD + (k % 3 - 1)) * PD + x + 1];
+            const float c = b[4];
+            bool pk = true;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                pk = pk && (a[k] < c) && (n[k] < c);
+                if (k != 4) pk = pk && (b[k] < c);
+            }
+            flags[rb + x] = pk ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                a[k] = b[k];
+                b[k] = n[k];
+            }
+        }
+        flags[rb + PD - 1] = 0;
+    } else if (t < 81 + PD * PD) { /* rows on a face of the patch hold no peaks */
+        const int q = t - 81, y = q % PD, z = q / PD;
+        if (y == 0 || y == PD - 1 || z == 0 || z == PD - 1) {
+#pragma unroll
+            for (int x = 0; x < PD; x++) flags[(z * PD + y) * PD + x] = 0;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64) {
