@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--mode", default="volumes", choices=["volumes", "zslab"],
                     help="N > 1: 'volumes' = one volume per GPU (default, weak scaling; the Z-slab run of ONE volume is "
                          "attached as `zslab`); 'zslab' = only the Z-slab run (strong scaling)")
-    ap.add_argument("--zslab-limit", type=int, default=240,
+    ap.add_argument("--zslab-limit", type=int, default=90,
                     help="N > 1, mode volumes: seconds the attached Z-slab run may take (0 = do not attach it)")
     args = ap.parse_args()
 
