@@ -465,19 +465,39 @@ __device__ __forceinline__ int wave_build_radius_list(unsigned short *rlist, int
     return *n_lds;
 }
 
+/* One pass of the separable patch blur: a thread takes a whole line of the axis and slides the filter window along it,
+ * one LDS read per output instead of one per tap (the per-keypoint kernels are bound by the LDS unit).  Per output the
+ * same chain as before: acc = 0, then taps in ascending order, positions outside the patch skipped. */
 template <int NT>
 __device__ __forceinline__ void blur_pass(const float *src, float *dst, int axis, const float *taps, int ntaps)
 {
     const int h = ntaps / 2;
     const int st = axis == 0 ? 1 : (axis == 1 ? PD : PD * PD);
-    for (int s = threadIdx.x; s < PV; s += NT) {
-        const int c = axis == 0 ? s % PD : (axis == 1 ? (s / PD) % PD : s / (PD * PD));
-        float acc = 0;
-        for (int j = 0; j < ntaps; j++) {
-            const int cc = c + j - h;
-            if (cc >= 0 && cc < PD) acc = acc + taps[j] * src[s + (cc - c) * st];
+    float tp[5], w[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) tp[j] = j < ntaps ? taps[j] : 0.0f;
+    for (int ln = threadIdx.x; ln < PD * PD; ln += NT) {
+        const int base = axis == 0 ? ln * PD : (axis == 1 ? (ln / PD) * PD * PD + ln % PD : ln);
+#pragma unroll
+        for (int j = 0; j < 5; j++) { /* window of output 0: positions -h .. +h */
+            const int pos = j - h;
+            w[j] = (j < ntaps && pos >= 0 && pos < PD) ? src[base + pos * st] : 0.0f;
         }
-        dst[s] = acc;
+#pragma unroll
+        for (int c = 0; c < PD; c++) {
+            float acc = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int cc = c + j - h;
+                if (j < ntaps && cc >= 0 && cc < PD) acc = acc + tp[j] * w[j];
+            }
+            dst[base + c * st] = acc;
+            const int nx = c + 1 + h; /* the position entering the window */
+            const float in = nx < PD ? src[base + nx * st] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = w[j + 1];
+            if (ntaps >= 1) w[ntaps - 1 < 4 ? ntaps - 1 : 4] = in;
+        }
     }
     __syncthreads();
 }
