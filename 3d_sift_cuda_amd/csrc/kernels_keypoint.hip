@@ -950,6 +950,12 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
 /* ---------------------------------------------------------------------- */
 /* Phase B: one output record per wavefront: re-sample, normalise, describe */
 /* ---------------------------------------------------------------------- */
+/* value of lane i (compile-time i) of a wavefront-wide float: v_readlane_b32 */
+__device__ __forceinline__ float lane_value(float x, int i)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
+}
+
 /* pair tables of msGenerateBRIEFindex method 2 (data, R/src_common/MultiScale.cpp:805-807) */
 __constant__ unsigned char c_brief_x[192] = {
     5,4,4,4,4,2,6,5,5,4,4,4,3,8,5,5,6,3,5,5,5,5,6,5,4,6,6,6,3,4,4,4,5,3,4,5,4,5,5,4,2,7,7,5,3,5,4,5,3,5,7,3,5,5,2,3,5,5,6,6,4,6,5,4,
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         for (int i = 0; i < 9; i++) ori[i] = kp->frames[fr * 9 + i];
     }
     const sift3d_level lv = p.levels[kp->lvl];
-    if (p.debug_stop >= 21 && p.debug_stop <= 25) { /* development aid: every record samples one cache-resident region (22: and runs to the end, 23/24/25: stops where 12/13/14 do) */
+    if (p.debug_stop >= 21 && p.debug_stop <= 26) { /* development aid: every record samples one cache-resident region (22: and runs to the end, 23/24/25: stops where 12/13/14 do, 26: after the bin chains) */
         wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
         if (p.debug_stop == 21) return;
     } else if (fr < 0) {
@@ -1115,16 +1121,20 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
                 const float mg = sm.u.v.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
                 acc += mg * wxs[x] * wys[y] * wzs[z];
             }
-            /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 */
+            if (p.debug_stop == 26) return;
+            /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 (lane i's value through v_readlane_b32: a scalar
+             * broadcast instead of an LDS permute per term) */
             float mn = 100000;
+#pragma unroll
             for (int i = 0; i < 64; i++) {
-                float vi = __shfl(acc, i);
+                float vi = lane_value(acc, i);
                 if (vi < mn) mn = vi;
             }
             float v = acc - mn;
             float ss = 0;
+#pragma unroll
             for (int i = 0; i < 64; i++) {
-                float vi = __shfl(v, i);
+                float vi = lane_value(v, i);
                 ss += vi * vi;
             }
             float div = 1.0f / sqrtf(ss);
@@ -1152,8 +1162,9 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
     if (!w0) return;
     /* NormalizeDataRankedPCs, MultiScale.cpp:207-233, order of :3148-3176 */
     int rank = 0;
+#pragma unroll
     for (int j = 0; j < 64; j++) {
-        float vj = __shfl(myval, j);
+        float vj = lane_value(myval, j);
         rank += (vj < myval || (vj == myval && j < lane)) ? 1 : 0;
     }
     sift3d_feature *out = recs + r;
