@@ -865,6 +865,22 @@ void o3_sort_high_low(o3_extremum *e, int n)
 }
 
 /* R/src_common/MultiScale.cpp:1987-2121 regFindFEATUREIOPeaks without callback on an 11^3 grid */
+
+/* Diagnostic (O3_TRACE_PEAKS=1): report orientation-histogram peaks near their keep threshold (0.8 of the
+ * strongest primary, 0.5 of the strongest secondary: MultiScale.cpp:2889,2972-2985).  A frame whose ratio sits on the
+ * threshold is where two builds of the same pipeline may legitimately differ by one record. */
+static double o3_trace_band = 1e-3; /* O3_TRACE_PEAKS=<band>: half-width of the reported ratio band (default 1e-3) */
+static int o3_trace_peaks(void)
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("O3_TRACE_PEAKS");
+        on = e != NULL;
+        if (e && atof(e) > 0 && atof(e) != 1.0) o3_trace_band = atof(e);
+    }
+    return on;
+}
+
 static int patch_peaks(const float *g, o3_extremum *out)
 {
     int n = 0;
@@ -886,6 +902,35 @@ static int patch_peaks(const float *g, o3_extremum *out)
                 }
             }
     return n;
+}
+
+/* Diagnostic companion of o3_trace_peaks(): cells of a blurred orientation histogram that fail the strict 26-neighbour
+ * test of patch_peaks only because of neighbours within 1e-5 (relative) of their own value, i.e. peaks another build of
+ * the same arithmetic (other rounding of the splat sums) may or may not see. */
+static void o3_trace_near_ties(const float *g, const o3_feature *ft, int primary)
+{
+    for (int z = 1; z < PD - 1; z++)
+        for (int y = 1; y < PD - 1; y++)
+            for (int x = 1; x < PD - 1; x++) {
+                const int idx = (z * PD + y) * PD + x;
+                const float c = g[idx];
+                if (!(c > 0)) continue;
+                int ties = 0, above = 0;
+                float worst = 0;
+                for (int dz = -1; dz <= 1; dz++)
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (!dz && !dy && !dx) continue;
+                            const float v = g[idx + (dz * PD + dy) * PD + dx];
+                            if (v < c) continue;
+                            if ((double)v - (double)c <= 1e-5 * (double)c) { ties++; if (v - c > worst) worst = v - c; }
+                            else above++;
+                        }
+                if (ties > 0 && above == 0)
+                    fprintf(stderr, "o3 peak-trace: kp (%.3f, %.3f, %.3f) primary %d: NEAR-TIE cell (%d,%d,%d) value %.9g, %d neighbour(s) "
+                            "within 1e-5 relative (largest excess %.3g = %.2f ulp)\n", ft->x, ft->y, ft->z, primary, x, y, z, c, ties,
+                            worst, (double)worst / (double)(nextafterf(c, 2 * c) - c));
+            }
 }
 
 /* R/src_common/MultiScale.cpp:2722-3037 determineCanonicalOrientation3D.
@@ -923,6 +968,7 @@ int o3_canonical_orientations(o3_feature *ft, float *ori_out, int max_ori)
             }
     o3_filter3d(t0, t2, PD, PD, PD, taps, ntaps);
     int npk = patch_peaks(t2, pk);
+    if (o3_trace_peaks()) o3_trace_near_ties(t2, ft, -1);
     o3_sort_high_low(pk, npk);
 
     for (int i = 0; i < npk && i < PD && i < max_ori; i++) {
@@ -935,6 +981,10 @@ int o3_canonical_orientations(o3_feature *ft, float *ori_out, int max_ori)
     int nret = 0;
     memset(ft->data, 0, sizeof(ft->data));
     for (int i = 0; i < npk && i < PD && nret < max_ori; i++) {
+        if (o3_trace_peaks() && i > 0 && fabs((double)pk[i].value / (double)pk[0].value - 0.8) < o3_trace_band)
+            fprintf(stderr, "o3 peak-trace: kp (%.3f, %.3f, %.3f) primary %d: value %.9g / max %.9g = %.9f -> %s\n", ft->x, ft->y,
+                    ft->z, i, pk[i].value, pk[0].value, (double)pk[i].value / (double)pk[0].value,
+                    pk[i].value < 0.8 * pk[0].value ? "rejected" : "kept");
         if (pk[i].value < 0.8 * pk[0].value) break;
         float p1[3], p2[3], p3[3];
         p1[0] = ori_data[i * 3]; p1[1] = ori_data[i * 3 + 1]; p1[2] = ori_data[i * 3 + 2];
@@ -966,8 +1016,13 @@ int o3_canonical_orientations(o3_feature *ft, float *ori_out, int max_ori)
                 }
         o3_filter3d(t0, t2, PD, PD, PD, taps, ntaps);
         int npk2 = patch_peaks(t2, pk2);
+        if (o3_trace_peaks()) o3_trace_near_ties(t2, ft, i);
         o3_sort_high_low(pk2, npk2);
         for (int j = 0; j < npk2 && nret < PD && nret < max_ori; j++) {
+            if (o3_trace_peaks() && j > 0 && fabs((double)pk2[j].value / (double)pk2[0].value - 0.5) < o3_trace_band)
+                fprintf(stderr, "o3 peak-trace: kp (%.3f, %.3f, %.3f) primary %d secondary %d: value %.9g / max %.9g = %.9f -> %s\n",
+                        ft->x, ft->y, ft->z, i, j, pk2[j].value, pk2[0].value, (double)pk2[j].value / (double)pk2[0].value,
+                        pk2[j].value < 0.5f * pk2[0].value ? "rejected" : "kept");
             if (pk2[j].value < 0.5f * pk2[0].value) break; /* fHist2ndPeakThreshold, MultiScale.cpp:40 */
             o3_interp_point(t2, PD, PD, PD, pk2[j].x, pk2[j].y, pk2[j].z, &p2[0], &p2[1], &p2[2]);
             p2[0] -= radius; p2[1] -= radius; p2[2] -= radius;

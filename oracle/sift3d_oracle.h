@@ -17,7 +17,15 @@
  *     and an un-vendored <znzlib.h>, which this image lacks, so they are
  *     unbuildable here; these stages are pinned end-to-end against the .key
  *     files written by the CPU featExtract binary the reference repository
- *     ships (R/bin/Linux/featExtract), committed under tests/golden/.
+ *     ships (R/bin/Linux/featExtract), committed under tests/golden/ in round
+ *     1.  Those files are frozen data: executing that binary is denied here
+ *     (no execute permission) and is not attempted by any route, so the set
+ *     cannot grow.
+ *   - o3_double_size / o3_halve_center (the -2+ / -2- resize,
+ *     R/src_common/FeatureIO.cpp:2452-2548,1670-1714): PARITY UNPINNED against
+ *     the reference - no fixture of the reference exists for them and their
+ *     source file does not compile here.  BRIEF / RRIEF / NRRIEF: likewise
+ *     unpinned (commented alternatives in the reference, MultiScale.cpp:1037-1045).
  *
  * Build: gcc -O2 -ffp-contract=off (no -march=native, no -ffast-math): FMA
  * contraction changes keypoints.
