@@ -255,6 +255,10 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     for (int i = 0; i < 6 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess;
     for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
+    /* nothing may depend on what hipMalloc hands back: the pad columns of pitched octaves are read as zeros */
+    for (int i = 0; i < 6 && ok; i++) ok = hipMemset(c->L[i], 0, tb) == hipSuccess;
+    for (int i = 0; i < 5 && ok; i++) ok = hipMemset(c->D[i], 0, tb) == hipSuccess;
+    ok = ok && hipMemset(c->vol, 0, vb) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_zeros, 512) == hipSuccess && hipMemset(c->d_zeros, 0, 512) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
@@ -1048,6 +1052,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 if (j == 3 && o + 1 < oct.size()) {
                     stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
                     HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
+                    /* the subsample writes the logical columns only: a pitched coarser octave (100 -> 50 -> pitch 52) needs its pad
+                     * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
+                    if (oct[o + 1].XP != oct[o + 1].X)
+                        HIPCHK(c, sift3d_launch_zero_pad(c->stream, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
                 }
                 sigma *= factor;
                 sig[j] = sigma;
@@ -1063,6 +1071,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             if (j == 3 && o + 1 < oct.size()) {
                 stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
                 HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
+                /* the subsample writes the logical columns only: a pitched coarser octave (100 -> 50 -> pitch 52) needs its pad
+                 * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
+                if (oct[o + 1].XP != oct[o + 1].X)
+                    HIPCHK(c, sift3d_launch_zero_pad(c->stream, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
             }
             sigma *= factor;
             sig[j] = sigma;

@@ -248,6 +248,27 @@ def test_context_reuse_across_row_lengths(built, oracle):
         assert len(got) == len(want) and (got["x"] == want["x"]).all() and (got["z"] == want["z"]).all()
 
 
+@pytest.mark.parametrize("dims", [(100, 100, 100), (72, 72, 72), (168, 40, 36)])
+def test_context_reuse_pitched_coarse_octaves(built, oracle, dims):
+    """Row lengths that ARE whole 16-byte vectors but whose coarser octaves are not (100 -> 50 -> pitch 52, 72 -> 36 ->
+    18 -> pitch 20, 168 -> 84 -> 42 -> pitch 44): the subsample writes the logical columns only, so the pad columns of a
+    coarse octave's first level must be zeroed by the pipeline itself.  A larger, dense, strongly offset volume goes
+    through the same context first so that those pad columns hold stale non-zero floats if the pipeline does not."""
+    big = vol_of(built, (128, 128, 128), 3) + np.float32(500.0)
+    vol = vol_of(built, dims, 21)
+    want, _ = oracle.extract(vol)
+    wc = oracle.candidates(vol)
+    with built.Context(128, 128, 128) as ctx:
+        ctx.set_volume(big)
+        assert len(ctx.extract()) > 0
+        ctx.set_volume(vol)
+        got = ctx.extract()
+        assert len(want) > 5 and _compare_records(got, want)
+        gc = ctx.detect()
+        assert len(gc) == len(wc) and all((gc[f] == wc[f]).all() for f in ("octave", "level", "is_max", "x", "y", "z"))
+        assert (bits(gc["value"]) == bits(wc["value"])).all()
+
+
 @pytest.mark.parametrize("dims", [(168, 164, 160), (166, 165, 161)])
 def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
     """A volume of more than 2^22 voxels: its finest octave is built by the one-launch blur kernels (register window
