@@ -159,9 +159,10 @@ int main(int argc, char **argv)
     if (times) fprintf(stderr, "# extraction: %.3f s (%lld records)\n", t1 - t0, (long long)n);
     t0 = t1;
 
-    char c1[200], c2[200], c3[400];
-    sprintf(c1, "Extraction Voxel Resolution (ijk) : %d %d %d", (int)PX, (int)PY, (int)PZ);
-    sprintf(c2, "Extraction Voxel Size (mm)  (ijk) : %f %f %f", 1.0f * img.dx, 1.0f * img.dy, 1.0f * img.dz);
+    /* %f of a float is at most 47 characters (-3.4e38): twelve matrix entries plus the label need < 700 bytes */
+    char c1[200], c2[256], c3[1024];
+    snprintf(c1, sizeof c1, "Extraction Voxel Resolution (ijk) : %d %d %d", (int)PX, (int)PY, (int)PZ);
+    snprintf(c2, sizeof c2, "Extraction Voxel Size (mm)  (ijk) : %f %f %f", 1.0f * img.dx, 1.0f * img.dy, 1.0f * img.dz);
     if (bWorldCoordinates) {
         /* featExtract.cpp:447-458, 548-564 */
         float(*m)[4] = img.qto_xyz;
@@ -176,11 +177,11 @@ int main(int argc, char **argv)
             }
         }
         sift3d_world_transform(feats, n, m);
-        sprintf(c3, "Feature Coordinate Space: millimeters (%s) : %f %f %f %f %f %f %f %f %f %f %f %f 0.0 0.0 0.0 1.0", name,
+        snprintf(c3, sizeof c3, "Feature Coordinate Space: millimeters (%s) : %f %f %f %f %f %f %f %f %f %f %f %f 0.0 0.0 0.0 1.0", name,
                 1.0f * m[0][0], 1.0f * m[0][1], 1.0f * m[0][2], 1.0f * m[0][3], 1.0f * m[1][0], 1.0f * m[1][1], 1.0f * m[1][2],
                 1.0f * m[1][3], 1.0f * m[2][0], 1.0f * m[2][1], 1.0f * m[2][2], 1.0f * m[2][3]);
     } else
-        sprintf(c3, "Feature Coordinate Space: voxels: 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0");
+        snprintf(c3, sizeof c3, "Feature Coordinate Space: voxels: 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0");
     const char *cm[3] = {c1, c2, c3};
     if (sift3d_write_key(argv[iArg + 1], feats, n, fEigThres, 3, cm) != 0) {
         fprintf(stderr, "Error: could not write %s\n", argv[iArg + 1]);

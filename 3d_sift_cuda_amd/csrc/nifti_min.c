@@ -117,6 +117,10 @@ int nifti_min_read(const char *path, nifti_min_image *img)
     img->ny = ndim >= 2 ? rd16(h, 44, sw) : 1;
     img->nz = ndim >= 3 ? rd16(h, 46, sw) : 1;
     img->nt = ndim >= 4 ? rd16(h, 48, sw) : 1;
+    if (img->nx < 1) { /* a row length of zero or less is not an image (ny, nz, nt of unused dimensions default to 1) */
+        gzclose(f);
+        return -1;
+    }
     if (img->nt < 1) img->nt = 1;
     if (img->ny < 1) img->ny = 1;
     if (img->nz < 1) img->nz = 1;

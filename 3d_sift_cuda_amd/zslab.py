@@ -165,6 +165,10 @@ class ZSlabExtractor:
         self.levels = []       # level table entries, index = level id
         self.level_ids = []
         self.stats = {"exchanges": 0, "exchange_bytes": 0}
+        # every DoG buffer an extrema pass was queued on: the library replays those passes from the recorded pointers when
+        # a candidate list overflows (cand_finalize), so all five DoG levels of every octave -- not only the L1..L3 / D1..D3
+        # the level table names -- must outlive candidates() / describe(); released by the next run()
+        self._keepalive = []
 
     # ---- halo exchange of one level buffer -------------------------------------------------
     def _exchange(self, buf, z0, z1, e0, width, has_lo, has_hi):
@@ -228,6 +232,7 @@ class ZSlabExtractor:
             be.extrema_append(D[l], D[l + 1], D[l + 2], lid, z0 - e0, z1 - e0)
             self.levels.append(be.level_entry(L[l + 1], D[l + 1], zo, e0, sig[l], sig[l + 1], sig[l + 2], factor))
             self.level_ids.append(lid)
+        self._keepalive.append(D)
         return L[3] if want_next else None
 
     # ---- the whole pyramid ----------------------------------------------------------------------
@@ -239,6 +244,7 @@ class ZSlabExtractor:
         K = plan.n_sharded
         be.reset()
         self.levels, self.level_ids = [], []
+        self._keepalive = []
         factor = 1.0
         vol = be.from_host(input_slab)
         nxt = None
@@ -362,9 +368,10 @@ def merge_by_group(parts):
     return allr[order]
 
 
-def gather_records(dist, rank, world, recs, grp, device, group=None):
+def gather_records(dist, rank, world, recs, grp, device, group=None, dtype=None):
     """Gather every rank's (records, group) on rank 0 with tensor collectives (sizes first, then padded
-    byte tensors) and merge them into the single-GPU order.  Returns the merged array on rank 0, None elsewhere."""
+    byte tensors) and merge them into the single-GPU order.  Returns the merged array on rank 0, None elsewhere.
+    dtype: the record dtype (the package's FEATURE_DTYPE); needed when rank 0 itself has no records."""
     import torch
     stage = dist.get_backend(group) == "gloo"
     dev = "cpu" if stage else device
@@ -387,13 +394,16 @@ def gather_records(dist, rank, world, recs, grp, device, group=None):
         gbs = [torch.zeros(mx, dtype=torch.int32, device=dev) for _ in range(world)]
         dist.gather(rb, rbs, dst=0, group=group)
         dist.gather(gb, gbs, dst=0, group=group)
-        dt = recs.dtype if recs is not None else None
+        dt = np.dtype(dtype) if dtype is not None else (recs.dtype if recs is not None else None)
+        if dt is None:
+            raise ValueError("gather_records: rank 0 has no records of its own, pass dtype=")
+        assert dt.itemsize == item, (dt.itemsize, item)
         parts = []
         for r in range(world):
             if counts[r] == 0:
                 continue
             a = rbs[r][:counts[r] * item].cpu().numpy()
-            parts.append((a.view(dt) if dt is not None else a, gbs[r][:counts[r]].cpu().numpy()))
+            parts.append((a.view(dt), gbs[r][:counts[r]].cpu().numpy()))
         return merge_by_group(parts)
     dist.gather(rb, None, dst=0, group=group)
     dist.gather(gb, None, dst=0, group=group)

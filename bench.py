@@ -76,7 +76,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
             ex = zs.ZSlabExtractor(be, plan, rank, dist)
             ex.run(slab, i0)
             recs, grp = ex.describe(desc_mode=args.desc, copy=False)   # views of the pinned download buffers
-            merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev)
+            merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev, dtype=pkg.FEATURE_DTYPE)
         return ex, merged
 
     for _ in range(max(1, args.warmup)):
@@ -120,11 +120,15 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
     dist.destroy_process_group()
 
 
+ZSLAB_FAILED_EXIT = 3   # exit code of every rank when the attached Z-slab run failed or timed out
+
+
 def zslab_beside(out, args, pkg, torch, dist, rank, world, local_rank, expect, limit_s):
     """N > 1, default mode: after the per-GPU-volume measurement, also run the Z-slab split of ONE volume over the same
     ranks and attach it to the line as `zslab`.  It is the only place this path meets RCCL on real links (the
-    development box has one GPU), so it runs under a watchdog: if a rank fails or the exchange stalls, rank 0 prints
-    the line without it and every rank leaves."""
+    development box has one GPU), so it runs under a watchdog: if a rank fails or the exchange stalls, rank 0 still
+    prints the line (its headline fields are complete; `zslab.status` says what happened) and then EVERY rank exits
+    with code 3 -- a GPU rank that crashed or hung must not look like a clean run to the launcher."""
     import threading
     done = threading.Event()
 
@@ -133,7 +137,7 @@ def zslab_beside(out, args, pkg, torch, dist, rank, world, local_rank, expect, l
             if rank == 0:
                 out["zslab"] = {"status": "no result within %d s (a rank failed or the exchange stalled)" % limit_s}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(ZSLAB_FAILED_EXIT)
     threading.Thread(target=watchdog, daemon=True).start()
     try:
         res = zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect)
@@ -146,7 +150,7 @@ def zslab_beside(out, args, pkg, torch, dist, rank, world, local_rank, expect, l
             done.wait(limit_s + 5)   # never returns normally: the watchdog ends this process
         out["zslab"] = {"status": "failed on rank 0: %r" % (e,)}
         print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(ZSLAB_FAILED_EXIT)
     done.set()
 
 

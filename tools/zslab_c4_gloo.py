@@ -28,7 +28,7 @@ with be.stream_scope():
     ex = zs.ZSlabExtractor(be, plan, rank, dist)
     ex.run(slab, i0)
     recs, grp = ex.describe(desc_mode=0, copy=False)
-    merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:0")
+    merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:0", dtype=pkg.FEATURE_DTYPE)
 dist.barrier()
 dt = time.perf_counter() - t0
 ctx.close()
