@@ -255,12 +255,14 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     for (int i = 0; i < 6 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess;
     for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
-    /* nothing may depend on what hipMalloc hands back: the pad columns of pitched octaves are read as zeros */
-    for (int i = 0; i < 6 && ok; i++) ok = hipMemset(c->L[i], 0, tb) == hipSuccess;
-    for (int i = 0; i < 5 && ok; i++) ok = hipMemset(c->D[i], 0, tb) == hipSuccess;
-    ok = ok && hipMemset(c->vol, 0, vb) == hipSuccess;
+    /* nothing may depend on what hipMalloc hands back: the pad columns of pitched octaves are read as zeros.  The clears
+     * go on the context's own stream and are waited for here: hipMemset runs on the null stream, which the context's
+     * non-blocking streams are NOT ordered with, so it could still be wiping a buffer the first extraction already uses */
+    for (int i = 0; i < 6 && ok; i++) ok = hipMemsetAsync(c->L[i], 0, tb, c->stream) == hipSuccess;
+    for (int i = 0; i < 5 && ok; i++) ok = hipMemsetAsync(c->D[i], 0, tb, c->stream) == hipSuccess;
+    ok = ok && hipMemsetAsync(c->vol, 0, vb, c->stream) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_zeros, 512) == hipSuccess && hipMemset(c->d_zeros, 0, 512) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_zeros, 512) == hipSuccess && hipMemsetAsync(c->d_zeros, 0, 512, c->stream) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
@@ -268,6 +270,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->surv_counts, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
     c->surv_set = 0;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess; /* the clears above are done before the context is handed out */
     if (!ok) {
         free_dev(c);
         if (c->stream) hipStreamDestroy(c->stream);
