@@ -499,6 +499,271 @@ __global__ __launch_bounds__(16 * TY, (NBUF == 3 ? 4 : 2)) void blur_fused_dma_k
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* no DMA may land after the workgroup has released its LDS */
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Second form of the register-window march ("ring" kernel), round 2.  Same tile, same three passes, same arithmetic;
+ * what changed is everything around the arithmetic:
+ *
+ *  - The DoG's input voxel ("previous level") is no longer re-read from memory R planes after the window load: the
+ *    x-pass thread already holds it (the centre 8 floats of its window) and drops it into an LDS ring of R+2 planes of
+ *    the tile (8 KB each), from which the thread that stores the DoG picks it up R steps later.  Read side: 4 B/voxel
+ *    plus halo instead of 8.
+ *  - Every global access is a buffer operation (buffer_load_dwordx4 / buffer_store_dwordx2 ... offen, plane offset in an
+ *    SGPR): a lane outside the volume carries the offset 0xFFFFFFFF and the hardware's bounds check returns zeros / drops
+ *    the store; a plane outside the volume uses a descriptor of zero records.  No pointer arithmetic in vector registers,
+ *    no zero page, no exec-mask branches around loads and stores -- so the loop body is straight-line code with a fixed
+ *    number of vector-memory operations, and the wait in front of the x pass is "all but this step's stores"
+ *    (s_waitcnt vmcnt(#stores)) instead of vmcnt(0).  The first form drained its own stores once per plane: with loads
+ *    or stores alone it took 0.21 / 0.24 ms at 512^3 (7 taps), with both 0.40.
+ *  - Lead-in steps (no output plane yet) issue their stores too, through a descriptor of zero records (dropped by the
+ *    bounds check), so that every step and every path into the loop carries the same vmcnt state.
+ *
+ * BR = output rows per thread: 2 (512 threads, 2 x 2 block, the first form's mapping) or 1 (1024 threads, 2 x 1 block,
+ * half the accumulator registers per thread: sixteen wavefronts per workgroup for the wide filters, which would
+ * otherwise sit at two wavefronts per SIMD).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+#define FB_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (the value composable_kernel uses for gfx90a..gfx950) */
+#define FB_OOB 0xFFFFFFFFu        /* >= any num_records: the lane's access is out of range by construction */
+
+template <int R, int BR>
+struct fb_ring_cfg {
+    static constexpr int TY = 32;
+    static constexpr int NT = 1024 / BR;
+    static constexpr int NR = TY + 2 * R;
+    static constexpr int XW = (NR * 8 + 63) / 64; /* wavefronts with an x-pass role */
+    static constexpr int P1ROWS = XW * 8;          /* rows those wavefronts write (>= NR; the surplus rows are never read) */
+    static constexpr int S = R + 2;                /* DoG-input ring: written for plane z+1 while plane z-R is read */
+    static constexpr int LDS_FLOATS = 2 * P1ROWS * FB_TX + S * TY * FB_TX;
+    /* workgroups per CU the LDS allows (160 KiB), capped at what 32 wavefronts per CU allow */
+    static constexpr int WG_LDS = (160 * 1024) / (LDS_FLOATS * 4);
+    static constexpr int WG_WAVES = 32 / (NT / 64);
+    static constexpr int WG = WG_LDS < WG_WAVES ? (WG_LDS < 1 ? 1 : WG_LDS) : WG_WAVES;
+    static constexpr int WAVES_PER_SIMD = WG * (NT / 64) / 4 > 4 ? 4 : WG * (NT / 64) / 4; /* never ask for fewer than 128 registers */
+};
+
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG>
+__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
+    const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zlen, int tiles_x,
+    int tiles_y, long long total, fb_taps2 t)
+{
+    using C = fb_ring_cfg<R, BR>;
+    constexpr int U = 2 * R + 1;
+    constexpr int TY = C::TY, NR = C::NR, XW = C::XW, P1ROWS = C::P1ROWS, S = C::S;
+    constexpr int H4 = ((R + 3) / 4) * 4; /* window halo, whole 16-byte vectors */
+    constexpr int WIN = 8 + 2 * H4, NV = WIN / 4;
+    constexpr int P1PL = P1ROWS * FB_TX, PVPL = TY * FB_TX;
+    static_assert(XW * 64 <= C::NT, "the x-pass wavefronts are wavefronts of the workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    float *const P1b = lds;
+    float *const pvb = lds + 2 * P1PL;
+
+    const long long lin = blockIdx.x;
+    const long long per = (total + 7) / 8;
+    const long long wi = (lin % 8) * per + lin / 8; /* XCD-aware tile order, as in the first form */
+    if (wi >= total) return;
+    const int tx = (int)(wi % tiles_x);
+    const int ty = (int)((wi / tiles_x) % tiles_y);
+    const int chunk = (int)(wi / ((long long)tiles_y * tiles_x));
+    const int x0 = tx * FB_TX, y0 = ty * TY;
+    const int zc0 = chunk * zlen;
+    const int zc1 = zc0 + zlen < Z ? zc0 + zlen : Z;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long XY = (long long)X * Y;
+    const unsigned plane_bytes = (unsigned)(XY * 4); /* X * Y < 2^29 */
+    const int zfirst = zc0 - R, zlast = zc1 - 1 + R;
+    const int zb = zfirst > 0 ? zfirst : 0; /* first plane the input descriptor covers */
+
+    /* Buffer descriptors.  Offsets are 32-bit: the launcher keeps (zlen + 2R + 2) planes below 4 GiB, every descriptor
+     * starts at this chunk's first plane, and its record count ends at the end of the volume. */
+    auto nrec = [&](int zfrom) -> unsigned {
+        const long long b = (long long)(Z - zfrom) * XY * 4;
+        return b > 0xFFFFFFF0ll ? 0xFFFFFFF0u : (unsigned)b;
+    };
+    const unsigned in_rec = nrec(zb);
+    const float *const in_base = in + (long long)zb * XY;
+    float *const out_base = HAS_OUT ? out + (long long)zc0 * XY : nullptr;
+    float *const dog_base = HAS_DOG ? dog + (long long)zc0 * XY : nullptr;
+    const unsigned st_rec = nrec(zc0);
+    /* The stores of a step are issued on EVERY step, lead-in steps included, through a descriptor whose record count is
+     * zero until the first output plane is complete: the bounds check drops them, but they count in vmcnt like real
+     * ones.  That keeps the number of vector-memory operations per step constant on every path into and around the
+     * loop, which is what lets the compiler wait with vmcnt(#stores + k) in front of the x pass instead of vmcnt(0). */
+    auto store_rsrc = [&](float *base, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? (int)st_rec : 0, FB_RSRC_FLAGS);
+    };
+
+    /* stage A role (wavefronts 0 .. XW-1): row ar of the x pass, outputs x0 + axs .. + 7.  Lanes past row NR-1 and rows
+     * outside the volume carry out-of-range offsets: they filter zeros into P1 rows nobody reads / rows that are zero. */
+    const bool xrole = wv < XW; /* wave-uniform */
+    const int ar = tid >> 3, axs = (tid & 7) * 8;
+    const int agy = y0 - R + ar;
+    const bool arow = ar < NR && agy >= 0 && agy < Y;
+    unsigned voff[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int gx = x0 + axs - H4 + 4 * k;
+        voff[k] = (arow && gx >= 0 && gx < X) ? (unsigned)(agy * X + gx) * 4u : FB_OOB;
+    }
+    const bool prow = ar >= R && ar < R + TY; /* a row of the tile itself: its centre 8 floats go to the DoG-input ring */
+
+    /* stage B/C role: column pair bcp, BR rows starting at row brow of the tile */
+    const int bcp = tid & 31, brow = (tid >> 5) * BR;
+    const int bx = x0 + 2 * bcp;
+    unsigned soff[BR];
+#pragma unroll
+    for (int r = 0; r < BR; r++) soff[r] = (bx < X && y0 + brow + r < Y) ? (unsigned)((y0 + brow + r) * X + bx) * 4u : FB_OOB;
+
+    v4f win[NV];
+    auto load_window = [&](int z) { /* wave-uniform z; a plane outside the volume reads through a descriptor of no records */
+        const bool ok = z >= 0 && z < Z;
+        const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void *)in_base, 0, ok ? (int)in_rec : 0, FB_RSRC_FLAGS);
+        const unsigned so = ok ? (unsigned)(z - zb) * plane_bytes : 0u;
+#pragma unroll
+        for (int k = 0; k < NV; k++) win[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)voff[k], (int)so, 0));
+    };
+    /* x pass of the plane in win[] into P1, centre of the window into the DoG-input ring slot pvs */
+    auto x_pass = [&](float *P1, float *pvs) {
+        /* Not every float of the window is a filter input (7 taps: floats 1..14 of 16).  Left to itself the register
+         * allocator hands the dead element of a loaded vector to a temporary right after the load is issued, and the
+         * write-after-write hazard on the in-flight load costs an s_waitcnt vmcnt(0) there, one plane early.  The empty
+         * asm makes all four elements live until this point, where the window is consumed anyway. */
+#pragma unroll
+        for (int k = 0; k < NV; k++) asm volatile("" : "+v"(win[k]));
+        v2f ev[WIN / 2], od[WIN / 2 - 1];
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            ev[2 * k].x = win[k].x; ev[2 * k].y = win[k].y;
+            ev[2 * k + 1].x = win[k].z; ev[2 * k + 1].y = win[k].w;
+        }
+#pragma unroll
+        for (int m = 0; m < WIN / 2 - 1; m++) {
+            od[m].x = ev[m].y; od[m].y = ev[m + 1].x;
+        }
+        if (HAS_DOG && prow) {
+            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs]) = win[H4 / 4];
+            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs + 4]) = win[H4 / 4 + 1];
+        }
+        v2f o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v2f acc = v2f(0.0f);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                constexpr int base = H4 - R;
+                const int sidx = base + 2 * e + j;
+                const v2f p = (sidx & 1) ? od[(sidx - 1) / 2] : ev[sidx / 2];
+                acc = acc + t.f[j] * p;
+            }
+            o[e] = acc;
+        }
+        v4f r0, r1;
+        r0.x = o[0].x; r0.y = o[0].y; r0.z = o[1].x; r0.w = o[1].y;
+        r1.x = o[2].x; r1.y = o[2].y; r1.z = o[3].x; r1.w = o[3].y;
+        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs]) = r0;
+        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs + 4]) = r1;
+    };
+
+    auto store_plane = [&](bool live, unsigned so, const v2f(&lv)[BR], const v2f(&dg)[BR]) {
+        if constexpr (HAS_OUT) {
+            const __amdgpu_buffer_rsrc_t r = store_rsrc(out_base, live);
+#pragma unroll
+            for (int q = 0; q < BR; q++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, lv[q]), r, (int)soff[q], (int)so, 2 /* nt */);
+        }
+        if constexpr (HAS_DOG) {
+            const __amdgpu_buffer_rsrc_t r = store_rsrc(dog_base, live);
+#pragma unroll
+            for (int q = 0; q < BR; q++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, dg[q]), r, (int)soff[q], (int)so, 2 /* nt */);
+        }
+    };
+
+    v2f acc[BR][U];
+#pragma unroll
+    for (int r = 0; r < BR; r++)
+#pragma unroll
+        for (int i = 0; i < U; i++) acc[r][i] = v2f(0.0f);
+    int phase = 0, cur = 0;
+    int wslot = 0; /* ring slot of the plane the x pass is working on; the plane stored this step sits in wslot + 1 (mod R+2) */
+
+    if (xrole) {
+        load_window(zfirst);
+        x_pass(P1b, pvb);              /* plane zfirst (zeros when it lies before the volume) */
+        load_window(zfirst + 1);
+    }
+    {
+        v2f z2[BR];
+#pragma unroll
+        for (int r = 0; r < BR; r++) z2[r] = v2f(0.0f);
+        store_plane(false, 0u, z2, z2); /* dropped; same vmcnt state as the loop's back edge */
+    }
+    wslot = 1;
+    lds_barrier();
+
+    /* one step: y pass of plane zin from P1[cur], x pass of plane zin + 1 into the other buffer, z pass; EMIT: plane
+     * zin - R is complete and is stored */
+    auto step = [&](int zin) {
+        const bool emit = zin - R >= zc0; /* wave-uniform: plane zin - R is complete (it is < zc1 by construction of zlast) */
+        const float *P1 = P1b + cur * P1PL;
+        v2f p[U + BR - 1];
+#pragma unroll
+        for (int q = 0; q < U + BR - 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(brow + q) * FB_TX + 2 * bcp]);
+        v2f g[BR];
+#pragma unroll
+        for (int r = 0; r < BR; r++) {
+            v2f a = v2f(0.0f);
+#pragma unroll
+            for (int j = 0; j < U; j++) a = a + t.f[j] * p[j + r];
+            g[r] = a;
+        }
+        if (xrole) {
+            x_pass(P1b + (cur ^ 1) * P1PL, pvb + wslot * PVPL);
+            load_window(zin + 2);
+        }
+        v2f a[BR];
+#pragma unroll
+        for (int r = 0; r < BR; r++) a[r] = v2f(0.0f);
+        switch (phase) {
+#define FB_PHASE(SS)                                                             \
+    case SS:                                                                     \
+        if constexpr (SS < U) {                                                  \
+            _Pragma("unroll") for (int r = 0; r < BR; r++) {                     \
+                _Pragma("unroll") for (int i = 0; i < U; i++) {                  \
+                    const int j = (SS - i + U) % U;                              \
+                    if (j == 0) acc[r][i] = v2f(0.0f) + t.f[0] * g[r];           \
+                    else acc[r][i] = acc[r][i] + t.f[j] * g[r];                  \
+                }                                                                \
+                a[r] = acc[r][(SS + 1) % U];                                     \
+            }                                                                    \
+        }                                                                        \
+        break;
+            FB_PHASE(0) FB_PHASE(1) FB_PHASE(2) FB_PHASE(3) FB_PHASE(4) FB_PHASE(5) FB_PHASE(6) FB_PHASE(7) FB_PHASE(8)
+            FB_PHASE(9) FB_PHASE(10) FB_PHASE(11) FB_PHASE(12) FB_PHASE(13) FB_PHASE(14) FB_PHASE(15) FB_PHASE(16)
+#undef FB_PHASE
+        default: break;
+        }
+        {
+            const unsigned so = emit ? (unsigned)(zin - R - zc0) * plane_bytes : 0u;
+            v2f dg[BR];
+            if constexpr (HAS_DOG) {
+                const int rslot = wslot + 1 == S ? 0 : wslot + 1;
+                const float *pvp = pvb + rslot * PVPL + brow * FB_TX + 2 * bcp;
+#pragma unroll
+                for (int r = 0; r < BR; r++) dg[r] = *reinterpret_cast<const v2f *>(pvp + r * FB_TX) - a[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < BR; r++) dg[r] = v2f(0.0f);
+            }
+            store_plane(emit, so, a, dg);
+        }
+        phase = phase + 1 == U ? 0 : phase + 1;
+        cur ^= 1;
+        wslot = wslot + 1 == S ? 0 : wslot + 1;
+        lds_barrier(); /* the other P1 buffer and the ring slot are complete, every wavefront has read this P1 buffer */
+    };
+    for (int zin = zfirst; zin <= zlast; zin++) step(zin); /* the first 2R steps are lead-in: their stores are dropped */
+}
+
 /* chunks along z: enough workgroups to fill every CU's resident slots while the 2R lead-in planes stay cheap */
 static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
 {
@@ -519,6 +784,52 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
         }
     }
     return best;
+}
+
+/* Ring kernel launcher.  Returns false when the shape is outside it (32-bit buffer offsets: a chunk with its lead-in
+ * planes must stay below 4 GiB), and the caller falls back to the first form. */
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG>
+static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
+{
+    using C = fb_ring_cfg<R, BR>;
+    static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
+    if (resident == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG>, C::NT, 0) != hipSuccess || n < 1) n = 1;
+        resident = n;
+    }
+    const int64_t plane_bytes = X * Y * 4;
+    const int64_t max_planes = (int64_t)0xFFFFFFF0ll / plane_bytes - 2 * R - 2; /* planes per chunk the offsets can address */
+    if (max_planes < 4 * R || max_planes < 1) return false;
+    const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + C::TY - 1) / C::TY);
+    const long long tiles = (long long)tiles_x * tiles_y;
+    int n = fused_chunks(R, Z, tiles, resident);
+    if ((Z + n - 1) / n > max_planes) n = (int)((Z + max_planes - 1) / max_planes);
+    const int zlen = (int)((Z + n - 1) / n);
+    const int nch = (int)((Z + zlen - 1) / zlen);
+    const long long total = tiles * nch;
+    const long long per = (total + 7) / 8;
+    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
+                       (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
+    return true;
+}
+
+template <int R, int BR>
+static bool launch_ring_br(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
+{
+    if (out && dog) return launch_ring_t<R, BR, true, true>(s, in, out, dog, X, Y, Z, t);
+    if (out) return launch_ring_t<R, BR, true, false>(s, in, out, dog, X, Y, Z, t);
+    return launch_ring_t<R, BR, false, true>(s, in, out, dog, X, Y, Z, t);
+}
+
+/* SIFT3D_RING_BR (A/B aid): rows per thread, 1 or 2 */
+template <int R>
+static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
+{
+    const char *env = getenv("SIFT3D_RING_BR");
+    const int br = env ? atoi(env) : 1; /* by measurement at 512^3: one row per thread is faster at every filter width */
+    if (br == 1) return launch_ring_br<R, 1>(s, in, out, dog, X, Y, Z, t);
+    return launch_ring_br<R, 2>(s, in, out, dog, X, Y, Z, t);
 }
 
 template <int R, int NBUF>
@@ -579,6 +890,10 @@ template <int R>
 static void launch_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X, int64_t Y,
                          int64_t Z, const fb_taps2 &t)
 {
+    {
+        const char *v = getenv("SIFT3D_FUSED_V"); /* A/B aid: 1 = the first form of the march; default = the ring kernel */
+        if (!(v && atoi(v) == 1) && launch_ring<R>(s, in, out, dog, X, Y, Z, t)) return;
+    }
     if constexpr (R >= 5 && R <= 7) { /* 17 taps: arithmetic-bound, the register window is faster */
         const char *dma = getenv("SIFT3D_FUSED_DMA"); /* A/B aid: 0 = the register-window kernel */
         if (!dma || atoi(dma) != 0) return launch_fused_dma<R>(s, in, out, dog, zeros, X, Y, Z, t);
