@@ -683,7 +683,7 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
     for (int r = 0; r < BR; r++)
 #pragma unroll
         for (int i = 0; i < U; i++) acc[r][i] = v2f(0.0f);
-    int phase = 0, cur = 0;
+    int cur = 0;
     int wslot = 0; /* ring slot of the plane the x pass is working on; the plane stored this step sits in wslot + 1 (mod R+2) */
 
     if (xrole) {
@@ -720,27 +720,26 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
             x_pass(P1b + (cur ^ 1) * P1PL, pvb + wslot * PVPL);
             load_window(zin + 2);
         }
+        /* ---- C: z pass, shift form.  Slot i holds the output plane that completes in i + 1 steps and therefore takes
+         * tap U-1-i of the new plane; the sum moves one slot down as it is updated (a three-operand add reads slot i+1 and
+         * writes slot i, so the shift costs nothing), slot U-1 restarts from 0 + f[0]*g.  Every slot index is a
+         * compile-time register without a switch on the plane's phase: the first form's switch cost 2R+1 register
+         * copies per step (the phi nodes of its cases), 2R+1 copies of the z-pass code and a basic-block boundary
+         * between the passes.  The taps are bit-symmetric (checked by the launcher), so f[j]*g and f[U-1-j]*g are
+         * one product: R+1 multiplies instead of 2R+1, the additions and their order unchanged. ---- */
         v2f a[BR];
 #pragma unroll
-        for (int r = 0; r < BR; r++) a[r] = v2f(0.0f);
-        switch (phase) {
-#define FB_PHASE(SS)                                                             \
-    case SS:                                                                     \
-        if constexpr (SS < U) {                                                  \
-            _Pragma("unroll") for (int r = 0; r < BR; r++) {                     \
-                _Pragma("unroll") for (int i = 0; i < U; i++) {                  \
-                    const int j = (SS - i + U) % U;                              \
-                    if (j == 0) acc[r][i] = v2f(0.0f) + t.f[0] * g[r];           \
-                    else acc[r][i] = acc[r][i] + t.f[j] * g[r];                  \
-                }                                                                \
-                a[r] = acc[r][(SS + 1) % U];                                     \
-            }                                                                    \
-        }                                                                        \
-        break;
-            FB_PHASE(0) FB_PHASE(1) FB_PHASE(2) FB_PHASE(3) FB_PHASE(4) FB_PHASE(5) FB_PHASE(6) FB_PHASE(7) FB_PHASE(8)
-            FB_PHASE(9) FB_PHASE(10) FB_PHASE(11) FB_PHASE(12) FB_PHASE(13) FB_PHASE(14) FB_PHASE(15) FB_PHASE(16)
-#undef FB_PHASE
-        default: break;
+        for (int r = 0; r < BR; r++) {
+            v2f prod[R + 1];
+#pragma unroll
+            for (int k = 0; k <= R; k++) prod[k] = t.f[k] * g[r];
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const int k = i < U - 1 - i ? i : U - 1 - i;
+                if (i + 1 < U) acc[r][i] = acc[r][i + 1] + prod[k];
+                else acc[r][i] = v2f(0.0f) + prod[k];
+            }
+            a[r] = acc[r][0];
         }
         {
             const unsigned so = emit ? (unsigned)(zin - R - zc0) * plane_bytes : 0u;
@@ -756,7 +755,6 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
             }
             store_plane(emit, so, a, dg);
         }
-        phase = phase + 1 == U ? 0 : phase + 1;
         cur ^= 1;
         wslot = wslot + 1 == S ? 0 : wslot + 1;
         lds_barrier(); /* the other P1 buffer and the ring slot are complete, every wavefront has read this P1 buffer */
@@ -827,7 +825,7 @@ template <int R>
 static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
 {
     const char *env = getenv("SIFT3D_RING_BR");
-    const int br = env ? atoi(env) : 1; /* by measurement at 512^3: one row per thread is faster at every filter width */
+    const int br = env ? atoi(env) : (R >= 7 ? 1 : 2); /* by measurement at 512^3: two rows per thread up to 13 taps, one row for 17 */
     if (br == 1) return launch_ring_br<R, 1>(s, in, out, dog, X, Y, Z, t);
     return launch_ring_br<R, 2>(s, in, out, dog, X, Y, Z, t);
 }
@@ -892,7 +890,11 @@ static void launch_fused(hipStream_t s, const float *in, float *out, float *dog,
 {
     {
         const char *v = getenv("SIFT3D_FUSED_V"); /* A/B aid: 1 = the first form of the march; default = the ring kernel */
-        if (!(v && atoi(v) == 1) && launch_ring<R>(s, in, out, dog, X, Y, Z, t)) return;
+        /* the ring kernel's z pass shares the product of taps j and 2R-j: only for taps that are symmetric bit for bit
+         * (sift3d_gauss_taps' always are: (j-R)^2 and the normalising sum are the same for both) */
+        bool sym = true;
+        for (int j = 0; j < R; j++) sym = sym && __builtin_bit_cast(unsigned, t.f[j].x) == __builtin_bit_cast(unsigned, t.f[2 * R - j].x);
+        if (sym && !(v && atoi(v) == 1) && launch_ring<R>(s, in, out, dog, X, Y, Z, t)) return;
     }
     if constexpr (R >= 5 && R <= 7) { /* 17 taps: arithmetic-bound, the register window is faster */
         const char *dma = getenv("SIFT3D_FUSED_DMA"); /* A/B aid: 0 = the register-window kernel */
