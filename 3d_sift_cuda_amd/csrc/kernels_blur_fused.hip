@@ -526,7 +526,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #define FB_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (the value composable_kernel uses for gfx90a..gfx950) */
 #define FB_OOB 0xFFFFFFFFu        /* >= any num_records: the lane's access is out of range by construction */
 
-template <int R, int BR>
+template <int R, int BR, int PF = 1>
 struct fb_ring_cfg {
     static constexpr int TY = 32;
     static constexpr int NT = 1024 / BR;
@@ -534,7 +534,13 @@ struct fb_ring_cfg {
     static constexpr int XW = (NR * 8 + 63) / 64; /* wavefronts with an x-pass role */
     static constexpr int P1ROWS = XW * 8;          /* rows those wavefronts write (>= NR; the surplus rows are never read) */
     static constexpr int S = R + 2;                /* DoG-input ring: written for plane z+1 while plane z-R is read */
-    static constexpr int LDS_FLOATS = 2 * P1ROWS * FB_TX + S * TY * FB_TX;
+    /* SINGLE: the configuration meant to run one workgroup per CU (two rows per thread, two planes of prefetch).  Its
+     * LDS request is padded past half of the CU's 160 KiB so that a second workgroup can never become resident, also on
+     * volumes with more tiles than CUs: two resident workgroups with two planes in flight each stream markedly slower
+     * (0.38 against 0.315 ms per 7-tap launch at 512^3). */
+    static constexpr bool SINGLE = PF == 2 && BR == 2;
+    static constexpr int LDS_NEEDED = 2 * P1ROWS * FB_TX + S * TY * FB_TX;
+    static constexpr int LDS_FLOATS = (SINGLE && LDS_NEEDED < 21 * 1024) ? 21 * 1024 : LDS_NEEDED;
     /* workgroups per CU the LDS allows (160 KiB), capped at what 32 wavefronts per CU allow */
     static constexpr int WG_LDS = (160 * 1024) / (LDS_FLOATS * 4);
     static constexpr int WG_WAVES = 32 / (NT / 64);
@@ -542,12 +548,16 @@ struct fb_ring_cfg {
     static constexpr int WAVES_PER_SIMD = WG * (NT / 64) / 4 > 4 ? 4 : WG * (NT / 64) / 4; /* never ask for fewer than 128 registers */
 };
 
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG>
-__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
+/* Register budget: with two planes of prefetch the 512-thread mapping is meant to run ONE workgroup per CU (two
+ * wavefronts per SIMD, up to 256 registers) -- a zero-arithmetic march of the same tiles streams 5.4-5.8 TB/s with one
+ * workgroup per CU and two z chunks against 4.4-4.9 with two per CU and four chunks (tools/stream_roof.hip), and the
+ * second plane in flight covers the latency the second workgroup covered. */
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
+__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
     const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zlen, int tiles_x,
     int tiles_y, long long total, fb_taps2 t)
 {
-    using C = fb_ring_cfg<R, BR>;
+    using C = fb_ring_cfg<R, BR, PF>;
     constexpr int U = 2 * R + 1;
     constexpr int TY = C::TY, NR = C::NR, XW = C::XW, P1ROWS = C::P1ROWS, S = C::S;
     constexpr int H4 = ((R + 3) / 4) * 4; /* window halo, whole 16-byte vectors */
@@ -615,35 +625,38 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
 #pragma unroll
     for (int r = 0; r < BR; r++) soff[r] = (bx < X && y0 + brow + r < Y) ? (unsigned)((y0 + brow + r) * X + bx) * 4u : FB_OOB;
 
-    v4f win[NV];
-    auto load_window = [&](int z) { /* wave-uniform z; a plane outside the volume reads through a descriptor of no records */
+    /* PF planes of window prefetch: plane z lives in buffer (z - zfirst) % PF and is loaded PF steps before its x pass */
+    v4f win[PF][NV];
+    auto load_window = [&](int z, auto bsel) {
+        constexpr int B = decltype(bsel)::value; /* wave-uniform z; a plane outside the volume reads through a descriptor of no records */
         const bool ok = z >= 0 && z < Z;
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void *)in_base, 0, ok ? (int)in_rec : 0, FB_RSRC_FLAGS);
         const unsigned so = ok ? (unsigned)(z - zb) * plane_bytes : 0u;
 #pragma unroll
-        for (int k = 0; k < NV; k++) win[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)voff[k], (int)so, 0));
+        for (int k = 0; k < NV; k++) win[B][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)voff[k], (int)so, 0));
     };
     /* x pass of the plane in win[] into P1, centre of the window into the DoG-input ring slot pvs */
-    auto x_pass = [&](float *P1, float *pvs) {
+    auto x_pass = [&](float *P1, float *pvs, auto bsel) {
+        constexpr int B = decltype(bsel)::value;
         /* Not every float of the window is a filter input (7 taps: floats 1..14 of 16).  Left to itself the register
          * allocator hands the dead element of a loaded vector to a temporary right after the load is issued, and the
          * write-after-write hazard on the in-flight load costs an s_waitcnt vmcnt(0) there, one plane early.  The empty
          * asm makes all four elements live until this point, where the window is consumed anyway. */
 #pragma unroll
-        for (int k = 0; k < NV; k++) asm volatile("" : "+v"(win[k]));
+        for (int k = 0; k < NV; k++) asm volatile("" : "+v"(win[B][k]));
         v2f ev[WIN / 2], od[WIN / 2 - 1];
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            ev[2 * k].x = win[k].x; ev[2 * k].y = win[k].y;
-            ev[2 * k + 1].x = win[k].z; ev[2 * k + 1].y = win[k].w;
+            ev[2 * k].x = win[B][k].x; ev[2 * k].y = win[B][k].y;
+            ev[2 * k + 1].x = win[B][k].z; ev[2 * k + 1].y = win[B][k].w;
         }
 #pragma unroll
         for (int m = 0; m < WIN / 2 - 1; m++) {
             od[m].x = ev[m].y; od[m].y = ev[m + 1].x;
         }
         if (HAS_DOG && prow) {
-            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs]) = win[H4 / 4];
-            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs + 4]) = win[H4 / 4 + 1];
+            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs]) = win[B][H4 / 4];
+            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs + 4]) = win[B][H4 / 4 + 1];
         }
         v2f o[4];
 #pragma unroll
@@ -686,10 +699,17 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
     int cur = 0;
     int wslot = 0; /* ring slot of the plane the x pass is working on; the plane stored this step sits in wslot + 1 (mod R+2) */
 
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, PF - 1>;
     if (xrole) {
-        load_window(zfirst);
-        x_pass(P1b, pvb);              /* plane zfirst (zeros when it lies before the volume) */
-        load_window(zfirst + 1);
+        load_window(zfirst, B0{});
+        x_pass(P1b, pvb, B0{});        /* plane zfirst (zeros when it lies before the volume) */
+        if constexpr (PF == 2) {
+            load_window(zfirst + 1, B1{});
+            load_window(zfirst + 2, B0{});
+        } else {
+            load_window(zfirst + 1, B0{});
+        }
     }
     {
         v2f z2[BR];
@@ -702,7 +722,7 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
 
     /* one step: y pass of plane zin from P1[cur], x pass of plane zin + 1 into the other buffer, z pass; EMIT: plane
      * zin - R is complete and is stored */
-    auto step = [&](int zin) {
+    auto step = [&](int zin, auto bsel) { /* bsel: the window buffer that holds plane zin + 1 */
         const bool emit = zin - R >= zc0; /* wave-uniform: plane zin - R is complete (it is < zc1 by construction of zlast) */
         const float *P1 = P1b + cur * P1PL;
         v2f p[U + BR - 1];
@@ -717,8 +737,8 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
             g[r] = a;
         }
         if (xrole) {
-            x_pass(P1b + (cur ^ 1) * P1PL, pvb + wslot * PVPL);
-            load_window(zin + 2);
+            x_pass(P1b + (cur ^ 1) * P1PL, pvb + wslot * PVPL, bsel);
+            load_window(zin + 1 + PF, bsel); /* the buffer is free again */
         }
         /* ---- C: z pass, shift form.  Slot i holds the output plane that completes in i + 1 steps and therefore takes
          * tap U-1-i of the new plane; the sum moves one slot down as it is updated (a three-operand add reads slot i+1 and
@@ -759,7 +779,17 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR>::WAVES_PER_SIMD)) vo
         wslot = wslot + 1 == S ? 0 : wslot + 1;
         lds_barrier(); /* the other P1 buffer and the ring slot are complete, every wavefront has read this P1 buffer */
     };
-    for (int zin = zfirst; zin <= zlast; zin++) step(zin); /* the first 2R steps are lead-in: their stores are dropped */
+    /* the first 2R steps are lead-in: their stores are dropped */
+    if constexpr (PF == 2) {
+        int zin = zfirst;
+        for (; zin + 1 <= zlast; zin += 2) {
+            step(zin, B1{});     /* plane zfirst + 1 went to buffer 1 */
+            step(zin + 1, B0{});
+        }
+        if (zin <= zlast) step(zin, B1{});
+    } else {
+        for (int zin = zfirst; zin <= zlast; zin++) step(zin, B0{});
+    }
 }
 
 /* chunks along z: enough workgroups to fill every CU's resident slots while the 2R lead-in planes stay cheap */
@@ -786,14 +816,14 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
 
 /* Ring kernel launcher.  Returns false when the shape is outside it (32-bit buffer offsets: a chunk with its lead-in
  * planes must stay below 4 GiB), and the caller falls back to the first form. */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG>
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
 static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
 {
-    using C = fb_ring_cfg<R, BR>;
+    using C = fb_ring_cfg<R, BR, PF>;
     static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
     if (resident == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG>, C::NT, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF>, C::NT, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     const int64_t plane_bytes = X * Y * 4;
@@ -807,17 +837,29 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     const int nch = (int)((Z + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
-    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
+    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
                        (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
     return true;
 }
 
+template <int R, int BR, int PF>
+static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
+{
+    if (out && dog) return launch_ring_t<R, BR, true, true, PF>(s, in, out, dog, X, Y, Z, t);
+    if (out) return launch_ring_t<R, BR, true, false, PF>(s, in, out, dog, X, Y, Z, t);
+    return launch_ring_t<R, BR, false, true, PF>(s, in, out, dog, X, Y, Z, t);
+}
+
+/* SIFT3D_RING_PF (A/B aid): planes of window prefetch, 1 or 2 */
 template <int R, int BR>
 static bool launch_ring_br(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
 {
-    if (out && dog) return launch_ring_t<R, BR, true, true>(s, in, out, dog, X, Y, Z, t);
-    if (out) return launch_ring_t<R, BR, true, false>(s, in, out, dog, X, Y, Z, t);
-    return launch_ring_t<R, BR, false, true>(s, in, out, dog, X, Y, Z, t);
+    const char *env = getenv("SIFT3D_RING_PF");
+    /* by measurement at 512^3: two planes in flight and one workgroup per CU for the two-rows-per-thread mapping (7 to 13
+     * taps); the 1024-thread mapping has 128 registers per thread and keeps one plane */
+    const int pf = env ? atoi(env) : (BR == 2 ? 2 : 1);
+    if (pf == 2) return launch_ring_pf<R, BR, 2>(s, in, out, dog, X, Y, Z, t);
+    return launch_ring_pf<R, BR, 1>(s, in, out, dog, X, Y, Z, t);
 }
 
 /* SIFT3D_RING_BR (A/B aid): rows per thread, 1 or 2 */
