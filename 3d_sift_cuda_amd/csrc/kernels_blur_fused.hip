@@ -526,13 +526,19 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #define FB_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format (the value composable_kernel uses for gfx90a..gfx950) */
 #define FB_OOB 0xFFFFFFFFu        /* >= any num_records: the lane's access is out of range by construction */
 
-template <int R, int BR, int PF = 1>
+/* XO = outputs per lane of the x pass: 8 (a wavefront filters 8 rows of the tile) or 4 (4 rows).  With 8, the TY + 2R rows
+ * are 5 or 6 wavefronts' worth, which sixteen wavefronts on four SIMDs cannot share evenly (two SIMDs carry two x-pass
+ * wavefronts, two carry one: 512 against 376 packed operations per plane at 17 taps); with 4 they are 10 to 12 wavefronts,
+ * three per SIMD.  Only the 1024-thread mapping has the wavefronts for that. */
+template <int R, int BR, int PF = 1, int XO = 8>
 struct fb_ring_cfg {
     static constexpr int TY = 32;
     static constexpr int NT = 1024 / BR;
     static constexpr int NR = TY + 2 * R;
-    static constexpr int XW = (NR * 8 + 63) / 64; /* wavefronts with an x-pass role */
-    static constexpr int P1ROWS = XW * 8;          /* rows those wavefronts write (>= NR; the surplus rows are never read) */
+    static constexpr int LPR = FB_TX / XO;                      /* lanes per row of the x pass */
+    static constexpr int RPW = 64 / LPR;                        /* rows per x-pass wavefront */
+    static constexpr int XW = (NR + RPW - 1) / RPW;             /* wavefronts with an x-pass role */
+    static constexpr int P1ROWS = XW * RPW;                     /* rows those wavefronts write (>= NR; the surplus rows are never read) */
     static constexpr int S = R + 2;                /* DoG-input ring: written for plane z+1 while plane z-R is read */
     /* SINGLE: the configuration meant to run one workgroup per CU (two rows per thread, two planes of prefetch).  Its
      * LDS request is padded past half of the CU's 160 KiB so that a second workgroup can never become resident, also on
@@ -552,16 +558,18 @@ struct fb_ring_cfg {
  * wavefronts per SIMD, up to 256 registers) -- a zero-arithmetic march of the same tiles streams 5.4-5.8 TB/s with one
  * workgroup per CU and two z chunks against 4.4-4.9 with two per CU and four chunks (tools/stream_roof.hip), and the
  * second plane in flight covers the latency the second workgroup covered. */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
-__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int XO>
+__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, XO>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
     const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zlen, int tiles_x,
     int tiles_y, long long total, fb_taps2 t)
 {
-    using C = fb_ring_cfg<R, BR, PF>;
+    using C = fb_ring_cfg<R, BR, PF, XO>;
     constexpr int U = 2 * R + 1;
     constexpr int TY = C::TY, NR = C::NR, XW = C::XW, P1ROWS = C::P1ROWS, S = C::S;
     constexpr int H4 = ((R + 3) / 4) * 4; /* window halo, whole 16-byte vectors */
-    constexpr int WIN = 8 + 2 * H4, NV = WIN / 4;
+    constexpr int WIN = XO + 2 * H4, NV = WIN / 4;
+    constexpr int LPR = C::LPR;
+    static_assert(XO == 8 || XO == 4, "a lane filters one or two 16-byte vectors of a row");
     constexpr int P1PL = P1ROWS * FB_TX, PVPL = TY * FB_TX;
     static_assert(XW * 64 <= C::NT, "the x-pass wavefronts are wavefronts of the workgroup");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -604,10 +612,10 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
         return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? (int)st_rec : 0, FB_RSRC_FLAGS);
     };
 
-    /* stage A role (wavefronts 0 .. XW-1): row ar of the x pass, outputs x0 + axs .. + 7.  Lanes past row NR-1 and rows
+    /* stage A role (wavefronts 0 .. XW-1): row ar of the x pass, outputs x0 + axs .. + XO-1.  Lanes past row NR-1 and rows
      * outside the volume carry out-of-range offsets: they filter zeros into P1 rows nobody reads / rows that are zero. */
     const bool xrole = wv < XW; /* wave-uniform */
-    const int ar = tid >> 3, axs = (tid & 7) * 8;
+    const int ar = tid / LPR, axs = (tid % LPR) * XO;
     const int agy = y0 - R + ar;
     const bool arow = ar < NR && agy >= 0 && agy < Y;
     unsigned voff[NV];
@@ -655,12 +663,12 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
             od[m].x = ev[m].y; od[m].y = ev[m + 1].x;
         }
         if (HAS_DOG && prow) {
-            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs]) = win[B][H4 / 4];
-            *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs + 4]) = win[B][H4 / 4 + 1];
-        }
-        v2f o[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+            for (int q = 0; q < XO / 4; q++) *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs + 4 * q]) = win[B][H4 / 4 + q];
+        }
+        v2f o[XO / 2];
+#pragma unroll
+        for (int e = 0; e < XO / 2; e++) {
             v2f acc = v2f(0.0f);
 #pragma unroll
             for (int j = 0; j < U; j++) {
@@ -671,11 +679,12 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
             }
             o[e] = acc;
         }
-        v4f r0, r1;
-        r0.x = o[0].x; r0.y = o[0].y; r0.z = o[1].x; r0.w = o[1].y;
-        r1.x = o[2].x; r1.y = o[2].y; r1.z = o[3].x; r1.w = o[3].y;
-        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs]) = r0;
-        *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs + 4]) = r1;
+#pragma unroll
+        for (int q = 0; q < XO / 4; q++) {
+            v4f r0;
+            r0.x = o[2 * q].x; r0.y = o[2 * q].y; r0.z = o[2 * q + 1].x; r0.w = o[2 * q + 1].y;
+            *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs + 4 * q]) = r0;
+        }
     };
 
     auto store_plane = [&](bool live, unsigned so, const v2f(&lv)[BR], const v2f(&dg)[BR]) {
@@ -816,14 +825,14 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident)
 
 /* Ring kernel launcher.  Returns false when the shape is outside it (32-bit buffer offsets: a chunk with its lead-in
  * planes must stay below 4 GiB), and the caller falls back to the first form. */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int XO>
 static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
 {
-    using C = fb_ring_cfg<R, BR, PF>;
+    using C = fb_ring_cfg<R, BR, PF, XO>;
     static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
     if (resident == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF>, C::NT, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, XO>, C::NT, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     const int64_t plane_bytes = X * Y * 4;
@@ -837,17 +846,29 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     const int nch = (int)((Z + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
-    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
+    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, XO>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
                        (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
     return true;
 }
 
+template <int R, int BR, int PF, int XO>
+static bool launch_ring_xo(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
+{
+    if (out && dog) return launch_ring_t<R, BR, true, true, PF, XO>(s, in, out, dog, X, Y, Z, t);
+    if (out) return launch_ring_t<R, BR, true, false, PF, XO>(s, in, out, dog, X, Y, Z, t);
+    return launch_ring_t<R, BR, false, true, PF, XO>(s, in, out, dog, X, Y, Z, t);
+}
+
+/* SIFT3D_RING_XO (A/B aid): outputs per x-pass lane, 8 or 4 (4 only with one row per thread: it needs the wavefronts) */
 template <int R, int BR, int PF>
 static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
 {
-    if (out && dog) return launch_ring_t<R, BR, true, true, PF>(s, in, out, dog, X, Y, Z, t);
-    if (out) return launch_ring_t<R, BR, true, false, PF>(s, in, out, dog, X, Y, Z, t);
-    return launch_ring_t<R, BR, false, true, PF>(s, in, out, dog, X, Y, Z, t);
+    if constexpr (BR == 1 && PF == 1) {
+        const char *env = getenv("SIFT3D_RING_XO");
+        const int xo = env ? atoi(env) : 8;
+        if (xo == 4) return launch_ring_xo<R, BR, PF, 4>(s, in, out, dog, X, Y, Z, t);
+    }
+    return launch_ring_xo<R, BR, PF, 8>(s, in, out, dog, X, Y, Z, t);
 }
 
 /* SIFT3D_RING_PF (A/B aid): planes of window prefetch, 1 or 2 */

@@ -38,7 +38,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TABLE = "r01_d_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
+PMC_TABLE = "r02_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
+BLUR_SOURCE = os.path.join("3d_sift_cuda_amd", "csrc", "kernels_blur_fused.hip")   # what the PMC table was measured on
+
+
+def blur_source_hash():
+    import hashlib
+    with open(os.path.join(ROOT, BLUR_SOURCE), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def kernel_name(stage, ntaps, dog, vec=4):
@@ -261,7 +268,9 @@ def main():
         fused_id = stage_names.index("blur_fused") if "blur_fused" in stage_names else -1
         sel = log[(log["stage"] == fused_id) & (log["nvox"] == nfullvox)]
         if len(sel):
-            dom_name = "blur_fused_kernel<R, tile rows, prefetch> / blur_fused_dma_kernel<R, 32, ring> for 11 and 13 taps (the %d launches per volume at %d^3: initial blur + five levels)" % (len(sel) // args.steps, n)
+            dom_name = ("blur_fused_ring_kernel<R, rows per thread, has level, has DoG, prefetch planes> "
+                        "(the %d launches per volume at %d^3: initial blur + five levels; 7 to 13 taps: two rows per thread, two "
+                        "planes of prefetch, one workgroup per CU; 17 taps: one row per thread, 1024 threads)" % (len(sel) // args.steps, n))
             dom_all = full[full["stage"] == fused_id]
             per_inst = []
             for taps in sorted(set(int(t) for t in sel["ntaps"])):
@@ -291,26 +300,32 @@ def main():
             accounting = "8 B/voxel per x or y pass, 16 B/voxel for the z pass with fused DoG store"
         big_ms, big_bytes = float(sel["ms"].sum()), float(sel["alg_bytes"].sum())
         achieved = big_bytes / (big_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_note = None, None
         pmc = os.path.join(ROOT, "profiles", PMC_TABLE)
-        if os.path.exists(pmc) and n == 512 and per_inst:
-            try:   # PMC bytes of every instantiation (keys "blur_fused_kernel<R, ...>"), averaged over the launches
+        if not os.path.exists(pmc):
+            traffic_note = "no PMC table profiles/%s" % PMC_TABLE
+        elif n != 512 or not per_inst:
+            traffic_note = "the PMC table holds 512^3 launches of the fused kernels only"
+        else:
+            try:   # PMC bytes of every instantiation (keys "blur_fused_ring_kernel<R, ...>"), averaged over the launches
                 tab = json.load(open(pmc))
+                # the table is only valid for the kernel source it was measured on: a stale table must not be quoted
+                if tab.get("_kernel_source_sha256") != blur_source_hash():
+                    raise LookupError("profiles/%s was measured on another version of %s (regenerate with tools/make_profiles.sh)"
+                                      % (PMC_TABLE, BLUR_SOURCE))
                 tot, cnt = 0.0, 0
                 for pi in per_inst:
-                    hit = [k for k in tab if k.startswith("blur_fused_kernel<%d," % (pi["taps"] // 2))
-                           or k.startswith("blur_fused_dma_kernel<%d," % (pi["taps"] // 2))]
-                    hit.sort(key=lambda k: "dma" not in k)   # 11 and 13 taps run the LDS-DMA instantiation
+                    hit = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % (pi["taps"] // 2))]
                     if not hit:
-                        raise KeyError(pi["taps"])
-                    v = tab[hit[0]]
+                        raise LookupError("no PMC entry for %d taps" % pi["taps"])
+                    v = tab[sorted(hit)[0]]
                     # the PMC pass stores level and DoG except for the sixth level; a launch that keeps only the level
                     # (initial blur) writes 4 B/voxel less than its PMC twin
                     w = v["hbm_bytes_per_launch_512"] - (4.0 * n ** 3 if (pi["alg_bytes_per_voxel"] < 9 and pi["taps"] != 17) else 0.0)
                     tot += w * pi["launches"]; cnt += pi["launches"]
                 traffic = tot / cnt
-            except Exception:
-                traffic = None
+            except Exception as e:
+                traffic, traffic_note = None, "dropped: %s" % (e,)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": dom_name,
@@ -323,7 +338,7 @@ def main():
                     "all_launches": {"launches": int(len(dom_all)), "avg_launch_ms": round(float(dom_all["ms"].mean()), 4),
                                      "achieved": round(float(dom_all["alg_bytes"].sum()) / (float(dom_all["ms"].sum()) * 1e-3) / 1e9, 1),
                                      "note": "every octave the kernel runs on, from the two breakdown steps after the timed region; compare with the per-kernel averages of rocprofv3 --stats"},
-                    "traffic_source": "profiles/" + PMC_TABLE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md), averaged over the launches" if traffic else None}
+                    "traffic_source": "profiles/" + PMC_TABLE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md), averaged over the launches" if traffic else traffic_note}
         pyr_ms = sum(v["ms"] for v in blur_groups.values())
         pyr_bytes = sum(v["bytes"] for v in blur_groups.values())
         pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

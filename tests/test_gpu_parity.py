@@ -47,7 +47,8 @@ FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37
                                                       (2, 32, "SIFT3D_FUSED_V=1,SIFT3D_FUSED_NBUF=3"), (3, 0, "SIFT3D_FUSED_V=1,SIFT3D_FUSED_NBUF=4"),
                                                       (0, 0, ""), (3, 0, "SIFT3D_FUSED_V=2,SIFT3D_RING_BR=1"),
                                                       (2, 0, "SIFT3D_FUSED_V=2,SIFT3D_RING_BR=2"),
-                                                      (3, 0, "SIFT3D_RING_PF=2,SIFT3D_RING_BR=2"), (0, 0, "SIFT3D_RING_PF=2,SIFT3D_RING_BR=1")])
+                                                      (3, 0, "SIFT3D_RING_PF=2,SIFT3D_RING_BR=2"), (0, 0, "SIFT3D_RING_PF=2,SIFT3D_RING_BR=1"),
+                                                      (2, 0, "SIFT3D_RING_BR=1,SIFT3D_RING_PF=1,SIFT3D_RING_XO=4")])
 def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, variant, monkeypatch):
     """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up), partial tiles
     in x and y, volumes thinner than the filter, several z chunks, the register-window form, the LDS-DMA form
