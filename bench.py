@@ -24,7 +24,8 @@ whole job), plus
                run on; per tap count in `per_instantiation`
   pyramid      Gauss-pyramid + DoG GB/s over all blur launches of a step
   cpu_baseline the CPU restatement (oracle/, single thread like the reference's
-               extractor) timed on this box on a 256^3 sample, N = 1 only
+               extractor) timed on this box on the 512^3 metric volume, N = 1 only;
+               cpu_baseline_ncores: its OpenMP build on all host cores of the box
 """
 import argparse
 import importlib
@@ -167,7 +168,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume (512 = the BASELINE metric)")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU-baseline sample volume (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=512,
+                    help="edge of the CPU-baseline volume (0 = skip); 512 = the metric volume itself, about 25 s on one core")
     ap.add_argument("--desc", type=int, default=0, help="0 SIFT-rank, 1 BRIEF, 2 RRIEF, 3 NRRIEF")
     ap.add_argument("--mode", default="volumes", choices=["volumes", "zslab"],
                     help="N > 1: 'volumes' = one volume per GPU (default, weak scaling; the Z-slab run of ONE volume is "
@@ -370,17 +372,41 @@ def main():
             "roofline": roofline, "pyramid": pyramid, "stages": stages,
         }
         if world == 1 and args.cpu_sample > 0:
+            # CPU baseline: the C restatement of the reference's CPU path, timed on this box's host
+            # cores on the same blob-field volume the GPU step works on (one step of the same workload).  One thread is
+            # the baseline proper, because the reference's extractor is single-threaded; the OpenMP build of the same
+            # restatement (bit-identical output) is the "fair CPU" line, with the number of threads it used.
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import _oracle
-            orc = _oracle.load()
             m = args.cpu_sample
             svol = pkg.synth_blobs(m, m, m, seed=12345)
-            c0 = time.perf_counter()
-            recs, st = orc.extract(svol, desc_mode=args.desc)
-            cdt = time.perf_counter() - c0
+            what = ("the metric volume itself: one step of the benchmark workload" if m == n else
+                    "a bounded sample of the workload (the metric volume is %d^3)" % n)
+
+            def timed(orc):
+                c0 = time.perf_counter()
+                recs, st = orc.extract(svol, desc_mode=args.desc)
+                return recs, st, time.perf_counter() - c0
+            recs, st, cdt = timed(_oracle.load())
             out["cpu_baseline"] = {"value": round(len(recs) / cdt, 1), "unit": "keypoints/s", "cores": 1, "kind": "port",
-                                   "sample": "oracle o3_extract (C restatement of the reference CPU path, gcc -O2 -ffp-contract=off, 1 thread) on a %d^3 blob-field volume: %d records in %.2f s (blur %.2f s, DoG %.2f s, detect %.2f s, keypoints %.2f s, descriptors %.2f s)"
-                                             % (m, len(recs), cdt, st.t_blur, st.t_dog, st.t_detect, st.t_features, st.t_desc)}
+                                   "sample": "oracle o3_extract (C restatement of the reference CPU path, gcc -O2 -ffp-contract=off, 1 thread) on a %d^3 blob-field volume, %s: %d records in %.2f s (blur %.2f s, DoG %.2f s, detect %.2f s, keypoints %.2f s, descriptors %.2f s)"
+                                             % (m, what, len(recs), cdt, st.t_blur, st.t_dog, st.t_detect, st.t_features, st.t_desc)}
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncores = os.cpu_count() or 1
+            # a one-GPU box of the pool is a 16-CPU share of its host, whatever the affinity mask shows
+            ncores = min(ncores, int(os.environ.get("SIFT3D_CPU_THREADS", "16")))
+            os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+            try:
+                recs2, st2, cdt2 = timed(_oracle.load_omp())
+                out["cpu_baseline_ncores"] = {
+                    "value": round(len(recs2) / cdt2, 1), "unit": "keypoints/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+                    "same_records_as_1_thread": bool(len(recs2) == len(recs) and recs2.tobytes() == recs.tobytes()),
+                    "sample": "the same restatement built with -fopenmp (blur / DoG / subsample / detect / per-keypoint / descriptor loops over %s threads), same %d^3 volume: %d records in %.2f s (blur %.2f s, DoG %.2f s, detect %.2f s, keypoints %.2f s, descriptors %.2f s)"
+                              % (os.environ["OMP_NUM_THREADS"], m, len(recs2), cdt2, st2.t_blur, st2.t_dog, st2.t_detect, st2.t_features, st2.t_desc)}
+            except OSError as e:   # the OpenMP library is an extra: its absence must not cost the line
+                out["cpu_baseline_ncores"] = {"value": None, "note": "OpenMP build of the oracle not available: %r" % (e,)}
     expect = feats.copy() if (rank == 0 and world > 1) else None
     ctx.close()
     del dvol

@@ -21,6 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define PD O3_PATCH_DIM
 #define PV O3_PATCH_VOX
@@ -101,60 +104,78 @@ void o3_filter3d(const float *in, float *out, int64_t X, int64_t Y, int64_t Z, c
 {
     const int h = n / 2;
     const int64_t XY = X * Y;
-    /* two volume-sized temporaries, kept between calls (single-threaded test
-     * infrastructure): re-faulting 2N floats per blur dominated the run time */
-    static float *ws = 0;
-    static size_t ws_n = 0;
+    /* two volume-sized temporaries, kept between calls: re-faulting 2N floats per blur dominated the run time.
+     * Thread-local: the OpenMP build (the multi-core CPU baseline, see the Makefile) also calls this function for the
+     * 11^3 orientation histograms from inside its per-keypoint parallel loop. */
+    static _Thread_local float *ws = 0;
+    static _Thread_local size_t ws_n = 0;
     if ((size_t)(2 * XY * Z) > ws_n) {
         free(ws);
         ws_n = (size_t)(2 * XY * Z);
         ws = (float *)malloc(sizeof(float) * ws_n);
     }
     float *t1 = ws, *t2 = ws + XY * Z;
-    float *line = (float *)calloc((size_t)(X + n), sizeof(float));
-    float *acc = (float *)malloc(sizeof(float) * (size_t)X);
+    /* Every output row is computed by one thread with the serial code's arithmetic, so the OpenMP build is bit-identical
+     * to the serial one (tests/test_oracle_pins.py checks it).  Inside a parallel region (patch-sized calls) the inner
+     * region runs on the calling thread alone. */
+#ifdef _OPENMP
+#pragma omp parallel if (XY * Z >= 32768)
+#endif
+    {
+        float *line = (float *)calloc((size_t)(X + n), sizeof(float));
+        float *acc = (float *)malloc(sizeof(float) * (size_t)X);
 
-    /* x pass */
-    for (int64_t r = 0; r < Y * Z; r++) {
-        const float *src = in + r * X;
-        float *dst = t1 + r * X;
-        memcpy(line + h, src, sizeof(float) * (size_t)X);
-        for (int64_t c = 0; c < X; c++) {
-            float s = 0;
-            for (int j = 0; j < n; j++) s += taps[j] * line[c + j];
-            dst[c] = s;
-        }
-    }
-    /* y pass */
-    for (int64_t z = 0; z < Z; z++) {
-        for (int64_t y = 0; y < Y; y++) {
-            for (int64_t x = 0; x < X; x++) acc[x] = 0;
-            for (int j = 0; j < n; j++) {
-                int64_t yy = y + j - h;
-                if (yy < 0 || yy >= Y) continue;
-                const float *src = t1 + z * XY + yy * X;
-                const float f = taps[j];
-                for (int64_t x = 0; x < X; x++) acc[x] += f * src[x];
+        /* x pass */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t r = 0; r < Y * Z; r++) {
+            const float *src = in + r * X;
+            float *dst = t1 + r * X;
+            memcpy(line + h, src, sizeof(float) * (size_t)X);
+            for (int64_t c = 0; c < X; c++) {
+                float s = 0;
+                for (int j = 0; j < n; j++) s += taps[j] * line[c + j];
+                dst[c] = s;
             }
-            memcpy(t2 + z * XY + y * X, acc, sizeof(float) * (size_t)X);
         }
-    }
-    /* z pass */
-    for (int64_t z = 0; z < Z; z++) {
-        for (int64_t y = 0; y < Y; y++) {
-            for (int64_t x = 0; x < X; x++) acc[x] = 0;
-            for (int j = 0; j < n; j++) {
-                int64_t zz = z + j - h;
-                if (zz < 0 || zz >= Z) continue;
-                const float *src = t2 + zz * XY + y * X;
-                const float f = taps[j];
-                for (int64_t x = 0; x < X; x++) acc[x] += f * src[x];
+        /* y pass */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t z = 0; z < Z; z++) {
+            for (int64_t y = 0; y < Y; y++) {
+                for (int64_t x = 0; x < X; x++) acc[x] = 0;
+                for (int j = 0; j < n; j++) {
+                    int64_t yy = y + j - h;
+                    if (yy < 0 || yy >= Y) continue;
+                    const float *src = t1 + z * XY + yy * X;
+                    const float f = taps[j];
+                    for (int64_t x = 0; x < X; x++) acc[x] += f * src[x];
+                }
+                memcpy(t2 + z * XY + y * X, acc, sizeof(float) * (size_t)X);
             }
-            memcpy(out + z * XY + y * X, acc, sizeof(float) * (size_t)X);
         }
+        /* z pass */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t z = 0; z < Z; z++) {
+            for (int64_t y = 0; y < Y; y++) {
+                for (int64_t x = 0; x < X; x++) acc[x] = 0;
+                for (int j = 0; j < n; j++) {
+                    int64_t zz = z + j - h;
+                    if (zz < 0 || zz >= Z) continue;
+                    const float *src = t2 + zz * XY + y * X;
+                    const float f = taps[j];
+                    for (int64_t x = 0; x < X; x++) acc[x] += f * src[x];
+                }
+                memcpy(out + z * XY + y * X, acc, sizeof(float) * (size_t)X);
+            }
+        }
+        free(acc);
+        free(line);
     }
-    free(acc);
-    free(line);
 }
 
 /* R/src_common/GaussBlur3D.cpp:1159-1258 gb3d_blur3d_interleave (CPU branch, z > 1) */
@@ -171,6 +192,9 @@ int o3_blur(const float *in, float *out, int64_t X, int64_t Y, int64_t Z, float 
 void o3_dog(const float *a, const float *b, float *out, int64_t n)
 {
     const float m = -1.0f;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (n >= 32768)
+#endif
     for (int64_t i = 0; i < n; i++) out[i] = a[i] + m * b[i];
 }
 
@@ -178,6 +202,9 @@ void o3_dog(const float *a, const float *b, float *out, int64_t n)
 void o3_subsample(const float *in, int64_t X, int64_t Y, int64_t Z, float *out)
 {
     const int64_t ox = X / 2, oy = Y / 2, oz = Z / 2;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (ox * oy * oz >= 32768)
+#endif
     for (int64_t z = 0; z < oz; z++)
         for (int64_t y = 0; y < oy; y++)
             for (int64_t x = 0; x < ox; x++) {
@@ -281,6 +308,47 @@ static void nbr_offsets(int64_t X, int64_t Y, int64_t off[26])
 /* R/src_common/MultiScale.cpp:2260-2400 regFindFEATUREIO + :2408-2524
  * peakFunction4D / valleyFunction4D with pfioL == NULL: strict extremum over
  * the 26 neighbours in C, then centre + 26 in H.  Raster z,y,x order. */
+/* The per-voxel test of the scan: +1 = maximum, -1 = minimum, 0 = neither (strict compares, as there). */
+static inline int detect_voxel(const float *H, const float *C, int64_t idx, const int64_t off[26])
+{
+    const float c = C[idx];
+    /* sign of (c - first neighbour) decides which test can still pass */
+    const float d0 = c - C[idx + off[0]];
+    int sg = (0.0f < d0) - (d0 < 0.0f);
+    if (sg == 0) return 0;
+    int ok = 1;
+    for (int n = 1; n < 26 && ok; n++) {
+        const float d = c - C[idx + off[n]];
+        int s = (0.0f < d) - (d < 0.0f);
+        ok &= (s == sg);
+    }
+    if (!ok) return 0;
+    if (sg > 0) { /* peak: all of H (centre + 26) strictly lower */
+        int p = (H[idx] < c);
+        for (int n = 0; n < 26 && p; n++) p &= (H[idx + off[n]] < c);
+        return p ? 1 : 0;
+    }
+    int p = (H[idx] > c);
+    for (int n = 0; n < 26 && p; n++) p &= (H[idx + off[n]] > c);
+    return p ? -1 : 0;
+}
+
+#ifdef _OPENMP
+typedef struct {
+    o3_extremum *v;
+    int64_t n, cap;
+} extvec;
+static void ev_push(extvec *e, int x, int y, int z, float c)
+{
+    if (e->n == e->cap) {
+        e->cap = e->cap ? 2 * e->cap : 1024;
+        e->v = (o3_extremum *)realloc(e->v, sizeof(o3_extremum) * (size_t)e->cap);
+    }
+    e->v[e->n].x = x; e->v[e->n].y = y; e->v[e->n].z = z; e->v[e->n].value = c;
+    e->n++;
+}
+#endif
+
 int o3_detect(const float *H, const float *C, int64_t X, int64_t Y, int64_t Z,
               o3_extremum *minima, int64_t cap_min, int64_t *n_min,
               o3_extremum *maxima, int64_t cap_max, int64_t *n_max)
@@ -289,42 +357,56 @@ int o3_detect(const float *H, const float *C, int64_t X, int64_t Y, int64_t Z,
     nbr_offsets(X, Y, off);
     int64_t nmin = 0, nmax = 0;
     int overflow = 0;
+#ifdef _OPENMP
+    if (X * Y * Z >= 32768) {
+        /* every thread scans a contiguous range of planes into lists of its own; ranges ascend with the thread number,
+         * so concatenating the lists in thread order is the serial raster order */
+        const int nt = omp_get_max_threads();
+        extvec *lmin = (extvec *)calloc((size_t)nt, sizeof(extvec)), *lmax = (extvec *)calloc((size_t)nt, sizeof(extvec));
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num(), n = omp_get_num_threads();
+            const int64_t planes = Z - 2 > 0 ? Z - 2 : 0;
+            const int64_t z0 = 1 + planes * t / n, z1 = 1 + planes * (t + 1) / n;
+            for (int64_t z = z0; z < z1; z++)
+                for (int64_t y = 1; y < Y - 1; y++)
+                    for (int64_t x = 1; x < X - 1; x++) {
+                        const int64_t idx = (z * Y + y) * X + x;
+                        const int k = detect_voxel(H, C, idx, off);
+                        if (k > 0) ev_push(&lmax[t], (int)x, (int)y, (int)z, C[idx]);
+                        else if (k < 0) ev_push(&lmin[t], (int)x, (int)y, (int)z, C[idx]);
+                    }
+        }
+        for (int t = 0; t < nt; t++) {
+            for (int64_t i = 0; i < lmin[t].n; i++, nmin++)
+                if (nmin < cap_min) minima[nmin] = lmin[t].v[i]; else overflow = 1;
+            for (int64_t i = 0; i < lmax[t].n; i++, nmax++)
+                if (nmax < cap_max) maxima[nmax] = lmax[t].v[i]; else overflow = 1;
+            free(lmin[t].v); free(lmax[t].v);
+        }
+        free(lmin); free(lmax);
+        *n_min = nmin;
+        *n_max = nmax;
+        return overflow ? -1 : 0;
+    }
+#endif
     for (int64_t z = 1; z < Z - 1; z++)
         for (int64_t y = 1; y < Y - 1; y++)
             for (int64_t x = 1; x < X - 1; x++) {
                 const int64_t idx = (z * Y + y) * X + x;
-                const float c = C[idx];
-                /* sign of (c - first neighbour) decides which test can still pass */
-                const float d0 = c - C[idx + off[0]];
-                int sg = (0.0f < d0) - (d0 < 0.0f);
-                if (sg == 0) continue;
-                int ok = 1;
-                for (int n = 1; n < 26 && ok; n++) {
-                    const float d = c - C[idx + off[n]];
-                    int s = (0.0f < d) - (d < 0.0f);
-                    ok &= (s == sg);
-                }
-                if (!ok) continue;
-                if (sg > 0) { /* peak: all of H (centre + 26) strictly lower */
-                    int p = (H[idx] < c);
-                    for (int n = 0; n < 26 && p; n++) p &= (H[idx + off[n]] < c);
-                    if (p) {
-                        if (nmax < cap_max) {
-                            maxima[nmax].x = (int)x; maxima[nmax].y = (int)y; maxima[nmax].z = (int)z;
-                            maxima[nmax].value = c;
-                        } else overflow = 1;
-                        nmax++;
-                    }
-                } else {
-                    int p = (H[idx] > c);
-                    for (int n = 0; n < 26 && p; n++) p &= (H[idx + off[n]] > c);
-                    if (p) {
-                        if (nmin < cap_min) {
-                            minima[nmin].x = (int)x; minima[nmin].y = (int)y; minima[nmin].z = (int)z;
-                            minima[nmin].value = c;
-                        } else overflow = 1;
-                        nmin++;
-                    }
+                const int k = detect_voxel(H, C, idx, off);
+                if (k > 0) {
+                    if (nmax < cap_max) {
+                        maxima[nmax].x = (int)x; maxima[nmax].y = (int)y; maxima[nmax].z = (int)z;
+                        maxima[nmax].value = C[idx];
+                    } else overflow = 1;
+                    nmax++;
+                } else if (k < 0) {
+                    if (nmin < cap_min) {
+                        minima[nmin].x = (int)x; minima[nmin].y = (int)y; minima[nmin].z = (int)z;
+                        minima[nmin].value = C[idx];
+                    } else overflow = 1;
+                    nmin++;
                 }
             }
     *n_min = nmin;
@@ -1232,6 +1314,54 @@ static int64_t generate_features(o3_feature *ft, const o3_extremum *mins, const 
                                  int64_t Z, featvec *fv, float eig_thres)
 {
     int64_t kept = 0;
+#ifdef _OPENMP
+    if (nmin + nmax >= 64) {
+        /* Keypoints are independent of each other (every field of the shared record is rewritten per keypoint), so each
+         * thread works on a record of its own and collects a keypoint's records in a list of that keypoint; the lists are
+         * appended in candidate order afterwards: the output is the serial output. */
+        const int64_t total = nmin + nmax;
+        featvec *lv = (featvec *)calloc((size_t)total, sizeof(featvec));
+#pragma omp parallel reduction(+ : kept)
+        {
+            o3_feature *f = (o3_feature *)malloc(sizeof(o3_feature));
+            *f = *ft;
+#pragma omp for schedule(dynamic, 8)
+            for (int64_t q = 0; q < total; q++) {
+                const int pass = q >= nmin;
+                const int64_t i = pass ? q - nmin : q;
+                const o3_extremum *e = pass == 0 ? mins : maxs;
+                const float *eh = pass == 0 ? minH : maxH;
+                const float *el = pass == 0 ? minL : maxL;
+                o3_interp_point(C, X, Y, Z, e[i].x, e[i].y, e[i].z, &f->x, &f->y, &f->z);
+                float cv = C[((int64_t)e[i].z * Y + e[i].y) * X + e[i].x];
+                f->scale = (float)(2 * o3_interp_quadratic(sH, sC, sL, eh[i], cv, el[i]));
+                f->x += 0.5f; f->y += 0.5f; f->z += 0.5f;
+                if (pass == 0) f->info &= ~O3_INFO_MIN0MAX1;
+                else f->info |= O3_INFO_MIN0MAX1;
+                kept += generate_feature(f, img, X, Y, Z, &lv[q], eig_thres);
+            }
+            free(f);
+        }
+        int64_t add = 0;
+        for (int64_t q = 0; q < total; q++) add += lv[q].n;
+        if (fv->n + add > fv->cap) {
+            fv->cap = fv->n + add + add / 4 + 256;
+            fv->v = (o3_feature *)realloc(fv->v, sizeof(o3_feature) * (size_t)fv->cap);
+        }
+        int64_t *at = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total + 1));
+        at[0] = fv->n;
+        for (int64_t q = 0; q < total; q++) at[q + 1] = at[q] + lv[q].n;
+#pragma omp parallel for schedule(static)
+        for (int64_t q = 0; q < total; q++) {
+            if (lv[q].n) memcpy(fv->v + at[q], lv[q].v, sizeof(o3_feature) * (size_t)lv[q].n);
+            free(lv[q].v);
+        }
+        fv->n = at[total];
+        free(at);
+        free(lv);
+        return kept;
+    }
+#endif
     for (int pass = 0; pass < 2; pass++) {
         const o3_extremum *e = pass == 0 ? mins : maxs;
         const float *eh = pass == 0 ? minH : maxH;
@@ -1453,6 +1583,9 @@ int o3_extract(const float *vol, int64_t X, int64_t Y, int64_t Z, float init_sca
     o3_pyramid_features(vol, X, Y, Z, init_scale, eig_thres, &fs, &n, &st);
     o3_record *r = (o3_record *)malloc(sizeof(o3_record) * (size_t)(n ? n : 1));
     double t0 = now_s();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
     for (int64_t i = 0; i < n; i++) {
         o3_feature *f = &fs[i];
         o3_normalize_patch(f->data);

@@ -8,6 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ODIR, "_build", "libsift3d_oracle.so")
+LIB_OMP = os.path.join(ODIR, "_build", "libsift3d_oracle_omp.so")   # the multi-core build: bench.py's "fair CPU" line
 CLI = os.path.join(ODIR, "_build", "featExtract_oracle")
 
 # the -w / -ws test case: an anisotropic blob field with a qform (qfac -1) and an sform that differ
@@ -180,6 +181,20 @@ def load():
             build()
         _inst = Oracle(C.CDLL(LIB))
     return _inst
+
+
+_inst_omp = None
+
+
+def load_omp():
+    """The OpenMP build of the same restatement (bit-identical output, checked by tests/test_oracle_pins.py).  Only
+    bench.py's multi-core CPU baseline uses it; the serial library stays the checker."""
+    global _inst_omp
+    if _inst_omp is None:
+        if not os.path.exists(LIB_OMP):
+            build()
+        _inst_omp = Oracle(C.CDLL(LIB_OMP))
+    return _inst_omp
 
 
 def load_ref():

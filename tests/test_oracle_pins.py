@@ -217,3 +217,21 @@ def test_double_size_record_count_and_its_one_near_tie(oracle, built, tmp_path):
     assert all(abs(ratio(l) - 0.5) > 0.03 for l in mine if " secondary " in l)       # nothing sits on the 0.5 threshold
     assert all(abs(ratio(l) - 0.8) > 0.025 for l in mine if " secondary " not in l)  # nor on the 0.8 one
     assert len(mine) == 9
+
+
+@pytest.mark.parametrize("dims,mode,scale", [((64, 64, 64), 0, 1.0), ((80, 64, 48), 1, 1.0), ((67, 45, 38), 2, 1.0), ((48, 48, 48), 3, 0.5)])
+def test_openmp_build_is_byte_identical(oracle, built, dims, mode, scale):
+    """oracle/_build/libsift3d_oracle_omp.so (bench.py's multi-core CPU baseline) against the serial checker: the same
+    bytes for the blur, the extrema lists in the same order, and the records, with several threads."""
+    omp = _oracle.load_omp()
+    vol = built.synth_blobs(*dims, seed=17)
+    if scale != 1.0:
+        vol = oracle.double_size(vol)
+        assert (bits(omp.double_size(built.synth_blobs(*dims, seed=17))) == bits(vol)).all()
+    assert (bits(omp.blur(vol, 3.0900158882141113)) == bits(oracle.blur(vol, 3.0900158882141113))).all()
+    a, b = oracle.candidates(vol, init_scale=scale) if scale != 1.0 else oracle.candidates(vol), None
+    b = omp.candidates(vol, init_scale=scale) if scale != 1.0 else omp.candidates(vol)
+    assert len(a) == len(b) and a.tobytes() == b.tobytes()
+    ra, _ = oracle.extract(vol, init_scale=scale, desc_mode=mode, size_factor=scale)
+    rb, _ = omp.extract(vol, init_scale=scale, desc_mode=mode, size_factor=scale)
+    assert len(ra) == len(rb) and len(ra) > 10 and ra.tobytes() == rb.tobytes()
