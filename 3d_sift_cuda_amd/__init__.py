@@ -137,6 +137,8 @@ def host_lib():
     L = C.CDLL(LIB_HOST)
     P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
     _sig(L.sift3d_synth_blobs, None, P, I64, I64, I64, C.c_uint32)
+    _sig(L.nifti_min_read, I, C.c_char_p, P)
+    _sig(L.nifti_min_free, None, P)
     _sig(L.nifti_min_write_f32, I, C.c_char_p, P, I, I, I, F, F, F)
     _sig(L.nifti_min_write_f32_ex, I, C.c_char_p, P, I, I, I, F, F, F, P, P)
     _sig(L.sift3d_write_key, I, C.c_char_p, P, I64, F, I, P)
@@ -165,6 +167,32 @@ def synth_blobs(nx, ny, nz, seed=12345):
     v = np.empty((nz, ny, nx), np.float32)
     host_lib().sift3d_synth_blobs(v.ctypes.data, nx, ny, nz, seed)
     return v
+
+
+class _NiftiMinImage(C.Structure):
+    """nifti_min_image (csrc/nifti_min.h)"""
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("nt", C.c_int), ("dx", C.c_float), ("dy", C.c_float),
+                ("dz", C.c_float), ("datatype", C.c_int), ("qform_code", C.c_int), ("sform_code", C.c_int),
+                ("qto_xyz", C.c_float * 16), ("sto_xyz", C.c_float * 16), ("data", C.POINTER(C.c_float))]
+
+
+def read_nifti(path):
+    """nifti_min_read: (volume float32 of shape (nt*nz, ny, nx), header dict).  Raises Sift3DError with the reader's code."""
+    img = _NiftiMinImage()
+    rc = host_lib().nifti_min_read(os.fsencode(path), C.byref(img))
+    if rc != 0:
+        e = Sift3DError("nifti_min_read(%s) -> %d" % (path, rc))
+        e.code = rc
+        raise e
+    try:
+        n = img.nx * img.ny * img.nz * img.nt
+        vol = np.ctypeslib.as_array(img.data, shape=(n,)).copy().reshape(img.nt * img.nz, img.ny, img.nx)
+        hdr = {"dims": (img.nx, img.ny, img.nz, img.nt), "voxel": (img.dx, img.dy, img.dz), "datatype": img.datatype,
+               "qform_code": img.qform_code, "sform_code": img.sform_code,
+               "qto_xyz": np.array(img.qto_xyz, np.float32).reshape(4, 4), "sto_xyz": np.array(img.sto_xyz, np.float32).reshape(4, 4)}
+    finally:
+        host_lib().nifti_min_free(C.byref(img))
+    return vol, hdr
 
 
 def write_nifti(path, vol, voxel=(1.0, 1.0, 1.0), qform=None, sform=None):

@@ -222,7 +222,7 @@ int nifti_min_read(const char *path, nifti_min_image *img)
     float *o = img->data;
     switch (img->datatype) {
     case 2: for (size_t i = 0; i < nvox; i++) o[i] = (float)((unsigned char *)raw)[i]; break;
-    case 256: for (size_t i = 0; i < nvox; i++) o[i] = (float)((char *)raw)[i]; break;
+    case 256: for (size_t i = 0; i < nvox; i++) o[i] = (float)((signed char *)raw)[i]; break; /* DT_INT8: plain char may be unsigned */
     case 512: for (size_t i = 0; i < nvox; i++) o[i] = (float)((unsigned short *)raw)[i]; break;
     case 4: for (size_t i = 0; i < nvox; i++) o[i] = (float)((short *)raw)[i]; break;
     case 768: for (size_t i = 0; i < nvox; i++) o[i] = (float)((unsigned int *)raw)[i]; break;

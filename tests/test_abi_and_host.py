@@ -163,3 +163,179 @@ def test_key_reader_and_binary_writer(built, oracle, tmp_path):
     open(bad, "w").write("# featExtract 1.1\nnothing here\n")
     with pytest.raises(built.Sift3DError):
         built.read_key(bad)
+
+
+# ---------------------------------------------------------------------------------------------------
+# nifti_min_read: every source datatype of reg_changeDatatype (R/featExtract/featExtract.cpp:18-77), both byte orders,
+# .nii / .nii.gz / .hdr + .img / .hdr + .img.gz.  Files are written here with numpy + struct (not by the product's
+# own float32 writer), so the reader is checked against an independent encoder.
+# ---------------------------------------------------------------------------------------------------
+NIFTI_TYPES = {2: np.uint8, 256: np.int8, 4: np.int16, 512: np.uint16, 8: np.int32, 768: np.uint32, 16: np.float32, 64: np.float64}
+
+
+def _nifti_bytes(arr, code, big_endian=False, pair=False, voxel=(1.0, 1.5, 2.0), slope=3.0, vox_offset=None, ndim=3, magic=None):
+    """(header bytes, voxel bytes) of a NIfTI-1 file holding arr (shape nz, ny, nx) as datatype `code`."""
+    import struct
+    e = ">" if big_endian else "<"
+    nz, ny, nx = arr.shape
+    h = bytearray(348)
+    struct.pack_into(e + "i", h, 0, 348)
+    struct.pack_into(e + "8h", h, 40, ndim, nx, ny, nz, 1, 1, 1, 1)
+    struct.pack_into(e + "h", h, 70, code)
+    struct.pack_into(e + "h", h, 72, 8 * np.dtype(NIFTI_TYPES.get(code, np.uint8)).itemsize)
+    struct.pack_into(e + "8f", h, 76, 1.0, voxel[0], voxel[1], voxel[2], 1.0, 1.0, 1.0, 1.0)
+    off = 0.0 if pair else 352.0
+    struct.pack_into(e + "f", h, 108, off if vox_offset is None else vox_offset)
+    struct.pack_into(e + "2f", h, 112, slope, 7.0)          # scl_slope / scl_inter: the reference ignores them
+    h[344:348] = (b"ni1\0" if pair else b"n+1\0") if magic is None else magic
+    data = np.ascontiguousarray(arr.astype(NIFTI_TYPES.get(code, np.uint8)))
+    if big_endian:
+        data = data.byteswap()
+    return bytes(h), data.tobytes()
+
+
+def _write_case(tmp_path, name, arr, code, **kw):
+    import gzip
+    pair = name.endswith(".hdr")
+    gz = name.endswith(".gz") or kw.pop("img_gz", False)
+    h, d = _nifti_bytes(arr, code, pair=pair, **kw)
+    p = str(tmp_path / name)
+    if pair:
+        open(p, "wb").write(h)
+        ip = p[:-4] + ".img"
+        if gz:
+            gzip.open(ip + ".gz", "wb").write(d)
+        else:
+            open(ip, "wb").write(d)
+    else:
+        blob = h + b"\0\0\0\0" + d
+        (gzip.open(p, "wb") if gz else open(p, "wb")).write(blob)
+    return p
+
+
+def _test_values(code, shape, rng):
+    dt = np.dtype(NIFTI_TYPES[code])
+    if dt.kind == "f":
+        v = (rng.standard_normal(shape) * 10.0 ** rng.integers(-3, 6, shape)).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        v = rng.integers(info.min, int(info.max) + 1, shape, dtype=np.int64).astype(dt)
+        v.flat[:4] = [info.min, info.max, 0, info.max // 2 + 1]      # extremes: sign handling, values above 2^24 round
+    return v
+
+
+@pytest.mark.parametrize("code", sorted(NIFTI_TYPES))
+def test_nifti_reader_all_datatypes(built, tmp_path, code):
+    rng = np.random.default_rng(code)
+    shape = (5, 7, 9)
+    v = _test_values(code, shape, rng)
+    want = v.astype(np.float32)                                      # the plain C cast of reg_changeDatatype
+    for name, kw in (("le.nii", {}), ("be.nii", {"big_endian": True}), ("le.nii.gz", {}), ("be.nii.gz", {"big_endian": True}),
+                     ("p_le.hdr", {}), ("p_be.hdr", {"big_endian": True}), ("p_gz.hdr", {"img_gz": True})):
+        p = _write_case(tmp_path, name, v, code, **kw)
+        got, hdr = built.read_nifti(p)
+        assert hdr["dims"] == (9, 7, 5, 1) and hdr["datatype"] == code, name
+        assert hdr["voxel"] == (1.0, 1.5, 2.0), name
+        assert got.shape == shape and got.dtype == np.float32
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), (name, code)   # scl_slope / scl_inter ignored
+        assert hdr["qform_code"] == 0 and hdr["sform_code"] == 0
+        assert np.allclose(np.diag(hdr["qto_xyz"]), [1.0, 1.5, 2.0, 1.0])            # method 1: voxel scaling only
+
+
+def test_nifti_reader_rejects_what_it_cannot_read(built, tmp_path):
+    v = np.arange(4 * 5 * 6, dtype=np.int16).reshape(4, 5, 6)
+
+    def code_of(name, **kw):
+        p = _write_case(tmp_path, name, v, kw.pop("code", 4), **kw)
+        try:
+            built.read_nifti(p)
+        except built.Sift3DError as e:
+            return e.code
+        return 0
+    assert code_of("ok.nii") == 0
+    assert code_of("rgb.nii", code=128) == -3                       # DT_RGB24: not a scalar type
+    assert code_of("cplx.nii", code=32) == -3
+    assert code_of("dim0.nii", ndim=0) == -1 and code_of("dim9.nii", ndim=9) == -1
+    p = _write_case(tmp_path, "short.nii", v, 4)
+    open(p, "r+b").truncate(352 + 100)                               # voxel data cut short
+    with pytest.raises(built.Sift3DError) as ei:
+        built.read_nifti(p)
+    assert ei.value.code == -2
+    open(str(tmp_path / "tiny.nii"), "wb").write(b"\x5c\x01\0\0" + b"\0" * 40)   # header cut short
+    with pytest.raises(built.Sift3DError) as ei:
+        built.read_nifti(str(tmp_path / "tiny.nii"))
+    assert ei.value.code == -1
+    h, d = _nifti_bytes(v, 4)
+    open(str(tmp_path / "badsize.nii"), "wb").write(b"\x01\x02\x03\x04" + h[4:] + b"\0\0\0\0" + d)   # sizeof_hdr is not 348 in either byte order
+    with pytest.raises(built.Sift3DError) as ei:
+        built.read_nifti(str(tmp_path / "badsize.nii"))
+    assert ei.value.code == -1
+    import struct
+    h = bytearray(h); struct.pack_into("<h", h, 42, -3)              # a negative row length
+    open(str(tmp_path / "negx.nii"), "wb").write(bytes(h) + b"\0\0\0\0" + d)
+    with pytest.raises(built.Sift3DError) as ei:
+        built.read_nifti(str(tmp_path / "negx.nii"))
+    assert ei.value.code == -1
+    open(str(tmp_path / "lonely.hdr"), "wb").write(_nifti_bytes(v, 4, pair=True)[0])   # header without its .img
+    with pytest.raises(built.Sift3DError) as ei:
+        built.read_nifti(str(tmp_path / "lonely.hdr"))
+    assert ei.value.code == -2
+    with pytest.raises(built.Sift3DError):
+        built.read_nifti(str(tmp_path / "does_not_exist.nii"))
+
+
+def test_nifti_reader_vox_offset_and_analyze(built, tmp_path):
+    """A single file whose voxels start beyond byte 352 (header extensions), and an Analyze-7.5 header (no NIfTI magic:
+    qform / sform codes are not trusted)."""
+    v = np.arange(3 * 4 * 5, dtype=np.float32).reshape(3, 4, 5) - 17.5
+    h, d = _nifti_bytes(v, 16, vox_offset=352.0 + 64)
+    open(str(tmp_path / "ext.nii"), "wb").write(h + b"\x01\0\0\0" + b"\xAA" * 64 + d)
+    got, _ = built.read_nifti(str(tmp_path / "ext.nii"))
+    assert (got == v).all()
+    import struct
+    h = bytearray(_nifti_bytes(v, 16, pair=True, magic=b"\0\0\0\0")[0])
+    struct.pack_into("<2h", h, 252, 2, 3)                            # garbage where NIfTI keeps the form codes
+    open(str(tmp_path / "an.hdr"), "wb").write(bytes(h))
+    open(str(tmp_path / "an.img"), "wb").write(d)
+    got, hdr = built.read_nifti(str(tmp_path / "an.hdr"))
+    assert (got == v).all() and hdr["qform_code"] == 0 and hdr["sform_code"] == 0
+
+
+def test_host_code_under_sanitizers(built, tmp_path):
+    """ASan + UBSan over the plain-C host code (nifti_min.c, world.c, keyfile.c, synth.c: `make asan`) on every file shape
+    above plus malformed ones, and over the oracle CLI (restatement + reader) on a small volume with the -2+ / -b / -w
+    options.  A sanitizer report makes the process exit non-zero."""
+    csrc = os.path.join(ROOT, "3d_sift_cuda_amd", "csrc")
+    for d in (csrc, os.path.join(ROOT, "oracle")):
+        r = subprocess.run(["make", "-C", d, "asan"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    drv = os.path.join(csrc, "_build", "host_asan_driver")
+    rng = np.random.default_rng(0)
+    files = []
+    for code in sorted(NIFTI_TYPES):
+        v = _test_values(code, (6, 5, 8), rng)
+        files.append(_write_case(tmp_path, "t%d.nii" % code, v, code, voxel=(1.0, 1.25, 2.0)))
+        files.append(_write_case(tmp_path, "b%d.nii.gz" % code, v, code, big_endian=True))
+        files.append(_write_case(tmp_path, "p%d.hdr" % code, v, code, img_gz=(code % 3 == 0)))
+    v = np.zeros((4, 4, 4), np.int16)
+    files.append(_write_case(tmp_path, "rgb.nii", v, 128))
+    p = _write_case(tmp_path, "cut.nii", v, 4); open(p, "r+b").truncate(400); files.append(p)
+    open(str(tmp_path / "junk.nii"), "wb").write(bytes(rng.integers(0, 256, 500, dtype=np.uint8))); files.append(str(tmp_path / "junk.nii"))
+    h, d = _nifti_bytes(v, 4, voxel=(0.0, -1.0, float("nan")))       # degenerate voxel sizes through the resampler
+    open(str(tmp_path / "vox.nii"), "wb").write(h + b"\0\0\0\0" + d); files.append(str(tmp_path / "vox.nii"))
+    files.append(str(tmp_path / "absent.nii"))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([drv, "read"] + files, capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    read_rc = {os.path.basename(l.split(" rc=")[0]): int(l.split(" rc=")[1].split()[0]) for l in r.stdout.splitlines()}
+    assert len(read_rc) == len(files) and sum(1 for v in read_rc.values() if v == 0) == 25   # the 24 well-formed files and vox.nii
+    assert read_rc["rgb.nii"] == -3 and read_rc["cut.nii"] == -2 and read_rc["junk.nii"] == -1 and read_rc["absent.nii"] == -1
+    assert "vox.nii rc=0" in r.stdout and "iso rc=-3" in r.stdout    # unusable voxel sizes are refused by the resampler, not crashed on
+    r = subprocess.run([drv, "keys", str(tmp_path)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "keys ok" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    cli = os.path.join(ROOT, "oracle", "_build", "featExtract_oracle_asan")
+    nii = str(tmp_path / "s.nii")
+    built.write_nifti(nii, built.synth_blobs(40, 36, 32, seed=5), voxel=(1.0, 1.25, 1.5), qform=(0.1, 0.2, 0.3, -3.0, 2.0, 5.0, -1.0))
+    for flags in ([], ["-2+", "-b"], ["-2-", "-bn"], ["-w", "-br"]):
+        r = subprocess.run([cli] + flags + [nii, str(tmp_path / "s.key")], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (flags, r.stderr[-3000:])
