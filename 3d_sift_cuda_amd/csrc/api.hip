@@ -54,6 +54,7 @@ struct sift3d_ctx {
     hipStream_t cand_stream;   /* where cand_append launches: stream, or ex_stream inside run_pipeline */
     hipEvent_t ev_oct[2];      /* octave's DoG levels complete / extrema launches complete */
     hipEvent_t ev_chunk[4];
+    hipEvent_t ev_fence[2];    /* ordering of the *_dev entry points with the legacy default stream (fence_in / fence_out) */
     bool own_stream;
     int64_t capN;   /* voxels of the largest volume */
     int64_t capTot; /* floats per level buffer: all octaves of a capN volume back to back */
@@ -243,7 +244,9 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     c->copy_stream = nullptr;
     for (int i = 0; i < 4; i++) c->ev_chunk[i] = nullptr;
+    c->ev_fence[0] = c->ev_fence[1] = nullptr;
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_fence[i], hipEventDisableTiming) == hipSuccess;
     c->ex_stream = c->cand_stream = nullptr;
     c->ev_oct[0] = c->ev_oct[1] = nullptr;
     ok = ok && hipStreamCreateWithFlags(&c->ex_stream, hipStreamNonBlocking) == hipSuccess;
@@ -280,6 +283,8 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
             if (c->ev_chunk[i]) hipEventDestroy(c->ev_chunk[i]);
         for (int i = 0; i < 2; i++)
             if (c->ev_oct[i]) hipEventDestroy(c->ev_oct[i]);
+        for (int i = 0; i < 2; i++)
+            if (c->ev_fence[i]) hipEventDestroy(c->ev_fence[i]);
         delete c;
         return nullptr;
     }
@@ -299,6 +304,7 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
     hipStreamDestroy(c->ex_stream);
     for (int i = 0; i < 4; i++) hipEventDestroy(c->ev_chunk[i]);
     for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_oct[i]);
+    for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_fence[i]);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -527,6 +533,39 @@ static int check_shape(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz)
     return SIFT3D_OK;
 }
 
+/* Ordering of device buffers handed to the *_dev entry points.  The context's own stream is non-blocking, i.e. not
+ * ordered with the legacy default stream -- the stream the reference itself runs on, and what a caller who never
+ * touched streams (torch's default stream on ROCm included) produces and consumes on.  While the context runs on its own
+ * stream, every *_dev entry point therefore (in) makes its stream wait for what the default stream has queued so far and
+ * (out) makes the default stream wait for what the call queued: the call behaves as if it had been issued on the default
+ * stream, without a host synchronisation.  A caller that works on a stream of its own hands it over once with
+ * sift3d_set_stream(); the context then runs ON that stream and no fence is needed. */
+static int fence_in(sift3d_ctx *c)
+{
+    if (!c->own_stream) return SIFT3D_OK;
+    HIPCHK(c, hipEventRecord(c->ev_fence[0], nullptr));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fence[0], 0));
+    return SIFT3D_OK;
+}
+
+static int fence_out(sift3d_ctx *c)
+{
+    if (!c->own_stream) return SIFT3D_OK;
+    HIPCHK(c, hipEventRecord(c->ev_fence[1], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(nullptr, c->ev_fence[1], 0));
+    return SIFT3D_OK;
+}
+
+/* runs op between the two fences */
+#define FENCED(c, op)                 \
+    do {                              \
+        int rc_ = fence_in(c);        \
+        if (rc_) return rc_;          \
+        rc_ = (op);                   \
+        if (rc_) return rc_;          \
+        return fence_out(c);          \
+    } while (0)
+
 /* ---- operator level ----------------------------------------------------- */
 extern "C" int sift3d_gauss_blur_dev(sift3d_ctx *c, const float *d_in, float *d_out, int64_t nx, int64_t ny, int64_t nz,
                                      float sigma, float min_value)
@@ -535,7 +574,7 @@ extern "C" int sift3d_gauss_blur_dev(sift3d_ctx *c, const float *d_in, float *d_
     if (rc) return rc;
     if (nz < 2) return set_err(c, SIFT3D_ERR_ARG, "2-D images are outside this path (featExtract rejects z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
-    return blur_dev(c, d_in, d_out, nullptr, nx, ny, nz, sigma, min_value);
+    FENCED(c, blur_dev(c, d_in, d_out, nullptr, nx, ny, nz, sigma, min_value));
 }
 
 extern "C" int sift3d_gauss_blur_dog_dev(sift3d_ctx *c, const float *d_in, float *d_out, float *d_dog, int64_t nx,
@@ -545,7 +584,7 @@ extern "C" int sift3d_gauss_blur_dog_dev(sift3d_ctx *c, const float *d_in, float
     if (rc) return rc;
     if (nz < 2) return set_err(c, SIFT3D_ERR_ARG, "2-D images are outside this path (featExtract rejects z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
-    return blur_dev(c, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value);
+    FENCED(c, blur_dev(c, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value));
 }
 
 extern "C" int sift3d_gauss_blur(sift3d_ctx *c, const float *in, float *out, int64_t nx, int64_t ny, int64_t nz,
@@ -570,8 +609,10 @@ extern "C" int sift3d_dog_dev(sift3d_ctx *c, const float *d_a, const float *d_b,
 {
     if (!c || n <= 0) return SIFT3D_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = fence_in(c);
+    if (rc) return rc;
     HIPCHK(c, sift3d_launch_dog(c->stream, d_a, d_b, d_out, n));
-    return SIFT3D_OK;
+    return fence_out(c);
 }
 
 extern "C" int sift3d_dog(sift3d_ctx *c, const float *a, const float *b, float *out, int64_t n)
@@ -594,8 +635,10 @@ extern "C" int sift3d_subsample2_dev(sift3d_ctx *c, const float *d_in, int64_t n
 {
     if (!c || nx < 2 || ny < 2 || nz < 2) return set_err(c, SIFT3D_ERR_ARG, "subsample needs every dimension >= 2");
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = fence_in(c);
+    if (rc) return rc;
     HIPCHK(c, sift3d_launch_subsample(c->stream, d_in, nx, nx, ny, nz, d_out, nx / 2));
-    return SIFT3D_OK;
+    return fence_out(c);
 }
 
 extern "C" int sift3d_subsample2(sift3d_ctx *c, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out)
@@ -815,11 +858,13 @@ extern "C" int sift3d_set_volume_dev(sift3d_ctx *c, const float *d_vol, int64_t 
     if (!d_vol) return set_err(c, SIFT3D_ERR_ARG, "null volume");
     if (nz <= 1) return set_err(c, SIFT3D_ERR_ARG, "Could not read volume (z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
+    rc = fence_in(c); /* the caller's volume may still be in the making on the default stream */
+    if (rc) return rc;
     rc = load_volume(c, d_vol, false, nx, ny, nz);
     if (rc) return rc;
     c->nx = nx; c->ny = ny; c->nz = nz;
     c->has_volume = true;
-    return SIFT3D_OK;
+    return fence_out(c); /* and the caller may overwrite it again once the copy has run */
 }
 
 extern "C" int sift3d_set_volume_resized(sift3d_ctx *c, const float *vol, int64_t nx, int64_t ny, int64_t nz, int resize)
@@ -1137,6 +1182,8 @@ extern "C" int sift3d_extrema_append_dev(sift3d_ctx *c, const float *d_prev, con
         nx * ny * nz_local > (int64_t)SIFT3D_KEY_IDX_MASK || level_id < 0 || level_id >= 96)
         return set_err(c, SIFT3D_ERR_ARG, "bad extrema_append arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = fence_in(c);
+    if (rc) return rc;
     return cand_append(c, {d_prev, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id}, true);
 }
 

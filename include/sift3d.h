@@ -82,10 +82,15 @@ int sift3d_device_count(void);
 sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz);
 void sift3d_destroy(sift3d_ctx *ctx);
 const char *sift3d_last_error(const sift3d_ctx *ctx);
-/* Optional: run on a caller-owned hipStream_t (e.g. torch's); NULL = the
- * context's own stream.  The context's own stream is created non-blocking: it is
- * not ordered with the legacy default stream, so device buffers handed to the
- * *_dev entry points must be complete (or this call must put both on one stream). */
+/* Optional: run on a caller-owned hipStream_t (e.g. one of torch's); NULL = the
+ * context's own stream.  Ordering of device buffers handed to the *_dev entry
+ * points: while the context runs on its own stream, every *_dev call is fenced
+ * against the legacy default stream in both directions with events (it waits for
+ * what the default stream has queued, and the default stream waits for what the
+ * call queued), so a caller that works on the default stream -- as the reference
+ * does, and as torch does unless told otherwise -- needs no synchronisation of
+ * its own.  A caller that produces or consumes on another stream passes that
+ * stream here; the context then runs on it and the fences are skipped. */
 int sift3d_set_stream(sift3d_ctx *ctx, void *hip_stream);
 int sift3d_sync(sift3d_ctx *ctx);
 void sift3d_free(void *p);

@@ -89,6 +89,55 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, varian
         assert (log["stage"] == built.STAGES.index("blur_fused")).all()   # the fused kernel is what ran
 
 
+def test_dev_entry_points_are_ordered_with_the_default_stream(built, oracle):
+    """A caller on the default stream (torch's, and the reference's own) needs no synchronisation around the *_dev entry
+    points: the input is still being produced by queued torch kernels when sift3d_gauss_blur_dog_dev is called, and torch
+    consumes the outputs right after the call returns.  Repeated with the buffers rewritten each round, so that a missing
+    fence shows as stale or half-written data."""
+    import torch
+    dims = (96, 80, 72)
+    nx, ny, nz = dims
+    sigma = 1.9465880393981934
+    base = vol_of(built, dims, 8)
+    want = {}
+    for k in range(4):
+        v = (base * np.float32(1 + k) + np.float32(k)).astype(np.float32)
+        b = oracle.blur(v, sigma)
+        want[k] = (b, oracle.dog(v, b), oracle.subsample(b))
+    with built.Context(*dims) as ctx:
+        d_base = torch.from_numpy(base).cuda()
+        d_in = torch.empty_like(d_base)
+        d_out, d_dog = torch.empty_like(d_base), torch.empty_like(d_base)
+        d_half = torch.empty((nz // 2, ny // 2, nx // 2), dtype=torch.float32, device="cuda")
+        junk = torch.empty((64, 1024, 1024), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for rnd in range(3):
+            for k in range(4):
+                for _ in range(3):
+                    junk.normal_()                                        # keeps the default stream busy ahead of the producer
+                d_in.copy_(d_base * float(1 + k) + float(k))              # producer: queued, not finished
+                d_out.fill_(float("nan")); d_dog.fill_(float("nan")); d_half.fill_(float("nan"))
+                ctx.gauss_blur_dog_dev(d_in.data_ptr(), d_out.data_ptr(), d_dog.data_ptr(), nx, ny, nz, sigma)
+                ctx.subsample2_dev(d_out.data_ptr(), nx, ny, nz, d_half.data_ptr())
+                got = (d_out.clone(), d_dog.clone(), d_half.clone())      # consumers on the default stream, no ctx.sync()
+                d_in.fill_(-1.0)                                          # and the input is overwritten straight away
+                for g, w, name in zip(got, want[k], ("level", "dog", "half")):
+                    assert (bits(g.cpu().numpy()) == bits(w)).all(), (rnd, k, name)
+    # the sequence that failed once in round 1 (before the fences): a tiny volume, the output cleared on the default
+    # stream immediately before the call.  The race is timing-dependent and could not be provoked on demand on the test
+    # boxes even without the fences (tools/fence_probe.py: 0 of 200), so this is a regression case, not a proof.
+    sd = (256, 8, 8)
+    sv = vol_of(built, sd, 5) - np.float32(1.5)
+    sw = oracle.blur(sv, 1.5198684930801392)
+    with built.Context(*sd) as ctx:
+        d_in = torch.from_numpy(sv).cuda()
+        d_out = torch.empty_like(d_in)
+        for it in range(50):
+            d_out.zero_()
+            ctx.gauss_blur_dev(d_in.data_ptr(), d_out.data_ptr(), sd[0], sd[1], sd[2], 1.5198684930801392)
+            assert (bits(d_out.clone().cpu().numpy()) == bits(sw)).all(), it
+
+
 def test_lds_float_atomic_add_rounds_like_the_alu(built):
     """The orientation-histogram splat adds with ds_add_f32: it must be the IEEE add the reference's CPU performs."""
     rng = np.random.default_rng(7)
