@@ -123,6 +123,7 @@ def hip_lib():
     _sig(L.sift3d_extrema_append_dev, I, P, P, P, P, I64, I64, I64, I, I64, I64)
     _sig(L.sift3d_candidates_dev, I, P, P, I, P, P)
     _sig(L.sift3d_describe_dev, I, P, P, I, I, F, F, P, P, P)
+    _sig(L.sift3d_set_max_octaves, I, P, I)
     _hip = L
     return L
 
@@ -424,6 +425,10 @@ class Context:
         gb = (C.c_char * (n.value * 4)).from_address(grp.value)
         recs, grp = np.frombuffer(rb, FEATURE_DTYPE, n.value), np.frombuffer(gb, np.int32, n.value)
         return (recs.copy(), grp.copy()) if copy else (recs, grp)
+
+    def set_max_octaves(self, n):
+        """0 = the reference's stop rule (default); n > 0 = at most n octaves."""
+        self._chk(self._L.sift3d_set_max_octaves(self._h, int(n)), "sift3d_set_max_octaves")
 
     def sync(self):
         self._chk(self._L.sift3d_sync(self._h), "sift3d_sync")

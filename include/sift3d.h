@@ -166,6 +166,11 @@ int sift3d_detect(sift3d_ctx *ctx, float initial_image_scale, sift3d_candidate *
  * eig_thres: 140 in featExtract.cpp:297.  *out is malloc'ed (sift3d_free). */
 int sift3d_extract(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
                    sift3d_feature **out, int64_t *n_out);
+/* Beyond the reference: stop the pyramid after n octaves.  n = 0 restores the reference's only
+ * rule -- halve until a dimension is <= 2 (R/src_common/MultiScale.cpp:337,359-360) -- which is also the default; the
+ * command line has no such option and never sets it.  Records are ordered octave-major, so a limited run returns
+ * exactly the leading records of the unlimited one. */
+int sift3d_set_max_octaves(sift3d_ctx *ctx, int n);
 /* Same, without the final host copy: *view points at the context's pinned download buffer and stays
  * valid until the next call on this context (or sift3d_destroy).  Do not free it. */
 int sift3d_extract_view(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,

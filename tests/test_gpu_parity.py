@@ -469,6 +469,55 @@ def test_full_size_properties(built):
         assert (again.view(np.uint8) == feats.view(np.uint8)).all()
 
 
+@pytest.mark.parametrize("dims,mode", [((168, 164, 160), 0), ((200, 120, 96), 2)])
+def test_early_keypoint_pass_gives_the_same_records(built, dims, mode, monkeypatch):
+    """SIFT3D_EARLY_KP=1 (octave 0's per-keypoint stage on a third stream, beside the coarser octaves) against the
+    default one-shot order: the same bytes, also on a reused context and after the default path ran on it."""
+    vol = vol_of(built, dims, 13)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract(desc_mode=mode)
+        t = ctx.timings()
+        assert len(want) > 1000 and t["stages"]["keypoint"]["launches"] == 1
+        oct0 = ctx.detect()
+        assert (oct0["octave"] == 0).sum() >= 256 and (oct0["octave"] > 0).any()   # enough for the early pass, and a remainder
+        monkeypatch.setenv("SIFT3D_EARLY_KP", "1")
+        for _ in range(3):
+            assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
+            assert ctx.timings()["stages"]["keypoint"]["launches"] == 2   # octave 0 early, the rest afterwards
+        monkeypatch.setenv("SIFT3D_EARLY_KP", "0")
+        assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
+    monkeypatch.setenv("SIFT3D_EARLY_KP", "1")
+    with built.Context(*dims) as ctx:                                   # fresh context: the early pass sizes the buffers itself
+        ctx.set_volume(vol)
+        assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
+        assert ctx.timings()["stages"]["keypoint"]["launches"] == 2
+
+
+def test_octave_limit_returns_the_leading_records(built, oracle):
+    """sift3d_set_max_octaves: records and candidates are octave-major, so a run limited to n octaves is a prefix of the
+    unlimited run (which is the oracle's)."""
+    dims = (128, 112, 96)
+    vol = vol_of(built, dims, 6)
+    want, _ = oracle.extract(vol)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        full, cfull = ctx.extract(), ctx.detect()
+        top = int(cfull["octave"].max())                      # the coarsest octave that still has validated extrema
+        assert _compare_records(full, want) and top >= 1
+        for n in range(1, top + 3):
+            ctx.set_max_octaves(n)
+            c = ctx.detect()
+            keep = cfull[cfull["octave"] < n]
+            assert len(c) == len(keep) and c.tobytes() == keep.tobytes()
+            f = ctx.extract()
+            assert ctx.timings()["n_octaves"] == min(n, 6)    # 128 x 112 x 96 has six octaves by the reference's stop rule
+            assert 0 < len(f) <= len(full) and (len(f) < len(full)) == (n <= top)
+            assert f.tobytes() == full[:len(f)].tobytes()
+        ctx.set_max_octaves(0)
+        assert ctx.extract().tobytes() == full.tobytes()
+
+
 def _record_properties(f, dims, rank_desc=True):
     """Size-independent properties of a record list (used where the oracle cannot run in test time)."""
     nx, ny, nz = dims
