@@ -529,7 +529,9 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
      * coarse octaves keep the three-pass path.  SIFT3D_BLUR_FUSED = 0 never / 2 always (tests, A/B timing). */
     const char *fenv = getenv("SIFT3D_BLUR_FUSED");
     const int fmode = fenv ? atoi(fenv) : 1;
-    if (fmode == 2 || (fmode == 1 && N >= (double)(1 << 22))) {
+    /* measured standalone (tools/bench_blur_ab.sh 128 / 64): below 2^22 voxels the one launch still beats the three for 7 and
+     * 9 taps (0.020 / 0.026 against 0.042 / 0.043 ms at 128^3), ties at 11-13 and loses at 17 */
+    if (fmode == 2 || (fmode == 1 && (N >= (double)(1 << 22) || (N >= (double)(1 << 18) && n <= 9)))) {
         stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N);
         hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, c->d_zeros, X, Y, Z, taps, n);
         if (e == hipSuccess) return SIFT3D_OK;

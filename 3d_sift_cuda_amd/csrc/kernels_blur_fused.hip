@@ -888,7 +888,9 @@ template <int R>
 static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t)
 {
     const char *env = getenv("SIFT3D_RING_BR");
-    const int br = env ? atoi(env) : (R >= 7 ? 1 : 2); /* by measurement at 512^3: two rows per thread up to 13 taps, one row for 17 */
+    /* by measurement: two rows per thread up to 13 taps and one row for 17 at 512^3 and 256^3; one row below 2^22 voxels,
+     * where a volume has fewer tiles than the chip has CUs and sixteen wavefronts per workgroup help */
+    const int br = env ? atoi(env) : ((R >= 7 || X * Y * Z < (1ll << 22)) ? 1 : 2);
     if (br == 1) return launch_ring_br<R, 1>(s, in, out, dog, X, Y, Z, t);
     return launch_ring_br<R, 2>(s, in, out, dog, X, Y, Z, t);
 }

@@ -325,16 +325,19 @@ def test_context_reuse_pitched_coarse_octaves(built, oracle, dims):
 
 @pytest.mark.parametrize("dims", [(168, 164, 160), (166, 165, 161)])
 def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
-    """A volume of more than 2^22 voxels: its finest octave is built by the one-launch blur kernels (register window
-    for 7, 9 and 17 taps, LDS-DMA ring for 11 and 13), the coarser ones by the three-pass kernels and the single-workgroup
-    octave kernel; the second shape has rows that are not whole 16-byte vectors (pitched rows).  Records against the oracle."""
+    """A volume of more than 2^22 voxels: its finest octave is built by the one-launch ring kernel (two rows per thread up
+    to 13 taps, one row for 17), the 7- and 9-tap levels of the next octave (2^18 voxels or more) too, with one row per
+    thread; everything else by the three-pass kernels and the single-workgroup octave kernel.  The second shape has rows
+    that are not whole 16-byte vectors (pitched rows).  Records against the oracle."""
     vol = vol_of(built, dims, 9)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)
         ctx.enable_timing(True)
         got = ctx.extract()
         log = ctx.launch_log()
-    assert (log["stage"] == built.STAGES.index("blur_fused")).sum() == 6       # initial blur + five levels of octave 0
+    fused = log[log["stage"] == built.STAGES.index("blur_fused")]
+    assert len(fused) == 8                    # octave 0: initial blur + five levels; octave 1: its 7- and 9-tap levels
+    assert sorted(fused["ntaps"][6:].tolist()) == [7, 9] and (fused["nvox"][6:] < fused["nvox"][0]).all()
     want, _ = oracle.extract(vol)
     assert len(want) > 200 and _compare_records(got, want)
 
