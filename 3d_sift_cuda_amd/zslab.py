@@ -20,6 +20,14 @@ Why the result equals the single-GPU result bit for bit:
 Halo widths: 8 slices feed the next blur (R <= 8); L1..L3 carry 32 slices because an 11^3 patch reaches
 < 29 slices from its keypoint (|offset| <= 5*sqrt(3) samples * 2*scale/5, scale <= 2*4.04); DoG levels need 1.
 
+Exchange schedule (round 2).  What the next blur waits for is only the 8-slice halo, so that is all a level exchanges
+on the critical path: five exchanges of 8 slices per octave and direction.  The other 24 slices of the patch halos of
+L1..L3 are needed by nothing before the per-keypoint stage (and by the subsample that seeds the next octave, which
+reads L3 on slab +- 16): they are fetched once per octave in ONE batched exchange issued as soon as L3 is complete and
+waited for at the end of the octave, so that on RCCL (which runs its transfers on a stream of its own) they move while
+L4, L5 and the extrema passes compute.  Round 1 exchanged 32 slices after each of L1..L3 and waited each time: the same
+112 slices per octave and direction, 96 of them on the critical path; now 40 are.
+
 The compute backend is pluggable: ``HipBackend`` drives the C-ABI ``*_dev`` operators on torch CUDA tensors;
 the CPU test-suite plugs the oracle in (tests/test_zslab_cpu.py) to check the slab logic with gloo, world size 2.
 """
@@ -164,22 +172,29 @@ class ZSlabExtractor:
         self.be, self.plan, self.rank, self.dist, self.group = backend, plan, rank, dist, group
         self.levels = []       # level table entries, index = level id
         self.level_ids = []
-        self.stats = {"exchanges": 0, "exchange_bytes": 0}
+        # exchange_bytes: everything this rank received and sent; of that, deferred_bytes moved in the once-per-octave
+        # patch-halo batch that overlaps L4 / L5 / extrema (critical = exchange_bytes - deferred_bytes)
+        self.stats = {"exchanges": 0, "exchange_bytes": 0, "deferred_exchanges": 0, "deferred_bytes": 0}
         # every DoG buffer an extrema pass was queued on: the library replays those passes from the recorded pointers when
         # a candidate list overflows (cand_finalize), so all five DoG levels of every octave -- not only the L1..L3 / D1..D3
         # the level table names -- must outlive candidates() / describe(); released by the next run()
         self._keepalive = []
 
     # ---- halo exchange of one level buffer -------------------------------------------------
-    def _exchange(self, buf, z0, z1, e0, width, has_lo, has_hi):
-        """Refresh [z0-width, z0) from the lower neighbour and [z1, z1+width) from the upper one."""
-        if self.dist is None or (not has_lo and not has_hi):
-            return
+    def _exchange(self, bufs, z0, z1, e0, width, has_lo, has_hi, inner=0, defer=False):
+        """Refresh, in every buffer of `bufs`, the slices [z0-width, z0-inner) from the lower neighbour and
+        [z1+inner, z1+width) from the upper one (and send it the mirror bands of this slab), as ONE batch of
+        point-to-point operations.  defer=True returns a closure that completes the batch (for the caller to run later:
+        the transfers of an RCCL batch proceed on the communicator's stream meanwhile); otherwise it is completed here."""
+        if self.dist is None or (not has_lo and not has_hi) or width <= inner:
+            return (lambda: None) if defer else None
+        if not isinstance(bufs, (list, tuple)):
+            bufs = [bufs]
         d, ops, back = self.dist, [], []
         self.be.before_exchange()
-        # gloo cannot move device memory: stage through the host (the 2-process single-GPU test); with
+        # gloo cannot move device memory: stage through the host (the single-GPU rehearsals); with
         # nccl (= RCCL) the slices go GPU to GPU over xGMI
-        stage = buf.is_cuda and d.get_backend(self.group) == "gloo"
+        stage = bufs[0].is_cuda and d.get_backend(self.group) == "gloo"
 
         def snd(t):
             return t.cpu() if stage else t
@@ -190,19 +205,32 @@ class ZSlabExtractor:
             h = t.cpu()
             back.append((t, h))
             return h
-        if has_lo:
-            ops.append(d.P2POp(d.isend, snd(buf[z0 - e0:z0 - e0 + width]), self.rank - 1, self.group))
-            ops.append(d.P2POp(d.irecv, rcv(buf[z0 - width - e0:z0 - e0]), self.rank - 1, self.group))
-        if has_hi:
-            ops.append(d.P2POp(d.isend, snd(buf[z1 - width - e0:z1 - e0]), self.rank + 1, self.group))
-            ops.append(d.P2POp(d.irecv, rcv(buf[z1 - e0:z1 - e0 + width]), self.rank + 1, self.group))
-        for r in d.batch_isend_irecv(ops):
-            r.wait()
-        for t, h in back:
-            t.copy_(h)
-        self.be.after_exchange()
+        n = width - inner
+        for buf in bufs:
+            if has_lo:   # my slices [z0+inner, z0+width) are the lower neighbour's upper band; its [z0-width, z0-inner) are mine
+                ops.append(d.P2POp(d.isend, snd(buf[z0 + inner - e0:z0 + width - e0]), self.rank - 1, self.group))
+                ops.append(d.P2POp(d.irecv, rcv(buf[z0 - width - e0:z0 - inner - e0]), self.rank - 1, self.group))
+            if has_hi:
+                ops.append(d.P2POp(d.isend, snd(buf[z1 - width - e0:z1 - inner - e0]), self.rank + 1, self.group))
+                ops.append(d.P2POp(d.irecv, rcv(buf[z1 + inner - e0:z1 + width - e0]), self.rank + 1, self.group))
+        works = d.batch_isend_irecv(ops)
+        nbytes = 2 * n * bufs[0].shape[1] * bufs[0].shape[2] * 4 * (int(has_lo) + int(has_hi)) * len(bufs)
         self.stats["exchanges"] += 1
-        self.stats["exchange_bytes"] += 2 * width * buf.shape[1] * buf.shape[2] * 4 * (int(has_lo) + int(has_hi))
+        self.stats["exchange_bytes"] += nbytes
+        if defer:
+            self.stats["deferred_exchanges"] += 1
+            self.stats["deferred_bytes"] += nbytes
+
+        def finish():
+            for r in works:
+                r.wait()
+            for t, h in back:
+                t.copy_(h)
+            self.be.after_exchange()
+        if defer:
+            return finish
+        finish()
+        return None
 
     # ---- one octave on one rank ---------------------------------------------------------------
     def _octave(self, o, L0, z0, z1, e0, e1, zo, has_lo, has_hi, extras, sig, factor, want_next):
@@ -218,20 +246,26 @@ class ZSlabExtractor:
         c0 = max(e0, z0 - BLUR_HALO) if has_lo else e0
         c1 = min(e1, z1 + BLUR_HALO) if has_hi else e1
         a, b = c0 - e0, c1 - e0
+        patch_halos = lambda: None
         for j in range(1, 6):
             be.blur_dog(L[j - 1][a:b], L[j][a:b], D[j - 1][a:b], extras[j - 1])
-            width = HALO if j in (1, 2, 3) else BLUR_HALO
-            self._exchange(L[j], z0, z1, e0, width, has_lo, has_hi)
+            # the next blur needs this level exact on slab +- BLUR_HALO: that, and no more, is exchanged here
+            self._exchange(L[j], z0, z1, e0, BLUR_HALO, has_lo, has_hi)
             # the fused DoG used the not-yet-exchanged margin of L[j]: redo it on the halo slices
             if has_lo:
                 be.dog(L[j - 1][a:z0 - e0], L[j][a:z0 - e0], D[j - 1][a:z0 - e0])
             if has_hi:
                 be.dog(L[j - 1][z1 - e0:b], L[j][z1 - e0:b], D[j - 1][z1 - e0:b])
+            if j == 3:
+                # L1..L3 are final: fetch the rest of their patch halos (slices BLUR_HALO..HALO beyond the faces) in one
+                # batch that completes while L4, L5 and the extrema passes run
+                patch_halos = self._exchange(L[1:4], z0, z1, e0, HALO, has_lo, has_hi, inner=BLUR_HALO, defer=True)
         for l in range(3):
             lid = o * 3 + l
             be.extrema_append(D[l], D[l + 1], D[l + 2], lid, z0 - e0, z1 - e0)
             self.levels.append(be.level_entry(L[l + 1], D[l + 1], zo, e0, sig[l], sig[l + 1], sig[l + 2], factor))
             self.level_ids.append(lid)
+        patch_halos()   # before the subsample below reads L3 beyond +- BLUR_HALO, and long before the per-keypoint stage
         self._keepalive.append(D)
         return L[3] if want_next else None
 

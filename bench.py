@@ -106,7 +106,12 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
                "workload": "ONE %d^3 float32 blob-field volume cut into %d Z-slabs, full featExtract path, all octaves" % (n, world),
                "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
                "parallelism": "zslab%d: halo exchange with torch.distributed (%s), coarse octaves on rank 0" % (world, dist.get_backend()),
-               "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"]}
+               "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"],
+               "halo_bytes_critical_per_rank_per_step": ex.stats["exchange_bytes"] - ex.stats["deferred_bytes"],
+               "halo_bytes_deferred_per_rank_per_step": ex.stats["deferred_bytes"],
+               "exchange_schedule": "per level: the 8-slice blur halo (what the next blur waits for); per octave: one deferred "
+                                    "batch with the other 24 slices of the L1..L3 patch halos, issued when L3 is complete and "
+                                    "waited for after the extrema passes (rank 0's counts; interior ranks exchange on both sides)"}
         if expect is not None:
             res["same_bytes_as_single_gpu"] = bool(merged is not None and len(merged) == len(expect)
                                                    and (merged.view(np.uint8) == expect.view(np.uint8)).all())
@@ -123,7 +128,9 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {k: res[k] for k in ("workload", "records", "sharded_octaves", "slab_bounds", "parallelism",
-                                           "halo_exchanges_per_step", "halo_bytes_per_rank_per_step")}}))
+                                           "halo_exchanges_per_step", "halo_bytes_per_rank_per_step",
+                                           "halo_bytes_critical_per_rank_per_step", "halo_bytes_deferred_per_rank_per_step",
+                                           "exchange_schedule")}}))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -696,7 +696,8 @@ def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert n_sharded >= 1 and stats["exchanges"] >= 5
+    assert n_sharded >= 1 and stats["exchanges"] == 6 * n_sharded and stats["deferred_exchanges"] == n_sharded
+    assert stats["deferred_bytes"] * 112 == stats["exchange_bytes"] * 72   # 8 slices per level on the critical path, 3 x 24 deferred
     vol = vol_of(built, dims, seed)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)

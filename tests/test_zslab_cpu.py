@@ -133,9 +133,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("dims,seed,world", [((40, 36, 160), 3, 2), ((36, 40, 130), 9, 2), ((28, 24, 208), 5, 3)])
+@pytest.mark.parametrize("dims,seed,world", [((40, 36, 160), 3, 2), ((36, 40, 130), 9, 2), ((28, 24, 208), 5, 3), ((24, 20, 272), 8, 4)])
 def test_gloo_ranks_match_serial_oracle(oracle, built, dims, seed, world):
-    """World size 2, and 3: the middle rank has a neighbour on both sides (what every interior rank of an 8-GPU run is)."""
+    """World size 2, 3 and 4: from 3 on there are ranks with a neighbour on both sides (what every interior rank of an
+    8-GPU run is).  The schedule under test exchanges 8 slices per level and defers the rest of the L1..L3 patch halos
+    to one batch per octave."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -148,6 +150,10 @@ def test_gloo_ranks_match_serial_oracle(oracle, built, dims, seed, world):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert n_sharded >= 1 and stats["exchanges"] >= 5
+    # rank 0's traffic per sharded octave: five 8-slice exchanges on the critical path, one deferred batch with the
+    # other 24 slices of L1, L2, L3: 40 against 72 slices
+    assert stats["deferred_exchanges"] == n_sharded and stats["exchanges"] == 6 * n_sharded
+    assert stats["deferred_bytes"] * 112 == stats["exchange_bytes"] * 72
     want = oracle.candidates(built.synth_blobs(*dims, seed=seed))
     assert len(want) > 20
     _same(merged, want)
