@@ -124,6 +124,7 @@ def hip_lib():
     _sig(L.sift3d_candidates_dev, I, P, P, I, P, P)
     _sig(L.sift3d_describe_dev, I, P, P, I, I, F, F, P, P, P)
     _sig(L.sift3d_set_max_octaves, I, P, I)
+    _sig(L.sift3d_extract_zslab, I, P, I, P, I64, I64, I64, F, I, F, F, P, P, P, C.c_char_p, I64)
     _hip = L
     return L
 
@@ -149,6 +150,33 @@ def host_lib():
     L.free_ptr.argtypes = [C.c_void_p]
     _host = L
     return L
+
+
+class ZSlabStats(C.Structure):
+    """sift3d_zslab_stats"""
+    _fields_ = [("n_ranks", C.c_int32), ("sharded_octaves", C.c_int32), ("exchanges", C.c_int64), ("halo_bytes_critical", C.c_int64),
+                ("halo_bytes_deferred", C.c_int64), ("gather_bytes", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
+                ("n_records", C.c_int64)]
+
+
+def extract_zslab(vol, devices, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
+    """sift3d_extract_zslab: the volume cut into one Z-slab per entry of `devices`, one process, halos by peer copies.
+    Returns (records, stats dict)."""
+    vol = _f32(vol)
+    nz, ny, nx = vol.shape
+    dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+    out, n, st, err = C.c_void_p(), C.c_int64(0), ZSlabStats(), C.create_string_buffer(512)
+    rc = hip_lib().sift3d_extract_zslab(dev, len(devices), vol.ctypes.data, nx, ny, nz, float(initial_image_scale), int(desc_mode),
+                                        float(eig_thres), float(size_factor), C.byref(out), C.byref(n), C.byref(st), err, 512)
+    if rc != 0:
+        e = Sift3DError("sift3d_extract_zslab -> %d: %s" % (rc, err.value.decode(errors="replace")))
+        e.code = rc
+        raise e
+    try:
+        recs = np.frombuffer((C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(out.value), FEATURE_DTYPE, n.value).copy() if n.value else np.zeros(0, FEATURE_DTYPE)
+    finally:
+        hip_lib().sift3d_free(out)
+    return recs, {k: getattr(st, k) for k, _ in ZSlabStats._fields_}
 
 
 def device_count():

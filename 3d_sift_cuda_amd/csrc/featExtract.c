@@ -50,6 +50,7 @@ int main(int argc, char **argv)
         return -1;
     }
     int device = -1;
+    int devices[64], n_devices = 0; /* -d0,1,2,3: one Z-slab per listed device */
     int iArg = 1;
     int bDoubleImageSize = 0;
     int desc_mode = SIFT3D_DESC_SIFT;
@@ -69,6 +70,17 @@ int main(int argc, char **argv)
                 return -1;
             }
             device = argv[iArg][2] - '0';
+            /* beyond the reference: -d0,1,2,3 cuts the volume into one Z-slab per listed device (sift3d_extract_zslab) */
+            n_devices = 0;
+            for (const char *p = argv[iArg] + 2; *p && n_devices < 64; p++) {
+                if (*p == ',') continue;
+                if (*p < '0' || *p > '9' || *p - '0' >= sift3d_device_count()) {
+                    printf("Error: unknown device: %d\n", *p - '0');
+                    print_options();
+                    return -1;
+                }
+                devices[n_devices++] = *p - '0';
+            }
             iArg++;
             break;
         case 'b':
@@ -126,8 +138,11 @@ int main(int argc, char **argv)
         return -1;
     }
     int64_t cx = PX > X ? PX : X, cy = PY > Y ? PY : Y, cz = PZ > Z ? PZ : Z;
-    sift3d_ctx *ctx = sift3d_create(device, cx, cy, cz);
-    if (!ctx) {
+    /* several devices: the single-device context is only needed for the -2+ / -2- resize (a volume that needs several
+     * GPUs would not fit it otherwise) */
+    const int multi = n_devices > 1;
+    sift3d_ctx *ctx = (!multi || bDoubleImageSize != 0) ? sift3d_create(device, cx, cy, cz) : NULL;
+    if (!ctx && (!multi || bDoubleImageSize != 0)) {
         printf("Error: could not extract features, insufficient memory.\n");
         return -1;
     }
@@ -144,15 +159,48 @@ int main(int argc, char **argv)
 
     sift3d_feature *feats = NULL;
     int64_t n = 0;
-    int rc = sift3d_set_volume_resized(ctx, img.data, X, Y, Z, bDoubleImageSize);
-    t1 = now_s();
-    if (times) fprintf(stderr, "# upload: %.3f s\n", t1 - t0);
-    t0 = t1;
-    if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
-    if (rc != SIFT3D_OK) {
-        fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
-        printf("Error: could not extract features, insufficient memory.\n");
-        return -1;
+    int rc = SIFT3D_OK;
+    if (multi) {
+        /* Z-slabs over the listed devices: the processing volume on the host (resized on the first device if asked),
+         * then one slab per device with halos by peer copies */
+        float *pv = img.data;
+        char zerr[512] = "";
+        sift3d_zslab_stats zst;
+        if (bDoubleImageSize != 0) {
+            pv = (float *)malloc(sizeof(float) * (size_t)(PX * PY * PZ));
+            if (!pv) rc = SIFT3D_ERR_MEMORY;
+            else rc = bDoubleImageSize > 0 ? sift3d_double_size(ctx, img.data, X, Y, Z, pv) : sift3d_halve_size(ctx, img.data, X, Y, Z, pv);
+            if (rc != SIFT3D_OK) snprintf(zerr, sizeof zerr, "%s", ctx ? sift3d_last_error(ctx) : "out of memory");
+            sift3d_destroy(ctx);
+            ctx = NULL;
+        }
+        t1 = now_s();
+        if (times) fprintf(stderr, "# resize: %.3f s\n", t1 - t0);
+        t0 = t1;
+        if (rc == SIFT3D_OK)
+            rc = sift3d_extract_zslab(devices, n_devices, pv, PX, PY, PZ, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n,
+                                      &zst, zerr, sizeof zerr);
+        if (pv != img.data) free(pv);
+        if (rc != SIFT3D_OK) {
+            fprintf(stderr, "sift3d: %s\n", zerr);
+            printf("Error: could not extract features, insufficient memory.\n");
+            return -1;
+        }
+        if (times)
+            fprintf(stderr, "# z-slabs: %d ranks, %d sharded octaves, %lld halo copies, %.1f MB on the critical path, %.1f MB deferred, %.1f MB gathered\n",
+                    (int)zst.n_ranks, (int)zst.sharded_octaves, (long long)zst.exchanges, zst.halo_bytes_critical / 1e6,
+                    zst.halo_bytes_deferred / 1e6, zst.gather_bytes / 1e6);
+    } else {
+        rc = sift3d_set_volume_resized(ctx, img.data, X, Y, Z, bDoubleImageSize);
+        t1 = now_s();
+        if (times) fprintf(stderr, "# upload: %.3f s\n", t1 - t0);
+        t0 = t1;
+        if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
+        if (rc != SIFT3D_OK) {
+            fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
+            printf("Error: could not extract features, insufficient memory.\n");
+            return -1;
+        }
     }
 
     t1 = now_s();

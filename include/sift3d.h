@@ -38,7 +38,7 @@ typedef enum {
     SIFT3D_ERR_DEVICE = -2,   /* HIP runtime error (sift3d_last_error has the text) */
     SIFT3D_ERR_MEMORY = -3,   /* host or device allocation failed */
     SIFT3D_ERR_CAPACITY = -4, /* caller-provided output array too small (counts are still exact) */
-    SIFT3D_ERR_COMM = -5      /* slab exchange callback failed */
+    SIFT3D_ERR_COMM = -5      /* a halo copy between slabs (sift3d_extract_zslab) failed */
 } sift3d_status;
 
 /* Descriptor selected by -b / -br / -bn (/root/reference/README.md:26-34;
@@ -208,6 +208,26 @@ int sift3d_candidates_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int 
  * call. */
 int sift3d_describe_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_levels, int desc_mode, float eig_thres,
                         float size_factor, const sift3d_feature **view, const int32_t **group_view, int64_t *n_out);
+
+/* ---- Z-slab extraction from C: one process, several devices ---------------------
+ * The whole volume (host memory) is cut into one Z-slab per entry of `devices` (the same partitioning, halo widths and
+ * exchange schedule as the per-process driver above), each slab on its own device, halos moved between the devices with
+ * hipMemcpyPeerAsync -- xGMI between the GPUs of a node -- queued behind events, so the host never waits inside the pyramid.
+ * The records come back merged in the single-GPU order and are the single-GPU records bit for bit.  A device may be listed
+ * more than once (the slab logic rehearsed on one GPU).  A volume too thin to shard (a slab must be 32 slices thick) runs
+ * whole on devices[0].  SIFT3D_ERR_COMM: a halo copy or its ordering failed; *err (err_len bytes, may be NULL) gets the text.
+ * *out is malloc'ed (sift3d_free). */
+typedef struct {
+    int32_t n_ranks, sharded_octaves;
+    int64_t exchanges;            /* halo copies queued on the critical path + deferred batches */
+    int64_t halo_bytes_critical;  /* the 8-slice halo every level needs before the next blur, all ranks */
+    int64_t halo_bytes_deferred;  /* the rest of the L1..L3 patch halos, copied beside L4 / L5 / extrema */
+    int64_t gather_bytes;         /* the first unsharded octave assembled on rank 0 */
+    int64_t n_extrema, n_keypoints, n_records;
+} sift3d_zslab_stats;
+int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
+                         float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,
+                         int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len);
 
 /* ---- measurement ------------------------------------------------------------
  * Device time per stage of the last sift3d_detect/sift3d_extract call, from

@@ -639,6 +639,63 @@ def test_volume_beyond_32_bit_indices(built):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Z-slab extraction driven from C: one process, one context per listed device, halos by hipMemcpyPeerAsync.  On the
+# one-GPU test box the same device is listed several times: the slab logic (plan, halo widths, thin + deferred exchange,
+# own-slice filtering, coarse-octave gather, merge order) runs exactly as on several devices, the copies are device-local.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims,seed,mode,devs,scale", [((96, 80, 160), 7, 0, [0, 0], 1.0), ((64, 72, 136), 11, 2, [0, 0], 1.0),
+                                                      ((72, 64, 232), 4, 0, [0, 0, 0], 1.0), ((68, 52, 272), 6, 1, [0, 0, 0, 0], 0.5),
+                                                      ((510, 37, 130), 5, 0, [0, 0], 1.0)])
+def test_c_zslab_driver_matches_single_gpu(built, dims, seed, mode, devs, scale):
+    vol = vol_of(built, dims, seed)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract(initial_image_scale=scale, desc_mode=mode, size_factor=scale)
+    got, st = built.extract_zslab(vol, devs, initial_image_scale=scale, desc_mode=mode, size_factor=scale)
+    assert len(want) > 50 and len(got) == len(want)
+    assert got.tobytes() == want.tobytes()                                  # bit-identical records, same order
+    assert st["n_ranks"] == len(devs) and st["sharded_octaves"] >= 1 and st["n_records"] == len(want)
+    # per interface and sharded octave: five 8-slice halos on the critical path, 3 x 24 slices deferred, both directions
+    assert st["halo_bytes_critical"] > 0 and st["halo_bytes_deferred"] * 40 == st["halo_bytes_critical"] * 72
+    assert st["gather_bytes"] > 0
+
+
+def test_c_zslab_driver_edge_cases(built):
+    vol = vol_of(built, (48, 40, 60), 3)                                    # too thin for 32-slice slabs: one rank, the serial path
+    with built.Context(48, 40, 60) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract()
+    got, st = built.extract_zslab(vol, [0, 0])
+    assert got.tobytes() == want.tobytes() and st["n_ranks"] == 1 and st["sharded_octaves"] == 0 and st["halo_bytes_critical"] == 0
+    got, st = built.extract_zslab(vol, [0])
+    assert got.tobytes() == want.tobytes()
+    zero, st = built.extract_zslab(np.zeros((160, 40, 36), np.float32), [0, 0])   # nothing to find, sharded
+    assert len(zero) == 0 and st["sharded_octaves"] >= 1
+    with pytest.raises(built.Sift3DError) as ei:
+        built.extract_zslab(vol, [0, 99])
+    assert ei.value.code == -1 and "no HIP device 99" in str(ei.value)
+
+
+def test_cli_several_devices(built, tmp_path):
+    """featExtract -d0,0 (one Z-slab per listed device) writes the .key of featExtract -d0, with and without -2+."""
+    nii = str(tmp_path / "in.nii")
+    built.write_nifti(nii, vol_of(built, (72, 64, 168), 21), voxel=(1.0, 1.0, 2.0))
+    small = str(tmp_path / "s.nii")
+    built.write_nifti(small, vol_of(built, (40, 36, 84), 22))
+    for flags, src in (([], nii), (["-br"], nii), (["-2+", "-b"], small)):
+        k1, k2 = str(tmp_path / "one.key"), str(tmp_path / "two.key")
+        r1 = subprocess.run([built.FEATEXTRACT, "-d0"] + flags + [src, k1], capture_output=True, text=True)
+        r2 = subprocess.run([built.FEATEXTRACT, "-d0,0"] + flags + [src, k2], capture_output=True, text=True,
+                            env=dict(os.environ, SIFT3D_CLI_TIMES="1"))
+        assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
+        assert r1.stdout == r2.stdout and r2.stdout.endswith("\nDone.\n")
+        assert "# z-slabs: 2 ranks" in r2.stderr
+        assert open(k1, "rb").read() == open(k2, "rb").read() and len(open(k1).readlines()) > 20
+    r = subprocess.run([built.FEATEXTRACT, "-d0,7", nii, str(tmp_path / "x.key")], capture_output=True, text=True)
+    assert r.returncode == 255 and "Error: unknown device: 7" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------
 # Z-slab mode on the GPU: two processes share the one GPU of the test box and exchange halos through gloo
 # (staged through the host); on a multi-GPU node the same driver runs with backend "nccl" (RCCL).
 # ---------------------------------------------------------------------------------------------------
