@@ -465,7 +465,8 @@ class Context:
         self._chk(self._L.sift3d_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None), "sift3d_set_stream")
 
     def enable_timing(self, on=True):
-        """False / 0 off, True / 1 every launch, 2 only the blur launches on the full-size volume."""
+        """False / 0 off, True / 1 every launch, 2 only the blur launches on the full-size volume, 3 every launch with the
+        extrema kept on the main stream (each launch timed alone)."""
         self._chk(self._L.sift3d_enable_timing(self._h, int(on)), "sift3d_enable_timing")
 
     def launch_log(self):

@@ -422,7 +422,7 @@ struct stage_scope {
         c->last.alg_bytes[stage] += bytes;
         /* events cost a few microseconds each (two per launch, ~170 launches: 1 ms of a 13 ms run at 512^3): mode 2
          * keeps them to the dominant kernels, the blur launches on the full-size volume */
-        timed = c->timing == 1 ||
+        timed = c->timing == 1 || c->timing == 3 ||
                 (c->timing == 2 && nvox == pitch_of(c->nx) * c->ny * c->nz &&
                  (stage == SIFT3D_STAGE_BLUR_FUSED || stage == SIFT3D_STAGE_BLUR_X || stage == SIFT3D_STAGE_BLUR_Y ||
                   stage == SIFT3D_STAGE_BLUR_Z_DOG));
@@ -480,7 +480,7 @@ extern "C" int sift3d_enable_timing(sift3d_ctx *c, int on)
     if (!c) return SIFT3D_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
+    c->timing = on < 0 ? 0 : (on > 3 ? 1 : on);
     timing_begin(c); /* operator-level *_dev calls accumulate from here until the log is read */
     return SIFT3D_OK;
 }
@@ -1193,9 +1193,14 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         }
         /* the extrema of this octave go to a second stream: they run beside the blurs of the coarser octaves, which are
          * launch-latency-bound and leave most of the chip idle */
-        HIPCHK(c, hipEventRecord(c->ev_oct[0], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->ex_stream, c->ev_oct[0], 0));
-        c->cand_stream = c->ex_stream;
+        /* timing mode 3 (measurement only): the extrema stay on the main stream, so that every launch's event pair times
+         * that launch alone instead of the launch plus whatever shares the chip with it */
+        hipStream_t exs = c->timing == 3 ? c->stream : c->ex_stream;
+        if (exs != c->stream) {
+            HIPCHK(c, hipEventRecord(c->ev_oct[0], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->ex_stream, c->ev_oct[0], 0));
+        }
+        c->cand_stream = exs;
         for (int l = 0; l < 3; l++) {
             const int id = (int)o * 3 + l;
             rc = cand_append(c, {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X}, true);
@@ -1215,8 +1220,8 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         if (o == 0 && early_ok) {
             /* octave 0's extrema are the first entries of the list (the passes of the coarser octaves follow on the same
              * stream): note how many there are, for the early per-keypoint pass below */
-            HIPCHK(c, hipMemcpyAsync(c->h_cnt0, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->ex_stream));
-            HIPCHK(c, hipEventRecord(c->ev_cnt0, c->ex_stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_cnt0, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, exs));
+            HIPCHK(c, hipEventRecord(c->ev_cnt0, exs));
         }
         fscale *= 2.0f;
         c->last.n_octaves++;

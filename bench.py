@@ -239,12 +239,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tim = ctx.timings()
-    full_logs = []
+    full_logs, excl_logs = [], []
     if rank == 0:
         ctx.enable_timing(1)
         for _ in range(2):
             ctx.extract(desc_mode=args.desc, copy=False)
             full_logs.append(ctx.launch_log())
+        ctx.enable_timing(3)   # the same with the extrema kept on the main stream: every launch timed alone
+        for _ in range(2):
+            ctx.extract(desc_mode=args.desc, copy=False)
+            excl_logs.append(ctx.launch_log())
         ctx.enable_timing(0)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
@@ -362,7 +366,21 @@ def main():
                 stages[s] = {"ms_per_step": round(float(sel["ms"].sum()) / nfull, 3), "launches_per_step": len(sel) // nfull}
         stages["_note"] = ("kernel time per stage from two extra steps with every launch bracketed by HIP events (that costs "
                            "about 1 ms per step, so those steps are outside the timed region); the extrema of an octave run "
-                           "beside the blurs of the coarser ones, so the stages add up to more than a step")
+                           "beside the blurs of the coarser ones, so the stages add up to more than a step and a blur launch's "
+                           "event pair also times the extrema kernels that share the chip with it; `exclusive_ms_per_step` is the "
+                           "same from two steps in which the extrema stay on the main stream (sift3d_enable_timing mode 3): every "
+                           "launch timed alone")
+        excl = np.concatenate(excl_logs)
+        for i, sname in enumerate(stage_names):
+            sel = excl[excl["stage"] == i]
+            if len(sel) and sname in stages:
+                stages[sname]["exclusive_ms_per_step"] = round(float(sel["ms"].sum()) / len(excl_logs), 3)
+        eb = excl[np.isin(excl["stage"], [stage_names.index(q) for q in ("blur_x", "blur_y", "blur_z_dog", "blur_fused", "octave_tiny")])]
+        pyramid["exclusive_ms_per_step"] = round(float(eb["ms"].sum()) / len(excl_logs), 3)
+        pyramid["exclusive_alg_GBs"] = round(float(eb["alg_bytes"].sum()) / (float(eb["ms"].sum()) * 1e-3) / 1e9, 1)
+        pyramid["exclusive_frac_of_peak"] = round(pyramid["exclusive_alg_GBs"] / HBM_PEAK_GBS, 4)
+        pyramid["accounting"] += ("; ms_per_step / frac_of_peak: blur launches timed while the finer octave's extrema share the chip "
+                                  "(the production schedule); exclusive_*: the same launches timed alone")
         out = {
             "metric": "keypoints/s (.key records per second; Gauss-pyramid GB/s vs HBM roofline in `pyramid`/`roofline`)",
             "value": round(total_records / (ms_per_step * 1e-3), 1),

@@ -252,7 +252,9 @@ typedef struct {
     double total_ms;                      /* first kernel to last, on the stream */
 } sift3d_timings;
 /* on: 0 off; 1 every launch bracketed by two events (full per-stage breakdown; costs about 1 ms per 512^3 run);
- * 2 only the blur launches on the full-size volume (the dominant kernels: what a benchmark can leave on). */
+ * 2 only the blur launches on the full-size volume (the dominant kernels: what a benchmark can leave on);
+ * 3 as 1, with the extrema passes kept on the main stream instead of running beside the coarser octaves' blurs: slower
+ *   overall, but every launch is then timed alone (exclusive kernel times). */
 int sift3d_enable_timing(sift3d_ctx *ctx, int on);
 int sift3d_get_timings(const sift3d_ctx *ctx, sift3d_timings *t);
 /* Per-launch log of the same call (needs timing enabled): one entry per kernel
