@@ -112,6 +112,8 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
                "exchange_schedule": "per level: the 8-slice blur halo (what the next blur waits for); per octave: one deferred "
                                     "batch with the other 24 slices of the L1..L3 patch halos, issued when L3 is complete and "
                                     "waited for after the extrema passes (rank 0's counts; interior ranks exchange on both sides)"}
+        import hashlib
+        res["records_sha256"] = hashlib.sha256(merged.tobytes()).hexdigest() if merged is not None else None
         if expect is not None:
             res["same_bytes_as_single_gpu"] = bool(merged is not None and len(merged) == len(expect)
                                                    and (merged.view(np.uint8) == expect.view(np.uint8)).all())
@@ -130,43 +132,68 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
             "config": {k: res[k] for k in ("workload", "records", "sharded_octaves", "slab_bounds", "parallelism",
                                            "halo_exchanges_per_step", "halo_bytes_per_rank_per_step",
                                            "halo_bytes_critical_per_rank_per_step", "halo_bytes_deferred_per_rank_per_step",
-                                           "exchange_schedule")}}))
+                                           "exchange_schedule", "records_sha256")}}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-ZSLAB_FAILED_EXIT = 3   # exit code of every rank when the attached Z-slab run failed or timed out
-
-
-def zslab_beside(out, args, pkg, torch, dist, rank, world, local_rank, expect, limit_s):
-    """N > 1, default mode: after the per-GPU-volume measurement, also run the Z-slab split of ONE volume over the same
-    ranks and attach it to the line as `zslab`.  It is the only place this path meets RCCL on real links (the
-    development box has one GPU), so it runs under a watchdog: if a rank fails or the exchange stalls, rank 0 still
-    prints the line (its headline fields are complete; `zslab.status` says what happened) and then EVERY rank exits
-    with code 3 -- a GPU rank that crashed or hung must not look like a clean run to the launcher."""
-    import threading
-    done = threading.Event()
-
-    def watchdog():
-        if not done.wait(limit_s):
-            if rank == 0:
-                out["zslab"] = {"status": "no result within %d s (a rank failed or the exchange stalled)" % limit_s}
-                print(json.dumps(out), flush=True)
-            os._exit(ZSLAB_FAILED_EXIT)
-    threading.Thread(target=watchdog, daemon=True).start()
+def zslab_child(args, world, expect, limit_s):
+    """N > 1, default mode, rank 0 only, AFTER the per-GPU-volume measurement is complete and its process group is gone:
+    run the Z-slab split of ONE volume over the same GPUs as a fresh child job (`bench.py --mode zslab` under
+    torch.distributed.run, its own rendezvous port, its own process group on the host) and return what goes into the line
+    as `zslab`.  It is the only place the slab exchange meets RCCL on real links -- the development box has one GPU -- so a
+    crash or a stall there is a result to report (status, exit code, the tail of its stderr), not something that may take
+    the headline measurement with it: the child is killed as a process group at the limit, the parent job always ends
+    normally."""
+    import hashlib
+    import signal
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+            "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--size", str(args.size), "--desc", str(args.desc), "--mode", "zslab"]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
-        res = zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect)
-        if rank == 0:
-            res["status"] = "ok"
-            out["zslab"] = res
-    except Exception as e:   # the other ranks are released by their own watchdogs
-        sys.stderr.write("bench.py: rank %d: zslab run failed: %r\n" % (rank, e))
-        if rank != 0:
-            done.wait(limit_s + 5)   # never returns normally: the watchdog ends this process
-        out["zslab"] = {"status": "failed on rank 0: %r" % (e,)}
-        print(json.dumps(out), flush=True)
-        os._exit(ZSLAB_FAILED_EXIT)
-    done.set()
+        so, se = p.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        # End exactly the job started here.  torch.distributed.run puts every rank in a session of its own, so the
+        # launcher's process group does not contain them: note their PIDs first, ask the launcher to stop (it terminates
+        # its ranks on SIGTERM), then kill whatever of it is still there.
+        import psutil
+        try:
+            kids = psutil.Process(p.pid).children(recursive=True)
+        except psutil.NoSuchProcess:
+            kids = []
+        p.send_signal(signal.SIGTERM)
+        try:
+            so, se = p.communicate(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            so, se = p.communicate()
+        for k in kids:
+            try:
+                if k.is_running():
+                    k.kill()
+            except psutil.NoSuchProcess:
+                pass
+        return {"status": "no result within %d s (a rank failed or the exchange stalled); the child job was killed" % limit_s,
+                "exit_code": None, "stderr_tail": se[-600:]}
+    line = None
+    for l in so.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+    if p.returncode != 0 or line is None:
+        return {"status": "the child job failed", "exit_code": p.returncode, "stderr_tail": se[-600:]}
+    d = json.loads(line)
+    res = {"status": "ok", "exit_code": 0, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "scaling": "strong"}
+    res.update(d["config"])
+    if expect is not None:
+        res["same_bytes_as_single_gpu"] = bool(res.get("records_sha256") == hashlib.sha256(expect.tobytes()).hexdigest())
+    return res
 
 
 def main():
@@ -181,10 +208,13 @@ def main():
     ap.add_argument("--mode", default="volumes", choices=["volumes", "zslab"],
                     help="N > 1: 'volumes' = one volume per GPU (default, weak scaling; the Z-slab run of ONE volume is "
                          "attached as `zslab`); 'zslab' = only the Z-slab run (strong scaling)")
-    ap.add_argument("--zslab-limit", type=int, default=90,
-                    help="N > 1, mode volumes: seconds the attached Z-slab run may take (0 = do not attach it)")
+    ap.add_argument("--zslab-limit", type=int, default=120,
+                    help="N > 1, mode volumes: seconds the attached Z-slab child job may take (0 = do not attach it)")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_DUMP_STACKS_AFTER"):   # diagnosis of a hang: every thread's Python stack to stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_DUMP_STACKS_AFTER"]), repeat=False, exit=False)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -251,8 +281,9 @@ def main():
             excl_logs.append(ctx.launch_log())
         ctx.enable_timing(0)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
-    rc = torch.tensor([float(nrec)], dtype=torch.float64, device="cuda:%d" % local_rank)
+    red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda:%d" % local_rank   # gloo: the one-GPU rehearsal
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rc = torch.tensor([float(nrec)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rc, op=dist.ReduceOp.SUM)
@@ -435,13 +466,14 @@ def main():
     expect = feats.copy() if (rank == 0 and world > 1) else None
     ctx.close()
     del dvol
-    if dist is not None and args.zslab_limit > 0:
-        zslab_beside(out if rank == 0 else None, args, pkg, torch, dist, rank, world, local_rank, expect, args.zslab_limit)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.destroy_process_group()   # the measurement is complete; ranks other than 0 are done and leave the GPUs
+    if rank == 0:
+        if world > 1 and args.zslab_limit > 0:
+            torch.cuda.empty_cache()
+            out["zslab"] = zslab_child(args, world, expect, args.zslab_limit)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
