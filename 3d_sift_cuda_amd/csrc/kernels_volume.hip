@@ -395,16 +395,45 @@ __device__ __forceinline__ float dpp_from_upper(float v) /* lane l gets lane l+1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+/* The hardware's own max / min (IEEE mode: a NaN operand yields the other one, as fmaxf / fminf do).  Written as
+ * instructions because fmaxf / fminf on values that come straight from memory make the compiler quiet possible signalling
+ * NaNs first -- one v_max_f32 v, v, v per loaded element, 12 % of the march loop's vector instructions -- which the
+ * instruction does itself. */
+__device__ __forceinline__ float ex_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float ex_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float ex_max3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float ex_min3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 /* max / min over the x-triple of every element of a row: rmax/rmin include the element, l2max/l2min do not */
 __device__ __forceinline__ void row_extrema(v4f a, float (&rmax)[4], float (&rmin)[4], float (&l2max)[4], float (&l2min)[4])
 {
     const float v[6] = {dpp_from_lower(a.w), a.x, a.y, a.z, a.w, dpp_from_upper(a.x)};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        l2max[e] = fmaxf(v[e], v[e + 2]);
-        l2min[e] = fminf(v[e], v[e + 2]);
-        rmax[e] = fmaxf(l2max[e], v[e + 1]);
-        rmin[e] = fminf(l2min[e], v[e + 1]);
+        l2max[e] = ex_max(v[e], v[e + 2]);
+        l2min[e] = ex_min(v[e], v[e + 2]);
+        rmax[e] = ex_max3(v[e], v[e + 2], v[e + 1]);
+        rmin[e] = ex_min3(v[e], v[e + 2], v[e + 1]);
     }
 }
 
@@ -510,10 +539,10 @@ __device__ __forceinline__ void ex_reduce_plane(const v4f (&raw)[EX_LOAD], ex_pl
         o.c[r][0] = cv.x; o.c[r][1] = cv.y; o.c[r][2] = cv.z; o.c[r][3] = cv.w;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            o.e8max[r][e] = fmaxf(fmaxf(rmax[r][e], rmax[r + 2][e]), l2max[r + 1][e]);
-            o.e8min[r][e] = fminf(fminf(rmin[r][e], rmin[r + 2][e]), l2min[r + 1][e]);
-            o.m[r][e] = fmaxf(fmaxf(rmax[r][e], rmax[r + 1][e]), rmax[r + 2][e]);
-            o.n[r][e] = fminf(fminf(rmin[r][e], rmin[r + 1][e]), rmin[r + 2][e]);
+            o.e8max[r][e] = ex_max3(rmax[r][e], rmax[r + 2][e], l2max[r + 1][e]);
+            o.e8min[r][e] = ex_min3(rmin[r][e], rmin[r + 2][e], l2min[r + 1][e]);
+            o.m[r][e] = ex_max3(rmax[r][e], rmax[r + 1][e], rmax[r + 2][e]);
+            o.n[r][e] = ex_min3(rmin[r][e], rmin[r + 1][e], rmin[r + 2][e]);
         }
     }
 }
@@ -573,8 +602,8 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const float c = ce.c[r][e];
-                const bool mx = c > fmaxf(ce.e8max[r][e], fmaxf(lo.m[r][e], hi.m[r][e]));
-                const bool mn = c < fminf(ce.e8min[r][e], fminf(lo.n[r][e], hi.n[r][e]));
+                const bool mx = c > ex_max3(ce.e8max[r][e], lo.m[r][e], hi.m[r][e]);
+                const bool mn = c < ex_min3(ce.e8min[r][e], lo.n[r][e], hi.n[r][e]);
                 const int x = xv + e;
                 const bool hit = (mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < Xl - 1 && y < Y - 1;
                 const unsigned long long m = __ballot(hit);
