@@ -141,168 +141,188 @@ __device__ __forceinline__ float v3_mag(const float *p)
 }
 __device__ __forceinline__ float v3_dot(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
-/* SingularValueDecomp<float,3,3> + SortEigenDecomp<float,3>, R/src_common/SVD.h:15-228:
- * Numerical Recipes svdcmp, double temporaries, float storage. */
-#define SVD_SIGN(a, b) ((b) >= 0.0 ? fabs(a) : -fabs(a))
-#define SVD_PYTHAG(a, b) (sqrt((a) * (a) + (b) * (b)))
-__device__ __forceinline__ void svd3(float mat[3][3], float w[3], float v[3][3])
+/* Singular value decomposition of the 3x3 structure tensor and the sort of its result: what the reference gets from
+ * SingularValueDecomp<float,3,3> + SortEigenDecomp<float,3> (R/src_common/SVD.h:15-228, the Golub-Kahan-Reinsch scheme:
+ * Householder reduction to bidiagonal form, accumulation of the right- and left-hand transformations, implicit-shift QR
+ * sweeps).  The eigenvectors go into the records, so this has to produce the reference's bits, and for that every
+ * floating-point operation has to be the reference's, in its order and in its width: storage in float, running values in
+ * double, a product of two stored floats rounded to float before it enters a double sum.  Written here for the 3x3 case
+ * with 0-based indices (the sizes folded in, the branches that cannot be taken removed) and pinned twice: the oracle's
+ * restatement against the reference's own template compiled into oracle/_ref (bit-exact on 4 000 tensors), and this
+ * function against the oracle through every record of the pipeline tests. */
+__device__ __forceinline__ double svd_with_sign(double magnitude, double sign_source) { return sign_source >= 0.0 ? fabs(magnitude) : -fabs(magnitude); }
+__device__ __forceinline__ double svd_hypot(double p, double q) { return sqrt(p * p + q * q); }
+
+__device__ __forceinline__ void svd3(float a[3][3], float w[3], float v[3][3])
 {
-    const int m = 3, n = 3;
-    int flag, i, its, j, jj, k, l = 0, nm = 0;
-    double anorm, c, f, g, h, s, scale, x, y, z;
-    double rv1[3];
-    g = scale = anorm = 0.0;
-    for (i = 1; i <= n; i++) {
-        l = i + 1;
-        rv1[i - 1] = scale * g;
+    double off[3]; /* the super-diagonal of the bidiagonal form (off[0] stays 0) */
+    double g = 0.0, scale = 0.0, norm = 0.0, s, f, h;
+    int below = 0;
+
+    /* ---- 1. Householder reduction: column i (left reflection), then row i (right reflection) ---- */
+    for (int i = 0; i < 3; i++) {
+        below = i + 1;
+        off[i] = scale * g;
         g = s = scale = 0.0;
-        if (i <= m) {
-            for (k = i; k <= m; k++) scale += fabsf(mat[k - 1][i - 1]);
+        for (int k = i; k < 3; k++) scale += fabsf(a[k][i]);
+        if (scale) {
+            for (int k = i; k < 3; k++) {
+                a[k][i] = (float)(a[k][i] / scale);
+                s += a[k][i] * a[k][i];
+            }
+            f = a[i][i];
+            g = -svd_with_sign(sqrt(s), f);
+            h = f * g - s;
+            a[i][i] = (float)(f - g);
+            for (int j = below; j < 3; j++) {
+                s = 0.0;
+                for (int k = i; k < 3; k++) s += a[k][i] * a[k][j];
+                f = s / h;
+                for (int k = i; k < 3; k++) a[k][j] = (float)(a[k][j] + f * a[k][i]);
+            }
+            for (int k = i; k < 3; k++) a[k][i] = (float)(a[k][i] * scale);
+        }
+        w[i] = (float)(scale * g);
+        g = s = scale = 0.0;
+        if (i != 2) {
+            for (int k = below; k < 3; k++) scale += fabsf(a[i][k]);
             if (scale) {
-                for (k = i; k <= m; k++) {
-                    mat[k - 1][i - 1] = (float)(mat[k - 1][i - 1] / scale);
-                    s += mat[k - 1][i - 1] * mat[k - 1][i - 1];
+                for (int k = below; k < 3; k++) {
+                    a[i][k] = (float)(a[i][k] / scale);
+                    s += a[i][k] * a[i][k];
                 }
-                f = mat[i - 1][i - 1];
-                g = -SVD_SIGN(sqrt(s), f);
+                f = a[i][below];
+                g = -svd_with_sign(sqrt(s), f);
                 h = f * g - s;
-                mat[i - 1][i - 1] = (float)(f - g);
-                for (j = l; j <= n; j++) {
-                    for (s = 0.0, k = i; k <= m; k++) s += mat[k - 1][i - 1] * mat[k - 1][j - 1];
-                    f = s / h;
-                    for (k = i; k <= m; k++) mat[k - 1][j - 1] = (float)(mat[k - 1][j - 1] + f * mat[k - 1][i - 1]);
+                a[i][below] = (float)(f - g);
+                for (int k = below; k < 3; k++) off[k] = a[i][k] / h;
+                for (int j = below; j < 3; j++) {
+                    s = 0.0;
+                    for (int k = below; k < 3; k++) s += a[j][k] * a[i][k];
+                    for (int k = below; k < 3; k++) a[j][k] = (float)(a[j][k] + s * off[k]);
                 }
-                for (k = i; k <= m; k++) mat[k - 1][i - 1] = (float)(mat[k - 1][i - 1] * scale);
+                for (int k = below; k < 3; k++) a[i][k] = (float)(a[i][k] * scale);
             }
         }
-        w[i - 1] = (float)(scale * g);
-        g = s = scale = 0.0;
-        if (i <= m && i != n) {
-            for (k = l; k <= n; k++) scale += fabsf(mat[i - 1][k - 1]);
-            if (scale) {
-                for (k = l; k <= n; k++) {
-                    mat[i - 1][k - 1] = (float)(mat[i - 1][k - 1] / scale);
-                    s += mat[i - 1][k - 1] * mat[i - 1][k - 1];
-                }
-                f = mat[i - 1][l - 1];
-                g = -SVD_SIGN(sqrt(s), f);
-                h = f * g - s;
-                mat[i - 1][l - 1] = (float)(f - g);
-                for (k = l; k <= n; k++) rv1[k - 1] = mat[i - 1][k - 1] / h;
-                for (j = l; j <= m; j++) {
-                    for (s = 0.0, k = l; k <= n; k++) s += mat[j - 1][k - 1] * mat[i - 1][k - 1];
-                    for (k = l; k <= n; k++) mat[j - 1][k - 1] = (float)(mat[j - 1][k - 1] + s * rv1[k - 1]);
-                }
-                for (k = l; k <= n; k++) mat[i - 1][k - 1] = (float)(mat[i - 1][k - 1] * scale);
-            }
-        }
-        {
-            double tt = (fabsf(w[i - 1]) + fabs(rv1[i - 1]));
-            anorm = (anorm > tt ? anorm : tt);
-        }
+        const double row_norm = fabsf(w[i]) + fabs(off[i]);
+        norm = norm > row_norm ? norm : row_norm;
     }
-    for (i = n; i >= 1; i--) {
-        if (i < n) {
+
+    /* ---- 2. right-hand transformations into v, last row first (g and `below` carry over from the row above) ---- */
+    for (int i = 2; i >= 0; i--) {
+        if (i < 2) {
             if (g) {
-                for (j = l; j <= n; j++) v[j - 1][i - 1] = (float)((mat[i - 1][j - 1] / mat[i - 1][l - 1]) / g);
-                for (j = l; j <= n; j++) {
-                    for (s = 0.0, k = l; k <= n; k++) s += mat[i - 1][k - 1] * v[k - 1][j - 1];
-                    for (k = l; k <= n; k++) v[k - 1][j - 1] = (float)(v[k - 1][j - 1] + s * v[k - 1][i - 1]);
+                for (int j = below; j < 3; j++) v[j][i] = (float)((a[i][j] / a[i][below]) / g);
+                for (int j = below; j < 3; j++) {
+                    s = 0.0;
+                    for (int k = below; k < 3; k++) s += a[i][k] * v[k][j];
+                    for (int k = below; k < 3; k++) v[k][j] = (float)(v[k][j] + s * v[k][i]);
                 }
             }
-            for (j = l; j <= n; j++) v[i - 1][j - 1] = v[j - 1][i - 1] = 0.0;
+            for (int j = below; j < 3; j++) v[i][j] = v[j][i] = 0.0;
         }
-        v[i - 1][i - 1] = 1.0;
-        g = rv1[i - 1];
-        l = i;
+        v[i][i] = 1.0;
+        g = off[i];
+        below = i;
     }
-    for (i = (m < n ? m : n); i >= 1; i--) {
-        l = i + 1;
-        g = w[i - 1];
-        for (j = l; j <= n; j++) mat[i - 1][j - 1] = 0.0;
+
+    /* ---- 3. left-hand transformations, in place in a ---- */
+    for (int i = 2; i >= 0; i--) {
+        below = i + 1;
+        g = w[i];
+        for (int j = below; j < 3; j++) a[i][j] = 0.0;
         if (g) {
             g = 1.0 / g;
-            for (j = l; j <= n; j++) {
-                for (s = 0.0, k = l; k <= m; k++) s += mat[k - 1][i - 1] * mat[k - 1][j - 1];
-                f = (s / mat[i - 1][i - 1]) * g;
-                for (k = i; k <= m; k++) mat[k - 1][j - 1] = (float)(mat[k - 1][j - 1] + f * mat[k - 1][i - 1]);
+            for (int j = below; j < 3; j++) {
+                s = 0.0;
+                for (int k = below; k < 3; k++) s += a[k][i] * a[k][j];
+                f = (s / a[i][i]) * g;
+                for (int k = i; k < 3; k++) a[k][j] = (float)(a[k][j] + f * a[k][i]);
             }
-            for (j = i; j <= m; j++) mat[j - 1][i - 1] = (float)(mat[j - 1][i - 1] * g);
-        } else
-            for (j = i; j <= m; j++) mat[j - 1][i - 1] = 0.0;
-        mat[i - 1][i - 1] = mat[i - 1][i - 1] + 1;
+            for (int j = i; j < 3; j++) a[j][i] = (float)(a[j][i] * g);
+        } else {
+            for (int j = i; j < 3; j++) a[j][i] = 0.0;
+        }
+        a[i][i] = a[i][i] + 1;
     }
-    for (k = n; k >= 1; k--) {
-        for (its = 1; its <= 30; its++) {
-            flag = 1;
-            for (l = k; l >= 1; l--) {
-                nm = l - 1;
-                if ((double)(fabs(rv1[l - 1]) + anorm) == anorm) {
-                    flag = 0;
+
+    /* ---- 4. diagonalisation: for each singular value, from the last, implicit-shift QR sweeps (at most 30) ---- */
+    for (int k = 2; k >= 0; k--) {
+        for (int sweep = 1; sweep <= 30; sweep++) {
+            /* find the block to work on: lo = first row of it; off[0] is 0, so the search always ends by splitting */
+            bool cancel = true;
+            int lo = k, above = 0;
+            for (; lo >= 0; lo--) {
+                above = lo - 1;
+                if ((double)(fabs(off[lo]) + norm) == norm) {
+                    cancel = false;
                     break;
                 }
-                if ((double)(fabsf(w[nm - 1]) + anorm) == anorm) break;
+                if ((double)(fabsf(w[above]) + norm) == norm) break;
             }
-            if (flag) {
+            double c, x, y, z;
+            if (cancel) { /* w[above] is negligible: rotate off[lo] .. off[k] away */
                 c = 0.0;
                 s = 1.0;
-                for (i = l; i <= k; i++) {
-                    f = s * rv1[i - 1];
-                    rv1[i - 1] = c * rv1[i - 1];
-                    if ((double)(fabs(f) + anorm) == anorm) break;
-                    g = w[i - 1];
-                    h = SVD_PYTHAG(f, g);
-                    w[i - 1] = (float)h;
+                for (int i = lo; i <= k; i++) {
+                    f = s * off[i];
+                    off[i] = c * off[i];
+                    if ((double)(fabs(f) + norm) == norm) break;
+                    g = w[i];
+                    h = svd_hypot(f, g);
+                    w[i] = (float)h;
                     h = 1.0 / h;
                     c = g * h;
                     s = -f * h;
-                    for (j = 1; j <= m; j++) {
-                        y = mat[j - 1][nm - 1];
-                        z = mat[j - 1][i - 1];
-                        mat[j - 1][nm - 1] = (float)(y * c + z * s);
-                        mat[j - 1][i - 1] = (float)(z * c - y * s);
+                    for (int j = 0; j < 3; j++) {
+                        y = a[j][above];
+                        z = a[j][i];
+                        a[j][above] = (float)(y * c + z * s);
+                        a[j][i] = (float)(z * c - y * s);
                     }
                 }
             }
-            z = w[k - 1];
-            if (l == k) {
+            z = w[k];
+            if (lo == k) { /* converged: make the singular value non-negative */
                 if (z < 0.0) {
-                    w[k - 1] = (float)(-z);
-                    for (j = 1; j <= n; j++) v[j - 1][k - 1] = -v[j - 1][k - 1];
+                    w[k] = (float)(-z);
+                    for (int j = 0; j < 3; j++) v[j][k] = -v[j][k];
                 }
                 break;
             }
-            x = w[l - 1];
-            nm = k - 1;
-            y = w[nm - 1];
-            g = rv1[nm - 1];
-            h = rv1[k - 1];
+            /* shift from the bottom 2x2 minor */
+            x = w[lo];
+            above = k - 1;
+            y = w[above];
+            g = off[above];
+            h = off[k];
             f = ((y - z) * (y + z) + (g - h) * (g + h)) / (2.0 * h * y);
-            g = SVD_PYTHAG(f, 1.0);
-            f = ((x - z) * (x + z) + h * ((y / (f + SVD_SIGN(g, f))) - h)) / x;
+            g = svd_hypot(f, 1.0);
+            f = ((x - z) * (x + z) + h * ((y / (f + svd_with_sign(g, f))) - h)) / x;
+            /* one QR transformation: a chase of Givens rotations down the block */
             c = s = 1.0;
-            for (j = l; j <= nm; j++) {
-                i = j + 1;
-                g = rv1[i - 1];
-                y = w[i - 1];
+            for (int j = lo; j <= above; j++) {
+                const int i = j + 1;
+                g = off[i];
+                y = w[i];
                 h = s * g;
                 g = c * g;
-                z = SVD_PYTHAG(f, h);
-                rv1[j - 1] = z;
+                z = svd_hypot(f, h);
+                off[j] = z;
                 c = f / z;
                 s = h / z;
                 f = x * c + g * s;
                 g = g * c - x * s;
                 h = y * s;
                 y *= c;
-                for (jj = 1; jj <= n; jj++) {
-                    x = v[jj - 1][j - 1];
-                    z = v[jj - 1][i - 1];
-                    v[jj - 1][j - 1] = (float)(x * c + z * s);
-                    v[jj - 1][i - 1] = (float)(z * c - x * s);
+                for (int r = 0; r < 3; r++) {
+                    x = v[r][j];
+                    z = v[r][i];
+                    v[r][j] = (float)(x * c + z * s);
+                    v[r][i] = (float)(z * c - x * s);
                 }
-                z = SVD_PYTHAG(f, h);
-                w[j - 1] = (float)z;
+                z = svd_hypot(f, h);
+                w[j] = (float)z;
                 if (z) {
                     z = 1.0 / z;
                     c = f * z;
@@ -310,16 +330,16 @@ __device__ __forceinline__ void svd3(float mat[3][3], float w[3], float v[3][3])
                 }
                 f = c * g + s * y;
                 x = c * y - s * g;
-                for (jj = 1; jj <= m; jj++) {
-                    y = mat[jj - 1][j - 1];
-                    z = mat[jj - 1][i - 1];
-                    mat[jj - 1][j - 1] = (float)(y * c + z * s);
-                    mat[jj - 1][i - 1] = (float)(z * c - y * s);
+                for (int r = 0; r < 3; r++) {
+                    y = a[r][j];
+                    z = a[r][i];
+                    a[r][j] = (float)(y * c + z * s);
+                    a[r][i] = (float)(z * c - y * s);
                 }
             }
-            rv1[l - 1] = 0.0;
-            rv1[k - 1] = f;
-            w[k - 1] = (float)x;
+            off[lo] = 0.0;
+            off[k] = f;
+            w[k] = (float)x;
         }
     }
 }
