@@ -561,7 +561,7 @@ struct fb_ring_cfg {
 template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int XO>
 __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, XO>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
     const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zlen, int tiles_x,
-    int tiles_y, long long total, fb_taps2 t)
+    int tiles_y, long long total, int prio, fb_taps2 t)
 {
     using C = fb_ring_cfg<R, BR, PF, XO>;
     constexpr int U = 2 * R + 1;
@@ -708,6 +708,9 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, XO>::WAVES_PER_S
     int cur = 0;
     int wslot = 0; /* ring slot of the plane the x pass is working on; the plane stored this step sits in wslot + 1 (mod R+2) */
 
+    /* The x-pass wavefronts carry the longest step (x + y + z pass against y + z) and everyone meets them at the barrier:
+     * give them issue priority over the wavefronts that share their SIMD (`prio`: 0 leaves the arbitration to age). */
+    if (xrole && prio) __builtin_amdgcn_s_setprio(2);
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, PF - 1>;
     if (xrole) {
@@ -846,8 +849,10 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     const int nch = (int)((Z + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
+    static const char *penv = getenv("SIFT3D_RING_PRIO"); /* A/B aid: 0 = no issue priority for the x-pass wavefronts */
+    const int prio = penv ? atoi(penv) : 0;
     hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, XO>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
-                       (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
+                       (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, prio, t);
     return true;
 }
 

@@ -17,6 +17,25 @@ __global__ void k_copy(const v4f *__restrict__ a, v4f *__restrict__ b, long long
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) b[i] = a[i];
 }
+// four independent 16-byte loads per thread in flight before the first store, one-shot grid (what a tuned elementwise kernel does)
+__global__ __launch_bounds__(256) void k_copy4(const v4f *__restrict__ a, v4f *__restrict__ b, long long n)
+{
+    const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+    v4f v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (i0 + 256 * u < n) v[u] = a[i0 + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (i0 + 256 * u < n) b[i0 + 256 * u] = v[u];
+}
+__global__ __launch_bounds__(256) void k_1r2w4(const v4f *__restrict__ a, v4f *__restrict__ b, v4f *__restrict__ c, long long n)
+{
+    const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+    v4f v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (i0 + 256 * u < n) v[u] = a[i0 + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (i0 + 256 * u < n) { b[i0 + 256 * u] = v[u]; c[i0 + 256 * u] = v[u] + v[u]; }
+}
 __global__ void k_1r2w(const v4f *__restrict__ a, v4f *__restrict__ b, v4f *__restrict__ c, long long n, int nt)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -48,6 +67,61 @@ __global__ __launch_bounds__(1024) void k_tile(const float *__restrict__ a, floa
         p0 = q0; p1 = q1;
     }
 }
+// the tile march with PFD planes of the tile in flight per thread (a register ring)
+template <int PFD>
+__global__ __launch_bounds__(512) void k_tile_pf(const float *__restrict__ a, float *__restrict__ b, float *__restrict__ c, int X, int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total)
+{
+    const long long lin = blockIdx.x, per = (total + 7) / 8, w = (lin % 8) * per + lin / 8;
+    if (w >= total) return;
+    const int tx = (int)(w % tiles_x), ty = (int)((w / tiles_x) % tiles_y), ch = (int)(w / ((long long)tiles_x * tiles_y));
+    const int bcp = threadIdx.x & 31, brs = threadIdx.x >> 5;
+    const long long XY = (long long)X * Y;
+    const long long off0 = (long long)(ty * 32 + 2 * brs) * X + tx * 64 + 2 * bcp, off1 = off0 + X;
+    const int z0 = ch * zlen, z1 = z0 + zlen < Z ? z0 + zlen : Z;
+    v2f r0[PFD], r1[PFD];
+#pragma unroll
+    for (int q = 0; q < PFD; q++) {
+        const int z = z0 + q < z1 ? z0 + q : z1 - 1;
+        r0[q] = *reinterpret_cast<const v2f *>(a + z * XY + off0); r1[q] = *reinterpret_cast<const v2f *>(a + z * XY + off1);
+    }
+    for (int z = z0; z < z1; z += PFD) {
+#pragma unroll
+        for (int q = 0; q < PFD; q++) {
+            if (z + q >= z1) break;
+            const v2f p0 = r0[q], p1 = r1[q];
+            const int zn = z + q + PFD < z1 ? z + q + PFD : z1 - 1;
+            r0[q] = *reinterpret_cast<const v2f *>(a + zn * XY + off0); r1[q] = *reinterpret_cast<const v2f *>(a + zn * XY + off1);
+            __builtin_nontemporal_store(p0, reinterpret_cast<v2f *>(b + (z + q) * XY + off0));
+            __builtin_nontemporal_store(p1, reinterpret_cast<v2f *>(b + (z + q) * XY + off1));
+            __builtin_nontemporal_store(p0 + p0, reinterpret_cast<v2f *>(c + (z + q) * XY + off0));
+            __builtin_nontemporal_store(p1 + p1, reinterpret_cast<v2f *>(c + (z + q) * XY + off1));
+        }
+    }
+}
+// the same march with 16-byte accesses: a thread owns 4 consecutive x of ONE row of the 64 x 32 tile (16 lanes per row)
+template <int PFD>
+__global__ __launch_bounds__(512) void k_tile16(const float *__restrict__ a, float *__restrict__ b, float *__restrict__ c, int X, int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total)
+{
+    const long long lin = blockIdx.x, per = (total + 7) / 8, w = (lin % 8) * per + lin / 8;
+    if (w >= total) return;
+    const int tx = (int)(w % tiles_x), ty = (int)((w / tiles_x) % tiles_y), ch = (int)(w / ((long long)tiles_x * tiles_y));
+    const long long XY = (long long)X * Y;
+    const long long off = (long long)(ty * 32 + (threadIdx.x >> 4)) * X + tx * 64 + 4 * (threadIdx.x & 15);
+    const int z0 = ch * zlen, z1 = z0 + zlen < Z ? z0 + zlen : Z;
+    v4f r[PFD];
+#pragma unroll
+    for (int q = 0; q < PFD; q++) r[q] = *reinterpret_cast<const v4f *>(a + (z0 + q < z1 ? z0 + q : z1 - 1) * XY + off);
+    for (int z = z0; z < z1; z += PFD) {
+#pragma unroll
+        for (int q = 0; q < PFD; q++) {
+            if (z + q >= z1) break;
+            const v4f p = r[q];
+            r[q] = *reinterpret_cast<const v4f *>(a + (z + q + PFD < z1 ? z + q + PFD : z1 - 1) * XY + off);
+            __builtin_nontemporal_store(p, reinterpret_cast<v4f *>(b + (z + q) * XY + off));
+            __builtin_nontemporal_store(p + p, reinterpret_cast<v4f *>(c + (z + q) * XY + off));
+        }
+    }
+}
 int main(int argc, char **argv)
 {
     const int N = argc > 1 ? atoi(argv[1]) : 512, reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -73,6 +147,25 @@ int main(int argc, char **argv)
     timeit("copy (1 read + 1 write, float4)", 8.0 * n, [&] { hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, (const v4f *)a, (v4f *)b, n / 4); });
     timeit("1 read + 2 writes, float4", 12.0 * n, [&] { hipLaunchKernelGGL(k_1r2w, dim3(grid), dim3(256), 0, 0, (const v4f *)a, (v4f *)b, (v4f *)c, n / 4, 0); });
     timeit("1 read + 2 writes, float4, nt stores", 12.0 * n, [&] { hipLaunchKernelGGL(k_1r2w, dim3(grid), dim3(256), 0, 0, (const v4f *)a, (v4f *)b, (v4f *)c, n / 4, 1); });
+    timeit("copy, 4 loads in flight per thread, one-shot grid", 8.0 * n, [&] { hipLaunchKernelGGL(k_copy4, dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, 0, (const v4f *)a, (v4f *)b, n / 4); });
+    timeit("1 read + 2 writes, 4 loads in flight, one-shot", 12.0 * n, [&] { hipLaunchKernelGGL(k_1r2w4, dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, 0, (const v4f *)a, (v4f *)b, (v4f *)c, n / 4); });
+    for (int nch : {2, 4}) {
+        const int tiles_x = N / 64, tiles_y = N / 32, zlen = (N + nch - 1) / nch;
+        const long long total = (long long)tiles_x * tiles_y * nch, per = (total + 7) / 8;
+        char nm[96];
+        snprintf(nm, sizeof nm, "tile march 64x32, %d chunks, 1 plane in flight", nch);
+        timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile_pf<1>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+        snprintf(nm, sizeof nm, "tile march 64x32, %d chunks, 2 planes in flight", nch);
+        timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile_pf<2>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+        snprintf(nm, sizeof nm, "tile march 64x32, %d chunks, 4 planes in flight", nch);
+        timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile_pf<4>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+        snprintf(nm, sizeof nm, "tile march 64x32, %d chunks, 16-B accesses, 2 planes in flight", nch);
+        timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile16<2>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+        snprintf(nm, sizeof nm, "tile march 64x32, %d chunks, 16-B accesses, 4 planes in flight", nch);
+        timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile16<4>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+        snprintf(nm, sizeof nm, "tile march 64x32, %d chunks, 8 planes in flight", nch);
+        timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile_pf<8>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+    }
     struct cfg { int threads, nch, lds; };
     for (cfg c : {cfg{512, 2, 0}, cfg{512, 4, 0}, cfg{512, 4, 90 * 1024}, cfg{512, 8, 90 * 1024}, cfg{1024, 2, 0}, cfg{1024, 4, 0}, cfg{1024, 8, 0}}) {
         const int TYt = 2 * (c.threads / 32);
