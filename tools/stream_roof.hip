@@ -98,6 +98,40 @@ __global__ __launch_bounds__(512) void k_tile_pf(const float *__restrict__ a, fl
         }
     }
 }
+// the march with tiles of other shapes at the same area: LX lanes (of 2 floats) per row, 512 threads, 2 rows per thread ->
+// tile = 2*LX floats wide by 2*(512/LX) rows: LX 32 = 64 x 32, 64 = 128 x 16, 128 = 256 x 8, 256 = 512 x 4
+template <int PFD, int LX>
+__global__ __launch_bounds__(1024) void k_tile_w(const float *__restrict__ a, float *__restrict__ b, float *__restrict__ c, int X, int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total)
+{
+    constexpr int TW = 2 * LX;
+    const int TH = 2 * ((int)blockDim.x / LX);
+    const long long lin = blockIdx.x, per = (total + 7) / 8, w = (lin % 8) * per + lin / 8;
+    if (w >= total) return;
+    const int tx = (int)(w % tiles_x), ty = (int)((w / tiles_x) % tiles_y), ch = (int)(w / ((long long)tiles_x * tiles_y));
+    const int bcp = threadIdx.x % LX, brs = threadIdx.x / LX;
+    const long long XY = (long long)X * Y;
+    const long long off0 = (long long)(ty * TH + 2 * brs) * X + tx * TW + 2 * bcp, off1 = off0 + X;
+    const int z0 = ch * zlen, z1 = z0 + zlen < Z ? z0 + zlen : Z;
+    v2f r0[PFD], r1[PFD];
+#pragma unroll
+    for (int q = 0; q < PFD; q++) {
+        const int z = z0 + q < z1 ? z0 + q : z1 - 1;
+        r0[q] = *reinterpret_cast<const v2f *>(a + z * XY + off0); r1[q] = *reinterpret_cast<const v2f *>(a + z * XY + off1);
+    }
+    for (int z = z0; z < z1; z += PFD) {
+#pragma unroll
+        for (int q = 0; q < PFD; q++) {
+            if (z + q >= z1) break;
+            const v2f p0 = r0[q], p1 = r1[q];
+            const int zn = z + q + PFD < z1 ? z + q + PFD : z1 - 1;
+            r0[q] = *reinterpret_cast<const v2f *>(a + zn * XY + off0); r1[q] = *reinterpret_cast<const v2f *>(a + zn * XY + off1);
+            __builtin_nontemporal_store(p0, reinterpret_cast<v2f *>(b + (z + q) * XY + off0));
+            __builtin_nontemporal_store(p1, reinterpret_cast<v2f *>(b + (z + q) * XY + off1));
+            __builtin_nontemporal_store(p0 + p0, reinterpret_cast<v2f *>(c + (z + q) * XY + off0));
+            __builtin_nontemporal_store(p1 + p1, reinterpret_cast<v2f *>(c + (z + q) * XY + off1));
+        }
+    }
+}
 // the same march with 16-byte accesses: a thread owns 4 consecutive x of ONE row of the 64 x 32 tile (16 lanes per row)
 template <int PFD>
 __global__ __launch_bounds__(512) void k_tile16(const float *__restrict__ a, float *__restrict__ b, float *__restrict__ c, int X, int Y, int Z, int zlen, int tiles_x, int tiles_y, long long total)
@@ -165,6 +199,30 @@ int main(int argc, char **argv)
         timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile16<4>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
         snprintf(nm, sizeof nm, "tile march 64x32, %d chunks, 8 planes in flight", nch);
         timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(k_tile_pf<8>, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+    }
+    {
+        const int nch = 2, zlen = (N + nch - 1) / nch;
+        auto run_w = [&](const char *nm, auto kern, int tw, int th) {
+            const int tiles_x = N / tw, tiles_y = N / th;
+            const long long total = (long long)tiles_x * tiles_y * nch, per = (total + 7) / 8;
+            timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(kern, dim3((unsigned)(8 * per)), dim3(512), 0, 0, a, b, c, N, N, N, zlen, tiles_x, tiles_y, total); });
+        };
+        run_w("tile shape  64 x 32, 2 chunks, 2 planes in flight", k_tile_w<2, 32>, 64, 32);
+        run_w("tile shape 128 x 16, 2 chunks, 2 planes in flight", k_tile_w<2, 64>, 128, 16);
+        run_w("tile shape 256 x  8, 2 chunks, 2 planes in flight", k_tile_w<2, 128>, 256, 8);
+        run_w("tile shape 512 x  4, 2 chunks, 2 planes in flight", k_tile_w<2, 256>, 512, 4);
+        run_w("tile shape  64 x 32 again", k_tile_w<2, 32>, 64, 32);
+        auto run_big = [&](const char *nm, auto kern, int tw, int th, int chunks) {   // 1024 threads: twice the area
+            const int zl = (N + chunks - 1) / chunks, tiles_x = N / tw, tiles_y = N / th;
+            const long long total = (long long)tiles_x * tiles_y * chunks, per = (total + 7) / 8;
+            timeit(nm, 12.0 * n, [&] { hipLaunchKernelGGL(kern, dim3((unsigned)(8 * per)), dim3(1024), 0, 0, a, b, c, N, N, N, zl, tiles_x, tiles_y, total); });
+        };
+        run_big("1024 thr, tile 128 x 32, 4 chunks (256 WGs), 2 planes", k_tile_w<2, 64>, 128, 32, 4);
+        run_big("1024 thr, tile 128 x 32, 4 chunks (256 WGs), 4 planes", k_tile_w<4, 64>, 128, 32, 4);
+        run_big("1024 thr, tile 256 x 16, 4 chunks (256 WGs), 2 planes", k_tile_w<2, 128>, 256, 16, 4);
+        run_big("1024 thr, tile 512 x  8, 4 chunks (256 WGs), 2 planes", k_tile_w<2, 256>, 512, 8, 4);
+        run_big("1024 thr, tile  64 x 64, 4 chunks (256 WGs), 2 planes", k_tile_w<2, 32>, 64, 64, 4);
+        run_w("tile shape  64 x 32 once more", k_tile_w<2, 32>, 64, 32);
     }
     struct cfg { int threads, nch, lds; };
     for (cfg c : {cfg{512, 2, 0}, cfg{512, 4, 0}, cfg{512, 4, 90 * 1024}, cfg{512, 8, 90 * 1024}, cfg{1024, 2, 0}, cfg{1024, 4, 0}, cfg{1024, 8, 0}}) {
