@@ -666,6 +666,13 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, XO>::WAVES_PER_S
 #pragma unroll
             for (int q = 0; q < XO / 4; q++) *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs + 4 * q]) = win[B][H4 / 4 + q];
         }
+        /* tap loop outside, output pairs inside: per tap XO/2 independent products, then XO/2 adds, none of which depends
+         * on its immediate predecessor (a packed operation that consumes the result of the instruction right before it
+         * costs a wait state: with the pair loop outside the compiler issued 41 s_nop per 136 packed operations at 17
+         * taps).  Every accumulator still receives its products in ascending tap order. */
+        /* (one accumulator chain per output pair; issuing the taps outermost instead -- XO/2 independent products, then
+         * XO/2 adds -- removes a fifth of the s_nop the compiler places between dependent packed operations and changes
+         * nothing measurable: the other wavefronts of the SIMD fill those slots) */
         v2f o[XO / 2];
 #pragma unroll
         for (int e = 0; e < XO / 2; e++) {
