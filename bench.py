@@ -424,7 +424,11 @@ def main():
                                    % (n, ["SIFT-rank", "BRIEF", "RRIEF", "NRRIEF"][args.desc]),
                        "records_per_volume": int(nrec), "octaves": int(tim["n_octaves"]), "extrema": int(tim["n_extrema"]),
                        "keypoints": int(tim["n_keypoints"]),
-                       "parallelism": "1 volume per GPU (independent volumes, no collective)" if world > 1 else "single GPU"},
+                       "parallelism": "1 volume per GPU (independent volumes, no collective)" if world > 1 else "single GPU",
+                       "descriptor_parity": ("SIFT-rank: pinned against the reference (see DESIGN.md section 2)" if args.desc == 0 else
+                                             "BRIEF / RRIEF / NRRIEF exist in the reference only as commented alternatives "
+                                             "(MultiScale.cpp:1037-1045): HIP == oracle bit for bit, but the oracle rows are unpinned "
+                                             "against the reference")},
             "roofline": roofline, "pyramid": pyramid, "stages": stages,
         }
         if world == 1 and args.cpu_sample > 0:

@@ -660,6 +660,22 @@ def test_c_zslab_driver_matches_single_gpu(built, dims, seed, mode, devs, scale)
     assert st["gather_bytes"] > 0
 
 
+def test_config_c5_shape_of_work_on_one_gpu(built):
+    """BASELINE config C5 (2048 x 2048 x 1024 over 8 GPUs, NRRIEF) needs eight GPUs at its own size.  Its shape of work --
+    eight Z-slabs of 128 slices, six ranks with a neighbour on both sides, three sharded octaves, the NRRIEF descriptor -- is
+    rehearsed here with the rows and columns cut to 192 x 160: the C driver with device 0 listed eight times against the
+    single-GPU extraction of the same volume, byte for byte."""
+    dims = (192, 160, 1024)
+    vol = vol_of(built, dims, 2025)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract(desc_mode=built.DESC_NRRIEF)
+    got, st = built.extract_zslab(vol, [0] * 8, desc_mode=built.DESC_NRRIEF)
+    assert st["n_ranks"] == 8 and st["sharded_octaves"] == 3
+    assert len(want) > 5000 and got.tobytes() == want.tobytes()
+    assert st["halo_bytes_deferred"] * 40 == st["halo_bytes_critical"] * 72
+
+
 def test_c_zslab_driver_edge_cases(built):
     vol = vol_of(built, (48, 40, 60), 3)                                    # too thin for 32-slice slabs: one rank, the serial path
     with built.Context(48, 40, 60) as ctx:
