@@ -125,6 +125,9 @@ def hip_lib():
     _sig(L.sift3d_describe_dev, I, P, P, I, I, F, F, P, P, P)
     _sig(L.sift3d_set_max_octaves, I, P, I)
     _sig(L.sift3d_extract_zslab, I, P, I, P, I64, I64, I64, F, I, F, F, P, P, P, C.c_char_p, I64)
+    _sig(L.sift3d_zslab_create, P, P, I, I64, I64, I64, C.c_char_p, I64)
+    _sig(L.sift3d_zslab_extract, I, P, P, F, I, F, F, P, P, P, C.c_char_p, I64)
+    _sig(L.sift3d_zslab_destroy, None, P)
     _hip = L
     return L
 
@@ -156,7 +159,7 @@ class ZSlabStats(C.Structure):
     """sift3d_zslab_stats"""
     _fields_ = [("n_ranks", C.c_int32), ("sharded_octaves", C.c_int32), ("exchanges", C.c_int64), ("halo_bytes_critical", C.c_int64),
                 ("halo_bytes_deferred", C.c_int64), ("gather_bytes", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
-                ("n_records", C.c_int64)]
+                ("n_records", C.c_int64), ("wall_ms", C.c_double)]
 
 
 def extract_zslab(vol, devices, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
@@ -177,6 +180,52 @@ def extract_zslab(vol, devices, initial_image_scale=1.0, desc_mode=DESC_SIFT, ei
     finally:
         hip_lib().sift3d_free(out)
     return recs, {k: getattr(st, k) for k, _ in ZSlabStats._fields_}
+
+
+class ZSlab:
+    """sift3d_zslab_create / _extract / _destroy: the slabs' contexts kept between volumes of one shape."""
+
+    def __init__(self, nx, ny, nz, devices):
+        self._L = hip_lib()
+        dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+        err = C.create_string_buffer(512)
+        self._h = self._L.sift3d_zslab_create(dev, len(devices), nx, ny, nz, err, 512)
+        if not self._h:
+            raise Sift3DError("sift3d_zslab_create: %s" % err.value.decode(errors="replace"))
+        self.shape = (nz, ny, nx)
+
+    def extract(self, vol, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
+        vol = _f32(vol)
+        assert vol.shape == self.shape, (vol.shape, self.shape)
+        out, n, st, err = C.c_void_p(), C.c_int64(0), ZSlabStats(), C.create_string_buffer(512)
+        rc = self._L.sift3d_zslab_extract(self._h, vol.ctypes.data, float(initial_image_scale), int(desc_mode), float(eig_thres),
+                                          float(size_factor), C.byref(out), C.byref(n), C.byref(st), err, 512)
+        if rc != 0:
+            e = Sift3DError("sift3d_zslab_extract -> %d: %s" % (rc, err.value.decode(errors="replace")))
+            e.code = rc
+            raise e
+        try:
+            recs = np.frombuffer((C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(out.value), FEATURE_DTYPE, n.value).copy() if n.value else np.zeros(0, FEATURE_DTYPE)
+        finally:
+            self._L.sift3d_free(out)
+        return recs, {k: getattr(st, k) for k, _ in ZSlabStats._fields_}
+
+    def close(self):
+        if self._h:
+            self._L.sift3d_zslab_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count():

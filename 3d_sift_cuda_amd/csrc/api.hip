@@ -14,6 +14,7 @@
  * exactly one x, one y and one z(+DoG) pass and read by one extrema pass.
  */
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1445,19 +1446,42 @@ struct zs_rank {
     hipEvent_t ev_level = nullptr;     /* this rank's current level is complete (its own slices are final) */
     hipEvent_t ev_l3 = nullptr;        /* L1..L3 of the current octave are complete */
     hipEvent_t ev_patch = nullptr;     /* the patch-halo copies into this rank are done */
-    std::vector<float *> allocs;       /* everything this run allocated on the device */
+    std::vector<float *> allocs;       /* what this run had to allocate beside the arena */
+    float *arena = nullptr;            /* one block reused from run to run (sized after the first run of a handle) */
+    int64_t arena_cap = 0, arena_used = 0, need = 0; /* floats */
     float *L[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *D[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t z0 = 0, z1 = 0, e0 = 0, e1 = 0; /* current octave: own slices [z0, z1), buffer extent [e0, e1) */
     bool lo = false, hi = false;
     std::vector<sift3d_level> levels;
     float *alloc(int64_t nfloats)
     {
+        nfloats = ((nfloats > 0 ? nfloats : 1) + 63) / 64 * 64; /* 256-byte granules */
+        need += nfloats;
+        if (arena && arena_used + nfloats <= arena_cap) {
+            float *p = arena + arena_used;
+            arena_used += nfloats;
+            return p;
+        }
         float *p = nullptr;
-        if (hipMalloc((void **)&p, sizeof(float) * (size_t)(nfloats > 0 ? nfloats : 1)) != hipSuccess) return nullptr;
+        if (hipMalloc((void **)&p, sizeof(float) * (size_t)nfloats) != hipSuccess) return nullptr;
         allocs.push_back(p);
         return p;
     }
+    /* end of a run: drop what was allocated beside the arena and make the arena big enough for a run like this one */
+    void recycle()
+    {
+        for (float *p : allocs) hipFree(p);
+        allocs.clear();
+        if (need > arena_cap) {
+            hipFree(arena);
+            arena = nullptr;
+            arena_cap = 0;
+            if (hipMalloc((void **)&arena, sizeof(float) * (size_t)need) == hipSuccess) arena_cap = need;
+        }
+        arena_used = need = 0;
+    }
 };
+
 
 #define ZS_HIP(call)                                                                                                   \
     do {                                                                                                               \
@@ -1487,37 +1511,105 @@ struct zs_rank {
     } while (0)
 } // namespace
 
-extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
-                                    float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
-                                    sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
+struct sift3d_zslab {
+    zs_plan plan;
+    std::vector<int> devices;
+    std::vector<zs_rank> R; /* one per slab; a single one when the volume is too thin to shard */
+    sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
+};
+
+extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
+{
+    if (!h) return;
+    for (zs_rank &q : h->R) {
+        if (!q.c) continue;
+        hipSetDevice(q.dev);
+        hipStreamSynchronize(q.c->stream);
+        if (q.copy_stream) { hipStreamSynchronize(q.copy_stream); hipStreamDestroy(q.copy_stream); }
+        for (float *p : q.allocs) hipFree(p);
+        hipFree(q.arena);
+        if (q.ev_level) hipEventDestroy(q.ev_level);
+        if (q.ev_l3) hipEventDestroy(q.ev_l3);
+        if (q.ev_patch) hipEventDestroy(q.ev_patch);
+        sift3d_destroy(q.c);
+    }
+    delete h;
+}
+
+extern "C" sift3d_zslab *sift3d_zslab_create(const int *devices, int n_devices, int64_t nx, int64_t ny, int64_t nz, char *err, int64_t err_len)
+{
+    char errbuf[512] = "";
+    int rc = SIFT3D_OK;
+    if (err && err_len > 0) err[0] = 0;
+    auto fail = [&](const char *msg) -> sift3d_zslab * {
+        if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", msg);
+        return nullptr;
+    };
+    if (!devices || n_devices < 1 || n_devices > 64 || nx <= 0 || ny <= 0 || nz <= 1) return fail("bad arguments");
+    const int ndev = sift3d_device_count();
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= ndev) {
+            snprintf(errbuf, sizeof errbuf, "no HIP device %d", devices[i]);
+            return fail(errbuf);
+        }
+    sift3d_zslab *h = new sift3d_zslab(nx, ny, nz, n_devices);
+    const int S = h->plan.K > 0 ? n_devices : 1; /* too thin to shard: the whole volume on the first device */
+    h->devices.assign(devices, devices + n_devices);
+    h->R.resize((size_t)S);
+    for (int r = 0; r < S; r++) {
+        zs_rank &q = h->R[(size_t)r];
+        q.dev = devices[r];
+        int64_t i0 = 0, i1 = nz;
+        if (S > 1) h->plan.input_range(r, i0, i1);
+        ZS_HIP(hipSetDevice(q.dev));
+        q.c = sift3d_create(q.dev, nx, ny, (i1 - i0) + 2 * ZS_HALO);
+        if (!q.c) {
+            snprintf(errbuf, sizeof errbuf, "rank %d: no context on device %d (memory?)", r, q.dev);
+            rc = SIFT3D_ERR_MEMORY;
+            goto done;
+        }
+        ZS_HIP(hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking));
+        ZS_HIP(hipEventCreateWithFlags(&q.ev_level, hipEventDisableTiming));
+        ZS_HIP(hipEventCreateWithFlags(&q.ev_l3, hipEventDisableTiming));
+        ZS_HIP(hipEventCreateWithFlags(&q.ev_patch, hipEventDisableTiming));
+        for (int p = 0; p < S; p++) /* direct copies between the devices where the fabric allows (errors: already on, or same device) */
+            if (devices[p] != q.dev) (void)hipDeviceEnablePeerAccess(devices[p], 0);
+        (void)hipGetLastError();
+    }
+done:
+    if (rc != SIFT3D_OK) {
+        sift3d_zslab_destroy(h);
+        return fail(errbuf);
+    }
+    return h;
+}
+
+extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_scale, int desc_mode, float eig_thres,
+                                    float size_factor, sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
+                                    int64_t err_len)
 {
     char errbuf[512] = "";
     int rc = SIFT3D_OK;
     int r = 0;
     if (err && err_len > 0) err[0] = 0;
-    if (!devices || n_devices < 1 || n_devices > 64 || !vol || !out || !n_out || nx <= 0 || ny <= 0 || nz <= 1 ||
-        desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) {
+    if (!h || !vol || !out || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) {
         if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
         return SIFT3D_ERR_ARG;
     }
-    const int ndev = sift3d_device_count();
-    for (int i = 0; i < n_devices; i++)
-        if (devices[i] < 0 || devices[i] >= ndev) {
-            if (err && err_len > 0) snprintf(err, (size_t)err_len, "no HIP device %d", devices[i]);
-            return SIFT3D_ERR_ARG;
-        }
     *out = nullptr;
     *n_out = 0;
-    zs_plan plan(nx, ny, nz, n_devices);
-    const int S = plan.K > 0 ? n_devices : 1; /* too thin to shard: the whole volume on the first device */
+    const zs_plan &plan = h->plan;
+    const int64_t nx = plan.nx, ny = plan.ny, nz = plan.nz;
+    std::vector<zs_rank> &R = h->R;
+    const int S = (int)R.size();
     const int K = plan.K;
     sift3d_zslab_stats st;
     memset(&st, 0, sizeof st);
     st.n_ranks = S;
     st.sharded_octaves = S > 1 ? K : 0;
-    std::vector<zs_rank> R((size_t)S);
     std::vector<std::vector<sift3d_feature>> recs((size_t)S);
     std::vector<std::vector<int>> grps((size_t)S);
+    const auto wall0 = std::chrono::steady_clock::now();
 
     /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
     float sigma_init = 0.5f;
@@ -1538,27 +1630,13 @@ extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const flo
     for (int i = 0; i < 64; i++) next0[i] = nullptr;
     float fscale = 1.0f;
 
-    /* ---- contexts, input slabs, level 0 of octave 0 ---- */
+    /* ---- input slabs, level 0 of octave 0 ---- */
     for (r = 0; r < S; r++) {
         zs_rank &q = R[(size_t)r];
-        q.dev = devices[r];
         int64_t i0 = 0, i1 = nz;
         if (S > 1) plan.input_range(r, i0, i1);
         ZS_HIP(hipSetDevice(q.dev));
-        q.c = sift3d_create(q.dev, nx, ny, (i1 - i0) + 2 * ZS_HALO);
-        if (!q.c) {
-            snprintf(errbuf, sizeof errbuf, "rank %d: no context on device %d (memory?)", r, q.dev);
-            rc = SIFT3D_ERR_MEMORY;
-            goto done;
-        }
-        ZS_HIP(hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_level, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_l3, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_patch, hipEventDisableTiming));
         q.levels.assign(plan.oct.size() * 3, sift3d_level());
-        for (int p = 0; p < S; p++) /* direct copies between the devices where the fabric allows (errors: already on, or same device) */
-            if (devices[p] != q.dev) (void)hipDeviceEnablePeerAccess(devices[p], 0);
-        (void)hipGetLastError();
         ZS_RC(cand_reset(q.c));
         timing_begin(q.c);
         /* level 0 = initial blur of the input, on slab +- 8 from input slab +- 16 */
@@ -1770,19 +1848,35 @@ extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const flo
     }
 
 done:
-    for (size_t i = 0; i < R.size(); i++) {
+    for (size_t i = 0; i < R.size(); i++) { /* everything queued has to be done before the buffers go back */
         zs_rank &q = R[i];
-        if (!q.c) continue;
         hipSetDevice(q.dev);
         hipStreamSynchronize(q.c->stream);
-        if (q.copy_stream) { hipStreamSynchronize(q.copy_stream); hipStreamDestroy(q.copy_stream); }
-        for (float *p : q.allocs) hipFree(p);
-        if (q.ev_level) hipEventDestroy(q.ev_level);
-        if (q.ev_l3) hipEventDestroy(q.ev_l3);
-        if (q.ev_patch) hipEventDestroy(q.ev_patch);
-        sift3d_destroy(q.c);
+        hipStreamSynchronize(q.copy_stream);
     }
+    for (size_t i = 0; i < R.size(); i++) {
+        hipSetDevice(R[i].dev);
+        R[i].recycle();
+    }
+    st.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = st;
     if (rc != SIFT3D_OK && err && err_len > 0) snprintf(err, (size_t)err_len, "%s", errbuf);
+    return rc;
+}
+
+extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
+                                    float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                                    sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
+{
+    if (out) *out = nullptr;
+    if (n_out) *n_out = 0;
+    if (!vol || !out || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) {
+        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
+        return SIFT3D_ERR_ARG;
+    }
+    sift3d_zslab *h = sift3d_zslab_create(devices, n_devices, nx, ny, nz, err, err_len);
+    if (!h) return (err && err_len > 0 && strstr(err, "memory")) ? SIFT3D_ERR_MEMORY : SIFT3D_ERR_ARG;
+    const int rc = sift3d_zslab_extract(h, vol, initial_image_scale, desc_mode, eig_thres, size_factor, out, n_out, stats, err, err_len);
+    sift3d_zslab_destroy(h);
     return rc;
 }

@@ -147,9 +147,9 @@ __device__ __forceinline__ float v3_dot(const float *a, const float *b) { return
  * sweeps).  The eigenvectors go into the records, so this has to produce the reference's bits, and for that every
  * floating-point operation has to be the reference's, in its order and in its width: storage in float, running values in
  * double, a product of two stored floats rounded to float before it enters a double sum.  Written here for the 3x3 case
- * with 0-based indices (the sizes folded in, the branches that cannot be taken removed) and pinned twice: the oracle's
- * restatement against the reference's own template compiled into oracle/_ref (bit-exact on 4 000 tensors), and this
- * function against the oracle through every record of the pipeline tests. */
+ * with 0-based indices (the sizes folded in, the branches that cannot be taken removed) and pinned twice by the test
+ * suite: its CPU restatement against the reference's own template compiled from source (bit-exact on 4 000 tensors), and
+ * this function against that restatement through every record of the pipeline tests. */
 __device__ __forceinline__ double svd_with_sign(double magnitude, double sign_source) { return sign_source >= 0.0 ? fabs(magnitude) : -fabs(magnitude); }
 __device__ __forceinline__ double svd_hypot(double p, double q) { return sqrt(p * p + q * q); }
 

@@ -224,10 +224,20 @@ typedef struct {
     int64_t halo_bytes_deferred;  /* the rest of the L1..L3 patch halos, copied beside L4 / L5 / extrema */
     int64_t gather_bytes;         /* the first unsharded octave assembled on rank 0 */
     int64_t n_extrema, n_keypoints, n_records;
+    double wall_ms;               /* host wall time of the extraction: upload of the slabs, pyramid, per-keypoint stage, download, merge */
 } sift3d_zslab_stats;
 int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
                          float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,
                          int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len);
+/* The same with the contexts, streams and events of the slabs kept between volumes of one shape: create once, extract any
+ * number of volumes (the level buffers of a run come from one arena per slab, sized after the first run), destroy.
+ * sift3d_extract_zslab is create + extract + destroy; creating the contexts dominates its wall time. */
+typedef struct sift3d_zslab sift3d_zslab;
+sift3d_zslab *sift3d_zslab_create(const int *devices, int n_devices, int64_t nx, int64_t ny, int64_t nz, char *err, int64_t err_len);
+int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_scale, int desc_mode, float eig_thres,
+                         float size_factor, sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
+                         int64_t err_len);
+void sift3d_zslab_destroy(sift3d_zslab *h);
 
 /* ---- measurement ------------------------------------------------------------
  * Device time per stage of the last sift3d_detect/sift3d_extract call, from

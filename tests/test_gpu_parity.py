@@ -660,6 +660,29 @@ def test_c_zslab_driver_matches_single_gpu(built, dims, seed, mode, devs, scale)
     assert st["gather_bytes"] > 0
 
 
+def test_c_zslab_handle_is_reusable(built):
+    """sift3d_zslab_create / _extract / _destroy: several volumes of one shape through one handle (the first run sizes the
+    arena the later ones use), alternating descriptor modes; every result is the single-GPU one, byte for byte."""
+    dims = (80, 72, 200)
+    vols = [vol_of(built, dims, sd) for sd in (41, 42)] + [np.zeros(dims[::-1], np.float32)]
+    with built.Context(*dims) as ctx:
+        want = {}
+        for i, v in enumerate(vols):
+            ctx.set_volume(v)
+            for mode in (0, 3):
+                want[(i, mode)] = ctx.extract(desc_mode=mode)
+    with built.ZSlab(dims[0], dims[1], dims[2], [0, 0, 0]) as h:
+        for rnd in range(2):
+            for i, v in enumerate(vols):
+                for mode in (0, 3):
+                    got, st = h.extract(v, desc_mode=mode)
+                    assert got.tobytes() == want[(i, mode)].tobytes(), (rnd, i, mode)
+                    assert st["n_ranks"] == 3 and st["wall_ms"] > 0
+    assert len(want[(0, 0)]) > 100 and len(want[(2, 0)]) == 0
+    with pytest.raises(built.Sift3DError):
+        built.ZSlab(dims[0], dims[1], dims[2], [0, 42])
+
+
 def test_config_c5_shape_of_work_on_one_gpu(built):
     """BASELINE config C5 (2048 x 2048 x 1024 over 8 GPUs, NRRIEF) needs eight GPUs at its own size.  Its shape of work --
     eight Z-slabs of 128 slices, six ranks with a neighbour on both sides, three sharded octaves, the NRRIEF descriptor -- is

@@ -11,10 +11,17 @@ nx, ny, nz = (int(v) for v in sys.argv[1:4])
 devs = [int(v) for v in sys.argv[4].split(",")]
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 vol = pkg.synth_blobs(nx, ny, nz, seed=12345)
-for it in range(reps):
-    t0 = time.perf_counter(); recs, st = pkg.extract_zslab(vol, devs); dt = time.perf_counter() - t0
-    print("z-slabs over devices %s: %d records in %.1f ms wall (incl. contexts, upload of %.2f GB, download); %s" % (devs, len(recs), dt * 1e3, vol.nbytes / 1e9, st), flush=True)
+t0 = time.perf_counter(); recs, st = pkg.extract_zslab(vol, devs); dt = time.perf_counter() - t0
+print("one-shot (contexts created and destroyed inside the call): %d records in %.1f ms wall; %s" % (len(recs), dt * 1e3, st), flush=True)
+t0 = time.perf_counter()
+with pkg.ZSlab(nx, ny, nz, devs) as h:
+    print("handle created in %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+    for it in range(reps + 1):
+        recs, st = h.extract(vol)
+        print("  extract %d through the handle: %d records, %.1f ms wall (upload of %.2f GB of slabs, pyramid, per-keypoint stage, download, merge)%s"
+              % (it, len(recs), st["wall_ms"], vol.nbytes / 1e9, "  [first run: buffers allocated one by one, arena sized afterwards]" if it == 0 else ""), flush=True)
 with pkg.Context(nx, ny, nz, device=devs[0]) as ctx:
     t0 = time.perf_counter(); ctx.set_volume(vol); want = ctx.extract(); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); ctx.set_volume(vol); ctx.extract(); dt1 = time.perf_counter() - t0
     t0 = time.perf_counter(); ctx.extract(copy=False); dt2 = time.perf_counter() - t0
-print("single device: %d records, %.1f ms with upload, %.1f ms resident; identical bytes: %s" % (len(want), dt * 1e3, dt2 * 1e3, recs.tobytes() == want.tobytes()))
+print("single device: %d records, %.1f ms with upload (first call %.1f), %.1f ms resident; identical bytes: %s" % (len(want), dt1 * 1e3, dt * 1e3, dt2 * 1e3, recs.tobytes() == want.tobytes()))
