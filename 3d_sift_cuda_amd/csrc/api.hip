@@ -1536,11 +1536,14 @@ extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
     delete h;
 }
 
-extern "C" sift3d_zslab *sift3d_zslab_create(const int *devices, int n_devices, int64_t nx, int64_t ny, int64_t nz, char *err, int64_t err_len)
+/* status_out (may be NULL) receives the sift3d_status behind a NULL result */
+static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_t nx, int64_t ny, int64_t nz, char *err, int64_t err_len,
+                                       int *status_out)
 {
     char errbuf[512] = "";
     int rc = SIFT3D_OK;
     if (err && err_len > 0) err[0] = 0;
+    if (status_out) *status_out = SIFT3D_ERR_ARG;
     auto fail = [&](const char *msg) -> sift3d_zslab * {
         if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", msg);
         return nullptr;
@@ -1577,11 +1580,17 @@ extern "C" sift3d_zslab *sift3d_zslab_create(const int *devices, int n_devices, 
         (void)hipGetLastError();
     }
 done:
+    if (status_out) *status_out = rc;
     if (rc != SIFT3D_OK) {
         sift3d_zslab_destroy(h);
         return fail(errbuf);
     }
     return h;
+}
+
+extern "C" sift3d_zslab *sift3d_zslab_create(const int *devices, int n_devices, int64_t nx, int64_t ny, int64_t nz, char *err, int64_t err_len)
+{
+    return zslab_create_impl(devices, n_devices, nx, ny, nz, err, err_len, nullptr);
 }
 
 extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_scale, int desc_mode, float eig_thres,
@@ -1874,8 +1883,9 @@ extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const flo
         if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
         return SIFT3D_ERR_ARG;
     }
-    sift3d_zslab *h = sift3d_zslab_create(devices, n_devices, nx, ny, nz, err, err_len);
-    if (!h) return (err && err_len > 0 && strstr(err, "memory")) ? SIFT3D_ERR_MEMORY : SIFT3D_ERR_ARG;
+    int status = SIFT3D_ERR_ARG;
+    sift3d_zslab *h = zslab_create_impl(devices, n_devices, nx, ny, nz, err, err_len, &status);
+    if (!h) return status != SIFT3D_OK ? status : SIFT3D_ERR_MEMORY;
     const int rc = sift3d_zslab_extract(h, vol, initial_image_scale, desc_mode, eig_thres, size_factor, out, n_out, stats, err, err_len);
     sift3d_zslab_destroy(h);
     return rc;
