@@ -419,26 +419,31 @@ __device__ __forceinline__ float serial_sum_patch(const float *d)
      * previous block is being added, so the LDS latency stays off the add chain */
     float acc = 0;
     const v4f *d4 = reinterpret_cast<const v4f *>(d);
-    v4f cur[8], nxt[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) cur[q] = d4[q];
-    for (int blk = 0; blk < 41; blk++) {
-        if (blk + 1 < 41) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) nxt[q] = d4[(blk + 1) * 8 + q];
-        }
+    /* two register buffers used alternately (the block loop unrolled by two): a single buffer pair with a copy at the end
+     * of every block cost 32 register moves per 32 additions, doubling the instructions of a chain that runs on one lane */
+    v4f a[8], b[8];
+    auto add_block = [&](const v4f(&blk)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const v4f v = cur[q];
+            const v4f v = blk[q];
             if (SQUARE) {
                 acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
             } else {
                 acc += v.x; acc += v.y; acc += v.z; acc += v.w;
             }
         }
+    };
 #pragma unroll
-        for (int q = 0; q < 8; q++) cur[q] = nxt[q];
+    for (int q = 0; q < 8; q++) a[q] = d4[q];
+    for (int blk = 0; blk + 1 < 41; blk += 2) { /* blocks blk (in a) and blk + 1 (into b), then blk + 2 into a */
+#pragma unroll
+        for (int q = 0; q < 8; q++) b[q] = d4[(blk + 1) * 8 + q];
+        add_block(a);
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = d4[(blk + 2) * 8 + q]; /* blk + 2 <= 40: the last block, added after the loop */
+        add_block(b);
     }
+    add_block(a); /* block 40 */
     for (int i = 41 * 32; i < PV; i++) acc += SQUARE ? d[i] * d[i] : d[i];
     return acc;
 }
