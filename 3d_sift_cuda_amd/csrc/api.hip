@@ -40,6 +40,11 @@ struct level_job {
     int z_lo, z_hi;
     int lvl_id;
     int64_t Xl;      /* logical row length (0: same as X) */
+    /* neighbour levels that are not stored (sift3d_extrema_lazy): the level below is dp - prev_b; the level above is
+     * next_g - blur(next_g, next_taps), evaluated around the candidates only (dn is NULL then) */
+    const float *prev_b = nullptr, *next_g = nullptr;
+    float next_taps[2 * SIFT3D_FAST_MAX_R + 1] = {};
+    int next_ntaps = 0;
 };
 
 struct octave_dims {
@@ -74,6 +79,9 @@ struct sift3d_ctx {
     int64_t cand_cap;
     unsigned long long *d_count; /* [0] validated extrema, [1] own-level survivors of the level in flight, [2] survivor overflow high-water mark */
     sift3d_survivor *surv;
+    sift3d_survivor2 *list2;         /* extrema that passed the level below, waiting for the lazily evaluated level above */
+    int64_t list2_cap;
+    unsigned long long *list2_counts; /* one length word per extrema pass (SIFT3D_SURV_SETS), zeroed with surv_counts */
     unsigned long long *surv_counts; /* segment counters of the own-level list: SIFT3D_SURV_SETS sets */
     int surv_set;                    /* next unused set since the last reset */
     int64_t surv_cap;
@@ -152,6 +160,8 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->vals_b);
     hipFree(c->d_count);
     hipFree(c->surv);
+    hipFree(c->list2);
+    hipFree(c->list2_counts);
     hipFree(c->surv_counts);
     hipFree(c->sort_tmp);
     hipFree(c->scan_tmp);
@@ -230,6 +240,9 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->vals_a = c->vals_b = nullptr;
     c->d_count = nullptr;
     c->surv = nullptr;
+    c->list2 = nullptr;
+    c->list2_cap = 0;
+    c->list2_counts = nullptr;
     c->surv_counts = nullptr;
     c->surv_cap = 0;
     c->surv_div = 64;
@@ -285,6 +298,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
     ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->surv_counts, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->list2_counts, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
     c->surv_set = 0;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess; /* the clears above are done before the context is handed out */
     if (!ok) {
@@ -729,6 +743,7 @@ static int cand_reset(sift3d_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
     /* every extrema pass of the run gets its own counter set: one memset here instead of one per pass */
     HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, c->stream));
     c->surv_set = 0;
     return SIFT3D_OK;
 }
@@ -743,9 +758,35 @@ static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
     int64_t cover = j.X * j.Y * j.Z / c->surv_div + 64 * 1024; /* split evenly over 64 segments */
     if (cover > c->surv_cap) cover = c->surv_cap;
     const bool fresh = c->surv_set < SIFT3D_SURV_SETS;
-    unsigned long long *counters = c->surv_counts + (size_t)(fresh ? c->surv_set++ : SIFT3D_SURV_SETS - 1) * SIFT3D_SURV_COUNTERS;
+    const int set = fresh ? c->surv_set++ : SIFT3D_SURV_SETS - 1;
+    unsigned long long *counters = c->surv_counts + (size_t)set * SIFT3D_SURV_COUNTERS;
+    sift3d_extrema_lazy lz;
+    memset(&lz, 0, sizeof(lz));
+    const bool lazy = j.prev_b || j.next_g;
+    if (lazy) {
+        lz.prev_b = j.prev_b;
+        lz.next_g = j.next_g;
+        if (j.next_g) {
+            /* the second list holds a subset of the own-level list: the same capacity always suffices */
+            if (c->list2_cap < cover) {
+                HIPCHK(c, hipStreamSynchronize(st)); /* an earlier pass may still be reading the list */
+                hipFree(c->list2);
+                c->list2 = nullptr;
+                c->list2_cap = 0;
+                HIPCHK(c, hipMalloc((void **)&c->list2, sizeof(sift3d_survivor2) * (size_t)cover));
+                c->list2_cap = cover;
+            }
+            lz.ntaps = j.next_ntaps;
+            memcpy(lz.taps, j.next_taps, sizeof(lz.taps));
+            lz.list2 = c->list2;
+            lz.list2_count = c->list2_counts + (size_t)set * SIFT3D_LIST2_COUNTERS;
+            lz.list2_cap = c->list2_cap;
+            if (!fresh) HIPCHK(c, hipMemsetAsync(lz.list2_count, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS, st));
+        }
+    }
     HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Xl ? j.Xl : j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
-                                    c->vals_a, c->d_count, c->cand_cap, c->surv, counters, c->d_count + 2, cover, !fresh));
+                                    c->vals_a, c->d_count, c->cand_cap, c->surv, counters, c->d_count + 2, cover, !fresh,
+                                    lazy ? &lz : nullptr));
     return SIFT3D_OK;
 }
 
@@ -753,6 +794,7 @@ static int cand_replay(sift3d_ctx *c)
 {
     HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, c->stream));
     c->surv_set = 0;
     for (const level_job &j : c->jobs) {
         int rc = cand_append(c, j, false);
@@ -1160,6 +1202,26 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 else sc.cancel();
             }
         }
+        /* Levels nothing reads in full are not computed in full.  D_0 is only ever looked at around the extrema of D_1
+         * and D_4 around those of D_3 (26 + 27 + 27 test), and L_5 exists only to make D_4.  The reference does the same
+         * in its own way: it never materialises the DoG level above a detection level but takes G1 - G2 at the 27
+         * positions (validateDifferencePeak3D, MultiScale.cpp:1135-1223) -- though it still blurs the whole volume for
+         * L_5.  Here D_0 is taken as L_0 - L_1 at those positions and L_5 is filtered only in the 27-voxel neighbourhood
+         * of what passed every other test (extrema_validate_lazy_kernel: same operations, same order, same bits).  Per
+         * octave that is one 17-tap blur of the whole volume and two DoG stores less.  SIFT3D_LAZY_LEVELS=0 (A/B, tests):
+         * every level stored, as before. */
+        const char *lenv = getenv("SIFT3D_LAZY_LEVELS");
+        float next_taps[SIFT3D_MAX_TAPS];
+        int next_ntaps = 0;
+        bool lazy = !tiny_done && d.XP >= 8 && d.Y >= 3 && d.Z >= 3 && d.XP * d.Y < (1ll << 29) && !(lenv && atoi(lenv) == 0);
+        if (lazy) {
+            float sg = 1.6f; /* sigma entering j = 5, accumulated as the loop below does */
+            for (int j = 1; j < 5; j++) sg *= factor;
+            next_ntaps = sift3d_gauss_taps(sg * sqrtf(factor * factor - 1.0f), 0.01f, next_taps);
+            if (next_ntaps < 3 || next_ntaps > 2 * SIFT3D_FAST_MAX_R + 1) lazy = false;
+        }
+        const int lazy_from = lenv ? atoi(lenv) - 1 : 0; /* A/B aid: SIFT3D_LAZY_LEVELS=n+1: the level above D_3 is stored on octaves below n */
+        const bool lazy_next = lazy && (int)o >= lazy_from;
         for (int j = 1; j < 6; j++) {
             if (tiny_done) {
                 if (j == 3 && o + 1 < oct.size()) {
@@ -1177,10 +1239,13 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             const float ex = sigma * sqrtf(factor * factor - 1.0f);
             /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
             /* nothing reads L_5: only D_4 = L_4 - L_5 is needed, so the last level is not stored */
-            rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, c->D[j - 1] + d.off, d.XP, d.Y, d.Z, ex, 0.01f);
-            if (rc) return rc;
-            if (d.XP != d.X) /* the blur ran over the pitched width: its pad columns go back to zero */
-                HIPCHK(c, sift3d_launch_zero_pad(c->stream, j < 5 ? c->L[j] + d.off : nullptr, c->D[j - 1] + d.off, d.XP, d.X, d.Y * d.Z));
+            if (!(lazy_next && j == 5)) {
+                float *dst_dog = (lazy && j == 1) ? nullptr : c->D[j - 1] + d.off;
+                rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.Y, d.Z, ex, 0.01f);
+                if (rc) return rc;
+                if (d.XP != d.X) /* the blur ran over the pitched width: its pad columns go back to zero */
+                    HIPCHK(c, sift3d_launch_zero_pad(c->stream, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.X, d.Y * d.Z));
+            }
             if (j == 3 && o + 1 < oct.size()) {
                 stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
                 HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
@@ -1204,7 +1269,18 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         c->cand_stream = exs;
         for (int l = 0; l < 3; l++) {
             const int id = (int)o * 3 + l;
-            rc = cand_append(c, {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X}, true);
+            level_job job = {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X};
+            if (lazy && l == 0) { /* the level below D_1 is L_0 - L_1 */
+                job.dp = c->L[0] + d.off;
+                job.prev_b = c->L[1] + d.off;
+            }
+            if (lazy_next && l == 2) { /* the level above D_3 is L_4 - blur(L_4) */
+                job.dn = nullptr;
+                job.next_g = c->L[4] + d.off;
+                job.next_ntaps = next_ntaps;
+                for (int q = 0; q < next_ntaps; q++) job.next_taps[q] = next_taps[q];
+            }
+            rc = cand_append(c, job, true);
             if (rc) { c->cand_stream = nullptr; return rc; }
             sift3d_level &lv = levels[(size_t)id];
             lv.img = c->L[l + 1] + d.off;

@@ -437,6 +437,13 @@ __device__ __forceinline__ void row_extrema(v4f a, float (&rmax)[4], float (&rmi
     }
 }
 
+/* The own-level list is cut into EX_SEGS segments, each with its own counter (one returning atomic on a single word
+ * saturates near 88 per microsecond chip-wide; the marching kernel appends in batches of 64 or more, so the rate per
+ * counter is low).  A segment holds one contiguous range of z: blockIdx.y counts planes / chunks of planes, so the
+ * segments taken in order are the volume taken in slabs -- which is what lets the third phase of a lazily evaluated
+ * level walk its candidates slab by slab and find the blocks it reads still in the caches. */
+__device__ __forceinline__ int ex_segment_of_z_block() { return (int)(((unsigned long long)blockIdx.y * EX_SEGS) / gridDim.y); }
+
 /* First phase.  One wavefront = 248 output voxels along x (64 lanes x float4; the first and last lane
  * only supply x-neighbours) by EX_ROWS rows of ONE plane: it loads EX_ROWS+2 rows of the three planes
  * z-1, z, z+1 as twelve independent 16-byte loads per lane (all in flight together, re-reads are L1/L2
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
                 /* own-level extremum: hand it to the second phase.  One returning atomic on a single word
                  * saturates near 88 per microsecond chip-wide, so the list is cut into EX_SEGS segments with
                  * counters 256 bytes apart and a workgroup appends to the segment its index hashes to */
-                const int seg = (int)((blockIdx.x + 7u * blockIdx.y) % EX_SEGS);
+                const int seg = ex_segment_of_z_block();
                 const unsigned long long slot = atomicAdd(surv_count + seg * EX_SEG_STRIDE, 1ull);
                 if ((long long)slot < surv_cap) {
                     sift3d_survivor sv;
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
         yy = yy < Y ? yy : Y - 1;
         roff[r] = (long long)yy * X + xld;
     }
-    const int seg = (int)((blockIdx.x + 7u * blockIdx.y) % EX_SEGS);
+    const int seg = ex_segment_of_z_block();
     auto load_plane = [&](v4f(&raw)[EX_LOAD], int z) { /* z <= Z - 1 always: z_last <= Z - 1 */
 #pragma unroll
         for (int r = 0; r < EX_LOAD; r++) raw[r] = vload<4>(dcur + (long long)z * XY + roff[r]);
@@ -659,14 +666,24 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
 
 /* Second phase: one thread per own-level extremum checks centre + 26 of d_prev and of d_next and
  * appends the survivors as (key, value) pairs.  The list length lives in device memory, so the grid
- * is sized for the capacity and surplus threads leave at once (no host round trip). */
-__global__ __launch_bounds__(256) void extrema_validate_kernel(const float *__restrict__ dprev, const float *__restrict__ dnext,
+ * is sized for the capacity and surplus threads leave at once (no host round trip).
+ *
+ * PAIR: the level below is not stored as a DoG volume; its value at a voxel is gprev_a[i] - gprev_b[i], the two
+ * Gaussian levels it is the difference of -- which is how the reference itself validates against a DoG level it never
+ * materialises (validateDifferencePeak3D, R/src_common/MultiScale.cpp:1135-1223: fG1 - fG2 at the 27 positions).
+ * DEFER: the level above is not stored either, nor is the Gaussian level it would be made from: what passes the test
+ * against the level below goes to a second list, and extrema_validate_lazy_kernel evaluates that Gaussian level at the
+ * 27 positions around each entry. */
+template <bool PAIR, bool DEFER>
+__global__ __launch_bounds__(256) void extrema_validate_kernel(const float *__restrict__ dprev, const float *__restrict__ gprev_b,
+                                                               const float *__restrict__ dnext,
                                                                int X, int Y, const sift3d_survivor *__restrict__ surv,
                                                                const unsigned long long *__restrict__ surv_count,
                                                                long long surv_cap, unsigned long long *surv_overflow,
                                                                int lvl_id, unsigned long long *__restrict__ keys,
                                                                sift3d_cval *__restrict__ vals, unsigned long long *count,
-                                                               long long cap)
+                                                               long long cap, sift3d_survivor2 *__restrict__ list2,
+                                                               unsigned long long *list2_count, long long list2_cap)
 {
     const int seg = blockIdx.y; /* surv_cap is the capacity of one segment */
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -675,35 +692,204 @@ __global__ __launch_bounds__(256) void extrema_validate_kernel(const float *__re
         if (i == 0) atomicMax(surv_overflow, (unsigned long long)n * EX_SEGS);
         n = surv_cap;
     }
-    if (i >= n) return;
-    const sift3d_survivor sv = surv[(long long)seg * surv_cap + i];
+    bool ok = i < n;
+    if (!DEFER && !ok) return;
+    sift3d_survivor sv;
+    sv.idx = 0; sv.value = 0.0f; sv.is_max = 0;
+    if (ok) sv = surv[(long long)seg * surv_cap + i];
     const long long XY = (long long)X * Y;
     const float c = sv.value;
     const bool mx = sv.is_max != 0;
-    bool ok = true;
-    const float *lv[2] = {dprev, dnext};
-    for (int l = 0; l < 2 && ok; l++) {
-        const float *d = lv[l];
-        if (!d) continue;
+    float hval = 0.0f;
+    auto prev_at = [&](long long j) -> float { return PAIR ? dprev[j] - gprev_b[j] : dprev[j]; };
+    if (ok) {
         for (int dz = -1; dz <= 1 && ok; dz++) {
             float q[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) q[k] = d[sv.idx + dz * XY + (k / 3 - 1) * X + (k % 3 - 1)];
+            for (int k = 0; k < 9; k++) q[k] = prev_at(sv.idx + dz * XY + (k / 3 - 1) * X + (k % 3 - 1));
+            if (dz == 0) hval = q[4];
 #pragma unroll
             for (int k = 0; k < 9; k++) ok = ok && (mx ? (q[k] < c) : (q[k] > c));
         }
     }
-    if (!ok) return;
-    const unsigned long long slot = atomicAdd(count, 1ull);
-    if ((long long)slot < cap) {
-        sift3d_cval r;
-        r.value = c;
-        r.h = dprev[sv.idx];
-        r.l = dnext ? dnext[sv.idx] : 0.0f;
-        r.pad = 0.0f;
-        keys[slot] = ((unsigned long long)lvl_id << SIFT3D_KEY_LVL_SHIFT) |
-                     ((unsigned long long)(mx ? 1 : 0) << SIFT3D_KEY_MAX_SHIFT) | (unsigned long long)sv.idx;
-        vals[slot] = r;
+    if constexpr (DEFER) {
+        /* one returning atomic per wavefront: the entries of a wavefront go to consecutive slots */
+        const unsigned long long m = __ballot(ok);
+        if (m == 0) return;
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(list2_count + seg, (unsigned long long)__popcll(m));
+        const int src = (int)__builtin_ctzll(m);
+        base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(base >> 32), src) << 32) |
+               (unsigned)__builtin_amdgcn_readlane((int)(base & 0xffffffffull), src);
+        if (!ok) return;
+        const long long slot = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < list2_cap) { /* list2_cap: entries per segment, as for the own-level list this is a subset of: never binds */
+            sift3d_survivor2 e; /* the third phase walks its list one entry per wavefront: the divisions are done here, per lane */
+            e.x = (int)(sv.idx % X);
+            e.y = (int)((sv.idx / X) % Y);
+            e.z = (int)(sv.idx / XY);
+            e.is_max = mx ? 1 : 0;
+            e.value = c;
+            e.h = hval;
+            list2[(long long)seg * list2_cap + slot] = e;
+        }
+        return;
+    } else {
+        if (ok && dnext) {
+            for (int dz = -1; dz <= 1 && ok; dz++) {
+                float q[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) q[k] = dnext[sv.idx + dz * XY + (k / 3 - 1) * X + (k % 3 - 1)];
+#pragma unroll
+                for (int k = 0; k < 9; k++) ok = ok && (mx ? (q[k] < c) : (q[k] > c));
+            }
+        }
+        if (!ok) return;
+        const unsigned long long slot = atomicAdd(count, 1ull);
+        if ((long long)slot < cap) {
+            sift3d_cval r;
+            r.value = c;
+            r.h = hval;
+            r.l = dnext ? dnext[sv.idx] : 0.0f;
+            r.pad = 0.0f;
+            keys[slot] = ((unsigned long long)lvl_id << SIFT3D_KEY_LVL_SHIFT) |
+                         ((unsigned long long)(mx ? 1 : 0) << SIFT3D_KEY_MAX_SHIFT) | (unsigned long long)sv.idx;
+            vals[slot] = r;
+        }
+    }
+}
+
+/* Third phase of a level whose upper neighbour is not stored (the last detection level of an octave): the level above
+ * would be D_next = G - blur(G), with blur(G) a Gaussian level nothing else ever reads.  The reference filters the whole
+ * volume for it (R/src_common/MultiScale.cpp:405-413) and then looks at 27 voxels around each candidate
+ * (validateDifference*3D, :1135-1318); here only those 27 voxels are computed, from the (2R+3)^3 block of G around the
+ * candidate, with the operations of the full filter in its order: x pass, y pass, z pass, each output = 0, then
+ * + f[j] * input in ascending j with a separate multiply and add, inputs outside the volume read as zero
+ * (blur_3d_simpleborders, R/src_common/GaussBlur3D.cpp:329-479) -- the same bits as blur_fused_ring_kernel /
+ * blur_x_kernel + blur_col_kernel produce for those voxels.
+ *
+ * One 64-lane workgroup per candidate, taken from the list in a grid-stride loop (the list length is only known on the
+ * device).  The kernel is bound by instruction issue (a 512^3 volume has ~22 000 such candidates on its finest octave,
+ * ~150 million filter taps), so: the whole block is requested at once through buffer loads (plane base in the descriptor,
+ * 32-bit offsets, out-of-volume lanes and planes answered with zeros by the bounds check -- no address arithmetic, no
+ * selects) and consumed as it arrives; the x pass takes TWO planes per step as packed pairs (3 (2R+3) lanes, one 8-byte
+ * LDS read + one packed multiply + one packed add per tap); then the y pass over all planes (9 (2R+3) outputs), the z
+ * pass (27 outputs) and the comparison on 27 lanes. */
+typedef float ex_v2f __attribute__((ext_vector_type(2)));
+#define EX_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format */
+template <int R>
+__global__ __launch_bounds__(64) void extrema_validate_lazy_kernel(const float *__restrict__ g, int X, int Xl, int Y, int Z,
+                                                                  const sift3d_survivor2 *__restrict__ list,
+                                                                  const unsigned long long *__restrict__ list_count,
+                                                                  long long list_cap, int lvl_id,
+                                                                  unsigned long long *__restrict__ keys,
+                                                                  sift3d_cval *__restrict__ vals, unsigned long long *count,
+                                                                  long long cap, sift3d_taps t)
+{
+    constexpr int U = 2 * R + 1, W = 2 * R + 3, PL = W * W, NLD = (PL + 63) / 64, NP = (W + 1) / 2;
+    static_assert(3 * W <= 64, "the x pass of a plane pair fits one wavefront");
+    __shared__ ex_v2f raw[2][PL];
+    __shared__ float t1[2 * NP * W * 3]; /* [plane][row][dx] (one spare plane: W is odd) */
+    __shared__ float t2[W * 9];          /* [plane][dy][dx] */
+    const int lane = threadIdx.x;
+    /* the list comes in EX_SEGS segments of list_cap entries, one per slab of z (lane = segment): position p of the
+     * whole list, segments in order, is entry p - before[s] of the segment s with before[s] <= p < before[s] + len[s] */
+    long long len = (long long)list_count[lane];
+    len = len < list_cap ? len : list_cap;
+    long long before = len; /* inclusive prefix sum over the 64 lanes */
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long up = __shfl_up(before, d, 64);
+        if (lane >= d) before += up;
+    }
+    const long long n = __shfl(before, 63, 64);
+    before -= len;
+    const long long XY = (long long)X * Y;
+    const int plane_bytes = (int)(XY * 4); /* the launcher keeps X * Y below 2^29 */
+    for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+        const int sg = __popcll(__ballot(before <= i)) - 1; /* before[] ascends: the last segment that starts at or before i */
+        const long long first = __shfl(before, sg, 64);
+        const sift3d_survivor2 e = list[(long long)sg * list_cap + (i - first)];
+        const int x = __builtin_amdgcn_readfirstlane(e.x), y = __builtin_amdgcn_readfirstlane(e.y), z = __builtin_amdgcn_readfirstlane(e.z);
+        const bool mx = __builtin_amdgcn_readfirstlane(e.is_max) != 0;
+        const float c = e.value;
+        /* byte offsets of this lane's elements inside a plane; outside the volume: beyond any record count */
+        unsigned eoff[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int el = lane + 64 * k;
+            const int gy = y + el / W - (R + 1), gx = x + el % W - (R + 1);
+            eoff[k] = (el < PL && gy >= 0 && gy < Y && gx >= 0 && gx < Xl) ? (unsigned)(gy * X + gx) * 4u : 0xFFFFFFFFu;
+        }
+        float nx[2 * NP][NLD];
+#pragma unroll
+        for (int pz = 0; pz < 2 * NP; pz++) {
+            const int gz = z + pz - (R + 1);
+            const bool zin = pz < W && gz >= 0 && gz < Z; /* wave-uniform */
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(g + (zin ? (long long)gz * XY : 0ll)), 0, zin ? plane_bytes : 0, EX_RSRC_FLAGS);
+#pragma unroll
+            for (int k = 0; k < NLD; k++) nx[pz][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)eoff[k], 0, 0));
+        }
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++) {
+            ex_v2f *rb = raw[pp & 1]; /* two buffers: the x pass of a pair overlaps the arrival of the next */
+#pragma unroll
+            for (int k = 0; k < NLD; k++)
+                if (lane + 64 * k < PL) {
+                    ex_v2f v;
+                    v.x = nx[2 * pp][k];
+                    v.y = nx[2 * pp + 1][k];
+                    rb[lane + 64 * k] = v;
+                }
+            __syncthreads();
+            if (lane < 3 * W) {
+                const int row = lane / 3, dx = lane % 3;
+                ex_v2f acc = ex_v2f(0.0f);
+#pragma unroll
+                for (int j = 0; j < U; j++) acc = acc + ex_v2f(t.f[j]) * rb[row * W + dx + j];
+                t1[((2 * pp) * W + row) * 3 + dx] = acc.x;
+                t1[((2 * pp + 1) * W + row) * 3 + dx] = acc.y;
+            }
+        }
+        __syncthreads();
+        for (int o = lane; o < W * 9; o += 64) {
+            const int pz = o / 9, dy = (o / 3) % 3, dx = o % 3;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < U; j++) acc = acc + t.f[j] * t1[(pz * W + dy + j) * 3 + dx];
+            t2[o] = acc;
+        }
+        __syncthreads();
+        bool ok = true;
+        float dcen = 0.0f;
+        const long long idx = (long long)z * XY + (long long)y * X + x;
+        if (lane < 27) {
+            const int dz = lane / 9, dy = (lane / 3) % 3, dx = lane % 3;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < U; j++) acc = acc + t.f[j] * t2[(dz + j) * 9 + dy * 3 + dx];
+            const float d = g[idx + (long long)(dz - 1) * XY + (long long)(dy - 1) * X + (dx - 1)] - acc;
+            ok = mx ? (d < c) : (d > c);
+            dcen = d;
+        }
+        const bool all = __ballot(!ok) == 0ull;
+        const float lval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dcen), 13));
+        if (all && lane == 0) {
+            const unsigned long long slot = atomicAdd(count, 1ull);
+            if ((long long)slot < cap) {
+                sift3d_cval r;
+                r.value = c;
+                r.h = e.h;
+                r.l = lval;
+                r.pad = 0.0f;
+                keys[slot] = ((unsigned long long)lvl_id << SIFT3D_KEY_LVL_SHIFT) |
+                             ((unsigned long long)(mx ? 1 : 0) << SIFT3D_KEY_MAX_SHIFT) | (unsigned long long)idx;
+                vals[slot] = r;
+            }
+        }
+        __syncthreads(); /* raw / t1 / t2 are free for the next candidate */
     }
 }
 
@@ -1027,13 +1213,29 @@ hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, i
     return hipGetLastError();
 }
 
+template <int R>
+static void launch_validate_lazy(hipStream_t s, const sift3d_extrema_lazy &lz, int64_t X, int64_t Xl, int64_t Y, int64_t Z, int lvl_id,
+                                 unsigned long long *keys, sift3d_cval *vals, unsigned long long *count, int64_t cap)
+{
+    sift3d_taps t;
+    for (int i = 0; i < 2 * SIFT3D_FAST_MAX_R + 1; i++) t.f[i] = i < lz.ntaps ? lz.taps[i] : 0.0f;
+    /* a grid-stride loop over a list whose length only the device knows: enough single-wavefront workgroups to fill
+     * the chip (256 CUs x 16), never more than the list can hold */
+    long long wgs = X * Y * Z / 2048; /* the finest octaves fill the chip; a coarse one does not pay for 4096 idle workgroups */
+    wgs = wgs < 64 ? 64 : (wgs > 4096 ? 4096 : wgs);
+    if (wgs > lz.list2_cap) wgs = lz.list2_cap;
+    hipLaunchKernelGGL(extrema_validate_lazy_kernel<R>, dim3((unsigned)wgs), dim3(64), 0, s, lz.next_g, (int)X, (int)Xl, (int)Y, (int)Z,
+                       lz.list2, lz.list2_count, (long long)(lz.list2_cap / EX_SEGS), lvl_id, keys, vals, count, (long long)cap, t);
+}
+
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
                                  int64_t Xl, int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
                                  sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
                                  unsigned long long *surv_count, unsigned long long *surv_overflow, int64_t surv_cap,
-                                 bool zero_counters)
+                                 bool zero_counters, const sift3d_extrema_lazy *lazy)
 {
     if (Xl < 3 || Y < 3 || Z < 3) return hipSuccess;
+    const bool pair = lazy && lazy->prev_b, defer = lazy && lazy->next_g;
     /* X: row pitch (== Xl for a dense volume), Xl: logical row length; interior planes 1..Z-2, further restricted to [z_lo, z_hi) (Z-slab mode keeps only its own slices) */
     const int z0 = z_lo > 1 ? z_lo : 1;
     const int z1 = z_hi < (int)Z - 1 ? z_hi : (int)Z - 1;
@@ -1060,15 +1262,41 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
         if (zchunk >= 2)
             hipLaunchKernelGGL(extrema_march_kernel, grid, dim3(256), 0, s, dcur, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk, xtiles,
                                surv, surv_count, (long long)(surv_cap / EX_SEGS));
-        else
+        else /* reads the own level only: its neighbour-level arguments are unused */
             hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk,
                                xtiles, surv, surv_count, (long long)(surv_cap / EX_SEGS));
         /* the second launch covers the list capacity, reads the true length on the device, and flags an
          * overflow for cand_finalize to widen the list and replay */
         const long long segcap = surv_cap / EX_SEGS; /* the caller sized surv_cap: capacity == threads of the second launch */
-        hipLaunchKernelGGL(extrema_validate_kernel, dim3((unsigned)((segcap + 255) / 256), EX_SEGS), dim3(256), 0, s, dprev, dnext,
-                           (int)X, (int)Y, surv, surv_count, segcap, surv_overflow, lvl_id, keys, vals, count, (long long)cap);
+        const dim3 vgrid((unsigned)((segcap + 255) / 256), EX_SEGS);
+#define SIFT3D_VALIDATE(PAIR_, DEFER_)                                                                                                   \
+    hipLaunchKernelGGL((extrema_validate_kernel<PAIR_, DEFER_>), vgrid, dim3(256), 0, s, dprev, pair ? lazy->prev_b : nullptr,          \
+                       defer ? nullptr : dnext, (int)X, (int)Y, surv, surv_count, segcap, surv_overflow, lvl_id, keys, vals, count,      \
+                       (long long)cap, defer ? lazy->list2 : nullptr, defer ? lazy->list2_count : nullptr,                               \
+                       (long long)(defer ? lazy->list2_cap / EX_SEGS : 0))
+        if (pair && defer) SIFT3D_VALIDATE(true, true);
+        else if (pair) SIFT3D_VALIDATE(true, false);
+        else if (defer) SIFT3D_VALIDATE(false, true);
+        else SIFT3D_VALIDATE(false, false);
+#undef SIFT3D_VALIDATE
+        if (defer) {
+            const int R = lazy->ntaps / 2;
+            if (lazy->ntaps != 2 * R + 1 || R < 1 || R > SIFT3D_FAST_MAX_R || !lazy->list2 || !lazy->list2_count || lazy->list2_cap <= 0 ||
+                X * Y >= (1ll << 29))
+                return hipErrorInvalidValue;
+            switch (R) {
+            case 1: launch_validate_lazy<1>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            case 2: launch_validate_lazy<2>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            case 3: launch_validate_lazy<3>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            case 4: launch_validate_lazy<4>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            case 5: launch_validate_lazy<5>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            case 6: launch_validate_lazy<6>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            case 7: launch_validate_lazy<7>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            default: launch_validate_lazy<8>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
+            }
+        }
     } else {
+        if (pair || defer) return hipErrorNotSupported; /* the caller keeps such shapes on stored DoG levels */
         dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(z1 - z0));
         hipLaunchKernelGGL(extrema_generic_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Xl, (int)Y, (int)Z, z0,
                            lvl_id, keys, vals, count, (long long)cap);

@@ -31,6 +31,14 @@ struct sift3d_survivor {
     float value;
     int is_max;
 };
+/* an extremum that passed the test against the level below, on its way to the test against a level above that is
+ * evaluated around it instead of being stored (extrema_validate_lazy_kernel) */
+struct sift3d_survivor2 {
+    int x, y, z;   /* position in the (pitched) volume */
+    int is_max;
+    float value;
+    float h;       /* the level below at the extremum */
+};
 struct sift3d_cval {
     float value, h, l, pad; /* DoG at the extremum, one level below (H), one level above (L) */
 };
@@ -79,13 +87,28 @@ hipError_t sift3d_launch_tiny_octave(hipStream_t s, const float *L0, const sift3
 hipError_t sift3d_launch_double_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, int64_t Y, int64_t Z, float *out);
 /* X: row pitch, Xl: logical row length (Xl == X for a dense volume) */
+/* Neighbour levels that are not stored as DoG volumes (NULL or all-zero: both neighbours are the stored dprev / dnext).
+ * prev_b: the level below is dprev - prev_b, two Gaussian levels.  next_g: the level above is next_g - blur(next_g, taps),
+ * and blur(next_g) is evaluated only at the 27 voxels around each extremum that passed everything else (dnext is ignored;
+ * ntaps <= 2 * SIFT3D_FAST_MAX_R + 1, rows of whole 16-byte vectors). */
+struct sift3d_extrema_lazy {
+    const float *prev_b;
+    const float *next_g;
+    float taps[2 * SIFT3D_FAST_MAX_R + 1];
+    int ntaps;
+    sift3d_survivor2 *list2;         /* 64 segments of list2_cap / 64 entries, one per slab of z, like the own-level list */
+    unsigned long long *list2_count; /* SIFT3D_LIST2_COUNTERS words, zeroed by the caller */
+    int64_t list2_cap;               /* at least surv_cap of the same call */
+};
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
                                  int64_t Xl, int64_t Y, int64_t Z, int z_lo, int z_hi, int lvl_id, unsigned long long *keys,
                                  sift3d_cval *vals, unsigned long long *count, int64_t cap, sift3d_survivor *surv,
                                  unsigned long long *surv_count /* SIFT3D_SURV_COUNTERS words */,
-                                 unsigned long long *surv_overflow, int64_t surv_cap, bool zero_counters);
+                                 unsigned long long *surv_overflow, int64_t surv_cap, bool zero_counters,
+                                 const sift3d_extrema_lazy *lazy = nullptr);
 #define SIFT3D_SURV_SETS 96 /* one counter set per extrema pass of a pipeline run, zeroed together */
 #define SIFT3D_SURV_COUNTERS (64 * 32)
+#define SIFT3D_LIST2_COUNTERS 64
 
 /* ---- per-keypoint stage (kernels_keypoint.hip) ---- */
 struct sift3d_kp_params {

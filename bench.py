@@ -313,8 +313,9 @@ def main():
         sel = log[(log["stage"] == fused_id) & (log["nvox"] == nfullvox)]
         if len(sel):
             dom_name = ("blur_fused_ring_kernel<R, rows per thread, has level, has DoG, prefetch planes> "
-                        "(the %d launches per volume at %d^3: initial blur + five levels; 7 to 13 taps: two rows per thread, two "
-                        "planes of prefetch, one workgroup per CU; 17 taps: one row per thread, 1024 threads)" % (len(sel) // args.steps, n))
+                        "(the %d launches per volume at %d^3: initial blur + the levels stored in full -- L1..L4 by default, the "
+                        "17-tap level L5 only exists around the candidates of D3 (extrema_validate_lazy_kernel); two rows per "
+                        "thread, two planes of prefetch, one workgroup per CU)" % (len(sel) // args.steps, n))
             dom_all = full[full["stage"] == fused_id]
             per_inst = []
             for taps in sorted(set(int(t) for t in sel["ntaps"])):
@@ -325,8 +326,8 @@ def main():
                                          "launches": int(len(q)), "avg_launch_ms": round(float(q["ms"].mean()), 4),
                                          "GBs": round(float(q["alg_bytes"].sum()) / (float(q["ms"].sum()) * 1e-3) / 1e9, 1)})
             accounting = ("fused x+y+z+DoG launches: compulsory bytes only -- read the level once, write what is kept (level and "
-                          "DoG: 12 B/voxel; initial blur: level only, sixth level: DoG only: 8 B/voxel); the three-pass form of "
-                          "the same work is credited 32 (24) B/voxel")
+                          "DoG: 12 B/voxel; initial blur and L1, whose DoG is not stored: level only, 8 B/voxel); the three-pass "
+                          "form of the same work is credited 32 (24) B/voxel")
         else:   # rows that are not whole 16-byte vectors: three-pass kernels; dominant = slowest instantiation at n^3
             big = {}
             for r in log[log["nvox"] == nfullvox]:

@@ -325,9 +325,10 @@ def test_context_reuse_pitched_coarse_octaves(built, oracle, dims):
 
 @pytest.mark.parametrize("dims", [(168, 164, 160), (166, 165, 161)])
 def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
-    """A volume of more than 2^22 voxels: its finest octave is built by the one-launch ring kernel (two rows per thread up
-    to 13 taps, one row for 17), the 7- and 9-tap levels of the next octave (2^18 voxels or more) too, with one row per
-    thread; everything else by the three-pass kernels and the single-workgroup octave kernel.  The second shape has rows
+    """A volume of more than 2^22 voxels: its finest octave is built by the one-launch ring kernel (two rows per thread;
+    the 17-tap level is never filtered in full: test_lazy_levels_*), the 7- and 9-tap levels of the next octave (2^18
+    voxels or more) too, with one row per thread; everything else by the three-pass kernels and the single-workgroup
+    octave kernel.  The second shape has rows
     that are not whole 16-byte vectors (pitched rows).  Records against the oracle."""
     vol = vol_of(built, dims, 9)
     with built.Context(*dims) as ctx:
@@ -336,8 +337,9 @@ def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
         got = ctx.extract()
         log = ctx.launch_log()
     fused = log[log["stage"] == built.STAGES.index("blur_fused")]
-    assert len(fused) == 8                    # octave 0: initial blur + five levels; octave 1: its 7- and 9-tap levels
-    assert sorted(fused["ntaps"][6:].tolist()) == [7, 9] and (fused["nvox"][6:] < fused["nvox"][0]).all()
+    assert len(fused) == 7                    # octave 0: initial blur + four levels; octave 1: its 7- and 9-tap levels
+    assert fused["ntaps"][:5].tolist() == [9, 7, 9, 11, 13]
+    assert sorted(fused["ntaps"][5:].tolist()) == [7, 9] and (fused["nvox"][5:] < fused["nvox"][0]).all()
     want, _ = oracle.extract(vol)
     assert len(want) > 200 and _compare_records(got, want)
 
@@ -495,6 +497,41 @@ def test_early_keypoint_pass_gives_the_same_records(built, dims, mode, monkeypat
         ctx.set_volume(vol)
         assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
         assert ctx.timings()["stages"]["keypoint"]["launches"] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,noise", [((168, 164, 160), 0.0), ((96, 50, 67), 4.0), ((40, 36, 33), 0.0), ((9, 70, 64), 1.0)])
+def test_lazy_levels_give_the_same_candidates_and_records(built, oracle, dims, noise, monkeypatch):
+    """The default pipeline stores neither D_0 nor D_4 nor L_5 (the level below D_1 is taken as L_0 - L_1 around the
+    extrema, the level above D_3 is filtered only in the 27-voxel neighbourhood of what passed every other test);
+    SIFT3D_LAZY_LEVELS=0 stores and filters everything as the reference does.  Candidates (with the DoG values one level
+    below and above) and records are the same bytes both ways, and the candidates are the oracle's."""
+    vol = vol_of(built, dims, 29)
+    if noise:
+        vol = vol + (np.random.default_rng(5).standard_normal(vol.shape) * noise).astype(np.float32)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        cand = ctx.detect()
+        recs = ctx.extract()
+        stages = ctx.timings()["stages"]
+        monkeypatch.setenv("SIFT3D_LAZY_LEVELS", "0")
+        cand_full = ctx.detect()
+        recs_full = ctx.extract()
+        stages_full = ctx.timings()["stages"]
+        monkeypatch.delenv("SIFT3D_LAZY_LEVELS")
+        assert ctx.extract().tobytes() == recs.tobytes()
+    assert len(cand) > 5
+    assert cand.tobytes() == cand_full.tobytes()
+    assert recs.tobytes() == recs_full.tobytes()
+    want = oracle.candidates(vol)
+    assert len(want) == len(cand)
+    for f in ("octave", "level", "is_max", "x", "y", "z"):
+        assert (cand[f] == want[f]).all(), f
+    for f in ("value", "h_value", "l_value"):
+        assert (cand[f].view(np.uint32) == want[f].view(np.uint32)).all(), f
+    # fewer blur launches on every octave that is not a single-workgroup one
+    n_blur = lambda st: sum(st[k]["launches"] for k in ("blur_fused", "blur_x"))
+    assert n_blur(stages) < n_blur(stages_full)
 
 
 def test_octave_limit_returns_the_leading_records(built, oracle):
