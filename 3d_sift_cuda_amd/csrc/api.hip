@@ -24,6 +24,8 @@
 
 #include "sift3d_internal.h"
 
+#define SIFT3D_D4TINY_FLOATS 32768 /* room for the octaves of at most SIFT3D_TINY_VOX voxels of one volume, pitched rows included */
+
 struct timed_launch {
     int stage;
     hipEvent_t e0, e1;
@@ -68,8 +70,10 @@ struct sift3d_ctx {
     int64_t capN;   /* voxels of the largest volume */
     int64_t capTot; /* floats per level buffer: all octaves of a capN volume back to back */
     float *vol;   /* input volume */
-    float *L[6];  /* Gaussian levels, every octave resident (octave o at offset off_o) */
-    float *D[5];  /* DoG levels, same layout */
+    float *L[6];  /* Gaussian levels, every octave resident (octave o at offset off_o); L[5] is never stored and stays NULL */
+    float *D[5];  /* DoG levels, same layout; D[4] is only allocated when an octave has to store its last DoG level in full
+                   * (ensure_level_buffer): by default that level is evaluated around the candidates only */
+    float *D4tiny; /* the last DoG level of the octaves that one workgroup builds whole (at most SIFT3D_TINY_VOX voxels each) */
     float *T[2];  /* x- and y-pass intermediates */
     float *d_taps;
     float *d_zeros; /* 512 bytes: 256 of 0.0f (what the fused blur reads outside the volume), then 256 it may write (store sink) */
@@ -150,6 +154,7 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->vol);
     for (int i = 0; i < 6; i++) hipFree(c->L[i]);
     for (int i = 0; i < 5; i++) hipFree(c->D[i]);
+    hipFree(c->D4tiny);
     hipFree(c->T[0]);
     hipFree(c->T[1]);
     hipFree(c->d_taps);
@@ -235,6 +240,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->vol = nullptr;
     for (int i = 0; i < 6; i++) c->L[i] = nullptr;
     for (int i = 0; i < 5; i++) c->D[i] = nullptr;
+    c->D4tiny = nullptr;
     c->T[0] = c->T[1] = c->d_taps = c->d_zeros = nullptr;
     c->keys_a = c->keys_b = nullptr;
     c->vals_a = c->vals_b = nullptr;
@@ -281,14 +287,16 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     const size_t vb = sizeof(float) * (size_t)c->capN;
     const size_t tb = sizeof(float) * (size_t)c->capTot;
     ok = ok && hipMalloc((void **)&c->vol, vb) == hipSuccess;
-    for (int i = 0; i < 6 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess;
-    for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
+    for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->D4tiny, sizeof(float) * SIFT3D_D4TINY_FLOATS) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
     /* nothing may depend on what hipMalloc hands back: the pad columns of pitched octaves are read as zeros.  The clears
      * go on the context's own stream and are waited for here: hipMemset runs on the null stream, which the context's
      * non-blocking streams are NOT ordered with, so it could still be wiping a buffer the first extraction already uses */
-    for (int i = 0; i < 6 && ok; i++) ok = hipMemsetAsync(c->L[i], 0, tb, c->stream) == hipSuccess;
-    for (int i = 0; i < 5 && ok; i++) ok = hipMemsetAsync(c->D[i], 0, tb, c->stream) == hipSuccess;
+    for (int i = 0; i < 5 && ok; i++) ok = hipMemsetAsync(c->L[i], 0, tb, c->stream) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = hipMemsetAsync(c->D[i], 0, tb, c->stream) == hipSuccess;
+    ok = ok && hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream) == hipSuccess;
     ok = ok && hipMemsetAsync(c->vol, 0, vb, c->stream) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_zeros, 512) == hipSuccess && hipMemsetAsync(c->d_zeros, 0, 512, c->stream) == hipSuccess;
@@ -897,14 +905,30 @@ extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d
 }
 
 /* ---- pipeline ------------------------------------------------------------ */
+/* A level buffer the default pipeline does not need (D[4]): allocated, and cleared like the others, the first time an
+ * octave has to store that level in full. */
+static int ensure_level_buffer(sift3d_ctx *c, float **buf)
+{
+    if (*buf) return SIFT3D_OK;
+    if (hipMalloc((void **)buf, sizeof(float) * (size_t)c->capTot) != hipSuccess) {
+        *buf = nullptr;
+        return set_err(c, SIFT3D_ERR_MEMORY, "a level buffer of %lld floats could not be allocated", (long long)c->capTot);
+    }
+    HIPCHK(c, hipMemsetAsync(*buf, 0, sizeof(float) * (size_t)c->capTot, c->stream));
+    return SIFT3D_OK;
+}
+
 /* The pipeline's copy of the volume has its rows padded to whole 16-byte vectors (octave_list).  When the padded
  * geometry changes, every level buffer is cleared once: the pad columns are never written afterwards. */
 static int load_volume(sift3d_ctx *c, const float *src, bool from_host, int64_t nx, int64_t ny, int64_t nz)
 {
     const int64_t xp = pitch_of(nx);
     if (xp != nx && (c->pad_nx != nx || c->pad_ny != ny || c->pad_nz != nz)) {
-        for (int i = 0; i < 6; i++) HIPCHK(c, hipMemsetAsync(c->L[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
-        for (int i = 0; i < 5; i++) HIPCHK(c, hipMemsetAsync(c->D[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
+        for (int i = 0; i < 6; i++)
+            if (c->L[i]) HIPCHK(c, hipMemsetAsync(c->L[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
+        for (int i = 0; i < 5; i++)
+            if (c->D[i]) HIPCHK(c, hipMemsetAsync(c->D[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream));
         HIPCHK(c, hipMemsetAsync(c->vol, 0, sizeof(float) * (size_t)c->capN, c->stream));
         c->pad_nx = nx; c->pad_ny = ny; c->pad_nz = nz;
     }
@@ -1161,6 +1185,9 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     rc = cand_reset(c);
     if (rc) return rc;
 
+    int64_t tiny_base = -1; /* float offset of the first octave of at most SIFT3D_TINY_VOX voxels */
+    for (const octave_dims &d : oct)
+        if (tiny_base < 0 && d.X * d.Y * d.Z <= SIFT3D_TINY_VOX) tiny_base = d.off;
     std::vector<sift3d_level> levels(oct.size() * 3);
     /* SIFT3D_EARLY_KP=1: run the per-keypoint stage of octave 0 on a third stream as soon as its extrema are in, beside
      * the blurs and extrema of the coarser octaves (below).  Off by default: measured at 512^3 it changes nothing
@@ -1179,7 +1206,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         /* an octave of at most 4096 voxels: all five levels in one single-workgroup launch instead of fifteen */
         static const char *tenv = getenv("SIFT3D_TINY_OCTAVE"); /* A/B aid: 0 = the per-level launches */
         bool tiny_done = false;
-        if (d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && !(tenv && atoi(tenv) == 0)) {
+        /* the last DoG level of such an octave lives in a small buffer of its own, at the octave's offset from the first of them */
+        float *const d4tiny = (tiny_base >= 0 && d.off >= tiny_base && d.off - tiny_base + d.XP * d.Y * d.Z <= SIFT3D_D4TINY_FLOATS)
+                                  ? c->D4tiny + (d.off - tiny_base) : nullptr;
+        if (d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && d4tiny && !(tenv && atoi(tenv) == 0)) {
             sift3d_octave_taps ot;
             sift3d_octave_out oo;
             float sg = sigma;
@@ -1191,7 +1221,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 for (int q = 0; ok && q < n; q++) ot.f[j - 1][q] = taps[q];
                 ot.n[j - 1] = n;
                 oo.L[j - 1] = j < 5 ? c->L[j] + d.off : nullptr;
-                oo.D[j - 1] = c->D[j - 1] + d.off;
+                oo.D[j - 1] = j < 5 ? c->D[j - 1] + d.off : d4tiny;
                 sg *= factor;
             }
             if (ok) {
@@ -1240,6 +1270,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
             /* nothing reads L_5: only D_4 = L_4 - L_5 is needed, so the last level is not stored */
             if (!(lazy_next && j == 5)) {
+                if (j == 5) {
+                    rc = ensure_level_buffer(c, &c->D[4]);
+                    if (rc) return rc;
+                }
                 float *dst_dog = (lazy && j == 1) ? nullptr : c->D[j - 1] + d.off;
                 rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.Y, d.Z, ex, 0.01f);
                 if (rc) return rc;
@@ -1269,7 +1303,8 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         c->cand_stream = exs;
         for (int l = 0; l < 3; l++) {
             const int id = (int)o * 3 + l;
-            level_job job = {c->D[l] + d.off, c->D[l + 1] + d.off, c->D[l + 2] + d.off, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X};
+            const float *dnext = l < 2 ? c->D[l + 2] + d.off : (tiny_done ? d4tiny : (lazy_next ? nullptr : c->D[4] + d.off));
+            level_job job = {c->D[l] + d.off, c->D[l + 1] + d.off, dnext, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X};
             if (lazy && l == 0) { /* the level below D_1 is L_0 - L_1 */
                 job.dp = c->L[0] + d.off;
                 job.prev_b = c->L[1] + d.off;
