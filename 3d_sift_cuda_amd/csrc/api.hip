@@ -1131,9 +1131,24 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
             if (rc) return rc;
             HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), c->stream));
             HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec, c->offs, ncand, c->rec_kp, c->rec_frame, c->d_count + 3));
-            /* The records are 324 bytes each: their download is a millisecond at 512^3.  Describe them in up to four
-             * slices and copy each slice on a second stream while the next one is being computed. */
+            /* The records are 324 bytes each: 60 MB, a millisecond of PCIe, at 512^3.  By default the descriptor kernel stores
+             * them straight into the pinned host buffer (it is mapped into the device's address space): the bytes cross the
+             * bus while the kernel runs and nothing is left to copy when it ends.  SIFT3D_DIRECT_HOST=0 (A/B): the earlier
+             * form, records into device memory in four slices, each slice copied on a second stream while the next one is
+             * computed -- which leaves the copy of the last slice (a quarter of the records, 0.3-0.5 ms) after the kernel. */
             stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nrec_total);
+            const char *denv = getenv("SIFT3D_DIRECT_HOST");
+            sift3d_feature *d_hrecs = nullptr;
+            int *d_hgroup = nullptr;
+            bool direct = !(denv && atoi(denv) == 0);
+            if (direct && (hipHostGetDevicePointer((void **)&d_hrecs, c->h_recs, 0) != hipSuccess ||
+                           hipHostGetDevicePointer((void **)&d_hgroup, c->h_group, 0) != hipSuccess)) {
+                (void)hipGetLastError();
+                direct = false;
+            }
+            if (direct) {
+                HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, d_hrecs, d_hgroup, taps5));
+            } else {
             const int nslice = nrec_total >= 32768 ? 4 : 1;
             const int64_t per = (nrec_total + nslice - 1) / nslice;
             for (int k = 0; k < nslice; k++) {
@@ -1145,6 +1160,7 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
                 HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_chunk[k], 0));
                 HIPCHK(c, hipMemcpyAsync(c->h_recs + o, c->recs + o, sizeof(sift3d_feature) * (size_t)m, hipMemcpyDeviceToHost, c->copy_stream));
                 HIPCHK(c, hipMemcpyAsync(c->h_group + o, c->rec_group + o, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->copy_stream));
+            }
             }
         }
     }

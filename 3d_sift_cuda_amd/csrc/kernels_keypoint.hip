@@ -1194,20 +1194,29 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
     }
     sift3d_feature *out = recs + r;
     out->desc[lane] = (float)rank;
-    if (lane == 0) {
+    /* The seventeen words in front of the descriptor, one lane each: one 68-byte store instead of seventeen 4-byte ones by
+     * lane 0 (the records may lie in host memory, where every store is a transaction on the bus). */
+    static_assert(offsetof(sift3d_feature, desc) == 17 * 4 && offsetof(sift3d_feature, ori) == 16 && offsetof(sift3d_feature, eigs) == 52 &&
+                      offsetof(sift3d_feature, info) == 64, "record layout: x y z scale ori[9] eigs[3] info desc[64]");
+    if (lane < 17) {
         /* octave -> image space (MultiScale.cpp:531-543), then fSizeFactor (featExtract.cpp:502-505) */
-        float sc = kp->scale, xx = kp->x, yy = kp->y, zz = kp->z;
         const float fac = lv.octave_factor, add = 0;
-        sc *= fac;
-        xx = xx * fac + add;
-        yy = yy * fac + add;
-        zz = zz * fac + add;
-        xx *= p.size_factor; yy *= p.size_factor; zz *= p.size_factor; sc *= p.size_factor;
-        out->x = xx; out->y = yy; out->z = zz; out->scale = sc;
-        for (int i = 0; i < 9; i++) out->ori[i] = fr < 0 ? kp->ori0[i] : kp->frames[fr * 9 + i];
-        for (int i = 0; i < 3; i++) out->eigs[i] = kp->eigs[i];
-        out->info = kp->info | (fr < 0 ? 0u : SIFT3D_INFO_REORIENT);
-        rec_group[r] = kp->lvl * 2 + ((kp->info & SIFT3D_INFO_MIN0MAX1) ? 1 : 0);
+        unsigned word;
+        if (lane < 4) {
+            float v = lane == 0 ? kp->x : (lane == 1 ? kp->y : (lane == 2 ? kp->z : kp->scale));
+            if (lane == 3) v *= fac;
+            else v = v * fac + add;
+            v *= p.size_factor;
+            word = __builtin_bit_cast(unsigned, v);
+        } else if (lane < 13) {
+            word = __builtin_bit_cast(unsigned, fr < 0 ? kp->ori0[lane - 4] : kp->frames[fr * 9 + lane - 4]);
+        } else if (lane < 16) {
+            word = __builtin_bit_cast(unsigned, kp->eigs[lane - 13]);
+        } else {
+            word = kp->info | (fr < 0 ? 0u : SIFT3D_INFO_REORIENT);
+        }
+        reinterpret_cast<unsigned *>(out)[lane] = word;
+        if (lane == 0) rec_group[r] = kp->lvl * 2 + ((kp->info & SIFT3D_INFO_MIN0MAX1) ? 1 : 0);
     }
 }
 
