@@ -60,7 +60,8 @@ class LevelDesc(C.Structure):
                 ("sigma_l", C.c_float), ("octave_factor", C.c_float)]
 
 
-LAUNCH_DTYPE = np.dtype([("stage", "<i4"), ("ntaps", "<i4"), ("nvox", "<i8"), ("alg_bytes", "<f8"), ("ms", "<f8")])
+LAUNCH_DTYPE = np.dtype([("stage", "<i4"), ("ntaps", "<i4"), ("nvox", "<i8"), ("alg_bytes", "<f8"), ("ms", "<f8"),
+                         ("start_ms", "<f8")])
 
 
 def build(verbose=False):

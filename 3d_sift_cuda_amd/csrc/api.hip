@@ -33,6 +33,7 @@ struct timed_launch {
     int64_t nvox;
     double bytes;
     float ms;
+    float start_ms;
 };
 
 /* One detection level: which buffers, which dims, which slices to keep */
@@ -60,9 +61,16 @@ struct sift3d_ctx {
     hipStream_t copy_stream;   /* record download, overlapped with the descriptor launches */
     hipStream_t ex_stream;     /* extrema detection of an octave, overlapped with the blurs of the coarser octaves */
     hipStream_t cand_stream;   /* where cand_append launches: stream, or ex_stream inside run_pipeline */
+    hipStream_t ex_stream2;    /* extrema of the octaves after the first (run_pipeline: the first octave's wait for the second's levels) */
+    hipEvent_t ev_ex2[2];      /* levels of such an octave complete / its extrema launches complete */
+    sift3d_survivor *surv2;    /* own-level list of that stream (the passes of one stream share a list, one after the other) */
+    int64_t surv2_cap;
+    int surv_sel;              /* which list cand_append uses: 0 = surv, 1 = surv2 */
     hipStream_t kp_stream;     /* per-keypoint stage of the finest octave, beside the blurs and extrema of the coarser ones */
     hipEvent_t ev_cnt0, ev_kp; /* octave 0's extrema are in the list (its count is in h_cnt0) / the early keypoint launch is done */
-    unsigned long long *h_cnt0; /* pinned: d_count as it stood after octave 0's extrema passes */
+    unsigned long long *h_cnt0; /* pinned, 8 words: [0..3] d_count as it stood after octave 0's extrema passes (early pass); [4..7] the
+                                 * small read-backs the host waits for (extrema counts, record total, keypoint count): a copy into
+                                 * pageable memory goes through a staging buffer and costs tens of microseconds more */
     hipEvent_t ev_oct[2];      /* octave's DoG levels complete / extrema launches complete */
     hipEvent_t ev_chunk[4];
     hipEvent_t ev_fence[2];    /* ordering of the *_dev entry points with the legacy default stream (fence_in / fence_out) */
@@ -83,8 +91,9 @@ struct sift3d_ctx {
     int64_t cand_cap;
     unsigned long long *d_count; /* [0] validated extrema, [1] own-level survivors of the level in flight, [2] survivor overflow high-water mark */
     sift3d_survivor *surv;
-    sift3d_survivor2 *list2;         /* extrema that passed the level below, waiting for the lazily evaluated level above */
-    int64_t list2_cap;
+    sift3d_survivor2 *list2[2];      /* extrema that passed the level below, waiting for the lazily evaluated level above: one list
+                                      * per extrema stream (surv_sel) */
+    int64_t list2_cap[2];
     unsigned long long *list2_counts; /* one length word per extrema pass (SIFT3D_SURV_SETS), zeroed with surv_counts */
     unsigned long long *surv_counts; /* segment counters of the own-level list: SIFT3D_SURV_SETS sets */
     int surv_set;                    /* next unused set since the last reset */
@@ -165,7 +174,9 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->vals_b);
     hipFree(c->d_count);
     hipFree(c->surv);
-    hipFree(c->list2);
+    hipFree(c->surv2);
+    hipFree(c->list2[0]);
+    hipFree(c->list2[1]);
     hipFree(c->list2_counts);
     hipFree(c->surv_counts);
     hipFree(c->sort_tmp);
@@ -246,8 +257,8 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->vals_a = c->vals_b = nullptr;
     c->d_count = nullptr;
     c->surv = nullptr;
-    c->list2 = nullptr;
-    c->list2_cap = 0;
+    c->list2[0] = c->list2[1] = nullptr;
+    c->list2_cap[0] = c->list2_cap[1] = 0;
     c->list2_counts = nullptr;
     c->surv_counts = nullptr;
     c->surv_cap = 0;
@@ -273,15 +284,22 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_fence[i], hipEventDisableTiming) == hipSuccess;
     c->ex_stream = c->cand_stream = nullptr;
+    c->ex_stream2 = nullptr;
+    c->ev_ex2[0] = c->ev_ex2[1] = nullptr;
+    c->surv2 = nullptr;
+    c->surv2_cap = 0;
+    c->surv_sel = 0;
     c->ev_oct[0] = c->ev_oct[1] = nullptr;
     ok = ok && hipStreamCreateWithFlags(&c->ex_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->ex_stream2, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_ex2[i], hipEventDisableTiming) == hipSuccess;
     c->kp_stream = nullptr;
     c->ev_cnt0 = c->ev_kp = nullptr;
     c->h_cnt0 = nullptr;
     ok = ok && hipStreamCreateWithFlags(&c->kp_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_cnt0, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_kp, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * 4, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * 8, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_oct[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
     const size_t vb = sizeof(float) * (size_t)c->capN;
@@ -314,6 +332,9 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
         if (c->stream) hipStreamDestroy(c->stream);
         if (c->copy_stream) hipStreamDestroy(c->copy_stream);
         if (c->ex_stream) hipStreamDestroy(c->ex_stream);
+        if (c->ex_stream2) hipStreamDestroy(c->ex_stream2);
+        for (int i = 0; i < 2; i++)
+            if (c->ev_ex2[i]) hipEventDestroy(c->ev_ex2[i]);
         if (c->kp_stream) hipStreamDestroy(c->kp_stream);
         if (c->ev_cnt0) hipEventDestroy(c->ev_cnt0);
         if (c->ev_kp) hipEventDestroy(c->ev_kp);
@@ -341,6 +362,9 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
     hipStreamDestroy(c->copy_stream);
     hipStreamSynchronize(c->ex_stream);
     hipStreamDestroy(c->ex_stream);
+    hipStreamSynchronize(c->ex_stream2);
+    hipStreamDestroy(c->ex_stream2);
+    for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_ex2[i]);
     hipStreamSynchronize(c->kp_stream);
     hipStreamDestroy(c->kp_stream);
     hipEventDestroy(c->ev_cnt0);
@@ -467,7 +491,7 @@ struct stage_scope {
         if (stage < 0) return;
         if (timed) {
             hipEventRecord(e1, st);
-            c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f});
+            c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f, 0.0f});
         }
     }
 };
@@ -490,6 +514,9 @@ static void timing_end(sift3d_ctx *c)
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) c->last.ms[t.stage] += ms;
         t.ms = ms;
+        float since = 0;
+        if (hipEventElapsedTime(&since, c->launches.front().e0, t.e0) != hipSuccess) since = 0;
+        t.start_ms = since;
     }
     c->resolved = c->launches.size();
     if (!c->launches.empty()) {
@@ -528,6 +555,7 @@ extern "C" int sift3d_get_launch_log(const sift3d_ctx *c, sift3d_launch_record *
         out[i].nvox = t.nvox;
         out[i].alg_bytes = t.bytes;
         out[i].ms = t.ms;
+        out[i].start_ms = t.start_ms;
     }
     return *n > cap ? SIFT3D_ERR_CAPACITY : SIFT3D_OK;
 }
@@ -765,6 +793,18 @@ static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
      * sized at 1/surv_div of its voxels; an overflow is flagged on the device and handled in cand_finalize */
     int64_t cover = j.X * j.Y * j.Z / c->surv_div + 64 * 1024; /* split evenly over 64 segments */
     if (cover > c->surv_cap) cover = c->surv_cap;
+    sift3d_survivor *surv = c->surv;
+    if (c->surv_sel > 0) { /* a pass on the second extrema stream: that stream's own list, grown on demand */
+        if (c->surv2_cap < cover) {
+            HIPCHK(c, hipStreamSynchronize(st));
+            hipFree(c->surv2);
+            c->surv2 = nullptr;
+            c->surv2_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->surv2, sizeof(sift3d_survivor) * (size_t)cover));
+            c->surv2_cap = cover;
+        }
+        surv = c->surv2;
+    }
     const bool fresh = c->surv_set < SIFT3D_SURV_SETS;
     const int set = fresh ? c->surv_set++ : SIFT3D_SURV_SETS - 1;
     unsigned long long *counters = c->surv_counts + (size_t)set * SIFT3D_SURV_COUNTERS;
@@ -776,24 +816,25 @@ static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
         lz.next_g = j.next_g;
         if (j.next_g) {
             /* the second list holds a subset of the own-level list: the same capacity always suffices */
-            if (c->list2_cap < cover) {
+            const int li = c->surv_sel > 0 ? 1 : 0;
+            if (c->list2_cap[li] < cover) {
                 HIPCHK(c, hipStreamSynchronize(st)); /* an earlier pass may still be reading the list */
-                hipFree(c->list2);
-                c->list2 = nullptr;
-                c->list2_cap = 0;
-                HIPCHK(c, hipMalloc((void **)&c->list2, sizeof(sift3d_survivor2) * (size_t)cover));
-                c->list2_cap = cover;
+                hipFree(c->list2[li]);
+                c->list2[li] = nullptr;
+                c->list2_cap[li] = 0;
+                HIPCHK(c, hipMalloc((void **)&c->list2[li], sizeof(sift3d_survivor2) * (size_t)cover));
+                c->list2_cap[li] = cover;
             }
             lz.ntaps = j.next_ntaps;
             memcpy(lz.taps, j.next_taps, sizeof(lz.taps));
-            lz.list2 = c->list2;
+            lz.list2 = c->list2[li];
             lz.list2_count = c->list2_counts + (size_t)set * SIFT3D_LIST2_COUNTERS;
-            lz.list2_cap = c->list2_cap;
+            lz.list2_cap = c->list2_cap[li];
             if (!fresh) HIPCHK(c, hipMemsetAsync(lz.list2_count, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS, st));
         }
     }
     HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Xl ? j.Xl : j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
-                                    c->vals_a, c->d_count, c->cand_cap, c->surv, counters, c->d_count + 2, cover, !fresh,
+                                    c->vals_a, c->d_count, c->cand_cap, surv, counters, c->d_count + 2, cover, !fresh,
                                     lazy ? &lz : nullptr));
     return SIFT3D_OK;
 }
@@ -816,8 +857,9 @@ static int cand_replay(sift3d_ctx *c)
 static int cand_finalize(sift3d_ctx *c, int64_t *count_out, int64_t *n_sorted = nullptr)
 {
     for (int attempt = 0; attempt < 4; attempt++) {
-        unsigned long long cnt[3] = {0, 0, 0}; /* validated extrema, survivors of the last level, survivor overflow */
-        HIPCHK(c, hipMemcpyAsync(cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+        unsigned long long *cnt = c->h_cnt0 + 4; /* validated extrema, survivors of the last level, survivor overflow */
+        cnt[0] = cnt[1] = cnt[2] = 0;
+        HIPCHK(c, hipMemcpyAsync(cnt, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if ((cnt[2] > 0 || (int64_t)cnt[0] > c->cand_cap) && n_sorted && *n_sorted > 0) {
             /* the early pass worked on a list that is about to be rebuilt (and possibly reallocated): let it drain, drop it */
@@ -1094,7 +1136,7 @@ static void kp_params_of(sift3d_ctx *c, int desc_mode, float eig_thres, float si
 /* n_done: leading candidates whose keypoint stage has already been queued on kp_stream (ev_kp marks its end) with the
  * level table already on the device */
 static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode,
-                           float eig_thres, float size_factor, int64_t *n_out, int64_t n_done = 0)
+                           float eig_thres, float size_factor, int64_t *n_out, int64_t n_done = 0, bool levels_on_device = false)
 {
     float taps3[SIFT3D_MAX_TAPS], taps5[SIFT3D_MAX_TAPS];
     if (sift3d_gauss_taps(0.5f, 0.01f, taps3) != 3 || sift3d_gauss_taps((float)0.95, (float)0.01, taps5) != 5)
@@ -1110,7 +1152,8 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
         rc = ensure_kp_buffers(c, ncand, 0);
         if (rc) return rc;
         if (n_done > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_kp, 0)); /* kps / nrec / patch0 of the early part are complete */
-        else HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->stream));
+        else if (!levels_on_device)
+            HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->stream));
         sift3d_kp_params p;
         kp_params_of(c, desc_mode, eig_thres, size_factor, p);
         if (ncand > n_done) {
@@ -1121,7 +1164,8 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
                                                c->nrec + n_done, taps3));
         }
         HIPCHK(c, sift3d_scan_counts(c->stream, c->scan_tmp, c->scan_tmp_bytes, c->nrec, c->offs, ncand));
-        int last[2] = {0, 0};
+        int *last = reinterpret_cast<int *>(c->h_cnt0 + 4); /* pinned */
+        last[0] = last[1] = 0;
         HIPCHK(c, hipMemcpyAsync(&last[0], c->offs + (ncand - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(&last[1], c->nrec + (ncand - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1164,7 +1208,8 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
             }
         }
     }
-    unsigned long long nkp = 0;
+    unsigned long long &nkp = c->h_cnt0[6]; /* pinned */
+    nkp = 0;
     if (nrec_total) HIPCHK(c, hipMemcpyAsync(&nkp, c->d_count + 3, sizeof(nkp), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (nrec_total) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
@@ -1214,6 +1259,65 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     const bool early_ok = extract && oct.size() > 1 && eenv && atoi(eenv) == 1;
     float fscale = 1;
     float sig[7];
+    struct ex_plan {
+        bool tiny_done, lazy, lazy_next;
+        float *d4tiny;
+        int next_ntaps;
+        float next_taps[2 * SIFT3D_FAST_MAX_R + 1];
+        float sig[7];
+        float fscale;
+    };
+    std::vector<ex_plan> plans(oct.size());
+    const char *xenv = getenv("SIFT3D_EX_SCHED");
+    const bool new_sched = !(xenv && atoi(xenv) == 0) && !early_ok;
+    bool used_second = false;
+    /* the three detection levels of octave o on extrema stream `which` (0: ex_stream, 1: ex_stream2), behind everything
+     * queued on the main stream so far */
+    auto enqueue_extrema = [&](size_t o, int which) -> int {
+        const octave_dims &d = oct[o];
+        const ex_plan &pl = plans[o];
+        /* timing mode 3 (measurement only): the extrema stay on the main stream, so that every launch's event pair times
+         * that launch alone instead of the launch plus whatever shares the chip with it */
+        hipStream_t exs = c->timing == 3 ? c->stream : (which == 0 ? c->ex_stream : c->ex_stream2);
+        if (exs != c->stream) {
+            hipEvent_t ev = which == 0 ? c->ev_oct[0] : c->ev_ex2[0];
+            HIPCHK(c, hipEventRecord(ev, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(exs, ev, 0));
+            if (which == 1) used_second = true;
+        }
+        c->cand_stream = exs;
+        c->surv_sel = (exs != c->stream && which == 1) ? 1 : 0;
+        int rc_ = SIFT3D_OK;
+        for (int l = 0; l < 3 && !rc_; l++) {
+            const int id = (int)o * 3 + l;
+            const float *dnext = l < 2 ? c->D[l + 2] + d.off : (pl.tiny_done ? pl.d4tiny : (pl.lazy_next ? nullptr : c->D[4] + d.off));
+            level_job job = {c->D[l] + d.off, c->D[l + 1] + d.off, dnext, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X};
+            if (pl.lazy && l == 0) { /* the level below D_1 is L_0 - L_1 */
+                job.dp = c->L[0] + d.off;
+                job.prev_b = c->L[1] + d.off;
+            }
+            if (pl.lazy_next && l == 2) { /* the level above D_3 is L_4 - blur(L_4) */
+                job.dn = nullptr;
+                job.next_g = c->L[4] + d.off;
+                job.next_ntaps = pl.next_ntaps;
+                for (int q = 0; q < pl.next_ntaps; q++) job.next_taps[q] = pl.next_taps[q];
+            }
+            rc_ = cand_append(c, job, true);
+            sift3d_level &lv = levels[(size_t)id];
+            lv.img = c->L[l + 1] + d.off;
+            lv.dogc = c->D[l + 1] + d.off;
+            lv.X = (int)d.X; lv.Y = (int)d.Y; lv.Z = (int)d.Z;
+            lv.XP = (int)d.XP;
+            lv.sigma_h = pl.sig[l]; lv.sigma_c = pl.sig[l + 1]; lv.sigma_l = pl.sig[l + 2];
+            lv.octave_factor = pl.fscale;
+            lv.Zl = (int)d.Z;
+            lv.z_off = 0;
+            lv.pad = 0;
+        }
+        c->cand_stream = nullptr;
+        c->surv_sel = 0;
+        return rc_;
+    };
     for (size_t o = 0; o < oct.size(); o++) {
         const octave_dims &d = oct[o];
         const double N = (double)d.X * d.Y * d.Z;
@@ -1307,47 +1411,38 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             sigma *= factor;
             sig[j] = sigma;
         }
-        /* the extrema of this octave go to a second stream: they run beside the blurs of the coarser octaves, which are
-         * launch-latency-bound and leave most of the chip idle */
-        /* timing mode 3 (measurement only): the extrema stay on the main stream, so that every launch's event pair times
-         * that launch alone instead of the launch plus whatever shares the chip with it */
-        hipStream_t exs = c->timing == 3 ? c->stream : c->ex_stream;
-        if (exs != c->stream) {
-            HIPCHK(c, hipEventRecord(c->ev_oct[0], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->ex_stream, c->ev_oct[0], 0));
-        }
-        c->cand_stream = exs;
-        for (int l = 0; l < 3; l++) {
-            const int id = (int)o * 3 + l;
-            const float *dnext = l < 2 ? c->D[l + 2] + d.off : (tiny_done ? d4tiny : (lazy_next ? nullptr : c->D[4] + d.off));
-            level_job job = {c->D[l] + d.off, c->D[l + 1] + d.off, dnext, d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X};
-            if (lazy && l == 0) { /* the level below D_1 is L_0 - L_1 */
-                job.dp = c->L[0] + d.off;
-                job.prev_b = c->L[1] + d.off;
+        /* the extrema of this octave go to another stream: see enqueue_extrema above */
+        ex_plan &pl = plans[o];
+        pl.tiny_done = tiny_done;
+        pl.d4tiny = d4tiny;
+        pl.lazy = lazy;
+        pl.lazy_next = lazy_next;
+        pl.next_ntaps = next_ntaps;
+        for (int q = 0; q < next_ntaps && q < 2 * SIFT3D_FAST_MAX_R + 1; q++) pl.next_taps[q] = next_taps[q];
+        for (int q = 0; q < 7; q++) pl.sig[q] = sig[q];
+        pl.fscale = fscale;
+        /* Octave 0's extrema fill the chip for a millisecond, and so do octave 1's blurs for a third of one, while everything
+         * coarser is a chain of small launches that leaves it idle: octave 0's extrema therefore wait until octave 1's levels
+         * are done and then run beside that chain; the extrema of the coarser octaves go to a stream of their own so that
+         * they do not queue up behind octave 0's.  (Started right after octave 0's own levels they shared the chip with
+         * octave 1's blurs -- both three to ten times slower for it -- and the chain of octaves 2.. ran alone afterwards,
+         * a millisecond of mostly idle chip.)  SIFT3D_EX_SCHED=0 (A/B): every octave's extrema right behind its levels,
+         * all on one stream. */
+        if (o == 0 && !(new_sched && oct.size() > 1)) {
+            rc = enqueue_extrema(0, 0);
+            if (rc) return rc;
+        } else if (o >= 1) {
+            if (o == 1 && new_sched) {
+                rc = enqueue_extrema(0, 0);
+                if (rc) return rc;
             }
-            if (lazy_next && l == 2) { /* the level above D_3 is L_4 - blur(L_4) */
-                job.dn = nullptr;
-                job.next_g = c->L[4] + d.off;
-                job.next_ntaps = next_ntaps;
-                for (int q = 0; q < next_ntaps; q++) job.next_taps[q] = next_taps[q];
-            }
-            rc = cand_append(c, job, true);
-            if (rc) { c->cand_stream = nullptr; return rc; }
-            sift3d_level &lv = levels[(size_t)id];
-            lv.img = c->L[l + 1] + d.off;
-            lv.dogc = c->D[l + 1] + d.off;
-            lv.X = (int)d.X; lv.Y = (int)d.Y; lv.Z = (int)d.Z;
-            lv.XP = (int)d.XP;
-            lv.sigma_h = sig[l]; lv.sigma_c = sig[l + 1]; lv.sigma_l = sig[l + 2];
-            lv.octave_factor = fscale;
-            lv.Zl = (int)d.Z;
-            lv.z_off = 0;
-            lv.pad = 0;
+            rc = enqueue_extrema(o, new_sched ? 1 : 0);
+            if (rc) return rc;
         }
-        c->cand_stream = nullptr;
         if (o == 0 && early_ok) {
             /* octave 0's extrema are the first entries of the list (the passes of the coarser octaves follow on the same
              * stream): note how many there are, for the early per-keypoint pass below */
+            hipStream_t exs = c->timing == 3 ? c->stream : c->ex_stream;
             HIPCHK(c, hipMemcpyAsync(c->h_cnt0, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, exs));
             HIPCHK(c, hipEventRecord(c->ev_cnt0, exs));
         }
@@ -1356,6 +1451,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     }
     HIPCHK(c, hipEventRecord(c->ev_oct[1], c->ex_stream)); /* the candidate counts are read on the main stream */
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_oct[1], 0));
+    if (used_second) {
+        HIPCHK(c, hipEventRecord(c->ev_ex2[1], c->ex_stream2));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ex2[1], 0));
+    }
     /* Early per-keypoint pass.  Everything above is queued, the device is minutes of host time behind: wait until octave
      * 0's extrema are in (the coarser octaves are still blurring, launch-latency-bound, on a mostly idle chip), then sort
      * them and run their keypoint kernel on a third stream beside that chain.  The reference itself generates the
@@ -1384,12 +1483,16 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             HIPCHK(c, hipEventRecord(c->ev_kp, c->kp_stream));
         }
     }
+    /* the level table goes to the device now, behind the pyramid, not after the host has waited for the extrema count */
+    const bool levels_early = extract && n0 == 0 && levels.size() <= 96;
+    if (levels_early)
+        HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->stream));
     int64_t ncand = 0;
     rc = cand_finalize(c, &ncand, &n0);
     if (rc) return rc;
     c->last.n_extrema = ncand;
     if (!extract) return candidates_to_host(c, levels, ncand, cands_out, n_out);
-    rc = describe_sorted(c, levels, ncand, desc_mode, eig_thres, size_factor, n_out, n0);
+    rc = describe_sorted(c, levels, ncand, desc_mode, eig_thres, size_factor, n_out, n0, levels_early);
     if (rc) return rc;
     *feats_out = c->h_recs; /* pinned, owned by the context */
     return SIFT3D_OK;

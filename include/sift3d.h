@@ -276,6 +276,7 @@ typedef struct {
     int64_t nvox;   /* voxels (or keypoints / records) the launch covered */
     double alg_bytes;
     double ms;
+    double start_ms; /* when the launch began, counted from the first timed launch of the call (a timeline across the streams) */
 } sift3d_launch_record;
 int sift3d_get_launch_log(const sift3d_ctx *ctx, sift3d_launch_record *out, int64_t cap, int64_t *n);
 
