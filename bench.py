@@ -39,7 +39,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TABLE = "r02_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
+PMC_TABLE = "r02b_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
 BLUR_SOURCE = os.path.join("3d_sift_cuda_amd", "csrc", "kernels_blur_fused.hip")   # what the PMC table was measured on
 
 
@@ -360,13 +360,18 @@ def main():
                                       % (PMC_TABLE, BLUR_SOURCE))
                 tot, cnt = 0.0, 0
                 for pi in per_inst:
-                    hit = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % (pi["taps"] // 2))]
-                    if not hit:
+                    R = pi["taps"] // 2
+                    with_dog = pi["alg_bytes_per_voxel"] > 9
+                    # template arguments: <R, rows per thread, has level, has DoG, prefetch planes, outputs per lane>
+                    exact = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and
+                             (", true, true," in k) == with_dog and (with_dog or ", true, false," in k)]
+                    twin = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and ", true, true," in k]
+                    if exact:
+                        w = tab[sorted(exact)[0]]["hbm_bytes_per_launch_512"]
+                    elif twin:   # a level-only launch measured through its level + DoG twin: 4 B/voxel less written
+                        w = tab[sorted(twin)[0]]["hbm_bytes_per_launch_512"] - 4.0 * n ** 3
+                    else:
                         raise LookupError("no PMC entry for %d taps" % pi["taps"])
-                    v = tab[sorted(hit)[0]]
-                    # the PMC pass stores level and DoG except for the sixth level; a launch that keeps only the level
-                    # (initial blur) writes 4 B/voxel less than its PMC twin
-                    w = v["hbm_bytes_per_launch_512"] - (4.0 * n ** 3 if (pi["alg_bytes_per_voxel"] < 9 and pi["taps"] != 17) else 0.0)
                     tot += w * pi["launches"]; cnt += pi["launches"]
                 traffic = tot / cnt
             except Exception as e:

@@ -15,8 +15,22 @@ torch.cuda.synchronize()
 sig = {7: 1.2262736558914185, 9: 1.5450079441070557, 11: 1.9465880393981934, 13: 2.452547311782837, 17: 3.0900158882141113}
 N = n ** 3
 print("N=%d^3  bytes/pass: %.3f GB" % (n, 8 * N / 1e9))
-for taps, s in sig.items():
-    outp = 0 if taps == 17 else b.data_ptr()   # as in the pyramid: the sixth level (17 taps) is not stored, only its DoG
+cases = [(taps, s, True) for taps, s in sig.items()] + [(7, sig[7], False), (9, 1.5198684930801392, False)]   # level-only: L1 and the initial blur
+for taps, s, with_dog in cases:
+    outp = 0 if taps == 17 else b.data_ptr()   # the 17-tap level, when it is filtered in full (SIFT3D_LAZY_LEVELS=0), is not stored, only its DoG
+    if not with_dog:
+        for _ in range(2):
+            ctx.gauss_blur_dev(a.data_ptr(), b.data_ptr(), n, n, n, s)
+        ctx.enable_timing(True)
+        for _ in range(reps):
+            ctx.gauss_blur_dev(a.data_ptr(), b.data_ptr(), n, n, n, s)
+        log = ctx.launch_log()
+        ctx.enable_timing(False)
+        sel = log[log["stage"] == 7]
+        if len(sel):
+            ms = float(np.median(sel["ms"]))
+            print("taps %2d: fused %.3f ms  %.0f GB/s (8N, level only)" % (taps, ms, 8 * N / ms / 1e6))
+        continue
     for _ in range(2):
         ctx.gauss_blur_dog_dev(a.data_ptr(), outp, d.data_ptr(), n, n, n, s)
     ctx.enable_timing(True)
