@@ -1368,7 +1368,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             float sg = 1.6f; /* sigma entering j = 5, accumulated as the loop below does */
             for (int j = 1; j < 5; j++) sg *= factor;
             next_ntaps = sift3d_gauss_taps(sg * sqrtf(factor * factor - 1.0f), 0.01f, next_taps);
-            if (next_ntaps < 3 || next_ntaps > 2 * SIFT3D_FAST_MAX_R + 1) lazy = false;
+            if (next_ntaps != 2 * SIFT3D_FAST_MAX_R + 1) lazy = false; /* the one filter length the third phase is built for */
         }
         const int lazy_from = lenv ? atoi(lenv) - 1 : 0; /* A/B aid: SIFT3D_LAZY_LEVELS=n+1: the level above D_3 is stored on octaves below n */
         const bool lazy_next = lazy && (int)o >= lazy_from;
@@ -1900,6 +1900,17 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
         const int64_t X = plan.oct[(size_t)o][0], Y = plan.oct[(size_t)o][1], zo = plan.oct[(size_t)o][2], XY = X * Y;
         const bool sharded = S > 1 && o < K;
         const int nr = sharded ? S : 1; /* the gathered octaves live on rank 0 */
+        /* As on one device (run_pipeline): D_0 is read as L_0 - L_1 around the extrema of D_1, and L_5 -- hence D_4 -- is
+         * filtered only around the candidates of D_3, from L_4.  A slab then blurs four levels instead of five and exchanges
+         * four halos per octave instead of five; the third extrema phase reads L_4 nine slices beyond a candidate, so L_4's
+         * halo is refreshed nine slices deep instead of eight.  Rows that are not whole 16-byte vectors keep every level
+         * stored (the extrema kernels of such rows take stored levels only), as does SIFT3D_LAZY_LEVELS=0. */
+        float taps5[SIFT3D_MAX_TAPS];
+        const int ntaps5 = sift3d_gauss_taps(extras[4], 0.01f, taps5);
+        const char *lzenv = getenv("SIFT3D_LAZY_LEVELS");
+        const bool lazy = ntaps5 == 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X >= 8 && XY < (1ll << 29) && Y >= 3 && zo >= 3 &&
+                          !(lzenv && atoi(lzenv) == 0);
+        const int nlev = lazy ? 4 : 5;
         for (r = 0; r < nr; r++) {
             zs_rank &q = R[(size_t)r];
             if (sharded) plan.slab(r, o, q.z0, q.z1); else { q.z0 = 0; q.z1 = zo; }
@@ -1909,12 +1920,13 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
             q.e1 = q.hi ? std::min<int64_t>(zo, q.z1 + ZS_HALO) : q.z1;
             ZS_HIP(hipSetDevice(q.dev));
             q.L[0] = next0[r];
-            for (int j = 1; j < 6; j++) q.L[j] = q.alloc((q.e1 - q.e0) * XY);
-            for (int j = 0; j < 5; j++) q.D[j] = q.alloc((q.e1 - q.e0) * XY);
-            for (int j = 1; j < 6; j++)
-                if (!q.L[j] || !q.D[j - 1]) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
+            for (int j = 1; j < 6; j++) q.L[j] = j <= nlev ? q.alloc((q.e1 - q.e0) * XY) : nullptr;
+            for (int j = 0; j < 5; j++) q.D[j] = (lazy && (j == 0 || j == 4)) ? nullptr : q.alloc((q.e1 - q.e0) * XY);
+            for (int j = 1; j <= nlev; j++)
+                if (!q.L[j] || (!q.D[j - 1] && !(lazy && j == 1))) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
         }
-        for (int j = 1; j < 6; j++) {
+        for (int j = 1; j <= nlev; j++) {
+            const int64_t hb = (lazy && j == 4) ? ZS_BLUR + 1 : ZS_BLUR; /* slices of this level's halo refreshed from the neighbours */
             /* every rank: level j on slab +- 8 (clipped to the buffer: at a face of the whole volume the buffer ends at the
              * face, which is what makes the zero border exact), D_{j-1} fused */
             for (r = 0; r < nr; r++) {
@@ -1922,7 +1934,7 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
                 const int64_t c0 = q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0, c1 = q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1;
                 const int64_t a = c0 - q.e0, b = c1 - q.e0;
                 ZS_HIP(hipSetDevice(q.dev));
-                ZS_RC(blur_dev(q.c, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] + a * XY, X, Y, b - a, extras[j - 1], 0.01f));
+                ZS_RC(blur_dev(q.c, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] ? q.D[j - 1] + a * XY : nullptr, X, Y, b - a, extras[j - 1], 0.01f));
                 ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
                 if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
             }
@@ -1931,11 +1943,11 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
             for (r = 0; r < nr; r++) {
                 zs_rank &q = R[(size_t)r];
                 ZS_HIP(hipSetDevice(q.dev));
-                const size_t bytes = sizeof(float) * (size_t)(ZS_BLUR * XY);
+                const size_t bytes = sizeof(float) * (size_t)(hb * XY);
                 if (q.lo) {
                     zs_rank &p = R[(size_t)r - 1];
                     ZS_COMM(hipStreamWaitEvent(q.c->stream, p.ev_level, 0));
-                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z0 - ZS_BLUR - q.e0) * XY, q.dev, p.L[j] + (q.z0 - ZS_BLUR - p.e0) * XY, p.dev, bytes, q.c->stream));
+                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z0 - hb - q.e0) * XY, q.dev, p.L[j] + (q.z0 - hb - p.e0) * XY, p.dev, bytes, q.c->stream));
                     st.halo_bytes_critical += (int64_t)bytes;
                     st.exchanges++;
                 }
@@ -1947,9 +1959,9 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
                     st.exchanges++;
                 }
                 const int64_t a = (q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0) - q.e0, b = (q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1) - q.e0;
-                if (q.lo && q.z0 - q.e0 > a)
+                if (q.D[j - 1] && q.lo && q.z0 - q.e0 > a)
                     ZS_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] + a * XY, (q.z0 - q.e0 - a) * XY));
-                if (q.hi && b > q.z1 - q.e0)
+                if (q.D[j - 1] && q.hi && b > q.z1 - q.e0)
                     ZS_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + (q.z1 - q.e0) * XY, q.L[j] + (q.z1 - q.e0) * XY, q.D[j - 1] + (q.z1 - q.e0) * XY, (b - (q.z1 - q.e0)) * XY));
             }
             if (j == 3) {
@@ -1991,6 +2003,16 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
             for (int l = 0; l < 3; l++) {
                 const int id = o * 3 + l;
                 level_job jb = {q.D[l], q.D[l + 1], q.D[l + 2], X, Y, q.e1 - q.e0, (int)(q.z0 - q.e0), (int)(q.z1 - q.e0), id, 0};
+                if (lazy && l == 0) { /* the level below D_1 is L_0 - L_1 */
+                    jb.dp = q.L[0];
+                    jb.prev_b = q.L[1];
+                }
+                if (lazy && l == 2) { /* the level above D_3 is L_4 - blur(L_4) */
+                    jb.dn = nullptr;
+                    jb.next_g = q.L[4];
+                    jb.next_ntaps = ntaps5;
+                    for (int t = 0; t < ntaps5; t++) jb.next_taps[t] = taps5[t];
+                }
                 ZS_RC(cand_append(q.c, jb, true));
                 sift3d_level &lv = q.levels[(size_t)id];
                 lv.img = q.L[l + 1]; lv.dogc = q.D[l + 1];

@@ -1284,16 +1284,10 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
             if (lazy->ntaps != 2 * R + 1 || R < 1 || R > SIFT3D_FAST_MAX_R || !lazy->list2 || !lazy->list2_count || lazy->list2_cap <= 0 ||
                 X * Y >= (1ll << 29))
                 return hipErrorInvalidValue;
-            switch (R) {
-            case 1: launch_validate_lazy<1>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            case 2: launch_validate_lazy<2>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            case 3: launch_validate_lazy<3>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            case 4: launch_validate_lazy<4>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            case 5: launch_validate_lazy<5>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            case 6: launch_validate_lazy<6>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            case 7: launch_validate_lazy<7>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            default: launch_validate_lazy<8>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap); break;
-            }
+            /* the level above the last detection level is always the 17-tap one (sigma 3.09: the schedule of
+             * MultiScale.cpp:288-294 does not depend on the input), so that is the one instantiation */
+            if (R != SIFT3D_FAST_MAX_R) return hipErrorNotSupported;
+            launch_validate_lazy<SIFT3D_FAST_MAX_R>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap);
         }
     } else {
         if (pair || defer) return hipErrorNotSupported; /* the caller keeps such shapes on stored DoG levels */

@@ -692,8 +692,14 @@ def test_c_zslab_driver_matches_single_gpu(built, dims, seed, mode, devs, scale)
     assert len(want) > 50 and len(got) == len(want)
     assert got.tobytes() == want.tobytes()                                  # bit-identical records, same order
     assert st["n_ranks"] == len(devs) and st["sharded_octaves"] >= 1 and st["n_records"] == len(want)
-    # per interface and sharded octave: five 8-slice halos on the critical path, 3 x 24 slices deferred, both directions
-    assert st["halo_bytes_critical"] > 0 and st["halo_bytes_deferred"] * 40 == st["halo_bytes_critical"] * 72
+    # per interface and sharded octave, both directions: 3 x 24 slices deferred; on the critical path the 8-slice halos of
+    # L1..L3 and 9 slices of L4 (the 17-tap level is only evaluated around candidates, from L4) -- or, for rows that are not
+    # whole 16-byte vectors, five 8-slice halos (every level stored)
+    # (a sharded octave whose rows are not whole vectors -- 68 -> 34 -- stores every level while the octave above it does not)
+    d, c = st["halo_bytes_deferred"], st["halo_bytes_critical"]
+    assert c > 0 and 33 * d <= 72 * c <= 40 * d
+    if all((dims[0] >> o) % 4 == 0 for o in range(st["sharded_octaves"])):
+        assert 33 * d == 72 * c
     assert st["gather_bytes"] > 0
 
 
@@ -733,7 +739,7 @@ def test_config_c5_shape_of_work_on_one_gpu(built):
     got, st = built.extract_zslab(vol, [0] * 8, desc_mode=built.DESC_NRRIEF)
     assert st["n_ranks"] == 8 and st["sharded_octaves"] == 3
     assert len(want) > 5000 and got.tobytes() == want.tobytes()
-    assert st["halo_bytes_deferred"] * 40 == st["halo_bytes_critical"] * 72
+    assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72   # 8 + 8 + 8 + 9 slices of L1..L4 on the critical path
 
 
 def test_c_zslab_driver_edge_cases(built):
