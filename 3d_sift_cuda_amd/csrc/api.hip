@@ -63,6 +63,7 @@ struct sift3d_ctx {
     hipStream_t cand_stream;   /* where cand_append launches: stream, or ex_stream inside run_pipeline */
     hipStream_t ex_stream2;    /* extrema of the octaves after the first (run_pipeline: the first octave's wait for the second's levels) */
     hipEvent_t ev_ex2[2];      /* levels of such an octave complete / its extrema launches complete */
+    hipEvent_t ev_reset;       /* the counters of the extrema passes have been cleared (on ex_stream) */
     sift3d_survivor *surv2;    /* own-level list of that stream (the passes of one stream share a list, one after the other) */
     int64_t surv2_cap;
     int surv_sel;              /* which list cand_append uses: 0 = surv, 1 = surv2 */
@@ -286,6 +287,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->ex_stream = c->cand_stream = nullptr;
     c->ex_stream2 = nullptr;
     c->ev_ex2[0] = c->ev_ex2[1] = nullptr;
+    c->ev_reset = nullptr;
     c->surv2 = nullptr;
     c->surv2_cap = 0;
     c->surv_sel = 0;
@@ -293,6 +295,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     ok = ok && hipStreamCreateWithFlags(&c->ex_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->ex_stream2, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_ex2[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) == hipSuccess;
     c->kp_stream = nullptr;
     c->ev_cnt0 = c->ev_kp = nullptr;
     c->h_cnt0 = nullptr;
@@ -335,6 +338,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
         if (c->ex_stream2) hipStreamDestroy(c->ex_stream2);
         for (int i = 0; i < 2; i++)
             if (c->ev_ex2[i]) hipEventDestroy(c->ev_ex2[i]);
+        if (c->ev_reset) hipEventDestroy(c->ev_reset);
         if (c->kp_stream) hipStreamDestroy(c->kp_stream);
         if (c->ev_cnt0) hipEventDestroy(c->ev_cnt0);
         if (c->ev_kp) hipEventDestroy(c->ev_kp);
@@ -365,6 +369,7 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
     hipStreamSynchronize(c->ex_stream2);
     hipStreamDestroy(c->ex_stream2);
     for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_ex2[i]);
+    hipEventDestroy(c->ev_reset);
     hipStreamSynchronize(c->kp_stream);
     hipStreamDestroy(c->kp_stream);
     hipEventDestroy(c->ev_cnt0);
@@ -773,13 +778,15 @@ extern "C" int sift3d_halve_size(sift3d_ctx *c, const float *in, int64_t nx, int
  * launch each, nothing synchronises), then finalize = one host synchronisation for the count, a
  * replay of the recorded launches into a bigger buffer if it overflowed (the DoG levels stay
  * resident), and the device radix sort. */
-static int cand_reset(sift3d_ctx *c)
+/* on: the stream the clears are queued on (the caller orders the extrema passes behind it) */
+static int cand_reset(sift3d_ctx *c, hipStream_t on = nullptr)
 {
+    if (!on) on = c->stream;
     c->jobs.clear();
-    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, on));
     /* every extrema pass of the run gets its own counter set: one memset here instead of one per pass */
-    HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, on));
+    HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, on));
     c->surv_set = 0;
     return SIFT3D_OK;
 }
@@ -1243,8 +1250,12 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     int rc = blur_dev(c, c->vol, c->L[0], nullptr, xp0, c->ny, c->nz, extra0, 0.01f);
     if (rc) return rc;
     if (xp0 != c->nx) HIPCHK(c, sift3d_launch_zero_pad(c->stream, c->L[0], nullptr, xp0, c->nx, c->ny * c->nz));
-    rc = cand_reset(c);
+    /* the counters of the extrema passes are cleared on the first extrema stream, idle until octave 1's levels are done,
+     * instead of between two blur launches of the main one (1.5 MB of counters: 25 us); the other streams that run
+     * extrema passes wait for ev_reset */
+    rc = cand_reset(c, c->ex_stream);
     if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_reset, c->ex_stream));
 
     int64_t tiny_base = -1; /* float offset of the first octave of at most SIFT3D_TINY_VOX voxels */
     for (const octave_dims &d : oct)
@@ -1279,6 +1290,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         /* timing mode 3 (measurement only): the extrema stay on the main stream, so that every launch's event pair times
          * that launch alone instead of the launch plus whatever shares the chip with it */
         hipStream_t exs = c->timing == 3 ? c->stream : (which == 0 ? c->ex_stream : c->ex_stream2);
+        if (exs != c->ex_stream) HIPCHK(c, hipStreamWaitEvent(exs, c->ev_reset, 0));
         if (exs != c->stream) {
             hipEvent_t ev = which == 0 ? c->ev_oct[0] : c->ev_ex2[0];
             HIPCHK(c, hipEventRecord(ev, c->stream));
