@@ -122,6 +122,8 @@ def hip_lib():
     _sig(L.sift3d_get_launch_log, I, P, P, I64, P)
     _sig(L.sift3d_candidates_reset, I, P)
     _sig(L.sift3d_extrema_append_dev, I, P, P, P, P, I64, I64, I64, I, I64, I64)
+    _sig(L.sift3d_lazy_levels_supported, I, I64, I64, I64, F)
+    _sig(L.sift3d_extrema_append_lazy_dev, I, P, P, P, P, P, P, P, F, I64, I64, I64, I, I64, I64)
     _sig(L.sift3d_candidates_dev, I, P, P, I, P, P)
     _sig(L.sift3d_describe_dev, I, P, P, I, I, F, F, P, P, P)
     _sig(L.sift3d_set_max_octaves, I, P, I)
@@ -471,6 +473,18 @@ class Context:
         self._chk(self._L.sift3d_extrema_append_dev(self._h, C.c_void_p(int(d_prev)), C.c_void_p(int(d_cur)),
                                                     C.c_void_p(int(d_next)), nx, ny, nz_local, int(level_id), int(z_lo),
                                                     int(z_hi)), "sift3d_extrema_append_dev")
+
+    def lazy_levels_supported(self, nx, ny, nz_local, next_sigma):
+        return bool(self._L.sift3d_lazy_levels_supported(nx, ny, nz_local, float(next_sigma)))
+
+    def extrema_append_lazy_dev(self, d_prev, g_prev_a, g_prev_b, d_cur, d_next, g_next, next_sigma, nx, ny, nz_local, level_id,
+                                z_lo, z_hi):
+        """Like extrema_append_dev with a neighbour level given as Gaussian levels instead of a stored DoG volume (0 = not
+        given): the level below as g_prev_a - g_prev_b, the level above as g_next - blur(g_next, next_sigma)."""
+        vp = lambda v: C.c_void_p(int(v)) if v else None
+        self._chk(self._L.sift3d_extrema_append_lazy_dev(self._h, vp(d_prev), vp(g_prev_a), vp(g_prev_b), vp(d_cur), vp(d_next),
+                                                         vp(g_next), float(next_sigma), nx, ny, nz_local, int(level_id), int(z_lo),
+                                                         int(z_hi)), "sift3d_extrema_append_lazy_dev")
 
     @staticmethod
     def _level_array(levels):

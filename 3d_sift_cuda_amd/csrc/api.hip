@@ -1533,6 +1533,45 @@ extern "C" int sift3d_extrema_append_dev(sift3d_ctx *c, const float *d_prev, con
     return cand_append(c, {d_prev, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id}, true);
 }
 
+/* shapes the second and third extrema phase take neighbour levels in unstored form for */
+static bool lazy_shape_ok(int64_t nx, int64_t ny, int64_t nz_local)
+{
+    return nx % 4 == 0 && nx >= 8 && ny >= 3 && nz_local >= 3 && nx * ny < (1ll << 29);
+}
+
+extern "C" int sift3d_lazy_levels_supported(int64_t nx, int64_t ny, int64_t nz_local, float next_sigma)
+{
+    float taps[SIFT3D_MAX_TAPS];
+    const char *lzenv = getenv("SIFT3D_LAZY_LEVELS");
+    if (lzenv && atoi(lzenv) == 0) return 0;
+    return lazy_shape_ok(nx, ny, nz_local) && sift3d_gauss_taps(next_sigma, 0.01f, taps) == 2 * SIFT3D_FAST_MAX_R + 1 ? 1 : 0;
+}
+
+extern "C" int sift3d_extrema_append_lazy_dev(sift3d_ctx *c, const float *d_prev, const float *g_prev_a, const float *g_prev_b,
+                                              const float *d_cur, const float *d_next, const float *g_next, float next_sigma,
+                                              int64_t nx, int64_t ny, int64_t nz_local, int level_id, int64_t z_lo, int64_t z_hi)
+{
+    if (!c || !d_cur || (!d_prev && !(g_prev_a && g_prev_b)) || (!d_next && !g_next)) return SIFT3D_ERR_ARG;
+    if (nx <= 0 || ny <= 0 || nz_local <= 0 || nx >= (1ll << 31) || ny >= (1ll << 31) || nz_local >= 65538 ||
+        nx * ny * nz_local > (int64_t)SIFT3D_KEY_IDX_MASK || level_id < 0 || level_id >= 96)
+        return set_err(c, SIFT3D_ERR_ARG, "bad extrema_append arguments");
+    float taps[SIFT3D_MAX_TAPS];
+    const int ntaps = d_next ? 0 : sift3d_gauss_taps(next_sigma, 0.01f, taps);
+    if (((!d_prev || !d_next) && !lazy_shape_ok(nx, ny, nz_local)) || (!d_next && ntaps != 2 * SIFT3D_FAST_MAX_R + 1))
+        return set_err(c, SIFT3D_ERR_ARG, "this shape or filter needs stored DoG levels (sift3d_lazy_levels_supported)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fence_in(c);
+    if (rc) return rc;
+    level_job jb = {d_prev ? d_prev : g_prev_a, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id};
+    if (!d_prev) jb.prev_b = g_prev_b;
+    if (!d_next) {
+        jb.next_ntaps = ntaps;
+        for (int q = 0; q < ntaps; q++) jb.next_taps[q] = taps[q];
+        jb.next_g = g_next;
+    }
+    return cand_append(c, jb, true);
+}
+
 static int levels_from_desc(sift3d_ctx *c, const sift3d_level_desc *ld, int n, std::vector<sift3d_level> &levels)
 {
     if (!ld || n <= 0 || n > 96) return set_err(c, SIFT3D_ERR_ARG, "bad level table");

@@ -147,6 +147,23 @@ class HipBackend:
         nz, ny, nx = dc.shape
         self.ctx.extrema_append_dev(dp.data_ptr(), dc.data_ptr(), dn.data_ptr(), nx, ny, nz, level_id, z_lo, z_hi)
 
+    # ---- neighbour levels that are not stored: optional part of the backend interface ----
+    def lazy_ok(self, shape, next_sigma):
+        nz, ny, nx = shape
+        return self.ctx.lazy_levels_supported(nx, ny, nz, next_sigma)
+
+    def extrema_append_pair(self, ga, gb, dc, dn, level_id, z_lo, z_hi):
+        """the level below is ga - gb"""
+        nz, ny, nx = dc.shape
+        self.ctx.extrema_append_lazy_dev(0, ga.data_ptr(), gb.data_ptr(), dc.data_ptr(), dn.data_ptr(), 0, 0.0, nx, ny, nz,
+                                         level_id, z_lo, z_hi)
+
+    def extrema_append_lazy_next(self, dp, dc, g, next_sigma, level_id, z_lo, z_hi):
+        """the level above is g - blur(g, next_sigma), evaluated around the candidates only"""
+        nz, ny, nx = dc.shape
+        self.ctx.extrema_append_lazy_dev(dp.data_ptr(), 0, 0, dc.data_ptr(), 0, g.data_ptr(), next_sigma, nx, ny, nz, level_id,
+                                         z_lo, z_hi)
+
     def level_entry(self, img, dogc, nz_global, z_offset, sh, sc, sl, factor):
         nz, ny, nx = img.shape
         return {"img": img.data_ptr(), "dogc": dogc.data_ptr(), "nx": nx, "ny": ny, "nz_local": nz, "nz_global": nz_global,
@@ -239,22 +256,31 @@ class ZSlabExtractor:
         be = self.be
         nzl = e1 - e0
         shape = (nzl, L0.shape[1], L0.shape[2])
-        L = [L0] + [be.empty(shape) for _ in range(5)]
-        D = [be.empty(shape) for _ in range(5)]
+        # As on one device: D0 is read as L0 - L1 around the extrema of D1, and L5 -- hence D4 -- is filtered only around the
+        # candidates of D3, from L4: four levels and four halos per octave instead of five, L4's halo nine slices deep (the
+        # third extrema phase reads L4 nine slices beyond a candidate).  A backend without that form, or a shape it does
+        # not take (rows that are not whole 16-byte vectors), stores every level.
+        lazy = hasattr(be, "lazy_ok") and be.lazy_ok(shape, extras[4])
+        nlev = 4 if lazy else 5
+        L = [L0] + [be.empty(shape) if j <= nlev else None for j in range(1, 6)]
+        D = [None if (lazy and j in (0, 4)) else be.empty(shape) for j in range(5)]
         # region recomputed per level: slab +- BLUR_HALO, clipped to what the buffer holds (at a face of the
         # whole volume the buffer ends at the face, which is what makes the zero border exact)
         c0 = max(e0, z0 - BLUR_HALO) if has_lo else e0
         c1 = min(e1, z1 + BLUR_HALO) if has_hi else e1
         a, b = c0 - e0, c1 - e0
         patch_halos = lambda: None
-        for j in range(1, 6):
-            be.blur_dog(L[j - 1][a:b], L[j][a:b], D[j - 1][a:b], extras[j - 1])
+        for j in range(1, nlev + 1):
+            if D[j - 1] is None:
+                be.blur(L[j - 1][a:b], L[j][a:b], extras[j - 1])
+            else:
+                be.blur_dog(L[j - 1][a:b], L[j][a:b], D[j - 1][a:b], extras[j - 1])
             # the next blur needs this level exact on slab +- BLUR_HALO: that, and no more, is exchanged here
-            self._exchange(L[j], z0, z1, e0, BLUR_HALO, has_lo, has_hi)
+            self._exchange(L[j], z0, z1, e0, BLUR_HALO + (1 if (lazy and j == 4) else 0), has_lo, has_hi)
             # the fused DoG used the not-yet-exchanged margin of L[j]: redo it on the halo slices
-            if has_lo:
+            if has_lo and D[j - 1] is not None:
                 be.dog(L[j - 1][a:z0 - e0], L[j][a:z0 - e0], D[j - 1][a:z0 - e0])
-            if has_hi:
+            if has_hi and D[j - 1] is not None:
                 be.dog(L[j - 1][z1 - e0:b], L[j][z1 - e0:b], D[j - 1][z1 - e0:b])
             if j == 3:
                 # L1..L3 are final: fetch the rest of their patch halos (slices BLUR_HALO..HALO beyond the faces) in one
@@ -262,11 +288,16 @@ class ZSlabExtractor:
                 patch_halos = self._exchange(L[1:4], z0, z1, e0, HALO, has_lo, has_hi, inner=BLUR_HALO, defer=True)
         for l in range(3):
             lid = o * 3 + l
-            be.extrema_append(D[l], D[l + 1], D[l + 2], lid, z0 - e0, z1 - e0)
+            if lazy and l == 0:
+                be.extrema_append_pair(L[0], L[1], D[1], D[2], lid, z0 - e0, z1 - e0)
+            elif lazy and l == 2:
+                be.extrema_append_lazy_next(D[2], D[3], L[4], extras[4], lid, z0 - e0, z1 - e0)
+            else:
+                be.extrema_append(D[l], D[l + 1], D[l + 2], lid, z0 - e0, z1 - e0)
             self.levels.append(be.level_entry(L[l + 1], D[l + 1], zo, e0, sig[l], sig[l + 1], sig[l + 2], factor))
             self.level_ids.append(lid)
         patch_halos()   # before the subsample below reads L3 beyond +- BLUR_HALO, and long before the per-keypoint stage
-        self._keepalive.append(D)
+        self._keepalive.append((D, L))   # a replay of the extrema passes reads D1..D3 and, in the unstored form, L0, L1 and L4
         return L[3] if want_next else None
 
     # ---- the whole pyramid ----------------------------------------------------------------------

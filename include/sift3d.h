@@ -199,6 +199,21 @@ int sift3d_candidates_reset(sift3d_ctx *ctx);
  * octave*3 + (DoG level - 1) orders the output. Asynchronous. */
 int sift3d_extrema_append_dev(sift3d_ctx *ctx, const float *d_prev, const float *d_cur, const float *d_next, int64_t nx,
                               int64_t ny, int64_t nz_local, int level_id, int64_t z_lo, int64_t z_hi);
+/* The same pass when a neighbour level is not stored as a DoG volume -- what the single-device pipeline does for the
+ * first and last detection level of an octave:
+ *   d_prev == NULL: the level below is g_prev_a - g_prev_b, the two Gaussian levels it is the difference of, read at the
+ *                   27 positions around an extremum (as the reference's validateDifferencePeak3D reads a level it never
+ *                   materialises, R/src_common/MultiScale.cpp:1135-1223);
+ *   d_next == NULL: the level above is g_next - blur(g_next, next_sigma), and that blur is evaluated only at the 27
+ *                   positions around each extremum that passed everything else, from the (2R+3)^3 block of g_next around
+ *                   it -- g_next must therefore be valid R+1 = 9 slices beyond the slices [z_lo, z_hi) (rows and planes
+ *                   outside the buffer read as zero, i.e. as the border of the whole volume).
+ * sift3d_lazy_levels_supported: 1 when this shape can take that form (rows of whole 16-byte vectors, a plane below
+ * 2^29 voxels, the 17-tap filter of the pyramid's last level); otherwise store the levels and use sift3d_extrema_append_dev. */
+int sift3d_lazy_levels_supported(int64_t nx, int64_t ny, int64_t nz_local, float next_sigma);
+int sift3d_extrema_append_lazy_dev(sift3d_ctx *ctx, const float *d_prev, const float *g_prev_a, const float *g_prev_b,
+                                   const float *d_cur, const float *d_next, const float *g_next, float next_sigma, int64_t nx,
+                                   int64_t ny, int64_t nz_local, int level_id, int64_t z_lo, int64_t z_hi);
 /* Sort what was collected and return it with whole-volume coordinates (malloc'ed, sift3d_free). */
 int sift3d_candidates_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_levels, sift3d_candidate **out,
                           int64_t *n_out);

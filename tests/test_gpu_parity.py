@@ -835,8 +835,16 @@ def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert n_sharded >= 1 and stats["exchanges"] == 6 * n_sharded and stats["deferred_exchanges"] == n_sharded
-    assert stats["deferred_bytes"] * 112 == stats["exchange_bytes"] * 72   # 8 slices per level on the critical path, 3 x 24 deferred
+    # per sharded octave: the 8-slice halos of L1..L3 and 9 slices of L4 on the critical path (the 17-tap level is only evaluated
+    # around candidates, from L4), one deferred batch of 3 x 24 slices; an octave whose rows are not whole 16-byte vectors stores
+    # every level: five 8-slice halos
+    lazy = [((dims[0] >> o) % 4 == 0 and (dims[0] >> o) >= 8) for o in range(n_sharded)]
+    assert n_sharded >= 1 and stats["deferred_exchanges"] == n_sharded
+    assert stats["exchanges"] == sum(5 if z else 6 for z in lazy)
+    if all(lazy):
+        assert stats["deferred_bytes"] * 105 == stats["exchange_bytes"] * 72
+    elif not any(lazy):
+        assert stats["deferred_bytes"] * 112 == stats["exchange_bytes"] * 72
     vol = vol_of(built, dims, seed)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)
