@@ -109,7 +109,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
                "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"],
                "halo_bytes_critical_per_rank_per_step": ex.stats["exchange_bytes"] - ex.stats["deferred_bytes"],
                "halo_bytes_deferred_per_rank_per_step": ex.stats["deferred_bytes"],
-               "exchange_schedule": "per level: the 8-slice blur halo (what the next blur waits for); per octave: one deferred "
+               "exchange_schedule": "per stored level (L1..L4: the 17-tap L5 is only evaluated around candidates, from L4): the 8-slice blur halo (what the next blur waits for; 9 slices of L4); per octave: one deferred "
                                     "batch with the other 24 slices of the L1..L3 patch halos, issued when L3 is complete and "
                                     "waited for after the extrema passes (rank 0's counts; interior ranks exchange on both sides)"}
         import hashlib
