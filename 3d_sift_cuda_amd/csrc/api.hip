@@ -107,6 +107,7 @@ struct sift3d_ctx {
     sift3d_level *d_levels;
     sift3d_dkp *kps;
     float *patch0; /* identity-frame patches of the extrema, kps_cap x 1331 floats */
+    int *sampler_tokens; /* per-CU counters of the descriptor kernel's sampling phase (zero whenever no kernel runs) */
     int *nrec, *offs; /* per-candidate record count and exclusive prefix */
     int64_t kps_cap;
     int *rec_kp, *rec_frame;
@@ -185,6 +186,7 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->d_levels);
     hipFree(c->kps);
     hipFree(c->patch0);
+    hipFree(c->sampler_tokens);
     hipFree(c->nrec);
     hipFree(c->offs);
     hipFree(c->rec_kp);
@@ -269,6 +271,7 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     c->d_levels = nullptr;
     c->kps = nullptr;
     c->patch0 = nullptr;
+    c->sampler_tokens = nullptr;
     c->nrec = c->offs = nullptr;
     c->rec_kp = c->rec_frame = nullptr;
     c->recs = nullptr;
@@ -323,6 +326,8 @@ extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t
     ok = ok && hipMalloc((void **)&c->d_zeros, 512) == hipSuccess && hipMemsetAsync(c->d_zeros, 0, 512, c->stream) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->sampler_tokens, sizeof(int) * SIFT3D_CU_SLOTS) == hipSuccess &&
+         hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
     c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
     ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
@@ -1138,6 +1143,11 @@ static void kp_params_of(sift3d_ctx *c, int desc_mode, float eig_thres, float si
     p.desc_mode = desc_mode;
     p.debug_stop = getenv("SIFT3D_KP_STOP") ? atoi(getenv("SIFT3D_KP_STOP")) : 0;
     p.patch0 = c->patch0;
+    /* workgroups per CU in the descriptor kernel's sampling phase at a time: by measurement at 512^3 (descriptor kernel 4.22 ms
+     * without a limit; 1: 6.6, 2: 4.5, 3: 4.09, 4: 4.03, 5: 4.12, 6-12: 4.15-4.18).  SIFT3D_SAMPLER_CAP=0: no limit */
+    const char *senv = getenv("SIFT3D_SAMPLER_CAP");
+    p.sampler_tokens = c->sampler_tokens;
+    p.sampler_cap = c->sampler_tokens ? (senv ? atoi(senv) : 4) : 0;
 }
 
 /* n_done: leading candidates whose keypoint stage has already been queued on kp_stream (ev_kp marks its end) with the

@@ -1041,8 +1041,31 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         const float *src = p.patch0 + (long long)rec_kp[r] * PV;
         for (int s = lane; s < PV; s += DESC_NT) sm.patch[s] = src[s];
         __syncthreads();
-    } else
-    wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
+    } else {
+        /* The gathers of this phase are paced by the L1's miss handling, and the fewer footprints (a patch's is the size of
+         * the whole L1) share a CU's L1 at a time the better it hits -- while the chains of the later phases want every
+         * resident workgroup they can hide under.  So at most sampler_cap workgroups per CU sample at once: one takes a
+         * token of its CU (a counter in memory, indexed by the hardware's XCC / SE / SH / CU numbers) before the phase and
+         * gives it back after it; the others wait asleep and cost no issue slots.  Which CU a counter really belongs to
+         * only affects speed. */
+        int *tok = nullptr;
+        if (p.sampler_cap > 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            tok = p.sampler_tokens + ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u));
+            if (lane == 0) {
+                for (;;) {
+                    if (atomicAdd(tok, 1) < p.sampler_cap) break;
+                    atomicSub(tok, 1);
+                    __builtin_amdgcn_s_sleep(64);
+                }
+            }
+            __syncthreads();
+        }
+        wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
+        if (tok && lane == 0) atomicSub(tok, 1);
+    }
     /* ... and every record is normalised once more in main (featExtract.cpp:480) */
     if (p.debug_stop == 11) return;
     wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);

@@ -119,7 +119,10 @@ struct sift3d_kp_params {
     int debug_stop; /* development aid: phase A returns after stage N (0 = run everything) */
     float *patch0;  /* per extremum: the identity-frame patch (1331 floats, normalised once) that phase A sampled anyway;
                      * phase B reads it for the un-reoriented record instead of sampling it again */
+    int *sampler_tokens; /* phase B: per-CU count of workgroups in their sampling phase (SIFT3D_CU_SLOTS ints, zero between runs) */
+    int sampler_cap;     /* at most this many per CU sample at a time (0: no limit) */
 };
+#define SIFT3D_CU_SLOTS 2048
 #define SIFT3D_MAX_FRAMES 11 /* determineCanonicalOrientation3D stops at FEATURE_3D_DIM frames */
 /* phase A result per extremum */
 struct sift3d_dkp {
