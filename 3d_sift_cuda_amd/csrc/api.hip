@@ -1207,6 +1207,8 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
                 (void)hipGetLastError();
                 direct = false;
             }
+            if (p.sampler_cap > 0) /* the per-CU tokens start from zero whatever became of an earlier launch */
+                HIPCHK(c, hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream));
             if (direct) {
                 HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, d_hrecs, d_hgroup, taps5));
             } else {

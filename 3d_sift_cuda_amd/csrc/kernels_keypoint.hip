@@ -1055,8 +1055,10 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             tok = p.sampler_tokens + ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u));
             if (lane == 0) {
-                for (;;) {
-                    if (atomicAdd(tok, 1) < p.sampler_cap) break;
+                /* (bounded: a counter that was left high -- it cannot be, every taker gives back -- must not hold the kernel
+                 * for ever; after ~0.1 s of waiting the workgroup samples without a token of its own) */
+                for (int tries = 0;; tries++) {
+                    if (atomicAdd(tok, 1) < p.sampler_cap || tries > 50000) break;
                     atomicSub(tok, 1);
                     __builtin_amdgcn_s_sleep(64);
                 }
