@@ -58,6 +58,23 @@ def kernel_name(stage, ntaps, dog, vec=4):
     return "blur_col_kernel<%d,%d,%s>" % (r, vec, "true" if dog else "false")
 
 
+def records_match(gpu, cpu):
+    """The GPU step's records against the CPU restatement's on the same volume (both in memory in the cpu_baseline leg):
+    integer fields and descriptors exact, float fields by largest absolute difference, and whether every byte agrees."""
+    res = {"gpu_records": int(len(gpu)), "cpu_records": int(len(cpu)), "same_count": bool(len(gpu) == len(cpu))}
+    if len(gpu) != len(cpu):
+        res["match"] = False
+        return res
+    res["info_equal"] = bool((gpu["info"] == cpu["info"]).all())
+    res["desc_equal"] = bool((gpu["desc"] == cpu["desc"]).all())
+    res["max_abs_diff"] = {f: float(np.abs(gpu[f].astype(np.float64) - cpu[f].astype(np.float64)).max()) if len(gpu) else 0.0
+                           for f in ("x", "y", "z", "scale", "ori", "eigs")}
+    res["bit_identical"] = bool(gpu.tobytes() == cpu.tobytes())
+    res["tolerance"] = 1e-4
+    res["match"] = bool(res["info_equal"] and res["desc_equal"] and all(v <= 1e-4 for v in res["max_abs_diff"].values()))
+    return res
+
+
 def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
     """ONE n^3 volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records on rank 0.
     Returns the result object on rank 0 (None elsewhere).  expect: the single-GPU records of the same volume, if the
@@ -269,6 +286,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tim = ctx.timings()
+    gpu_recs = feats.copy() if rank == 0 else None   # the timed region's last step (the pinned view is reused by the next call)
     full_logs, excl_logs = [], []
     if rank == 0:
         ctx.enable_timing(1)
@@ -454,6 +472,7 @@ def main():
                 recs, st = orc.extract(svol, desc_mode=args.desc)
                 return recs, st, time.perf_counter() - c0
             recs, st, cdt = timed(_oracle.load())
+            out["records_match_cpu"] = records_match(gpu_recs, recs) if m == n else None
             out["cpu_baseline"] = {"value": round(len(recs) / cdt, 1), "unit": "keypoints/s", "cores": 1, "kind": "port",
                                    "sample": "oracle o3_extract (C restatement of the reference CPU path, gcc -O2 -ffp-contract=off, 1 thread) on a %d^3 blob-field volume, %s: %d records in %.2f s (blur %.2f s, DoG %.2f s, detect %.2f s, keypoints %.2f s, descriptors %.2f s)"
                                              % (m, what, len(recs), cdt, st.t_blur, st.t_dog, st.t_detect, st.t_features, st.t_desc)}

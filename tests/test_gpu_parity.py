@@ -474,6 +474,27 @@ def test_full_size_properties(built):
         assert (again.view(np.uint8) == feats.view(np.uint8)).all()
 
 
+def test_config_c2_against_the_oracle(built, oracle):
+    """BASELINE config C2 at its own size -- 256^3 blob field (the SURVEY generator, seed 12345), every octave, SIFT-rank
+    descriptor -- record by record against the CPU restatement (about 7 s of one host core): integer fields and rank
+    descriptors exact, float fields within 1e-4 (north_star) and, as everywhere in this suite, bit-identical."""
+    n = 256
+    vol = vol_of(built, (n, n, n), 12345)
+    with built.Context(n, n, n) as ctx:
+        ctx.set_volume(vol)
+        got = ctx.extract()
+        cands = ctx.detect()
+    want, st = oracle.extract(vol)
+    assert len(want) == 19216 and st.n_octaves == 7          # the source-built reference's count (tests/golden/ref_counts.json)
+    assert _compare_records(got, want), "float fields are within 1e-4 but not bit-identical"
+    wc = oracle.candidates(vol)
+    assert len(cands) == len(wc) == 5546
+    for f in ("octave", "level", "is_max", "x", "y", "z"):
+        assert (cands[f] == wc[f]).all(), f
+    for f in ("value", "h_value", "l_value"):
+        assert (bits(cands[f]) == bits(wc[f])).all(), f
+
+
 @pytest.mark.parametrize("dims,mode", [((168, 164, 160), 0), ((200, 120, 96), 2)])
 def test_early_keypoint_pass_gives_the_same_records(built, dims, mode, monkeypatch):
     """SIFT3D_EARLY_KP=1 (octave 0's per-keypoint stage on a third stream, beside the coarser octaves) against the
@@ -740,6 +761,32 @@ def test_config_c5_shape_of_work_on_one_gpu(built):
     assert st["n_ranks"] == 8 and st["sharded_octaves"] == 3
     assert len(want) > 5000 and got.tobytes() == want.tobytes()
     assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72   # 8 + 8 + 8 + 9 slices of L1..L4 on the critical path
+
+
+def test_config_c5_plane_size_on_one_gpu(built):
+    """BASELINE config C5's own plane size: 2048 x 2048 rows and columns (2^22 voxels, 16 MiB per plane), NRRIEF.  At its
+    full depth (1024 slices, 8 GPUs) a rank holds 128 slices and its halos; here two such ranks -- 2048 x 2048 x 256, 2^30
+    voxels, three sharded octaves as in C5 -- run through the C slab driver on device 0 and must give the bytes of the
+    single-context extraction of the same volume.  This is where a 32-bit plane or byte offset in the kernels would show:
+    a slab buffer is 2.7 GB, the volume 4.3 GB, and level offsets pass 2^32 bytes."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip("needs about 160 GB of free HBM")
+    dims = (2048, 2048, 256)
+    vol = vol_of(built, dims, 2026)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract(desc_mode=built.DESC_NRRIEF).copy()
+        t = ctx.timings()
+    assert t["n_octaves"] == 7 and len(want) > 500000
+    _record_properties(want, dims, rank_desc=False)
+    # keypoints in the far corner of the volume exist (indices beyond 2^31 bytes into a level were addressed)
+    assert ((want["z"] > 200) & (want["y"] > 1800) & (want["x"] > 1800)).any()
+    got, st = built.extract_zslab(vol, [0, 0], desc_mode=built.DESC_NRRIEF)
+    assert st["n_ranks"] == 2 and st["sharded_octaves"] == 3
+    assert len(got) == len(want) and got.tobytes() == want.tobytes()
+    assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72
 
 
 def test_c_zslab_driver_edge_cases(built):
