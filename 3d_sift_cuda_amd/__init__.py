@@ -36,6 +36,9 @@ DESC_SIFT, DESC_BRIEF, DESC_RRIEF, DESC_NRRIEF = 0, 1, 2, 3
 INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
 STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
+# sift3d_tuning (include/sift3d.h)
+TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS = range(7)
+
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),
                           ("eigs", "<f4", (3,)), ("info", "<u4"), ("desc", "<f4", (64,))])
@@ -94,6 +97,9 @@ def hip_lib():
     P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
     _sig(L.sift3d_device_count, I)
     _sig(L.sift3d_create, P, I, I64, I64, I64)
+    _sig(L.sift3d_create_slab, P, I, I64, I64, I64)
+    _sig(L.sift3d_set_tuning, I, P, I, I)
+    _sig(L.sift3d_zslab_set_tuning, I, P, I, I)
     _sig(L.sift3d_destroy, None, P)
     _sig(L.sift3d_last_error, C.c_char_p, P)
     _sig(L.sift3d_set_stream, I, P, P)
@@ -213,6 +219,11 @@ class ZSlab:
             self._L.sift3d_free(out)
         return recs, {k: getattr(st, k) for k, _ in ZSlabStats._fields_}
 
+    def set_tuning(self, knob, value):
+        rc = self._L.sift3d_zslab_set_tuning(self._h, int(knob), int(value))
+        if rc != 0:
+            raise Sift3DError("sift3d_zslab_set_tuning(%d, %d) -> %d" % (knob, value, rc))
+
     def close(self):
         if self._h:
             self._L.sift3d_zslab_destroy(self._h)
@@ -323,14 +334,20 @@ def _f32(a):
 class Context:
     """Device-resident pyramid for volumes of up to nx*ny*nz voxels on one HIP device."""
 
-    def __init__(self, nx, ny, nz, device=0):
+    def __init__(self, nx, ny, nz, device=0, slab=False):
+        """slab=True: sift3d_create_slab -- a context for the Z-slab building blocks, without level buffers of its own."""
         self._L = hip_lib()
         if self._L.sift3d_device_count() <= 0:
             raise Sift3DError("no HIP device visible and there is no CPU fallback")
-        self._h = self._L.sift3d_create(int(device), int(nx), int(ny), int(nz))
+        make = self._L.sift3d_create_slab if slab else self._L.sift3d_create
+        self._h = make(int(device), int(nx), int(ny), int(nz))
         if not self._h:
-            raise Sift3DError("sift3d_create(device=%d, %d x %d x %d) failed" % (device, nx, ny, nz))
+            raise Sift3DError("sift3d_create%s(device=%d, %d x %d x %d) failed" % ("_slab" if slab else "", device, nx, ny, nz))
         self.device = device
+
+    def set_tuning(self, knob, value):
+        """sift3d_set_tuning: TUNE_* knobs (tests and A/B timing; no knob changes a result)."""
+        self._chk(self._L.sift3d_set_tuning(self._h, int(knob), int(value)), "sift3d_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None):

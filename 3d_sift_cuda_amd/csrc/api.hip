@@ -24,6 +24,11 @@
 
 #include "sift3d_internal.h"
 
+#define SIFT3D_KP_MAX_CHUNKS 16
+/* One chunk by default: measured at 512^3 (tools/kp_chunks.py, profiles/r03_kp_chunks.txt) 1: 10.33, 2: 10.31, 3: 10.47, 4: 10.47,
+ * 6: 10.73, 8: 10.99, 16: 11.20 ms per extraction -- seven keypoint workgroups fill a CU's LDS (7 x 23 KB), so a descriptor
+ * workgroup only becomes resident where a keypoint workgroup has retired, and the two kernels take turns instead of sharing. */
+#define SIFT3D_KP_DEFAULT_CHUNKS 1
 #define SIFT3D_D4TINY_FLOATS 32768 /* room for the octaves of at most SIFT3D_TINY_VOX voxels of one volume, pitched rows included */
 
 struct timed_launch {
@@ -61,19 +66,19 @@ struct sift3d_ctx {
     hipStream_t copy_stream;   /* record download, overlapped with the descriptor launches */
     hipStream_t ex_stream;     /* extrema detection of an octave, overlapped with the blurs of the coarser octaves */
     hipStream_t cand_stream;   /* where cand_append launches: stream, or ex_stream inside run_pipeline */
-    hipStream_t ex_stream2;    /* extrema of the octaves after the first (run_pipeline: the first octave's wait for the second's levels) */
+    hipStream_t ex_stream2;    /* extrema of the octaves after the first */
     hipEvent_t ev_ex2[2];      /* levels of such an octave complete / its extrema launches complete */
     hipEvent_t ev_reset;       /* the counters of the extrema passes have been cleared (on ex_stream) */
     sift3d_survivor *surv2;    /* own-level list of that stream (the passes of one stream share a list, one after the other) */
     int64_t surv2_cap;
     int surv_sel;              /* which list cand_append uses: 0 = surv, 1 = surv2 */
-    hipStream_t kp_stream;     /* per-keypoint stage of the finest octave, beside the blurs and extrema of the coarser ones */
-    hipEvent_t ev_cnt0, ev_kp; /* octave 0's extrema are in the list (its count is in h_cnt0) / the early keypoint launch is done */
-    unsigned long long *h_cnt0; /* pinned, 8 words: [0..3] d_count as it stood after octave 0's extrema passes (early pass); [4..7] the
-                                 * small read-backs the host waits for (extrema counts, record total, keypoint count): a copy into
-                                 * pageable memory goes through a staging buffer and costs tens of microseconds more */
+    hipStream_t kp_stream;     /* descriptor launches of the chunked per-keypoint stage, beside the keypoint kernel of the next chunk */
+    hipEvent_t ev_kpc[SIFT3D_KP_MAX_CHUNKS]; /* chunk i's keypoint kernel, scan and record map are complete */
+    hipEvent_t ev_desc;        /* the descriptor launches on kp_stream are complete */
+    unsigned long long *h_cnt0; /* pinned, 8 + SIFT3D_KP_MAX_CHUNKS words: [4..7] the small read-backs the host waits for (extrema counts,
+                                 * keypoint count), [8..] the record totals of the chunks: a copy into pageable memory goes through a
+                                 * staging buffer and costs tens of microseconds more */
     hipEvent_t ev_oct[2];      /* octave's DoG levels complete / extrema launches complete */
-    hipEvent_t ev_chunk[4];
     hipEvent_t ev_fence[2];    /* ordering of the *_dev entry points with the legacy default stream (fence_in / fence_out) */
     bool own_stream;
     int64_t capN;   /* voxels of the largest volume */
@@ -85,7 +90,6 @@ struct sift3d_ctx {
     float *D4tiny; /* the last DoG level of the octaves that one workgroup builds whole (at most SIFT3D_TINY_VOX voxels each) */
     float *T[2];  /* x- and y-pass intermediates */
     float *d_taps;
-    float *d_zeros; /* 512 bytes: 256 of 0.0f (what the fused blur reads outside the volume), then 256 it may write (store sink) */
     /* extrema as (key, value) pairs, unsorted (a) and sorted (b) */
     unsigned long long *keys_a, *keys_b;
     sift3d_cval *vals_a, *vals_b;
@@ -108,19 +112,31 @@ struct sift3d_ctx {
     sift3d_dkp *kps;
     float *patch0; /* identity-frame patches of the extrema, kps_cap x 1331 floats */
     int *sampler_tokens; /* per-CU counters of the descriptor kernel's sampling phase (zero whenever no kernel runs) */
+    int *d_rec_base;     /* chunked per-keypoint stage: first record of chunk i (SIFT3D_KP_MAX_CHUNKS + 1 ints; [n] = total) */
     int *nrec, *offs; /* per-candidate record count and exclusive prefix */
     int64_t kps_cap;
     int *rec_kp, *rec_frame;
-    sift3d_feature *recs;
-    int64_t recs_cap;
-    sift3d_feature *h_recs; /* pinned host mirror of recs: the download target, reused from call to call */
-    int *rec_group, *h_group; /* per record: level id * 2 + is_max (device, pinned host) */
-    int64_t h_recs_cap;
+    int64_t recs_cap;       /* records the arrays below hold: kps_cap * (1 + SIFT3D_MAX_FRAMES) */
+    sift3d_feature *h_recs; /* pinned host memory the descriptor kernel stores its records into; reused from call to call */
+    int *h_group;           /* per record: level id * 2 + is_max (pinned host) */
+    sift3d_feature *d_hrecs; /* the device's addresses of the two */
+    int *d_hgroup;
+    struct {                /* the per-keypoint stage in flight (describe_queue / _launch / _finish) */
+        sift3d_kp_params p;
+        float taps5[SIFT3D_MAX_TAPS];
+        int64_t ncand, nrec;
+        int nchunks, launched;
+        int64_t first[SIFT3D_KP_MAX_CHUNKS + 1];
+    } kp;
+    int dev_stop;           /* -DSIFT3D_DEV builds: sift3d_dev_set_stop */
+    bool count_queued;      /* cand_count_queue ran and nothing was appended since */
     std::vector<struct level_job> jobs; /* extrema launches since the last reset (replayed if the buffer must grow) */
     int64_t nx, ny, nz;
     int64_t pad_nx, pad_ny, pad_nz; /* geometry the pad columns of the level buffers were last cleared for */
     bool has_volume;
     int max_octaves; /* 0: the reference's only stop rule (a dimension <= 2); n > 0: at most n octaves */
+    int tune[SIFT3D_TUNE_COUNT]; /* sift3d_set_tuning */
+    bool lean;       /* a slab context: the caller owns the level buffers, none are allocated here */
     int timing; /* 0 off; 1 every launch bracketed by events; 2 only the blur launches of the finest octave */
     std::vector<timed_launch> launches;
     std::vector<hipEvent_t> pool;
@@ -149,6 +165,12 @@ static int set_err(sift3d_ctx *c, int code, const char *fmt, ...)
                            __LINE__);                                                                          \
     } while (0)
 
+/* entry points that work in the context's own level buffers: not on a slab context, which has none */
+#define NEED_LEVELS(c)                                                                                                  \
+    do {                                                                                                                \
+        if ((c) && (c)->lean) return set_err((c), SIFT3D_ERR_ARG, "%s needs a full context (sift3d_create), not a slab context", __func__); \
+    } while (0)
+
 extern "C" int sift3d_device_count(void)
 {
     int n = 0;
@@ -169,7 +191,6 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->T[0]);
     hipFree(c->T[1]);
     hipFree(c->d_taps);
-    hipFree(c->d_zeros);
     hipFree(c->keys_a);
     hipFree(c->keys_b);
     hipFree(c->vals_a);
@@ -187,12 +208,11 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->kps);
     hipFree(c->patch0);
     hipFree(c->sampler_tokens);
+    hipFree(c->d_rec_base);
     hipFree(c->nrec);
     hipFree(c->offs);
     hipFree(c->rec_kp);
     hipFree(c->rec_frame);
-    hipFree(c->recs);
-    hipFree(c->rec_group);
     if (c->h_recs) hipHostFree(c->h_recs);
     if (c->h_group) hipHostFree(c->h_group);
 }
@@ -231,134 +251,87 @@ static int alloc_cands(sift3d_ctx *c, int64_t cap)
     return ok ? SIFT3D_OK : SIFT3D_ERR_MEMORY;
 }
 
-extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz)
+static void destroy_sync_objects(sift3d_ctx *c)
+{
+    hipStream_t streams[] = {c->copy_stream, c->ex_stream, c->ex_stream2, c->kp_stream};
+    for (hipStream_t st : streams)
+        if (st) {
+            hipStreamSynchronize(st);
+            hipStreamDestroy(st);
+        }
+    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1]};
+    for (hipEvent_t e : events)
+        if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_kpc)
+        if (e) hipEventDestroy(e);
+    if (c->h_cnt0) hipHostFree(c->h_cnt0);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+}
+
+/* lean: a slab context (sift3d_create_slab) -- the caller owns the level buffers; only the pass intermediates, the
+ * candidate lists and the per-keypoint buffers live here */
+static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean)
 {
     if (nx <= 0 || ny <= 0 || nz <= 0) return nullptr;
     int n = sift3d_device_count();
     if (device < 0 || device >= n) return nullptr;
     if (hipSetDevice(device) != hipSuccess) return nullptr;
-    sift3d_ctx *c = new sift3d_ctx();
+    sift3d_ctx *c = new sift3d_ctx(); /* value-initialised: every pointer null, every count zero */
     c->device = device;
     c->own_stream = true;
+    c->lean = lean;
     c->capN = pitch_of(nx) * ny * nz; /* floats of the largest volume, rows padded to whole vectors */
-    c->err[0] = 0;
-    c->timing = 0;
-    c->pad_nx = c->pad_ny = c->pad_nz = 0;
-    c->pool_used = 0;
-    c->resolved = 0;
-    c->has_volume = false;
-    c->max_octaves = 0;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    c->nx = c->ny = c->nz = 0;
-    memset(&c->last, 0, sizeof(c->last));
-    c->vol = nullptr;
-    for (int i = 0; i < 6; i++) c->L[i] = nullptr;
-    for (int i = 0; i < 5; i++) c->D[i] = nullptr;
-    c->D4tiny = nullptr;
-    c->T[0] = c->T[1] = c->d_taps = c->d_zeros = nullptr;
-    c->keys_a = c->keys_b = nullptr;
-    c->vals_a = c->vals_b = nullptr;
-    c->d_count = nullptr;
-    c->surv = nullptr;
-    c->list2[0] = c->list2[1] = nullptr;
-    c->list2_cap[0] = c->list2_cap[1] = 0;
-    c->list2_counts = nullptr;
-    c->surv_counts = nullptr;
-    c->surv_cap = 0;
     c->surv_div = 64;
-    c->sort_tmp = c->scan_tmp = nullptr;
-    c->sort_tmp_bytes = c->scan_tmp_bytes = 0;
-    c->d_levels = nullptr;
-    c->kps = nullptr;
-    c->patch0 = nullptr;
-    c->sampler_tokens = nullptr;
-    c->nrec = c->offs = nullptr;
-    c->rec_kp = c->rec_frame = nullptr;
-    c->recs = nullptr;
-    c->kps_cap = c->recs_cap = 0;
-    c->h_recs = nullptr;
-    c->rec_group = c->h_group = nullptr;
-    c->h_recs_cap = 0;
+    c->tune[SIFT3D_TUNE_BLUR_FUSED] = 1;
+    c->tune[SIFT3D_TUNE_LAZY_LEVELS] = 1;
+    c->tune[SIFT3D_TUNE_TINY_OCTAVE] = 1;
+    c->tune[SIFT3D_TUNE_SAMPLER_CAP] = 4;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    c->copy_stream = nullptr;
-    for (int i = 0; i < 4; i++) c->ev_chunk[i] = nullptr;
-    c->ev_fence[0] = c->ev_fence[1] = nullptr;
-    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_fence[i], hipEventDisableTiming) == hipSuccess;
-    c->ex_stream = c->cand_stream = nullptr;
-    c->ex_stream2 = nullptr;
-    c->ev_ex2[0] = c->ev_ex2[1] = nullptr;
-    c->ev_reset = nullptr;
-    c->surv2 = nullptr;
-    c->surv2_cap = 0;
-    c->surv_sel = 0;
-    c->ev_oct[0] = c->ev_oct[1] = nullptr;
-    ok = ok && hipStreamCreateWithFlags(&c->ex_stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->ex_stream2, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_ex2[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) == hipSuccess;
-    c->kp_stream = nullptr;
-    c->ev_cnt0 = c->ev_kp = nullptr;
-    c->h_cnt0 = nullptr;
-    ok = ok && hipStreamCreateWithFlags(&c->kp_stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_cnt0, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_kp, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * 8, hipHostMallocDefault) == hipSuccess;
-    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_oct[i], hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 4 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
+    hipStream_t *streams[] = {&c->copy_stream, &c->ex_stream, &c->ex_stream2, &c->kp_stream};
+    for (hipStream_t *st : streams) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1]};
+    for (hipEvent_t *e : events) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    for (hipEvent_t &e : c->ev_kpc) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * (8 + SIFT3D_KP_MAX_CHUNKS), hipHostMallocDefault) == hipSuccess;
     const size_t vb = sizeof(float) * (size_t)c->capN;
     const size_t tb = sizeof(float) * (size_t)c->capTot;
-    ok = ok && hipMalloc((void **)&c->vol, vb) == hipSuccess;
-    for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess;
-    for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->D4tiny, sizeof(float) * SIFT3D_D4TINY_FLOATS) == hipSuccess;
-    for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
     /* nothing may depend on what hipMalloc hands back: the pad columns of pitched octaves are read as zeros.  The clears
      * go on the context's own stream and are waited for here: hipMemset runs on the null stream, which the context's
      * non-blocking streams are NOT ordered with, so it could still be wiping a buffer the first extraction already uses */
-    for (int i = 0; i < 5 && ok; i++) ok = hipMemsetAsync(c->L[i], 0, tb, c->stream) == hipSuccess;
-    for (int i = 0; i < 4 && ok; i++) ok = hipMemsetAsync(c->D[i], 0, tb, c->stream) == hipSuccess;
-    ok = ok && hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream) == hipSuccess;
-    ok = ok && hipMemsetAsync(c->vol, 0, vb, c->stream) == hipSuccess;
+    if (!lean) {
+        ok = ok && hipMalloc((void **)&c->vol, vb) == hipSuccess && hipMemsetAsync(c->vol, 0, vb, c->stream) == hipSuccess;
+        for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess && hipMemsetAsync(c->L[i], 0, tb, c->stream) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess && hipMemsetAsync(c->D[i], 0, tb, c->stream) == hipSuccess;
+        ok = ok && hipMalloc((void **)&c->D4tiny, sizeof(float) * SIFT3D_D4TINY_FLOATS) == hipSuccess &&
+             hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream) == hipSuccess;
+    }
+    for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_zeros, 512) == hipSuccess && hipMemsetAsync(c->d_zeros, 0, 512, c->stream) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->sampler_tokens, sizeof(int) * SIFT3D_CU_SLOTS) == hipSuccess &&
          hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_rec_base, sizeof(int) * (SIFT3D_KP_MAX_CHUNKS + 1)) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
     c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
     ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->surv_counts, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->list2_counts, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
-    c->surv_set = 0;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess; /* the clears above are done before the context is handed out */
     if (!ok) {
         free_dev(c);
-        if (c->stream) hipStreamDestroy(c->stream);
-        if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-        if (c->ex_stream) hipStreamDestroy(c->ex_stream);
-        if (c->ex_stream2) hipStreamDestroy(c->ex_stream2);
-        for (int i = 0; i < 2; i++)
-            if (c->ev_ex2[i]) hipEventDestroy(c->ev_ex2[i]);
-        if (c->ev_reset) hipEventDestroy(c->ev_reset);
-        if (c->kp_stream) hipStreamDestroy(c->kp_stream);
-        if (c->ev_cnt0) hipEventDestroy(c->ev_cnt0);
-        if (c->ev_kp) hipEventDestroy(c->ev_kp);
-        if (c->h_cnt0) hipHostFree(c->h_cnt0);
-        for (int i = 0; i < 4; i++)
-            if (c->ev_chunk[i]) hipEventDestroy(c->ev_chunk[i]);
-        for (int i = 0; i < 2; i++)
-            if (c->ev_oct[i]) hipEventDestroy(c->ev_oct[i]);
-        for (int i = 0; i < 2; i++)
-            if (c->ev_fence[i]) hipEventDestroy(c->ev_fence[i]);
+        destroy_sync_objects(c);
         delete c;
         return nullptr;
     }
     return c;
 }
+
+extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz) { return ctx_create(device, nx, ny, nz, false); }
+
+extern "C" sift3d_ctx *sift3d_create_slab(int device, int64_t nx, int64_t ny, int64_t nz_local) { return ctx_create(device, nx, ny, nz_local, true); }
 
 extern "C" void sift3d_destroy(sift3d_ctx *c)
 {
@@ -367,25 +340,28 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
     hipStreamSynchronize(c->stream);
     free_dev(c);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
-    hipStreamSynchronize(c->copy_stream);
-    hipStreamDestroy(c->copy_stream);
-    hipStreamSynchronize(c->ex_stream);
-    hipStreamDestroy(c->ex_stream);
-    hipStreamSynchronize(c->ex_stream2);
-    hipStreamDestroy(c->ex_stream2);
-    for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_ex2[i]);
-    hipEventDestroy(c->ev_reset);
-    hipStreamSynchronize(c->kp_stream);
-    hipStreamDestroy(c->kp_stream);
-    hipEventDestroy(c->ev_cnt0);
-    hipEventDestroy(c->ev_kp);
-    hipHostFree(c->h_cnt0);
-    for (int i = 0; i < 4; i++) hipEventDestroy(c->ev_chunk[i]);
-    for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_oct[i]);
-    for (int i = 0; i < 2; i++) hipEventDestroy(c->ev_fence[i]);
-    if (c->own_stream) hipStreamDestroy(c->stream);
+    destroy_sync_objects(c);
     delete c;
 }
+
+extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
+{
+    if (!c) return SIFT3D_ERR_ARG;
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS};
+    if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
+        return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
+    c->tune[knob] = value;
+    return SIFT3D_OK;
+}
+
+#ifdef SIFT3D_DEV
+extern "C" int sift3d_dev_set_stop(sift3d_ctx *c, int n)
+{
+    if (!c) return SIFT3D_ERR_ARG;
+    c->dev_stop = n;
+    return SIFT3D_OK;
+}
+#endif
 
 extern "C" int sift3d_set_stream(sift3d_ctx *c, void *s)
 {
@@ -437,6 +413,7 @@ __global__ void selftest_lds_add_kernel(const float *__restrict__ a, const float
 
 extern "C" int sift3d_selftest_lds_add(sift3d_ctx *c, const float *a, const float *b, int64_t n, float *valu, float *lds)
 {
+    NEED_LEVELS(c);
     if (!c || !a || !b || !valu || !lds || n <= 0 || 4 * n > c->capTot) return c ? set_err(c, SIFT3D_ERR_ARG, "bad self-test arguments") : SIFT3D_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     float *da = c->L[0], *db = c->L[0] + n, *dv = c->L[0] + 2 * n, *dl = c->L[0] + 3 * n;
@@ -576,40 +553,47 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
                     float min_value)
 {
     float taps[SIFT3D_MAX_TAPS];
+    hipStream_t ws = c->stream;
     int n = sift3d_gauss_taps(sigma, min_value, taps);
     if (n < 0) return set_err(c, SIFT3D_ERR_ARG, "bad blur parameters sigma=%g min=%g", sigma, min_value);
     const double N = (double)X * Y * Z;
     if (n == 1) { /* delta filter: out = 1*in */
-        if (out) HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, c->stream));
-        if (dog) HIPCHK(c, hipMemsetAsync(dog, 0, sizeof(float) * (size_t)N, c->stream));
+        if (out) HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, ws));
+        if (dog) HIPCHK(c, hipMemsetAsync(dog, 0, sizeof(float) * (size_t)N, ws));
         return SIFT3D_OK;
     }
     if (n / 2 > SIFT3D_FAST_MAX_R)
-        HIPCHK(c, hipMemcpyAsync(c->d_taps, taps, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_taps, taps, sizeof(float) * n, hipMemcpyHostToDevice, ws));
     /* One fused launch per level where the volume fills the chip (it marches along z with few, fat workgroups);
-     * coarse octaves keep the three-pass path.  SIFT3D_BLUR_FUSED = 0 never / 2 always (tests, A/B timing). */
-    const char *fenv = getenv("SIFT3D_BLUR_FUSED");
-    const int fmode = fenv ? atoi(fenv) : 1;
+     * coarse octaves keep the three-pass path.  SIFT3D_TUNE_BLUR_FUSED: 0 never / 2 always (tests, A/B timing). */
+    const int fmode = c->tune[SIFT3D_TUNE_BLUR_FUSED];
+    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS]};
     /* measured standalone (tools/bench_blur_ab.sh 128 / 64): below 2^22 voxels the one launch still beats the three for 7 and
      * 9 taps (0.020 / 0.026 against 0.042 / 0.043 ms at 128^3), ties at 11-13 and loses at 17 */
     if (fmode == 2 || (fmode == 1 && (N >= (double)(1 << 22) || (N >= (double)(1 << 18) && n <= 9)))) {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N);
-        hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, c->d_zeros, X, Y, Z, taps, n);
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N, ws);
+        hipError_t e = sift3d_launch_blur_fused(ws, in, out, dog, X, Y, Z, taps, n, &bt);
         if (e == hipSuccess) return SIFT3D_OK;
         if (e != hipErrorNotSupported) HIPCHK(c, e);
         sc.cancel();
     }
+    /* the three-pass form goes through the context's two intermediates: a volume beyond them (a gathered octave on a slab
+     * context sized for its slab) must not overrun them */
+    float *const T0 = c->T[0], *const T1 = c->T[1];
+    if ((int64_t)N > c->capN)
+        return set_err(c, SIFT3D_ERR_ARG, "a %lldx%lldx%lld blur needs pass intermediates of %lld floats, the context has %lld", (long long)X,
+                       (long long)Y, (long long)Z, (long long)N, (long long)c->capN);
     {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_X, 8.0 * N, n, (int64_t)N);
-        HIPCHK(c, sift3d_launch_blur_x(c->stream, in, c->T[0], X, Y, Z, taps, n, c->d_taps));
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_X, 8.0 * N, n, (int64_t)N, ws);
+        HIPCHK(c, sift3d_launch_blur_x(ws, in, T0, X, Y, Z, taps, n, c->d_taps));
     }
     {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_Y, 8.0 * N, n, (int64_t)N);
-        HIPCHK(c, sift3d_launch_blur_y(c->stream, c->T[0], c->T[1], X, Y, Z, taps, n, c->d_taps));
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_Y, 8.0 * N, n, (int64_t)N, ws);
+        HIPCHK(c, sift3d_launch_blur_y(ws, T0, T1, X, Y, Z, taps, n, c->d_taps));
     }
     {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_Z_DOG, (dog ? 16.0 : 8.0) * N, n, (int64_t)N);
-        HIPCHK(c, sift3d_launch_blur_z(c->stream, c->T[1], out ? out : c->T[0], dog ? in : nullptr, dog, X, Y, Z, taps, n, c->d_taps));
+        stage_scope sc(c, SIFT3D_STAGE_BLUR_Z_DOG, (dog ? 16.0 : 8.0) * N, n, (int64_t)N, ws);
+        HIPCHK(c, sift3d_launch_blur_z(ws, T1, out ? out : T0, dog ? in : nullptr, dog, X, Y, Z, taps, n, c->d_taps));
     }
     return SIFT3D_OK;
 }
@@ -681,6 +665,7 @@ extern "C" int sift3d_gauss_blur_dog_dev(sift3d_ctx *c, const float *d_in, float
 extern "C" int sift3d_gauss_blur(sift3d_ctx *c, const float *in, float *out, int64_t nx, int64_t ny, int64_t nz,
                                  float sigma, float min_value)
 {
+    NEED_LEVELS(c);
     int rc = check_shape(c, nx, ny, nz);
     if (rc) return rc;
     if (!in || !out) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
@@ -708,6 +693,7 @@ extern "C" int sift3d_dog_dev(sift3d_ctx *c, const float *d_a, const float *d_b,
 
 extern "C" int sift3d_dog(sift3d_ctx *c, const float *a, const float *b, float *out, int64_t n)
 {
+    NEED_LEVELS(c);
     if (!c || !a || !b || !out || n <= 0 || n > c->capN) return set_err(c, SIFT3D_ERR_ARG, "bad dog arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t by = sizeof(float) * (size_t)n;
@@ -734,6 +720,7 @@ extern "C" int sift3d_subsample2_dev(sift3d_ctx *c, const float *d_in, int64_t n
 
 extern "C" int sift3d_subsample2(sift3d_ctx *c, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out)
 {
+    NEED_LEVELS(c);
     int rc = check_shape(c, nx, ny, nz);
     if (rc) return rc;
     if (!in || !out) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
@@ -751,6 +738,7 @@ extern "C" int sift3d_subsample2(sift3d_ctx *c, const float *in, int64_t nx, int
 
 extern "C" int sift3d_double_size(sift3d_ctx *c, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out)
 {
+    NEED_LEVELS(c);
     if (!c || !in || !out || nx < 2 || ny < 2 || nz < 2 || 8 * nx * ny * nz > c->capN)
         return set_err(c, SIFT3D_ERR_ARG, "double_size: the context must hold the doubled volume");
     HIPCHK(c, hipSetDevice(c->device));
@@ -765,6 +753,7 @@ extern "C" int sift3d_double_size(sift3d_ctx *c, const float *in, int64_t nx, in
 
 extern "C" int sift3d_halve_size(sift3d_ctx *c, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out)
 {
+    NEED_LEVELS(c);
     int rc = check_shape(c, nx, ny, nz);
     if (rc) return rc;
     if (!in || !out || nx < 2 || ny < 2 || nz < 2) return set_err(c, SIFT3D_ERR_ARG, "halve_size needs every dimension >= 2");
@@ -798,6 +787,7 @@ static int cand_reset(sift3d_ctx *c, hipStream_t on = nullptr)
 
 static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
 {
+    c->count_queued = false;
     if (record) c->jobs.push_back(j);
     hipStream_t st = c->cand_stream ? c->cand_stream : c->stream;
     stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z, st);
@@ -864,20 +854,28 @@ static int cand_replay(sift3d_ctx *c)
     return SIFT3D_OK;
 }
 
-/* n_sorted (may be NULL): in, the leading candidates that are already sorted into keys_b / vals_b (the early pass of
- * run_pipeline); out, 0 if the extrema had to be replayed (everything before is void), else unchanged. */
-static int cand_finalize(sift3d_ctx *c, int64_t *count_out, int64_t *n_sorted = nullptr)
+/* The count of validated extrema comes back in two steps so that a driver with several contexts can queue the read-back
+ * on all of them before it waits for the first: cand_count_queue (asynchronous), cand_finalize (waits, replays the extrema
+ * launches into bigger lists if one overflowed, sorts). */
+static int cand_count_queue(sift3d_ctx *c)
+{
+    unsigned long long *cnt = c->h_cnt0 + 4; /* validated extrema, survivors of the last level, survivor overflow */
+    cnt[0] = cnt[1] = cnt[2] = 0;
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->stream));
+    c->count_queued = true;
+    return SIFT3D_OK;
+}
+
+static int cand_finalize(sift3d_ctx *c, int64_t *count_out)
 {
     for (int attempt = 0; attempt < 4; attempt++) {
-        unsigned long long *cnt = c->h_cnt0 + 4; /* validated extrema, survivors of the last level, survivor overflow */
-        cnt[0] = cnt[1] = cnt[2] = 0;
-        HIPCHK(c, hipMemcpyAsync(cnt, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((cnt[2] > 0 || (int64_t)cnt[0] > c->cand_cap) && n_sorted && *n_sorted > 0) {
-            /* the early pass worked on a list that is about to be rebuilt (and possibly reallocated): let it drain, drop it */
-            HIPCHK(c, hipStreamSynchronize(c->kp_stream));
-            *n_sorted = 0;
+        const unsigned long long *cnt = c->h_cnt0 + 4;
+        if (!c->count_queued) {
+            int rc = cand_count_queue(c);
+            if (rc) return rc;
         }
+        c->count_queued = false;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         if (cnt[2] > 0) { /* an own-level list was cut short: make room and redo the extrema launches */
             c->surv_div = 1;
             if ((int64_t)cnt[2] > c->surv_cap) {
@@ -897,12 +895,8 @@ static int cand_finalize(sift3d_ctx *c, int64_t *count_out, int64_t *n_sorted = 
             if (rc) return rc;
             continue;
         }
-        /* keys are octave-major and the early pass took exactly octave 0's candidates, so sorting the rest on its own
-         * and leaving it behind the early part is the sorted whole */
-        const int64_t done = n_sorted ? *n_sorted : 0;
-        if ((int64_t)cnt[0] > done)
-            HIPCHK(c, sift3d_sort_candidates(c->stream, c->sort_tmp, c->sort_tmp_bytes, c->keys_a + done, c->keys_b + done, c->vals_a + done,
-                                             c->vals_b + done, (int64_t)cnt[0] - done));
+        if (cnt[0] > 0)
+            HIPCHK(c, sift3d_sort_candidates(c->stream, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a, c->vals_b, (int64_t)cnt[0]));
         *count_out = (int64_t)cnt[0];
         return SIFT3D_OK;
     }
@@ -913,6 +907,7 @@ extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d
                               int64_t ny, int64_t nz, sift3d_extremum *minima, int64_t cap_min, int64_t *n_min,
                               sift3d_extremum *maxima, int64_t cap_max, int64_t *n_max)
 {
+    NEED_LEVELS(c);
     int rc = check_shape(c, nx, ny, nz);
     if (rc) return rc;
     if (!d_prev || !d_cur || !n_min || !n_max) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
@@ -1000,6 +995,7 @@ static int load_volume(sift3d_ctx *c, const float *src, bool from_host, int64_t 
 
 extern "C" int sift3d_set_volume(sift3d_ctx *c, const float *vol, int64_t nx, int64_t ny, int64_t nz)
 {
+    NEED_LEVELS(c);
     int rc = check_shape(c, nx, ny, nz);
     if (rc) return rc;
     if (!vol) return set_err(c, SIFT3D_ERR_ARG, "null volume");
@@ -1015,6 +1011,7 @@ extern "C" int sift3d_set_volume(sift3d_ctx *c, const float *vol, int64_t nx, in
 
 extern "C" int sift3d_set_volume_dev(sift3d_ctx *c, const float *d_vol, int64_t nx, int64_t ny, int64_t nz)
 {
+    NEED_LEVELS(c);
     int rc = check_shape(c, nx, ny, nz);
     if (rc) return rc;
     if (!d_vol) return set_err(c, SIFT3D_ERR_ARG, "null volume");
@@ -1031,6 +1028,7 @@ extern "C" int sift3d_set_volume_dev(sift3d_ctx *c, const float *d_vol, int64_t 
 
 extern "C" int sift3d_set_volume_resized(sift3d_ctx *c, const float *vol, int64_t nx, int64_t ny, int64_t nz, int resize)
 {
+    NEED_LEVELS(c);
     if (resize == 0) return sift3d_set_volume(c, vol, nx, ny, nz);
     if (!c || !vol || nx < 2 || ny < 2 || nz < 2 || nx * ny * nz > c->capN)
         return set_err(c, SIFT3D_ERR_ARG, "set_volume_resized: bad shape or null volume");
@@ -1051,45 +1049,41 @@ extern "C" int sift3d_set_volume_resized(sift3d_ctx *c, const float *vol, int64_
     return SIFT3D_OK;
 }
 
-static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t nrec)
+/* Buffers of the per-keypoint stage for ncand candidates.  A candidate yields at most 1 + SIFT3D_MAX_FRAMES records
+ * (determineCanonicalOrientation3D stops at that many frames), 4.2 on average on blob fields; the record arrays are sized
+ * for the worst case so that the chunks of the stage can write them before the host knows a total. */
+static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand)
 {
     if (ncand > c->kps_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->kp_stream));
         hipFree(c->kps); hipFree(c->nrec); hipFree(c->offs); hipFree(c->scan_tmp); hipFree(c->patch0);
-        c->kps = nullptr;
-        c->patch0 = nullptr;
-        c->nrec = c->offs = nullptr;
-        c->scan_tmp = nullptr;
-        c->kps_cap = ncand + ncand / 2 + 1024;
-        c->scan_tmp_bytes = sift3d_scan_temp_bytes(c->kps_cap) + 256;
-        HIPCHK(c, hipMalloc((void **)&c->kps, sizeof(sift3d_dkp) * (size_t)c->kps_cap));
-        HIPCHK(c, hipMalloc((void **)&c->patch0, sizeof(float) * SIFT3D_PATCH_VOX * (size_t)c->kps_cap));
-        HIPCHK(c, hipMalloc((void **)&c->nrec, sizeof(int) * (size_t)c->kps_cap));
-        HIPCHK(c, hipMalloc((void **)&c->offs, sizeof(int) * (size_t)c->kps_cap));
-        HIPCHK(c, hipMalloc(&c->scan_tmp, c->scan_tmp_bytes));
-    }
-    if (nrec > c->recs_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->recs);
-        hipFree(c->rec_kp);
-        hipFree(c->rec_frame);
-        hipFree(c->rec_group);
-        c->recs = nullptr;
-        c->rec_kp = c->rec_frame = c->rec_group = nullptr;
-        c->recs_cap = nrec + nrec / 2 + 1024;
-        HIPCHK(c, hipMalloc((void **)&c->recs, sizeof(sift3d_feature) * (size_t)c->recs_cap));
-        HIPCHK(c, hipMalloc((void **)&c->rec_kp, sizeof(int) * (size_t)c->recs_cap));
-        HIPCHK(c, hipMalloc((void **)&c->rec_frame, sizeof(int) * (size_t)c->recs_cap));
-        HIPCHK(c, hipMalloc((void **)&c->rec_group, sizeof(int) * (size_t)c->recs_cap));
-    }
-    if (nrec > c->h_recs_cap) {
+        hipFree(c->rec_kp); hipFree(c->rec_frame);
         if (c->h_recs) hipHostFree(c->h_recs);
         if (c->h_group) hipHostFree(c->h_group);
+        c->kps = nullptr;
+        c->patch0 = nullptr;
+        c->nrec = c->offs = c->rec_kp = c->rec_frame = nullptr;
+        c->scan_tmp = nullptr;
         c->h_recs = nullptr;
         c->h_group = nullptr;
-        c->h_recs_cap = nrec + nrec / 2 + 1024;
-        HIPCHK(c, hipHostMalloc((void **)&c->h_recs, sizeof(sift3d_feature) * (size_t)c->h_recs_cap, hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_group, sizeof(int) * (size_t)c->h_recs_cap, hipHostMallocDefault));
+        c->kps_cap = 0;
+        const int64_t cap = ncand + ncand / 2 + 1024, rcap = cap * (1 + SIFT3D_MAX_FRAMES);
+        c->scan_tmp_bytes = sift3d_scan_temp_bytes(cap) + 256;
+        HIPCHK(c, hipMalloc((void **)&c->kps, sizeof(sift3d_dkp) * (size_t)cap));
+        HIPCHK(c, hipMalloc((void **)&c->patch0, sizeof(float) * SIFT3D_PATCH_VOX * (size_t)cap));
+        HIPCHK(c, hipMalloc((void **)&c->nrec, sizeof(int) * (size_t)cap));
+        HIPCHK(c, hipMalloc((void **)&c->offs, sizeof(int) * (size_t)cap));
+        HIPCHK(c, hipMalloc(&c->scan_tmp, c->scan_tmp_bytes));
+        HIPCHK(c, hipMalloc((void **)&c->rec_kp, sizeof(int) * (size_t)rcap));
+        HIPCHK(c, hipMalloc((void **)&c->rec_frame, sizeof(int) * (size_t)rcap));
+        /* the records go straight into pinned host memory (mapped into the device's address space) */
+        HIPCHK(c, hipHostMalloc((void **)&c->h_recs, sizeof(sift3d_feature) * (size_t)rcap, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_group, sizeof(int) * (size_t)rcap, hipHostMallocDefault));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_hrecs, c->h_recs, 0));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_hgroup, c->h_group, 0));
+        c->kps_cap = cap;
+        c->recs_cap = rcap;
     }
     return SIFT3D_OK;
 }
@@ -1133,110 +1127,137 @@ static int candidates_to_host(sift3d_ctx *c, const std::vector<sift3d_level> &le
     return SIFT3D_OK;
 }
 
-/* Sorted candidates -> records in the pinned buffer: keypoint launch, scan, record map, descriptor
- * launch, download.  Two host synchronisations (record total, download). */
+/* ---- per-keypoint stage: sorted candidates -> records in the pinned host buffer ------------------------------------
+ * The two kernels of the stage are bound by different units of a CU (the keypoint kernel by its LDS
+ * atomics, the descriptor kernel by the L1's miss handling), so the sorted list is cut into chunks and the keypoint kernel
+ * of chunk i+1 runs on the main stream beside the descriptor kernel of chunk i on a second one.  Per chunk, on the main
+ * stream: keypoint kernel -> scan of the record counts inside the chunk -> record map (which also leaves the chunk's
+ * first-record index for the next chunk on the device) -> read-back of the chunk's end index.  The host then walks the
+ * chunks: wait for chunk i's end index (the device is already busy with chunk i+1), launch its descriptor kernel with an
+ * exact grid on the second stream.  The records are stored straight into pinned host memory while the kernels run: 60 MB
+ * cross the bus beside the compute at 512^3 and nothing is left to copy at the end.
+ * Three phases so that a driver with several contexts (the Z-slab driver) can keep all its devices busy:
+ *   describe_queue   everything on the main stream for all chunks (returns at once)
+ *   describe_launch  the descriptor launches (waits, chunk by chunk, for the keypoint side)
+ *   describe_finish  the one synchronisation at the end. */
 static void kp_params_of(sift3d_ctx *c, int desc_mode, float eig_thres, float size_factor, sift3d_kp_params &p)
 {
     p.levels = c->d_levels;
     p.eig_thres = eig_thres;
     p.size_factor = size_factor;
     p.desc_mode = desc_mode;
-    p.debug_stop = getenv("SIFT3D_KP_STOP") ? atoi(getenv("SIFT3D_KP_STOP")) : 0;
+    p.debug_stop = c->dev_stop;
     p.patch0 = c->patch0;
     /* workgroups per CU in the descriptor kernel's sampling phase at a time: by measurement at 512^3 (descriptor kernel 4.22 ms
-     * without a limit; 1: 6.6, 2: 4.5, 3: 4.09, 4: 4.03, 5: 4.12, 6-12: 4.15-4.18).  SIFT3D_SAMPLER_CAP=0: no limit */
-    const char *senv = getenv("SIFT3D_SAMPLER_CAP");
+     * without a limit; 1: 6.6, 2: 4.5, 3: 4.09, 4: 4.03, 5: 4.12, 6-12: 4.15-4.18) */
     p.sampler_tokens = c->sampler_tokens;
-    p.sampler_cap = c->sampler_tokens ? (senv ? atoi(senv) : 4) : 0;
+    p.sampler_cap = c->tune[SIFT3D_TUNE_SAMPLER_CAP];
 }
 
-/* n_done: leading candidates whose keypoint stage has already been queued on kp_stream (ev_kp marks its end) with the
- * level table already on the device */
-static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode,
-                           float eig_thres, float size_factor, int64_t *n_out, int64_t n_done = 0, bool levels_on_device = false)
+static int kp_chunks_for(const sift3d_ctx *c, int64_t ncand)
 {
-    float taps3[SIFT3D_MAX_TAPS], taps5[SIFT3D_MAX_TAPS];
-    if (sift3d_gauss_taps(0.5f, 0.01f, taps3) != 3 || sift3d_gauss_taps((float)0.95, (float)0.01, taps5) != 5)
+    int n = c->tune[SIFT3D_TUNE_KP_CHUNKS];
+    if (n <= 0) n = SIFT3D_KP_DEFAULT_CHUNKS;
+    if (n > SIFT3D_KP_MAX_CHUNKS) n = SIFT3D_KP_MAX_CHUNKS;
+    if (n > ncand) n = ncand > 0 ? (int)ncand : 1;
+    return n;
+}
+
+static int describe_queue(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode, float eig_thres,
+                          float size_factor, bool levels_on_device)
+{
+    float taps3[SIFT3D_MAX_TAPS];
+    if (sift3d_gauss_taps(0.5f, 0.01f, taps3) != 3 || sift3d_gauss_taps((float)0.95, (float)0.01, c->kp.taps5) != 5)
         return set_err(c, SIFT3D_ERR_ARG, "unexpected patch tap counts");
     if (levels.size() > 96) return set_err(c, SIFT3D_ERR_ARG, "too many levels");
-    int64_t nrec_total = 0;
-    int rc;
-    if (ncand > 0) {
-        if (n_done > 0 && ncand > c->kps_cap) { /* the early pass sized the buffers too small (it only knew octave 0's count): redo it */
-            HIPCHK(c, hipStreamSynchronize(c->kp_stream));
-            n_done = 0;
+    c->kp.ncand = ncand;
+    c->kp.nchunks = 0;
+    c->kp.launched = 0;
+    c->kp.nrec = 0;
+    if (ncand <= 0) return SIFT3D_OK;
+    int rc = ensure_kp_buffers(c, ncand);
+    if (rc) return rc;
+    if (!levels_on_device)
+        HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->stream));
+    kp_params_of(c, desc_mode, eig_thres, size_factor, c->kp.p);
+    const int nch = kp_chunks_for(c, ncand);
+    c->kp.nchunks = nch;
+    HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_rec_base, 0, sizeof(int), c->stream));
+    int *h_end = reinterpret_cast<int *>(c->h_cnt0 + 8); /* pinned: first record past chunk i */
+    for (int i = 0; i < nch; i++) {
+        const int64_t a = ncand * i / nch, b = ncand * (i + 1) / nch;
+        c->kp.first[i] = a;
+        c->kp.first[i + 1] = b;
+        h_end[i] = 0;
+        {
+            sift3d_kp_params q = c->kp.p;
+            q.patch0 = c->patch0 + (size_t)a * SIFT3D_PATCH_VOX; /* the kernel indexes everything by its block number */
+            stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, b - a);
+            HIPCHK(c, sift3d_launch_keypointsA(c->stream, q, c->keys_b + a, c->vals_b + a, b - a, c->kps + a, c->nrec + a, taps3));
         }
-        rc = ensure_kp_buffers(c, ncand, 0);
-        if (rc) return rc;
-        if (n_done > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_kp, 0)); /* kps / nrec / patch0 of the early part are complete */
-        else if (!levels_on_device)
-            HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->stream));
-        sift3d_kp_params p;
-        kp_params_of(c, desc_mode, eig_thres, size_factor, p);
-        if (ncand > n_done) {
-            sift3d_kp_params q = p;
-            q.patch0 = c->patch0 + (size_t)n_done * SIFT3D_PATCH_VOX; /* the kernel indexes everything by its block number */
-            stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, ncand - n_done);
-            HIPCHK(c, sift3d_launch_keypointsA(c->stream, q, c->keys_b + n_done, c->vals_b + n_done, ncand - n_done, c->kps + n_done,
-                                               c->nrec + n_done, taps3));
-        }
-        HIPCHK(c, sift3d_scan_counts(c->stream, c->scan_tmp, c->scan_tmp_bytes, c->nrec, c->offs, ncand));
-        int *last = reinterpret_cast<int *>(c->h_cnt0 + 4); /* pinned */
-        last[0] = last[1] = 0;
-        HIPCHK(c, hipMemcpyAsync(&last[0], c->offs + (ncand - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&last[1], c->nrec + (ncand - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        nrec_total = (int64_t)last[0] + last[1];
-        if (nrec_total > 0) {
-            rc = ensure_kp_buffers(c, 0, nrec_total);
-            if (rc) return rc;
-            HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), c->stream));
-            HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec, c->offs, ncand, c->rec_kp, c->rec_frame, c->d_count + 3));
-            /* The records are 324 bytes each: 60 MB, a millisecond of PCIe, at 512^3.  By default the descriptor kernel stores
-             * them straight into the pinned host buffer (it is mapped into the device's address space): the bytes cross the
-             * bus while the kernel runs and nothing is left to copy when it ends.  SIFT3D_DIRECT_HOST=0 (A/B): the earlier
-             * form, records into device memory in four slices, each slice copied on a second stream while the next one is
-             * computed -- which leaves the copy of the last slice (a quarter of the records, 0.3-0.5 ms) after the kernel. */
-            stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, nrec_total);
-            const char *denv = getenv("SIFT3D_DIRECT_HOST");
-            sift3d_feature *d_hrecs = nullptr;
-            int *d_hgroup = nullptr;
-            bool direct = !(denv && atoi(denv) == 0);
-            if (direct && (hipHostGetDevicePointer((void **)&d_hrecs, c->h_recs, 0) != hipSuccess ||
-                           hipHostGetDevicePointer((void **)&d_hgroup, c->h_group, 0) != hipSuccess)) {
-                (void)hipGetLastError();
-                direct = false;
-            }
-            if (p.sampler_cap > 0) /* the per-CU tokens start from zero whatever became of an earlier launch */
-                HIPCHK(c, hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream));
-            if (direct) {
-                HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp, c->rec_frame, nrec_total, d_hrecs, d_hgroup, taps5));
-            } else {
-            const int nslice = nrec_total >= 32768 ? 4 : 1;
-            const int64_t per = (nrec_total + nslice - 1) / nslice;
-            for (int k = 0; k < nslice; k++) {
-                const int64_t o = k * per, m = std::min<int64_t>(per, nrec_total - o);
-                if (m <= 0) break;
-                HIPCHK(c, sift3d_launch_descriptors(c->stream, p, c->kps, c->rec_kp + o, c->rec_frame + o, m, c->recs + o,
-                                                    c->rec_group + o, taps5));
-                HIPCHK(c, hipEventRecord(c->ev_chunk[k], c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_chunk[k], 0));
-                HIPCHK(c, hipMemcpyAsync(c->h_recs + o, c->recs + o, sizeof(sift3d_feature) * (size_t)m, hipMemcpyDeviceToHost, c->copy_stream));
-                HIPCHK(c, hipMemcpyAsync(c->h_group + o, c->rec_group + o, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->copy_stream));
-            }
-            }
-        }
+        HIPCHK(c, sift3d_scan_counts(c->stream, c->scan_tmp, c->scan_tmp_bytes, c->nrec + a, c->offs + a, b - a));
+        HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec + a, c->offs + a, b - a, (int)a, c->d_rec_base + i, c->rec_kp, c->rec_frame,
+                                       c->d_count + 3));
+        HIPCHK(c, hipMemcpyAsync(&h_end[i], c->d_rec_base + i + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_kpc[i], c->stream));
     }
+    return SIFT3D_OK;
+}
+
+static int describe_launch(sift3d_ctx *c)
+{
+    const int nch = c->kp.nchunks;
+    if (nch <= 0) return SIFT3D_OK;
+    const int *h_end = reinterpret_cast<const int *>(c->h_cnt0 + 8);
+    /* one chunk: the descriptor kernel follows on the main stream; several: on the second stream, beside the next chunk's
+     * keypoint kernel.  With every launch bracketed by events (timing modes 1 and 3) the launches stay on the main stream,
+     * so that an event pair times its kernel alone. */
+    const bool beside = nch > 1 && !(c->timing == 1 || c->timing == 3);
+    hipStream_t ds = beside ? c->kp_stream : c->stream;
+    int64_t base = 0;
+    for (int i = 0; i < nch; i++) {
+        HIPCHK(c, hipEventSynchronize(c->ev_kpc[i]));
+        const int64_t end = h_end[i], m = end - base;
+        if (end < base || end > c->recs_cap) return set_err(c, SIFT3D_ERR_DEVICE, "record map out of range (%lld of %lld)", (long long)end, (long long)c->recs_cap);
+        if (m > 0) {
+            stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, m, ds);
+            if (c->kp.p.sampler_cap > 0) /* the per-CU tokens start from zero whatever became of an earlier launch */
+                HIPCHK(c, hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, ds));
+            HIPCHK(c, sift3d_launch_descriptors(ds, c->kp.p, c->kps, c->rec_kp + base, c->rec_frame + base, m, c->d_hrecs + base,
+                                                c->d_hgroup + base, c->kp.taps5));
+        }
+        base = end;
+    }
+    c->kp.nrec = base;
+    c->kp.launched = 1;
+    if (beside) { /* the main stream ends behind the descriptor launches: one synchronisation covers both */
+        HIPCHK(c, hipEventRecord(c->ev_desc, c->kp_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_desc, 0));
+    }
+    return SIFT3D_OK;
+}
+
+static int describe_finish(sift3d_ctx *c, int64_t *n_out)
+{
     unsigned long long &nkp = c->h_cnt0[6]; /* pinned */
     nkp = 0;
-    if (nrec_total) HIPCHK(c, hipMemcpyAsync(&nkp, c->d_count + 3, sizeof(nkp), hipMemcpyDeviceToHost, c->stream));
+    if (c->kp.nrec) HIPCHK(c, hipMemcpyAsync(&nkp, c->d_count + 3, sizeof(nkp), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nrec_total) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     timing_end(c);
-    c->last.n_records = nrec_total;
+    c->last.n_records = c->kp.nrec;
     c->last.n_keypoints = (int64_t)nkp;
-    *n_out = nrec_total;
+    *n_out = c->kp.nrec;
     return SIFT3D_OK;
+}
+
+static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode,
+                           float eig_thres, float size_factor, int64_t *n_out, bool levels_on_device = false)
+{
+    int rc = describe_queue(c, levels, ncand, desc_mode, eig_thres, size_factor, levels_on_device);
+    if (!rc) rc = describe_launch(c);
+    if (!rc) rc = describe_finish(c, n_out);
+    return rc;
 }
 
 /* The whole single-GPU path.  Host synchronisations: the extrema count, the record count, the
@@ -1245,6 +1266,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                         sift3d_candidate **cands_out, sift3d_feature **feats_out, int64_t *n_out)
 {
     if (!c) return SIFT3D_ERR_ARG;
+    if (c->lean) return set_err(c, SIFT3D_ERR_ARG, "a slab context holds no pyramid (sift3d_create_slab)");
     if (!c->has_volume) return set_err(c, SIFT3D_ERR_ARG, "no volume set (sift3d_set_volume)");
     HIPCHK(c, hipSetDevice(c->device));
     timing_begin(c);
@@ -1273,13 +1295,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     for (const octave_dims &d : oct)
         if (tiny_base < 0 && d.X * d.Y * d.Z <= SIFT3D_TINY_VOX) tiny_base = d.off;
     std::vector<sift3d_level> levels(oct.size() * 3);
-    /* SIFT3D_EARLY_KP=1: run the per-keypoint stage of octave 0 on a third stream as soon as its extrema are in, beside
-     * the blurs and extrema of the coarser octaves (below).  Off by default: measured at 512^3 it changes nothing
-     * (11.65 against 11.61 ms per extraction) -- octave 0's extrema finish about when the coarse chain does, and what
-     * runs beside that chain takes from it what it gains.  Kept, and tested for identical records, because the
-     * balance shifts with the volume's shape. */
-    const char *eenv = getenv("SIFT3D_EARLY_KP");
-    const bool early_ok = extract && oct.size() > 1 && eenv && atoi(eenv) == 1;
     float fscale = 1;
     float sig[7];
     struct ex_plan {
@@ -1291,9 +1306,13 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         float fscale;
     };
     std::vector<ex_plan> plans(oct.size());
-    const char *xenv = getenv("SIFT3D_EX_SCHED");
-    const bool new_sched = !(xenv && atoi(xenv) == 0) && !early_ok;
     bool used_second = false;
+    /* One chain of levels on the main stream.  (Round 3 tried two: the octaves after the first -- some sixty small launches
+     * bound by launch latency, 0.5 ms of kernel time -- on a stream of their own from the moment the second octave's level 0
+     * exists, beside the first octave's last level and its extrema passes.  It cannot overlap: the fused blur runs one
+     * 84 KB-LDS workgroup per CU and two of them never share one, and the extrema march holds 8 wavefronts x 234 registers
+     * per CU, so the chain's first launches wait for the grid in front of them to drain either way -- 10.45 ms per 512^3
+     * extraction against 10.11; on a high-priority stream every launch of the chain took 55 - 120 us: 11.6 ms.) */
     /* the three detection levels of octave o on extrema stream `which` (0: ex_stream, 1: ex_stream2), behind everything
      * queued on the main stream so far */
     auto enqueue_extrema = [&](size_t o, int which) -> int {
@@ -1345,15 +1364,15 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     for (size_t o = 0; o < oct.size(); o++) {
         const octave_dims &d = oct[o];
         const double N = (double)d.X * d.Y * d.Z;
+        hipStream_t ws = c->stream;
         sigma = 1.6f;
         sig[0] = sigma;
         /* an octave of at most 4096 voxels: all five levels in one single-workgroup launch instead of fifteen */
-        static const char *tenv = getenv("SIFT3D_TINY_OCTAVE"); /* A/B aid: 0 = the per-level launches */
         bool tiny_done = false;
         /* the last DoG level of such an octave lives in a small buffer of its own, at the octave's offset from the first of them */
         float *const d4tiny = (tiny_base >= 0 && d.off >= tiny_base && d.off - tiny_base + d.XP * d.Y * d.Z <= SIFT3D_D4TINY_FLOATS)
                                   ? c->D4tiny + (d.off - tiny_base) : nullptr;
-        if (d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && d4tiny && !(tenv && atoi(tenv) == 0)) {
+        if (d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && d4tiny && c->tune[SIFT3D_TUNE_TINY_OCTAVE]) {
             sift3d_octave_taps ot;
             sift3d_octave_out oo;
             float sg = sigma;
@@ -1369,8 +1388,8 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 sg *= factor;
             }
             if (ok) {
-                stage_scope sc(c, SIFT3D_STAGE_OCTAVE_TINY, 40.0 * N, 0, (int64_t)N);
-                hipError_t e = sift3d_launch_tiny_octave(c->stream, c->L[0] + d.off, oo, d.X, d.XP, d.Y, d.Z, ot);
+                stage_scope sc(c, SIFT3D_STAGE_OCTAVE_TINY, 40.0 * N, 0, (int64_t)N, ws);
+                hipError_t e = sift3d_launch_tiny_octave(ws, c->L[0] + d.off, oo, d.X, d.XP, d.Y, d.Z, ot);
                 if (e == hipSuccess) tiny_done = true;
                 else if (e != hipErrorNotSupported) HIPCHK(c, e);
                 else sc.cancel();
@@ -1382,29 +1401,27 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
          * positions (validateDifferencePeak3D, MultiScale.cpp:1135-1223) -- though it still blurs the whole volume for
          * L_5.  Here D_0 is taken as L_0 - L_1 at those positions and L_5 is filtered only in the 27-voxel neighbourhood
          * of what passed every other test (extrema_validate_lazy_kernel: same operations, same order, same bits).  Per
-         * octave that is one 17-tap blur of the whole volume and two DoG stores less.  SIFT3D_LAZY_LEVELS=0 (A/B, tests):
-         * every level stored, as before. */
-        const char *lenv = getenv("SIFT3D_LAZY_LEVELS");
+         * octave that is one 17-tap blur of the whole volume and two DoG stores less.  SIFT3D_TUNE_LAZY_LEVELS = 0 (A/B,
+         * tests): every level stored, as before. */
         float next_taps[SIFT3D_MAX_TAPS];
         int next_ntaps = 0;
-        bool lazy = !tiny_done && d.XP >= 8 && d.Y >= 3 && d.Z >= 3 && d.XP * d.Y < (1ll << 29) && !(lenv && atoi(lenv) == 0);
+        bool lazy = !tiny_done && d.XP >= 8 && d.Y >= 3 && d.Z >= 3 && d.XP * d.Y < (1ll << 29) && c->tune[SIFT3D_TUNE_LAZY_LEVELS];
         if (lazy) {
             float sg = 1.6f; /* sigma entering j = 5, accumulated as the loop below does */
             for (int j = 1; j < 5; j++) sg *= factor;
             next_ntaps = sift3d_gauss_taps(sg * sqrtf(factor * factor - 1.0f), 0.01f, next_taps);
             if (next_ntaps != 2 * SIFT3D_FAST_MAX_R + 1) lazy = false; /* the one filter length the third phase is built for */
         }
-        const int lazy_from = lenv ? atoi(lenv) - 1 : 0; /* A/B aid: SIFT3D_LAZY_LEVELS=n+1: the level above D_3 is stored on octaves below n */
-        const bool lazy_next = lazy && (int)o >= lazy_from;
+        const bool lazy_next = lazy;
         for (int j = 1; j < 6; j++) {
             if (tiny_done) {
                 if (j == 3 && o + 1 < oct.size()) {
-                    stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
-                    HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
+                    stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N, ws);
+                    HIPCHK(c, sift3d_launch_subsample(ws, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
                     /* the subsample writes the logical columns only: a pitched coarser octave (100 -> 50 -> pitch 52) needs its pad
                      * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
                     if (oct[o + 1].XP != oct[o + 1].X)
-                        HIPCHK(c, sift3d_launch_zero_pad(c->stream, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
+                        HIPCHK(c, sift3d_launch_zero_pad(ws, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
                 }
                 sigma *= factor;
                 sig[j] = sigma;
@@ -1422,15 +1439,17 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.Y, d.Z, ex, 0.01f);
                 if (rc) return rc;
                 if (d.XP != d.X) /* the blur ran over the pitched width: its pad columns go back to zero */
-                    HIPCHK(c, sift3d_launch_zero_pad(c->stream, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.X, d.Y * d.Z));
+                    HIPCHK(c, sift3d_launch_zero_pad(ws, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.X, d.Y * d.Z));
             }
             if (j == 3 && o + 1 < oct.size()) {
-                stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N);
-                HIPCHK(c, sift3d_launch_subsample(c->stream, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
+                {
+                    stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N, ws);
+                    HIPCHK(c, sift3d_launch_subsample(ws, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
+                }
                 /* the subsample writes the logical columns only: a pitched coarser octave (100 -> 50 -> pitch 52) needs its pad
                  * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
                 if (oct[o + 1].XP != oct[o + 1].X)
-                    HIPCHK(c, sift3d_launch_zero_pad(c->stream, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
+                    HIPCHK(c, sift3d_launch_zero_pad(ws, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
             }
             sigma *= factor;
             sig[j] = sigma;
@@ -1450,25 +1469,17 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
          * are done and then run beside that chain; the extrema of the coarser octaves go to a stream of their own so that
          * they do not queue up behind octave 0's.  (Started right after octave 0's own levels they shared the chip with
          * octave 1's blurs -- both three to ten times slower for it -- and the chain of octaves 2.. ran alone afterwards,
-         * a millisecond of mostly idle chip.)  SIFT3D_EX_SCHED=0 (A/B): every octave's extrema right behind its levels,
-         * all on one stream. */
-        if (o == 0 && !(new_sched && oct.size() > 1)) {
+         * a millisecond of mostly idle chip: 10.75 against 10.50 ms per extraction.) */
+        if (o == 0 && oct.size() == 1) {
             rc = enqueue_extrema(0, 0);
             if (rc) return rc;
         } else if (o >= 1) {
-            if (o == 1 && new_sched) {
+            if (o == 1) {
                 rc = enqueue_extrema(0, 0);
                 if (rc) return rc;
             }
-            rc = enqueue_extrema(o, new_sched ? 1 : 0);
+            rc = enqueue_extrema(o, 1);
             if (rc) return rc;
-        }
-        if (o == 0 && early_ok) {
-            /* octave 0's extrema are the first entries of the list (the passes of the coarser octaves follow on the same
-             * stream): note how many there are, for the early per-keypoint pass below */
-            hipStream_t exs = c->timing == 3 ? c->stream : c->ex_stream;
-            HIPCHK(c, hipMemcpyAsync(c->h_cnt0, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, exs));
-            HIPCHK(c, hipEventRecord(c->ev_cnt0, exs));
         }
         fscale *= 2.0f;
         c->last.n_octaves++;
@@ -1479,44 +1490,16 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         HIPCHK(c, hipEventRecord(c->ev_ex2[1], c->ex_stream2));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ex2[1], 0));
     }
-    /* Early per-keypoint pass.  Everything above is queued, the device is minutes of host time behind: wait until octave
-     * 0's extrema are in (the coarser octaves are still blurring, launch-latency-bound, on a mostly idle chip), then sort
-     * them and run their keypoint kernel on a third stream beside that chain.  The reference itself generates the
-     * features of a level inside the octave loop (MultiScale.cpp:459-467); the list order is unchanged because keys are
-     * octave-major.  Anything irregular (overflow, few candidates) leaves n0 = 0: the one-shot path below. */
-    int64_t n0 = 0;
-    if (early_ok) {
-        float taps3[SIFT3D_MAX_TAPS];
-        HIPCHK(c, hipEventSynchronize(c->ev_cnt0));
-        const unsigned long long *h = c->h_cnt0;
-        if (h[2] == 0 && (int64_t)h[0] <= c->cand_cap && h[0] >= 256 && levels.size() <= 96 && sift3d_gauss_taps(0.5f, 0.01f, taps3) == 3) {
-            n0 = (int64_t)h[0];
-            if (c->kps_cap < n0 + n0 / 4 + 1024) { /* first run at this size: sized for the whole list (octave 0 holds ~7/8 of it) */
-                rc = ensure_kp_buffers(c, n0 + n0 / 2 + 4096, 0);
-                if (rc) return rc;
-            }
-            HIPCHK(c, hipStreamWaitEvent(c->kp_stream, c->ev_cnt0, 0));
-            HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->kp_stream));
-            HIPCHK(c, sift3d_sort_candidates(c->kp_stream, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a, c->vals_b, n0));
-            sift3d_kp_params p;
-            kp_params_of(c, desc_mode, eig_thres, size_factor, p);
-            {
-                stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, n0, c->kp_stream);
-                HIPCHK(c, sift3d_launch_keypointsA(c->kp_stream, p, c->keys_b, c->vals_b, n0, c->kps, c->nrec, taps3));
-            }
-            HIPCHK(c, hipEventRecord(c->ev_kp, c->kp_stream));
-        }
-    }
     /* the level table goes to the device now, behind the pyramid, not after the host has waited for the extrema count */
-    const bool levels_early = extract && n0 == 0 && levels.size() <= 96;
+    const bool levels_early = extract && levels.size() <= 96;
     if (levels_early)
         HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, c->stream));
     int64_t ncand = 0;
-    rc = cand_finalize(c, &ncand, &n0);
+    rc = cand_finalize(c, &ncand);
     if (rc) return rc;
     c->last.n_extrema = ncand;
     if (!extract) return candidates_to_host(c, levels, ncand, cands_out, n_out);
-    rc = describe_sorted(c, levels, ncand, desc_mode, eig_thres, size_factor, n_out, n0, levels_early);
+    rc = describe_sorted(c, levels, ncand, desc_mode, eig_thres, size_factor, n_out, levels_early);
     if (rc) return rc;
     *feats_out = c->h_recs; /* pinned, owned by the context */
     return SIFT3D_OK;
@@ -1542,7 +1525,9 @@ extern "C" int sift3d_extrema_append_dev(sift3d_ctx *c, const float *d_prev, con
     HIPCHK(c, hipSetDevice(c->device));
     int rc = fence_in(c);
     if (rc) return rc;
-    return cand_append(c, {d_prev, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id}, true);
+    rc = cand_append(c, {d_prev, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id}, true);
+    if (rc) return rc;
+    return fence_out(c); /* the caller may reuse the buffers once the pass has read them */
 }
 
 /* shapes the second and third extrema phase take neighbour levels in unstored form for */
@@ -1554,8 +1539,6 @@ static bool lazy_shape_ok(int64_t nx, int64_t ny, int64_t nz_local)
 extern "C" int sift3d_lazy_levels_supported(int64_t nx, int64_t ny, int64_t nz_local, float next_sigma)
 {
     float taps[SIFT3D_MAX_TAPS];
-    const char *lzenv = getenv("SIFT3D_LAZY_LEVELS");
-    if (lzenv && atoi(lzenv) == 0) return 0;
     return lazy_shape_ok(nx, ny, nz_local) && sift3d_gauss_taps(next_sigma, 0.01f, taps) == 2 * SIFT3D_FAST_MAX_R + 1 ? 1 : 0;
 }
 
@@ -1581,7 +1564,9 @@ extern "C" int sift3d_extrema_append_lazy_dev(sift3d_ctx *c, const float *d_prev
         for (int q = 0; q < ntaps; q++) jb.next_taps[q] = taps[q];
         jb.next_g = g_next;
     }
-    return cand_append(c, jb, true);
+    rc = cand_append(c, jb, true);
+    if (rc) return rc;
+    return fence_out(c);
 }
 
 static int levels_from_desc(sift3d_ctx *c, const sift3d_level_desc *ld, int n, std::vector<sift3d_level> &levels)
@@ -1611,10 +1596,12 @@ extern "C" int sift3d_candidates_dev(sift3d_ctx *c, const sift3d_level_desc *lev
     std::vector<sift3d_level> lv;
     int rc = levels_from_desc(c, levels, n_levels, lv);
     if (rc) return rc;
+    rc = fence_in(c); /* a replay of the extrema passes reads the caller's level buffers again */
+    if (rc) return rc;
     int64_t ncand = 0;
     rc = cand_finalize(c, &ncand);
     if (rc) return rc;
-    return candidates_to_host(c, lv, ncand, out, n_out);
+    return candidates_to_host(c, lv, ncand, out, n_out); /* ends with a host synchronisation: nothing is left in flight */
 }
 
 extern "C" int sift3d_describe_dev(sift3d_ctx *c, const sift3d_level_desc *levels, int n_levels, int desc_mode,
@@ -1627,11 +1614,13 @@ extern "C" int sift3d_describe_dev(sift3d_ctx *c, const sift3d_level_desc *level
     std::vector<sift3d_level> lv;
     int rc = levels_from_desc(c, levels, n_levels, lv);
     if (rc) return rc;
+    rc = fence_in(c); /* the keypoint and descriptor kernels read img / dogc of the level table: the caller's buffers */
+    if (rc) return rc;
     int64_t ncand = 0;
     rc = cand_finalize(c, &ncand);
     if (rc) return rc;
     c->last.n_extrema = ncand;
-    rc = describe_sorted(c, lv, ncand, desc_mode, eig_thres, size_factor, n_out);
+    rc = describe_sorted(c, lv, ncand, desc_mode, eig_thres, size_factor, n_out); /* ends with a host synchronisation */
     if (rc) return rc;
     *view = c->h_recs;
     if (group_view) *group_view = c->h_group;
@@ -1808,6 +1797,7 @@ struct sift3d_zslab {
     zs_plan plan;
     std::vector<int> devices;
     std::vector<zs_rank> R; /* one per slab; a single one when the volume is too thin to shard */
+    int lazy_levels = 1;    /* SIFT3D_TUNE_LAZY_LEVELS */
     sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
 };
 
@@ -1827,6 +1817,17 @@ extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
         sift3d_destroy(q.c);
     }
     delete h;
+}
+
+extern "C" int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value)
+{
+    if (!h) return SIFT3D_ERR_ARG;
+    for (zs_rank &q : h->R) {
+        const int rc = sift3d_set_tuning(q.c, knob, value);
+        if (rc) return rc;
+    }
+    if (knob == SIFT3D_TUNE_LAZY_LEVELS) h->lazy_levels = value;
+    return SIFT3D_OK;
 }
 
 /* status_out (may be NULL) receives the sift3d_status behind a NULL result */
@@ -1858,7 +1859,16 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
         int64_t i0 = 0, i1 = nz;
         if (S > 1) h->plan.input_range(r, i0, i1);
         ZS_HIP(hipSetDevice(q.dev));
-        q.c = sift3d_create(q.dev, nx, ny, (i1 - i0) + 2 * ZS_HALO);
+        /* a slab context owns no level buffers (they come from the rank's arena); its pass intermediates must hold the
+         * largest volume the rank ever blurs: its slab with halos, and on rank 0 the first unsharded octave, which is
+         * gathered there (nz / 2^K slices of a plane a 4^K-th the size: smaller than the slab unless the slabs are many) */
+        int64_t ctx_nz = (i1 - i0) + 2 * ZS_HALO;
+        if (r == 0 && S > 1 && (size_t)h->plan.K < h->plan.oct.size()) {
+            const std::vector<int64_t> &g = h->plan.oct[(size_t)h->plan.K];
+            const int64_t need = (pitch_of(g[0]) * g[1] * g[2] + pitch_of(nx) * ny - 1) / (pitch_of(nx) * ny);
+            ctx_nz = std::max(ctx_nz, need);
+        }
+        q.c = ctx_create(q.dev, nx, ny, ctx_nz, S > 1);
         if (!q.c) {
             snprintf(errbuf, sizeof errbuf, "rank %d: no context on device %d (memory?)", r, q.dev);
             rc = SIFT3D_ERR_MEMORY;
@@ -1967,12 +1977,10 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
          * filtered only around the candidates of D_3, from L_4.  A slab then blurs four levels instead of five and exchanges
          * four halos per octave instead of five; the third extrema phase reads L_4 nine slices beyond a candidate, so L_4's
          * halo is refreshed nine slices deep instead of eight.  Rows that are not whole 16-byte vectors keep every level
-         * stored (the extrema kernels of such rows take stored levels only), as does SIFT3D_LAZY_LEVELS=0. */
+         * stored (the extrema kernels of such rows take stored levels only), as does sift3d_zslab_set_tuning(SIFT3D_TUNE_LAZY_LEVELS, 0). */
         float taps5[SIFT3D_MAX_TAPS];
         const int ntaps5 = sift3d_gauss_taps(extras[4], 0.01f, taps5);
-        const char *lzenv = getenv("SIFT3D_LAZY_LEVELS");
-        const bool lazy = ntaps5 == 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X >= 8 && XY < (1ll << 29) && Y >= 3 && zo >= 3 &&
-                          !(lzenv && atoi(lzenv) == 0);
+        const bool lazy = ntaps5 == 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X >= 8 && XY < (1ll << 29) && Y >= 3 && zo >= 3 && h->lazy_levels;
         const int nlev = lazy ? 4 : 5;
         for (r = 0; r < nr; r++) {
             zs_rank &q = R[(size_t)r];
@@ -2138,18 +2146,38 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
         }
     }
 
-    /* ---- per-keypoint stage on every rank (queued device by device; each ends with its own host synchronisation) ---- */
-    for (r = 0; r < S; r++) {
-        zs_rank &q = R[(size_t)r];
-        ZS_HIP(hipSetDevice(q.dev));
-        ZS_HIP(hipStreamSynchronize(q.copy_stream));
-        int64_t ncand = 0, nrec = 0;
-        ZS_RC(cand_finalize(q.c, &ncand));
-        st.n_extrema += ncand;
-        ZS_RC(describe_sorted(q.c, q.levels, ncand, desc_mode, eig_thres, size_factor, &nrec));
-        recs[(size_t)r].assign(q.c->h_recs, q.c->h_recs + nrec);
-        grps[(size_t)r].assign(q.c->h_group, q.c->h_group + nrec);
-        st.n_keypoints += q.c->last.n_keypoints;
+    /* ---- per-keypoint stage on every rank, phase by phase across the ranks so that no device waits for another's host
+     * round trip: (1) every rank's extrema count is requested; (2) rank by rank the count is awaited, the candidates are
+     * sorted and the keypoint side of the stage is queued -- the devices before it are already computing; (3) rank by rank
+     * the descriptor launches follow the keypoint chunks; (4) one synchronisation per rank at the end. ---- */
+    {
+        std::vector<int64_t> ncands((size_t)S, 0);
+        for (r = 0; r < S; r++) {
+            zs_rank &q = R[(size_t)r];
+            ZS_HIP(hipSetDevice(q.dev));
+            /* (the main stream already waits for the deferred patch halos of every sharded octave: ev_patch above) */
+            ZS_RC(cand_count_queue(q.c));
+        }
+        for (r = 0; r < S; r++) {
+            zs_rank &q = R[(size_t)r];
+            ZS_HIP(hipSetDevice(q.dev));
+            ZS_RC(cand_finalize(q.c, &ncands[(size_t)r]));
+            st.n_extrema += ncands[(size_t)r];
+            ZS_RC(describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false));
+        }
+        for (r = 0; r < S; r++) {
+            ZS_HIP(hipSetDevice(R[(size_t)r].dev));
+            ZS_RC(describe_launch(R[(size_t)r].c));
+        }
+        for (r = 0; r < S; r++) {
+            zs_rank &q = R[(size_t)r];
+            int64_t nrec = 0;
+            ZS_HIP(hipSetDevice(q.dev));
+            ZS_RC(describe_finish(q.c, &nrec));
+            recs[(size_t)r].assign(q.c->h_recs, q.c->h_recs + nrec);
+            grps[(size_t)r].assign(q.c->h_group, q.c->h_group + nrec);
+            st.n_keypoints += q.c->last.n_keypoints;
+        }
     }
     {
         /* merge: within a group (level, is_max) slabs are in z order, so rank order is the serial raster order */

@@ -781,9 +781,13 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
     float *patch = sm.A;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     wave_sample_patch<KP_NT>(patch, lv.img, X, lv.XP, Y, Z, lv.Zl, lv.z_off, fx, fy, fz, scale, ident);
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 1) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
     wave_normalize_patch<KP_NT>(patch, sm.sc);
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 2) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
     const int nrad = wave_build_radius_list(sm.r.rlist, &sm.cnt[0]);
 
     /* determineOrientation3D, MultiScale.cpp:2541-2607: gradients (fioGenerateEdgeImages3D,
@@ -822,7 +826,9 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
         sm.sc[lane] = acc;
     }
     __syncthreads();
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 3) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
     /* The SVD + eigen test (one lane, double-precision internals) and the first orientation-histogram splat (one
      * wavefront, a chain of LDS atomics) do not depend on each other: the splat runs on wavefront 0 while lane 0 of
      * the last wavefront does the SVD.  For the ~15 % of the extrema the eigen test rejects the splat was wasted. */
@@ -883,12 +889,20 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
     }
     wave_splat_sequence(t0, nrad, sm.r.sp_base, sp4); /* wavefront 0; ends with a barrier */
     if (sm.sc[15] == 0.0f) return;
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 4 || p.debug_stop == 5) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 6) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
     wave_blur_patch<KP_NT>(t0, ta, t0, sm.taps, 3);
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 7) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
     const int npk = wave_peaks_sorted<KP_NT>(ta, sm.C.pk.flags, &sm.cnt[1], sm.C.pk.raw_idx, sm.C.pk.raw_val, sm.pk_idx, sm.pk_val);
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 8) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
 
     if (lane < npk && lane < PD && lane < 30) {
         float o[3];
@@ -933,13 +947,21 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
             sp4[q] = pq;
         }
         __syncthreads();
+#ifdef SIFT3D_DEV
         if (p.debug_stop == 31) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
         wave_splat_sequence(t0, nrad, sm.r.sp_base, sp4);
+#ifdef SIFT3D_DEV
         if (p.debug_stop == 32) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
         wave_blur_patch<KP_NT>(t0, ta, t0, sm.taps, 3);
+#ifdef SIFT3D_DEV
         if (p.debug_stop == 33) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
         const int npk2 = wave_peaks_sorted<KP_NT>(ta, sm.C.pk.flags, &sm.cnt[2], sm.C.pk.raw_idx, sm.C.pk.raw_val, sm.C.pk.pk2_idx, sm.C.pk.pk2_val);
+#ifdef SIFT3D_DEV
         if (p.debug_stop == 34) { if (lane == 0) nrec_out[k] = 0; return; }
+#endif
         const float pk20 = npk2 > 0 ? sm.C.pk.pk2_val[0] : 0.0f;
         for (int j = 0; j < npk2 && nret < PD && nret < 30; j++) {
             if (sm.C.pk.pk2_val[j] < 0.5f * pk20) break;
@@ -1032,10 +1054,13 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         for (int i = 0; i < 9; i++) ori[i] = kp->frames[fr * 9 + i];
     }
     const sift3d_level lv = p.levels[kp->lvl];
+#ifdef SIFT3D_DEV /* timing ablation (tools/desc_ablate.py): every record samples one cache-resident region */
     if (p.debug_stop >= 21 && p.debug_stop <= 26) { /* development aid: every record samples one cache-resident region (22: and runs to the end, 23/24/25: stops where 12/13/14 do, 26: after the bin chains) */
         wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
         if (p.debug_stop == 21) return;
-    } else if (fr < 0) {
+    } else
+#endif
+    if (fr < 0) {
         /* record 0 is sampled with the identity frame and normalised once inside generateFeature3D
          * (MultiScale.cpp:1742): phase A did exactly that and left the result in patch0 */
         const float *src = p.patch0 + (long long)rec_kp[r] * PV;
@@ -1069,9 +1094,13 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         if (tok && lane == 0) atomicSub(tok, 1);
     }
     /* ... and every record is normalised once more in main (featExtract.cpp:480) */
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 11) return;
+#endif
     wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);
+#ifdef SIFT3D_DEV
     if (p.debug_stop == 12 || p.debug_stop == 23) return;
+#endif
 
     const bool w0 = lane < 64; /* wavefront 0: lane = descriptor bin for everything that follows the parallel pre-pass */
     float myval = 0.0f;
@@ -1122,7 +1151,9 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
             sm.wtab[1][c] = 1.0f - w;
         }
         __syncthreads();
+#ifdef SIFT3D_DEV
         if (p.debug_stop == 13 || p.debug_stop == 24) return;
+#endif
         /* bucket the interior voxels by octant, keeping raster order inside a bucket (wavefront 0, ballots) */
         if (w0) {
             int cnt[8];
@@ -1158,7 +1189,9 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
             }
         }
         __syncthreads();
+#ifdef SIFT3D_DEV
         if (p.debug_stop == 14 || p.debug_stop == 25) return;
+#endif
         if (w0) {
             /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin over its octant's voxels */
             const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
@@ -1171,7 +1204,9 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
                 const float mg = sm.u.v.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
                 acc += mg * wxs[x] * wys[y] * wzs[z];
             }
+#ifdef SIFT3D_DEV
             if (p.debug_stop == 26) return;
+#endif
             /* msNormalizeDataPositive, MultiScale.cpp:1580-1611 (lane i's value through v_readlane_b32: a scalar
              * broadcast instead of an LDS permute per term) */
             float mn = 100000;
@@ -1245,16 +1280,20 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
     }
 }
 
-/* record r of keypoint k: rec_kp = k, rec_frame = -1 (un-reoriented) or the frame index */
-__global__ void recmap_kernel(const int *__restrict__ nrec, const int *__restrict__ offs, long long ncand,
-                              int *__restrict__ rec_kp, int *__restrict__ rec_frame, unsigned long long *kp_count)
+/* Record r of candidate k: rec_kp = k (counted over the whole sorted list), rec_frame = -1 (un-reoriented) or the frame
+ * index.  The per-keypoint stage runs over the list in chunks: nrec / offs belong to one chunk (offs = exclusive prefix of
+ * nrec inside the chunk), its first candidate is cand_off, its first record rec_base[0]; the kernel leaves the first record
+ * of the next chunk in rec_base[1]. */
+__global__ void recmap_kernel(const int *__restrict__ nrec, const int *__restrict__ offs, long long ncand, int cand_off,
+                              int *rec_base, int *__restrict__ rec_kp, int *__restrict__ rec_frame, unsigned long long *kp_count)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncand) return;
-    const int n = nrec[k], o = offs[k];
+    const int n = nrec[k], o = rec_base[0] + offs[k];
+    if (k == ncand - 1) rec_base[1] = o + n;
     if (n > 0) atomicAdd(kp_count, 1ull); /* keypoints that survived the bounds and eigenvalue tests (statistics) */
     for (int f = 0; f < n; f++) {
-        rec_kp[o + f] = (int)k;
+        rec_kp[o + f] = cand_off + (int)k;
         rec_frame[o + f] = f - 1;
     }
 }
@@ -1272,12 +1311,12 @@ hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, co
     return hipGetLastError();
 }
 
-hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame,
-                                unsigned long long *kp_count)
+hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int cand_off, int *rec_base,
+                                int *rec_kp, int *rec_frame, unsigned long long *kp_count)
 {
     if (ncand <= 0) return hipSuccess;
     hipLaunchKernelGGL(recmap_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s, nrec, offs, (long long)ncand,
-                       rec_kp, rec_frame, kp_count);
+                       cand_off, rec_base, rec_kp, rec_frame, kp_count);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
  * is GEMM-shaped, so no MFMA.
  */
 #include <cstdlib>
+#include <type_traits>
 
 #include "sift3d_internal.h"
 
@@ -385,6 +386,7 @@ __global__ void halve_size_kernel(const float *__restrict__ in, long long X, lon
 #define EX_STAGE (64 + 8 * 64) /* entries of a wavefront's staging buffer: flushed at 64, one step adds at most 8 per lane */
 #define EX_LOAD (EX_ROWS + 2) /* rows loaded per plane (one halo row on each side) */
 #define EX_XOUT 248        /* output voxels per wavefront along x: 64 lanes x float4 minus one halo lane each side */
+#define EX_RSRC_FLAGS 0x00020000 /* buffer descriptors: raw buffer, 32-bit data format */
 
 __device__ __forceinline__ float dpp_from_lower(float v) /* lane l gets lane l-1 (lane 0 keeps its own) */
 {
@@ -442,7 +444,12 @@ __device__ __forceinline__ void row_extrema(v4f a, float (&rmax)[4], float (&rmi
  * counter is low).  A segment holds one contiguous range of z: blockIdx.y counts planes / chunks of planes, so the
  * segments taken in order are the volume taken in slabs -- which is what lets the third phase of a lazily evaluated
  * level walk its candidates slab by slab and find the blocks it reads still in the caches. */
-__device__ __forceinline__ int ex_segment_of_z_block() { return (int)(((unsigned long long)blockIdx.y * EX_SEGS) / gridDim.y); }
+__device__ __forceinline__ int ex_segment_of_z_block()
+{
+    /* fewer z blocks than segments: segment = z block, and the launcher divides the list's capacity by the segments in use */
+    return gridDim.y >= EX_SEGS ? (int)(((unsigned long long)blockIdx.y * EX_SEGS) / gridDim.y) : (int)blockIdx.y;
+}
+static inline int ex_segments_in_use(unsigned z_blocks) { return z_blocks >= EX_SEGS ? EX_SEGS : (int)z_blocks; }
 
 /* First phase.  One wavefront = 248 output voxels along x (64 lanes x float4; the first and last lane
  * only supply x-neighbours) by EX_ROWS rows of ONE plane: it loads EX_ROWS+2 rows of the three planes
@@ -524,72 +531,71 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
     }
 }
 
-/* First phase, marching form (used when the volume has enough planes): the same wavefront tile, but the
- * wavefront walks a chunk of planes and keeps, for the three planes around the output plane, what the test
- * needs -- the 3x3 max/min around every voxel, the 8-neighbour max/min and the centre values -- so every
- * plane is loaded and reduced once instead of three times.  The decisions are the same max/min/compare
- * operations on the same values as extrema_kernel. */
-struct ex_plane {
-    float m[EX_ROWS][4], n[EX_ROWS][4];       /* 3x3 max / min around the voxel, centre included */
-    float e8max[EX_ROWS][4], e8min[EX_ROWS][4]; /* the 8 in-plane neighbours */
-    float c[EX_ROWS][4];
-};
-
-__device__ __forceinline__ void ex_reduce_plane(const v4f (&raw)[EX_LOAD], ex_plane &o)
-{
-    float rmax[EX_LOAD][4], rmin[EX_LOAD][4], l2max[EX_LOAD][4], l2min[EX_LOAD][4];
-#pragma unroll
-    for (int r = 0; r < EX_LOAD; r++) row_extrema(raw[r], rmax[r], rmin[r], l2max[r], l2min[r]);
-#pragma unroll
-    for (int r = 0; r < EX_ROWS; r++) {
-        const v4f cv = raw[r + 1];
-        o.c[r][0] = cv.x; o.c[r][1] = cv.y; o.c[r][2] = cv.z; o.c[r][3] = cv.w;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            o.e8max[r][e] = ex_max3(rmax[r][e], rmax[r + 2][e], l2max[r + 1][e]);
-            o.e8min[r][e] = ex_min3(rmin[r][e], rmin[r + 2][e], l2min[r + 1][e]);
-            o.m[r][e] = ex_max3(rmax[r][e], rmax[r + 1][e], rmax[r + 2][e]);
-            o.n[r][e] = ex_min3(rmin[r][e], rmin[r + 1][e], rmin[r + 2][e]);
-        }
-    }
-}
+/* First phase, marching form (used when the volume has enough planes).  A wavefront owns 248 x (64 lanes x float4; the
+ * first and last lane only supply x-neighbours) by EXM_ROWS rows and walks a chunk of planes; every plane is loaded and
+ * reduced once.  Round 3 form.  What a lane carries from plane to plane is, per voxel, four floats:
+ *   pm, pn    the 3x3 max / min (centre included) of the plane just below: the "26 neighbours" of the next plane's voxel
+ *             that lie in that plane;
+ *   cmx, cmn  the voxel's own value if it beat its 8 in-plane neighbours and the plane below (-inf / +inf otherwise): a
+ *             candidate waiting for the plane above.
+ * A step on plane p computes the 3x3 max m / min n and the 8-neighbour max / min of p, FINISHES plane p-1 (cmx > m: a
+ * maximum; cmn < n: a minimum -- a comparison with -inf / +inf is false, so non-candidates need no flag), and restarts the
+ * candidates from p.  The decisions are the max / min / compare operations of extrema_kernel on the same values --
+ * "c > every one of 26" == "c > max of 8" and "c > max of 9 below" and "c > max of 9 above" -- so the lists are the same.
+ * The round-2 form kept the five reduced arrays of three planes (195 registers for two rows); this one keeps four arrays of
+ * one plane, which pays for four rows per wavefront (six rows loaded for four instead of four for two: 1.5 instead of 2
+ * requests per voxel to L1/L2), two planes of prefetch in registers, and buffer loads (row offset in a VGPR, plane offset in
+ * an SGPR: no 64-bit address arithmetic in the loop).  The four wavefronts of a workgroup are neighbours in y, so the halo
+ * rows they share are L1 hits. */
+#ifndef EXM_ROWS
+#define EXM_ROWS 4
+#endif
+#define EXM_LOAD (EXM_ROWS + 2)
+#define EXM_STAGE (64 + 4 * 64) /* a wavefront's staging buffer: flushed at 64 after every row, a row adds at most 4 per lane */
 
 __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restrict__ dcur, int X, int Xl, int Y, int Z, int z_first,
-                                                            int z_last, int zchunk, int xtiles,
+                                                            int z_last, int zchunk, int xtiles, int ygroups,
                                                             sift3d_survivor *__restrict__ surv, unsigned long long *surv_count,
                                                             long long surv_cap)
 {
     const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6); /* wavefront index over (x tile, y tile) */
-    const int xt = wv % xtiles, yt = wv / xtiles;
-    const int y0 = 1 + yt * EX_ROWS;                 /* first output row */
-    if (y0 >= Y - 1) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* wave-uniform by construction: say so, or every buffer descriptor below lands in vector registers */
+    const int xt = blockIdx.x % xtiles, yg = blockIdx.x / xtiles;
+    const int y0 = 1 + (yg * 4 + wave) * EXM_ROWS;   /* first output row of this wavefront */
     const int za = z_first + blockIdx.y * zchunk;
-    if (za >= z_last) return;
-    const int zb = za + zchunk < z_last ? za + zchunk : z_last;
+    const int zb = za + zchunk < z_last ? za + zchunk : z_last; /* output planes za .. zb-1; plane zb <= Z-1 exists */
+    const bool idle = y0 >= Y - 1 || za >= z_last;             /* wave-uniform */
     const int xv = xt * EX_XOUT - 4 + lane * 4;
     const int xld = xv < 0 ? 0 : (xv > X - 4 ? X - 4 : xv);
     const long long XY = (long long)X * Y;
-    long long roff[EX_LOAD];
+    unsigned roff[EXM_LOAD];
 #pragma unroll
-    for (int r = 0; r < EX_LOAD; r++) {
+    for (int r = 0; r < EXM_LOAD; r++) {
         int yy = y0 - 1 + r;
         yy = yy < Y ? yy : Y - 1;
-        roff[r] = (long long)yy * X + xld;
+        roff[r] = (unsigned)(yy * X + xld) * 4u; /* X * Y < 2^29: a plane is below 2 GiB */
     }
     const int seg = ex_segment_of_z_block();
-    auto load_plane = [&](v4f(&raw)[EX_LOAD], int z) { /* z <= Z - 1 always: z_last <= Z - 1 */
+    /* the chunk's planes za-1 .. zb through one descriptor: (zchunk + 2) planes stay below 4 GiB (the launcher sees to it) */
+    const float *const chunk_base = dcur + (long long)(idle ? 0 : za - 1) * XY;
+    const int chunk_bytes = idle ? 0 : (int)(unsigned)((long long)(zb - za + 2) * XY * 4);
+    const unsigned plane_bytes = (unsigned)(XY * 4);
+    /* za-1 <= z.  The plane offset travels in an SGPR, which the hardware's bounds check does not see: a plane past zb
+     * (the prefetch runs two planes ahead; its data is never used) goes through a descriptor of no records instead */
+    auto load_plane = [&](v4f(&raw)[EXM_LOAD], int z) {
+        const bool ok = z <= zb; /* wave-uniform */
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)chunk_base, 0, ok ? chunk_bytes : 0, EX_RSRC_FLAGS);
+        const int so = ok ? (int)((unsigned)(z - (za - 1)) * plane_bytes) : 0;
 #pragma unroll
-        for (int r = 0; r < EX_LOAD; r++) raw[r] = vload<4>(dcur + (long long)z * XY + roff[r]);
+        for (int r = 0; r < EXM_LOAD; r++) raw[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff[r], so, 0));
     };
     /* Own-level extrema go to a staging buffer of the wavefront in LDS (compacted with a ballot and a prefix count) and
-     * from there to the list in batches: ONE returning atomic and a coalesced store per 64 or more of them.  The first
-     * version appended each one with its own returning atomicAdd; its result needs s_waitcnt vmcnt(0), which also drains
-     * the next plane's loads, and with ~1.5 extrema per wavefront and plane that was one exposed memory latency per step
-     * (0.33 ms per 512^3 level, 1.6 TB/s).  The order inside the list does not matter: the validated extrema are sorted
-     * by key. */
-    __shared__ sift3d_survivor stage_all[4][EX_STAGE];
-    sift3d_survivor *const stage = stage_all[threadIdx.x >> 6];
+     * from there to the list in batches: ONE returning atomic and a coalesced store per 64 or more of them (a returning
+     * atomic per extremum needs s_waitcnt vmcnt(0), which also drains the next plane's loads: 0.33 ms per 512^3 level in
+     * round 1).  The order inside the list does not matter: the validated extrema are sorted by key. */
+    __shared__ sift3d_survivor stage_all[4][EXM_STAGE];
+    sift3d_survivor *const stage = stage_all[wave];
+    if (idle) return;
     int pending = 0; /* wave-uniform */
     auto flush = [&]() {
         unsigned long long base = 0;
@@ -602,64 +608,104 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
         __builtin_amdgcn_wave_barrier();
         pending = 0;
     };
-    auto emit = [&](const ex_plane &lo, const ex_plane &ce, const ex_plane &hi, int z) {
+    auto stage_hits = [&](bool hit, float c, int is_max, int z, int y, int x) {
+        const unsigned long long m = __ballot(hit);
+        if (m) { /* wave-uniform */
+            if (hit) {
+                const int pos = pending + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                sift3d_survivor sv;
+                sv.idx = (long long)z * XY + (long long)y * X + x;
+                sv.value = c;
+                sv.is_max = is_max;
+                stage[pos] = sv;
+            }
+            pending += __popcll(m);
+        }
+    };
+    const float NEG = -__builtin_inff(), POS = __builtin_inff();
+    float pm[EXM_ROWS][4], pn[EXM_ROWS][4], cmx[EXM_ROWS][4], cmn[EXM_ROWS][4];
 #pragma unroll
-        for (int r = 0; r < EX_ROWS; r++) {
-            const int y = y0 + r;
+    for (int r = 0; r < EXM_ROWS; r++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            pm[r][e] = pn[r][e] = 0.0f;
+            cmx[r][e] = NEG; /* plane za-1 has no candidates here: it is the chunk below's, or the volume's face */
+            cmn[r][e] = POS;
+        }
+    const bool xlane = lane >= 1 && lane <= 62;
+    /* One plane: reduce it, finish the candidates of the plane below (plane z-1), start this plane's.  FIRST: plane za-1,
+     * of which only the 3x3 max / min are wanted. */
+    auto step = [&](const v4f(&raw)[EXM_LOAD], int z, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        /* a window of three reduced rows (slot = row % 3) and the in-row pair max / min of two (slot = row & 1) */
+        float rmax[3][4], rmin[3][4], l2max[2][4], l2min[2][4];
+        row_extrema(raw[0], rmax[0], rmin[0], l2max[0], l2min[0]);
+        row_extrema(raw[1], rmax[1], rmin[1], l2max[1], l2min[1]);
+#pragma unroll
+        for (int r = 0; r < EXM_ROWS; r++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int a = r % 3, b = (r + 1) % 3, c2 = (r + 2) % 3; /* window slots of rows r, r+1 (the output row), r+2 */
+            row_extrema(raw[r + 2], rmax[c2], rmin[c2], l2max[r & 1], l2min[r & 1]);
+            const v4f cv = raw[r + 1];
+            const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+            float oldx[4], oldn[4];
+            bool hx[4], hn[4], rowhit = false;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float c = ce.c[r][e];
-                const bool mx = c > ex_max3(ce.e8max[r][e], lo.m[r][e], hi.m[r][e]);
-                const bool mn = c < ex_min3(ce.e8min[r][e], lo.n[r][e], hi.n[r][e]);
-                const int x = xv + e;
-                const bool hit = (mx || mn) && lane >= 1 && lane <= 62 && x >= 1 && x < Xl - 1 && y < Y - 1;
-                const unsigned long long m = __ballot(hit);
-                if (m) { /* wave-uniform */
-                    if (hit) {
-                        const int pos = pending + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        sift3d_survivor sv;
-                        sv.idx = (long long)z * XY + (long long)y * X + x;
-                        sv.value = c;
-                        sv.is_max = mx ? 1 : 0;
-                        stage[pos] = sv;
+                const float m = ex_max3(rmax[a][e], rmax[b][e], rmax[c2][e]);
+                const float n = ex_min3(rmin[a][e], rmin[b][e], rmin[c2][e]);
+                if constexpr (!FIRST) {
+                    const float e8x = ex_max3(rmax[a][e], rmax[c2][e], l2max[(r + 1) & 1][e]);
+                    const float e8n = ex_min3(rmin[a][e], rmin[c2][e], l2min[(r + 1) & 1][e]);
+                    oldx[e] = cmx[r][e];
+                    oldn[e] = cmn[r][e];
+                    hx[e] = oldx[e] > m; /* the candidate of plane z-1 also beats the nine voxels above it */
+                    hn[e] = oldn[e] < n;
+                    rowhit = rowhit || hx[e] || hn[e];
+                    const float c = cc[e];
+                    cmx[r][e] = c > ex_max(e8x, pm[r][e]) ? c : NEG;
+                    cmn[r][e] = c < ex_min(e8n, pn[r][e]) ? c : POS;
+                }
+                pm[r][e] = m;
+                pn[r][e] = n;
+            }
+            if constexpr (!FIRST) {
+                /* the rare part: extrema of plane z-1 in row y0 + r, inside the searched x and y range */
+                const int y = y0 + r;
+                const bool rowok = xlane && y < Y - 1;
+                if (__ballot(rowhit && rowok)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int x = xv + e;
+                        const bool inx = rowok && x >= 1 && x < Xl - 1;
+                        /* a voxel is never both: one append serves the maximum and the minimum test */
+                        stage_hits((hx[e] || hn[e]) && inx, hx[e] ? oldx[e] : oldn[e], hx[e] ? 1 : 0, z - 1, y, x);
                     }
-                    pending += __popcll(m);
+                    if (pending >= 64) flush();
                 }
             }
         }
-        if (pending >= 64) flush(); /* at most 63 + 8 * 64 entries are ever staged */
     };
-    ex_plane A, B, C;
-    v4f raw[EX_LOAD], nxt[EX_LOAD];
-    load_plane(raw, za - 1);
-    load_plane(nxt, za);
-    ex_reduce_plane(raw, A);
-    load_plane(raw, za + 1);
-    ex_reduce_plane(nxt, B);
-    /* invariant at the top of a step for output plane z: A = plane z-1, B = plane z, raw = plane z+1 (in flight) */
-    int z = za;
-    for (; z + 2 < zb; z += 3) {
-        load_plane(nxt, z + 2);
-        ex_reduce_plane(raw, C);
-        emit(A, B, C, z);
-        load_plane(raw, z + 3 <= Z - 1 ? z + 3 : Z - 1);
-        ex_reduce_plane(nxt, A);
-        emit(B, C, A, z + 1);
-        load_plane(nxt, z + 4 <= Z - 1 ? z + 4 : Z - 1);
-        ex_reduce_plane(raw, B);
-        emit(C, A, B, z + 2);
-#pragma unroll
-        for (int r = 0; r < EX_LOAD; r++) raw[r] = nxt[r];
-        /* now A = plane z+2, B = plane z+3, raw = plane z+4: the invariant for output plane z+3 */
-    }
-    if (z < zb) {
-        if (z + 1 < zb) load_plane(nxt, z + 2);
-        ex_reduce_plane(raw, C);
-        emit(A, B, C, z);
-        if (z + 1 < zb) {
-            ex_reduce_plane(nxt, A);
-            emit(B, C, A, z + 1);
-        }
+    using T = std::true_type;
+    using F = std::false_type;
+    v4f w0[EXM_LOAD], w1[EXM_LOAD], w2[EXM_LOAD];
+    load_plane(w0, za - 1);
+    load_plane(w1, za);
+    load_plane(w2, za + 1);
+    step(w0, za - 1, T{});
+    /* planes za .. zb (zb only finishes zb-1).  Invariant at the top: w1 holds plane z, w2 plane z+1 (in flight), w0 is free;
+     * the three register windows rotate without copies, two planes are always in flight */
+    for (int z = za;;) {
+        load_plane(w0, z + 2);
+        step(w1, z, F{});
+        if (++z > zb) break;
+        load_plane(w1, z + 2);
+        step(w2, z, F{});
+        if (++z > zb) break;
+        load_plane(w2, z + 2);
+        step(w0, z, F{});
+        if (++z > zb) break;
     }
     if (pending > 0) flush();
 }
@@ -689,7 +735,7 @@ __global__ __launch_bounds__(256) void extrema_validate_kernel(const float *__re
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long n = (long long)surv_count[seg * EX_SEG_STRIDE];
     if (n > surv_cap) { /* the segment was cut short: tell the host how much room a replay needs */
-        if (i == 0) atomicMax(surv_overflow, (unsigned long long)n * EX_SEGS);
+        if (i == 0) atomicMax(surv_overflow, (unsigned long long)n * gridDim.y); /* gridDim.y = segments in use */
         n = surv_cap;
     }
     bool ok = i < n;
@@ -777,7 +823,6 @@ __global__ __launch_bounds__(256) void extrema_validate_kernel(const float *__re
  * LDS read + one packed multiply + one packed add per tap); then the y pass over all planes (9 (2R+3) outputs), the z
  * pass (27 outputs) and the comparison on 27 lanes. */
 typedef float ex_v2f __attribute__((ext_vector_type(2)));
-#define EX_RSRC_FLAGS 0x00020000 /* raw buffer, 32-bit data format */
 template <int R>
 __global__ __launch_bounds__(64) void extrema_validate_lazy_kernel(const float *__restrict__ g, int X, int Xl, int Y, int Z,
                                                                   const sift3d_survivor2 *__restrict__ list,
@@ -1022,11 +1067,6 @@ hipError_t sift3d_launch_blur_x(hipStream_t s, const float *in, float *out, int6
 static inline int chunk_len(int R, int64_t L, long long waves_x)
 {
     const int U = 2 * R + 1;
-    static const char *env = getenv("SIFT3D_COL_K"); /* tuning aid: force k groups per chunk */
-    if (env && atoi(env) >= 2) {
-        const int ch = atoi(env) * U - 2 * R;
-        return ch <= L ? ch : 0;
-    }
     /* cost of a choice = rows streamed (outputs + 2R lead-in rows per chunk + the overlap of the shifted
      * last chunk), inflated when the grid has fewer than ~2048 wavefronts (8 per CU) to hide latency */
     int best = 0;
@@ -1214,7 +1254,7 @@ hipError_t sift3d_launch_halve_size(hipStream_t s, const float *in, int64_t X, i
 }
 
 template <int R>
-static void launch_validate_lazy(hipStream_t s, const sift3d_extrema_lazy &lz, int64_t X, int64_t Xl, int64_t Y, int64_t Z, int lvl_id,
+static void launch_validate_lazy(hipStream_t s, const sift3d_extrema_lazy &lz, int nseg, int64_t X, int64_t Xl, int64_t Y, int64_t Z, int lvl_id,
                                  unsigned long long *keys, sift3d_cval *vals, unsigned long long *count, int64_t cap)
 {
     sift3d_taps t;
@@ -1225,7 +1265,7 @@ static void launch_validate_lazy(hipStream_t s, const sift3d_extrema_lazy &lz, i
     wgs = wgs < 64 ? 64 : (wgs > 4096 ? 4096 : wgs);
     if (wgs > lz.list2_cap) wgs = lz.list2_cap;
     hipLaunchKernelGGL(extrema_validate_lazy_kernel<R>, dim3((unsigned)wgs), dim3(64), 0, s, lz.next_g, (int)X, (int)Xl, (int)Y, (int)Z,
-                       lz.list2, lz.list2_count, (long long)(lz.list2_cap / EX_SEGS), lvl_id, keys, vals, count, (long long)cap, t);
+                       lz.list2, lz.list2_count, (long long)(lz.list2_cap / nseg), lvl_id, keys, vals, count, (long long)cap, t);
 }
 
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,
@@ -1248,32 +1288,38 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
             hipError_t e = hipMemsetAsync(surv_count, 0, sizeof(unsigned long long) * EX_SEGS * EX_SEG_STRIDE, s);
             if (e != hipSuccess) return e;
         }
-        /* marching form when chunks of >= 8 planes still give the chip a few thousand wavefronts */
+        /* marching form when chunks of >= 8 planes still give the chip a few thousand wavefronts (a wavefront of the march
+         * takes EXM_ROWS rows, the four of a workgroup are neighbours in y); its buffer descriptor covers a chunk and the two
+         * planes around it, which must stay below 4 GiB */
+        const int ytiles_m = (int)((Y - 2 + EXM_ROWS - 1) / EXM_ROWS), ygroups = (ytiles_m + 3) / 4;
+        const long long waves_m = (long long)xtiles * ytiles_m;
+        const long long plane_bytes = X * Y * 4;
         int zchunk = 1;
-        for (int zc = 32; zc >= 8; zc /= 2)
-            if (waves_xy * ((z1 - z0 + zc - 1) / zc) >= 4096) {
+        for (int zc = 64; zc >= 8; zc /= 2)
+            if (waves_m * ((z1 - z0 + zc - 1) / zc) >= 4096 && (zc + 2) * plane_bytes < (1ll << 32)) {
                 zchunk = zc;
                 break;
             }
-        static const char *env = getenv("SIFT3D_EX_ZCHUNK"); /* tuning aid */
-        if (env) zchunk = atoi(env) >= 1 ? atoi(env) : 1;
         const unsigned nz = (unsigned)((z1 - z0 + zchunk - 1) / zchunk);
-        dim3 grid((unsigned)((waves_xy + 3) / 4), nz);
-        if (zchunk >= 2)
+        const int nseg = ex_segments_in_use(nz);
+        const long long segcap = surv_cap / nseg; /* entries per segment of the own-level list */
+        if (zchunk >= 2) {
+            dim3 grid((unsigned)(xtiles * ygroups), nz);
             hipLaunchKernelGGL(extrema_march_kernel, grid, dim3(256), 0, s, dcur, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk, xtiles,
-                               surv, surv_count, (long long)(surv_cap / EX_SEGS));
-        else /* reads the own level only: its neighbour-level arguments are unused */
+                               ygroups, surv, surv_count, segcap);
+        } else { /* reads the own level only: its neighbour-level arguments are unused */
+            dim3 grid((unsigned)((waves_xy + 3) / 4), nz);
             hipLaunchKernelGGL(extrema_kernel, grid, dim3(256), 0, s, dprev, dcur, dnext, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk,
-                               xtiles, surv, surv_count, (long long)(surv_cap / EX_SEGS));
+                               xtiles, surv, surv_count, segcap);
+        }
         /* the second launch covers the list capacity, reads the true length on the device, and flags an
          * overflow for cand_finalize to widen the list and replay */
-        const long long segcap = surv_cap / EX_SEGS; /* the caller sized surv_cap: capacity == threads of the second launch */
-        const dim3 vgrid((unsigned)((segcap + 255) / 256), EX_SEGS);
+        const dim3 vgrid((unsigned)((segcap + 255) / 256), (unsigned)nseg);
 #define SIFT3D_VALIDATE(PAIR_, DEFER_)                                                                                                   \
     hipLaunchKernelGGL((extrema_validate_kernel<PAIR_, DEFER_>), vgrid, dim3(256), 0, s, dprev, pair ? lazy->prev_b : nullptr,          \
                        defer ? nullptr : dnext, (int)X, (int)Y, surv, surv_count, segcap, surv_overflow, lvl_id, keys, vals, count,      \
                        (long long)cap, defer ? lazy->list2 : nullptr, defer ? lazy->list2_count : nullptr,                               \
-                       (long long)(defer ? lazy->list2_cap / EX_SEGS : 0))
+                       (long long)(defer ? lazy->list2_cap / nseg : 0))
         if (pair && defer) SIFT3D_VALIDATE(true, true);
         else if (pair) SIFT3D_VALIDATE(true, false);
         else if (defer) SIFT3D_VALIDATE(false, true);
@@ -1287,7 +1333,7 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
             /* the level above the last detection level is always the 17-tap one (sigma 3.09: the schedule of
              * MultiScale.cpp:288-294 does not depend on the input), so that is the one instantiation */
             if (R != SIFT3D_FAST_MAX_R) return hipErrorNotSupported;
-            launch_validate_lazy<SIFT3D_FAST_MAX_R>(s, *lazy, X, Xl, Y, Z, lvl_id, keys, vals, count, cap);
+            launch_validate_lazy<SIFT3D_FAST_MAX_R>(s, *lazy, nseg, X, Xl, Y, Z, lvl_id, keys, vals, count, cap);
         }
     } else {
         if (pair || defer) return hipErrorNotSupported; /* the caller keeps such shapes on stored DoG levels */

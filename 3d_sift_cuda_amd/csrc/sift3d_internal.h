@@ -64,9 +64,14 @@ hipError_t sift3d_launch_blur_y(hipStream_t s, const float *in, float *out, int6
 /* prev/dog may be NULL (no DoG epilogue) */
 hipError_t sift3d_launch_blur_z(hipStream_t s, const float *in, float *out, const float *prev, float *dog, int64_t X,
                                 int64_t Y, int64_t Z, const float *taps, int ntaps, const float *d_taps);
-/* all three passes and the DoG in one kernel; hipErrorNotSupported when the shape is outside it */
-hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, const float *zeros, int64_t X,
-                                    int64_t Y, int64_t Z, const float *taps, int ntaps);
+/* all three passes and the DoG in one kernel; hipErrorNotSupported when the shape is outside it.  tune (may be NULL):
+ * what sift3d_set_tuning forces -- 0 = the launcher's own choice */
+struct sift3d_blur_tuning {
+    int z_chunks;        /* SIFT3D_TUNE_FUSED_CHUNKS */
+    int rows_per_thread; /* SIFT3D_TUNE_FUSED_ROWS: 2 = 512 threads, two planes of prefetch; 1 = 1024 threads, one plane */
+};
+hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z,
+                                    const float *taps, int ntaps, const sift3d_blur_tuning *tune);
 hipError_t sift3d_launch_dog(hipStream_t s, const float *a, const float *b, float *out, int64_t n);
 hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Xl, int64_t Y, int64_t Z, float *out,
                                    int64_t XPout);
@@ -116,7 +121,7 @@ struct sift3d_kp_params {
     float eig_thres;
     float size_factor;
     int desc_mode;
-    int debug_stop; /* development aid: phase A returns after stage N (0 = run everything) */
+    int debug_stop; /* -DSIFT3D_DEV builds only (timing ablation, tools/kp_ablate.py): the kernels return after stage N; 0 = run everything */
     float *patch0;  /* per extremum: the identity-frame patch (1331 floats, normalised once) that phase A sampled anyway;
                      * phase B reads it for the un-reoriented record instead of sampling it again */
     int *sampler_tokens; /* phase B: per-CU count of workgroups in their sampling phase (SIFT3D_CU_SLOTS ints, zero between runs) */
@@ -137,8 +142,10 @@ struct sift3d_dkp {
 /* nrec[k] = 0 (rejected) or 1 + number of canonical frames */
 hipError_t sift3d_launch_keypointsA(hipStream_t s, const sift3d_kp_params &p, const unsigned long long *keys,
                                     const sift3d_cval *vals, int64_t ncand, sift3d_dkp *kps, int *nrec, const float *taps3);
-hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int *rec_kp, int *rec_frame,
-                                unsigned long long *kp_count);
+/* nrec / offs: one chunk of the candidate list starting at candidate cand_off; rec_base[0] = its first record (in), rec_base[1] =
+ * the first record of the next chunk (out) */
+hipError_t sift3d_launch_recmap(hipStream_t s, const int *nrec, const int *offs, int64_t ncand, int cand_off, int *rec_base,
+                                int *rec_kp, int *rec_frame, unsigned long long *kp_count);
 hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, const sift3d_dkp *kps, const int *rec_kp,
                                      const int *rec_frame, int64_t nrec, sift3d_feature *recs, int *rec_group,
                                      const float *taps5);

@@ -104,11 +104,27 @@ class SlabPlan:
         return (max(0, z0 - h), min(self.nz, z1 + h))
 
 
+def slab_context_slices(plan, rank):
+    """nz_local for sift3d_create_slab on `rank`: the most slices of an nx * ny volume one call is handed -- the input slab
+    of the initial blur, a level buffer with its patch halos, and on rank 0 the first unsharded octave, which is gathered
+    there (a whole octave, but of planes a 4^K-th the size)."""
+    i0, i1 = plan.input_range(rank)
+    need = (i1 - i0) + 2 * HALO
+    K = plan.n_sharded
+    if rank == 0 and 0 < K < len(plan.octaves):
+        X, Y, Z = plan.octaves[K]
+        pitch = lambda x: (x + 3) // 4 * 4
+        plane = pitch(plan.nx) * plan.ny
+        need = max(need, (pitch(X) * Y * Z + plane - 1) // plane)
+    return need
+
+
 class HipBackend:
     """Compute on torch CUDA tensors through the C-ABI *_dev operators."""
 
-    def __init__(self, pkg, ctx, torch):
+    def __init__(self, pkg, ctx, torch, lazy_levels=True):
         self.pkg, self.ctx, self.torch = pkg, ctx, torch
+        self.lazy_levels = lazy_levels   # False: every level stored and filtered in full (the reference's schedule)
         # one non-default torch stream carries everything: torch allocations/copies, the library's kernels
         # (sift3d_set_stream) and the point where NCCL work is ordered against (its current stream)
         self.stream = torch.cuda.Stream(device=ctx.device)
@@ -150,7 +166,7 @@ class HipBackend:
     # ---- neighbour levels that are not stored: optional part of the backend interface ----
     def lazy_ok(self, shape, next_sigma):
         nz, ny, nx = shape
-        return self.ctx.lazy_levels_supported(nx, ny, nz, next_sigma)
+        return self.lazy_levels and self.ctx.lazy_levels_supported(nx, ny, nz, next_sigma)
 
     def extrema_append_pair(self, ga, gb, dc, dn, level_id, z_lo, z_hi):
         """the level below is ga - gb"""
@@ -185,8 +201,14 @@ class HipBackend:
 class ZSlabExtractor:
     """Runs the pyramid of ONE volume across the ranks of a torch.distributed group."""
 
-    def __init__(self, backend, plan, rank, dist=None, group=None):
+    def __init__(self, backend, plan, rank, dist=None, group=None, deferred_group=None):
+        """deferred_group: a second process group over the same ranks (dist.new_group()) for the once-per-octave batch of
+        deferred patch halos.  RCCL serialises the operations of one communicator on one internal stream, so on the main
+        group that batch (3 x 24 slices) would sit in front of the next level's 8-slice exchange; a group of its own has its
+        own communicator and stream.  None: the main group carries both (correct, but the deferred bytes then delay the
+        critical ones)."""
         self.be, self.plan, self.rank, self.dist, self.group = backend, plan, rank, dist, group
+        self.deferred_group = deferred_group
         self.levels = []       # level table entries, index = level id
         self.level_ids = []
         # exchange_bytes: everything this rank received and sent; of that, deferred_bytes moved in the once-per-octave
@@ -208,10 +230,11 @@ class ZSlabExtractor:
         if not isinstance(bufs, (list, tuple)):
             bufs = [bufs]
         d, ops, back = self.dist, [], []
+        grp = self.deferred_group if (defer and self.deferred_group is not None) else self.group
         self.be.before_exchange()
         # gloo cannot move device memory: stage through the host (the single-GPU rehearsals); with
         # nccl (= RCCL) the slices go GPU to GPU over xGMI
-        stage = bufs[0].is_cuda and d.get_backend(self.group) == "gloo"
+        stage = bufs[0].is_cuda and d.get_backend(grp) == "gloo"
 
         def snd(t):
             return t.cpu() if stage else t
@@ -225,11 +248,11 @@ class ZSlabExtractor:
         n = width - inner
         for buf in bufs:
             if has_lo:   # my slices [z0+inner, z0+width) are the lower neighbour's upper band; its [z0-width, z0-inner) are mine
-                ops.append(d.P2POp(d.isend, snd(buf[z0 + inner - e0:z0 + width - e0]), self.rank - 1, self.group))
-                ops.append(d.P2POp(d.irecv, rcv(buf[z0 - width - e0:z0 - inner - e0]), self.rank - 1, self.group))
+                ops.append(d.P2POp(d.isend, snd(buf[z0 + inner - e0:z0 + width - e0]), self.rank - 1, grp))
+                ops.append(d.P2POp(d.irecv, rcv(buf[z0 - width - e0:z0 - inner - e0]), self.rank - 1, grp))
             if has_hi:
-                ops.append(d.P2POp(d.isend, snd(buf[z1 - width - e0:z1 - inner - e0]), self.rank + 1, self.group))
-                ops.append(d.P2POp(d.irecv, rcv(buf[z1 + inner - e0:z1 + width - e0]), self.rank + 1, self.group))
+                ops.append(d.P2POp(d.isend, snd(buf[z1 - width - e0:z1 - inner - e0]), self.rank + 1, grp))
+                ops.append(d.P2POp(d.irecv, rcv(buf[z1 + inner - e0:z1 + width - e0]), self.rank + 1, grp))
         works = d.batch_isend_irecv(ops)
         nbytes = 2 * n * bufs[0].shape[1] * bufs[0].shape[2] * 4 * (int(has_lo) + int(has_hi)) * len(bufs)
         self.stats["exchanges"] += 1

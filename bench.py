@@ -85,8 +85,10 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
     dev = local_rank % max(1, ndev)
     plan = zs.SlabPlan(n, n, n, world)
     i0, i1 = plan.input_range(rank)
-    ctx = pkg.Context(n, n, (i1 - i0) + 2 * zs.HALO, device=dev)
+    ctx = pkg.Context(n, n, zs.slab_context_slices(plan, rank), device=dev, slab=True)   # no level buffers of its own
     be = zs.HipBackend(pkg, ctx, torch)
+    # the deferred patch-halo batch on a communicator of its own, so that it cannot queue in front of a level's halo
+    dgroup = dist.new_group(ranks=list(range(world)), backend=dist.get_backend())
     # the rank's input slices live in HBM before timing starts, as the volume of the per-GPU run does
     slab = torch.from_numpy(pkg.synth_blobs(n, n, n, seed=12345)[i0:i1].copy()).to("cuda:%d" % dev)
     torch.cuda.synchronize(dev)
@@ -98,7 +100,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
 
     def step():
         with be.stream_scope():
-            ex = zs.ZSlabExtractor(be, plan, rank, dist)
+            ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup)
             ex.run(slab, i0)
             recs, grp = ex.describe(desc_mode=args.desc, copy=False)   # views of the pinned download buffers
             merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev, dtype=pkg.FEATURE_DTYPE)
@@ -180,11 +182,14 @@ def zslab_child(args, world, expect, limit_s):
         # End exactly the job started here.  torch.distributed.run puts every rank in a session of its own, so the
         # launcher's process group does not contain them: note their PIDs first, ask the launcher to stop (it terminates
         # its ranks on SIGTERM), then kill whatever of it is still there.
-        import psutil
         try:
-            kids = psutil.Process(p.pid).children(recursive=True)
-        except psutil.NoSuchProcess:
-            kids = []
+            import psutil
+            try:
+                kids = psutil.Process(p.pid).children(recursive=True)
+            except psutil.NoSuchProcess:
+                kids = []
+        except ImportError:   # without psutil: the launcher's own termination of its ranks has to do
+            psutil, kids = None, []
         p.send_signal(signal.SIGTERM)
         try:
             so, se = p.communicate(timeout=20)

@@ -80,6 +80,12 @@ int sift3d_device_count(void);
  * HIP device `device` (0-based, as cudaSetDevice receives it in the reference).
  * NULL on failure. */
 sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz);
+/* A context for the Z-slab building blocks below only: the caller owns every level buffer, so none is allocated here
+ * (a twelfth of the memory of sift3d_create).  nz_local: the most slices of an nx * ny volume any one call will be handed
+ * (slab + halos).  The *_dev operators, sift3d_candidates_reset / _extrema_append*_dev / _candidates_dev / _describe_dev
+ * work; entry points that use the context's own pyramid (host-pointer operators, sift3d_set_volume*, sift3d_detect,
+ * sift3d_extract*) return SIFT3D_ERR_ARG. */
+sift3d_ctx *sift3d_create_slab(int device, int64_t nx, int64_t ny, int64_t nz_local);
 void sift3d_destroy(sift3d_ctx *ctx);
 const char *sift3d_last_error(const sift3d_ctx *ctx);
 /* Optional: run on a caller-owned hipStream_t (e.g. one of torch's); NULL = the
@@ -171,6 +177,24 @@ int sift3d_extract(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, fl
  * command line has no such option and never sets it.  Records are ordered octave-major, so a limited run returns
  * exactly the leading records of the unlimited one. */
 int sift3d_set_max_octaves(sift3d_ctx *ctx, int n);
+/* Implementation choices a caller may override (tests exercise both sides of each; none is needed for normal use, and
+ * none changes a result -- every combination returns the same bytes).  No environment variable is read anywhere in the
+ * library. */
+typedef enum {
+    SIFT3D_TUNE_BLUR_FUSED = 0, /* one fused x+y+z+DoG launch per level: 1 where it pays (default), 0 never, 2 wherever the shape allows */
+    SIFT3D_TUNE_FUSED_CHUNKS,   /* z chunks of the fused launch: 0 = cost model (default), n >= 1 forced */
+    SIFT3D_TUNE_FUSED_ROWS,     /* rows per thread of the fused launch: 0 = by filter and size (default), 1 or 2 forced */
+    SIFT3D_TUNE_LAZY_LEVELS,    /* 1 (default): D0, D4 and L5 of an octave are evaluated around the candidates only; 0: stored and
+                                 * filtered in full, as the reference's schedule does (MultiScale.cpp:405-413) */
+    SIFT3D_TUNE_TINY_OCTAVE,    /* 1 (default): an octave of at most 4096 voxels is built by one workgroup in one launch; 0: level by level */
+    SIFT3D_TUNE_SAMPLER_CAP,    /* workgroups of a CU that may sample a patch at a time in the descriptor kernel: 4 (default); 0: no limit */
+    SIFT3D_TUNE_KP_CHUNKS,      /* the per-keypoint stage in n chunks, the keypoint kernel of chunk i+1 on one stream beside the
+                                 * descriptor kernel of chunk i on another: 0 or 1 = one launch of each, one after the other
+                                 * (default: the overlap does not pay), up to 16 */
+    SIFT3D_TUNE_COUNT
+} sift3d_tuning;
+int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);
+
 /* Same, without the final host copy: *view points at the context's pinned download buffer and stays
  * valid until the next call on this context (or sift3d_destroy).  Do not free it. */
 int sift3d_extract_view(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
@@ -209,7 +233,8 @@ int sift3d_extrema_append_dev(sift3d_ctx *ctx, const float *d_prev, const float 
  *                   it -- g_next must therefore be valid R+1 = 9 slices beyond the slices [z_lo, z_hi) (rows and planes
  *                   outside the buffer read as zero, i.e. as the border of the whole volume).
  * sift3d_lazy_levels_supported: 1 when this shape can take that form (rows of whole 16-byte vectors, a plane below
- * 2^29 voxels, the 17-tap filter of the pyramid's last level); otherwise store the levels and use sift3d_extrema_append_dev. */
+ * 2^29 voxels, the 17-tap filter of the pyramid's last level); otherwise store the levels and use sift3d_extrema_append_dev.
+ * A pure function of its arguments. */
 int sift3d_lazy_levels_supported(int64_t nx, int64_t ny, int64_t nz_local, float next_sigma);
 int sift3d_extrema_append_lazy_dev(sift3d_ctx *ctx, const float *d_prev, const float *g_prev_a, const float *g_prev_b,
                                    const float *d_cur, const float *d_next, const float *g_next, float next_sigma, int64_t nx,
@@ -253,6 +278,8 @@ int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_
                          float size_factor, sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
                          int64_t err_len);
 void sift3d_zslab_destroy(sift3d_zslab *h);
+/* sift3d_set_tuning on every slab's context (and the driver's own use of SIFT3D_TUNE_LAZY_LEVELS) */
+int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value);
 
 /* ---- measurement ------------------------------------------------------------
  * Device time per stage of the last sift3d_detect/sift3d_extract call, from
@@ -294,6 +321,12 @@ typedef struct {
     double start_ms; /* when the launch began, counted from the first timed launch of the call (a timeline across the streams) */
 } sift3d_launch_record;
 int sift3d_get_launch_log(const sift3d_ctx *ctx, sift3d_launch_record *out, int64_t cap, int64_t *n);
+
+#ifdef SIFT3D_DEV
+/* Development builds only (make DEV=1; tools/kp_ablate.py, tools/desc_ablate.py): the per-keypoint kernels return after
+ * stage n (0 = run everything).  Not compiled into the product library. */
+int sift3d_dev_set_stop(sift3d_ctx *ctx, int n);
+#endif
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     src = open(os.path.join(ROOT, "include", "sift3d.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef SIFT3D_DEV.*?#endif", "", src, flags=re.S)   # development builds only (make DEV=1), not the product
     return sorted(set(re.findall(r"\b(sift3d_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -29,6 +30,19 @@ def test_library_exports_every_declared_symbol(built):
     lib = C.CDLL(built.LIB_HIP)
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
+    assert not hasattr(lib, "sift3d_dev_set_stop")   # the ablation hook is not in the product library
+
+
+def test_product_reads_no_environment_variable(built):
+    """No switch of the library hides in the caller's environment: the HIP translation units do not call getenv (the
+    knobs are sift3d_set_tuning), and their objects do not import the symbol (sort_scan.o does: rocPRIM's own headers)."""
+    csrc = os.path.join(ROOT, "3d_sift_cuda_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    for obj in ("api.o", "kernels_volume.o", "kernels_blur_fused.o", "kernels_keypoint.o", "gauss_taps.o"):
+        nm = subprocess.run(["nm", "--undefined-only", os.path.join(csrc, "_build", obj)], capture_output=True, text=True)
+        assert nm.returncode == 0 and "getenv" not in nm.stdout, obj
 
 
 def test_library_has_gfx950_code_object(built):

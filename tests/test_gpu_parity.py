@@ -43,28 +43,19 @@ FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37
 
 
 @pytest.mark.parametrize("dims", FUSED_SHAPES)
-@pytest.mark.parametrize("chunks,tile_rows,variant", [(0, 0, "SIFT3D_FUSED_V=1"), (3, 16, "SIFT3D_FUSED_V=1,SIFT3D_FUSED_DMA=0"),
-                                                      (2, 32, "SIFT3D_FUSED_V=1,SIFT3D_FUSED_NBUF=3"), (3, 0, "SIFT3D_FUSED_V=1,SIFT3D_FUSED_NBUF=4"),
-                                                      (0, 0, ""), (3, 0, "SIFT3D_FUSED_V=2,SIFT3D_RING_BR=1"),
-                                                      (2, 0, "SIFT3D_FUSED_V=2,SIFT3D_RING_BR=2"),
-                                                      (3, 0, "SIFT3D_RING_PF=2,SIFT3D_RING_BR=2"), (0, 0, "SIFT3D_RING_PF=2,SIFT3D_RING_BR=1"),
-                                                      (2, 0, "SIFT3D_RING_BR=1,SIFT3D_RING_PF=1,SIFT3D_RING_XO=4")])
-def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, tile_rows, variant, monkeypatch):
-    """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up), partial tiles
-    in x and y, volumes thinner than the filter, several z chunks, the register-window form, the LDS-DMA form
-    (11 and 13 taps) with both ring depths, and the ring kernel (buffer loads/stores, DoG input through an LDS ring)
-    with one and two output rows per thread: level and DoG bit-identical to the oracle."""
+@pytest.mark.parametrize("chunks,rows", [(0, 0), (3, 1), (2, 2), (3, 2), (1, 1), (5, 0)])
+def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows):
+    """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up, 2^18 for narrow filters):
+    partial tiles in x and y, volumes thinner than the filter, one or several z chunks, both thread mappings (one row per
+    thread with one plane of window prefetch; two rows with two planes) on every shape and filter: level and DoG
+    bit-identical to the oracle, for level + DoG, level only and DoG only."""
     import torch
-    monkeypatch.setenv("SIFT3D_BLUR_FUSED", "2")
-    for kv in filter(None, variant.split(",")):
-        monkeypatch.setenv(*kv.split("="))
-    if chunks:
-        monkeypatch.setenv("SIFT3D_FUSED_CHUNKS", str(chunks))
-    if tile_rows:
-        monkeypatch.setenv("SIFT3D_FUSED_TY", str(tile_rows))   # both tile heights on every shape
     vol = vol_of(built, dims, 5) - np.float32(1.5)
     nx, ny, nz = dims
     with built.Context(*dims) as ctx:
+        ctx.set_tuning(built.TUNE_BLUR_FUSED, 2)
+        ctx.set_tuning(built.TUNE_FUSED_CHUNKS, chunks)
+        ctx.set_tuning(built.TUNE_FUSED_ROWS, rows)
         d_in = torch.from_numpy(vol).cuda()
         d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
         torch.cuda.synchronize()
@@ -496,36 +487,50 @@ def test_config_c2_against_the_oracle(built, oracle):
 
 
 @pytest.mark.parametrize("dims,mode", [((168, 164, 160), 0), ((200, 120, 96), 2)])
-def test_early_keypoint_pass_gives_the_same_records(built, dims, mode, monkeypatch):
-    """SIFT3D_EARLY_KP=1 (octave 0's per-keypoint stage on a third stream, beside the coarser octaves) against the
-    default one-shot order: the same bytes, also on a reused context and after the default path ran on it."""
+def test_chunked_keypoint_stage_gives_the_same_records(built, dims, mode):
+    """The per-keypoint stage cut into chunks (keypoint kernel of chunk i+1 beside the descriptor kernel of chunk i, on two
+    streams) against one launch of each kernel: the same bytes for every chunk count, also when chunks are empty, on a reused
+    context, with every launch bracketed by timing events, and with the descriptor kernel's sampling limit off."""
     vol = vol_of(built, dims, 13)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)
+        ctx.set_tuning(built.TUNE_KP_CHUNKS, 1)
         want = ctx.extract(desc_mode=mode)
         t = ctx.timings()
-        assert len(want) > 1000 and t["stages"]["keypoint"]["launches"] == 1
-        oct0 = ctx.detect()
-        assert (oct0["octave"] == 0).sum() >= 256 and (oct0["octave"] > 0).any()   # enough for the early pass, and a remainder
-        monkeypatch.setenv("SIFT3D_EARLY_KP", "1")
-        for _ in range(3):
-            assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
-            assert ctx.timings()["stages"]["keypoint"]["launches"] == 2   # octave 0 early, the rest afterwards
-        monkeypatch.setenv("SIFT3D_EARLY_KP", "0")
+        assert len(want) > 1000 and t["stages"]["keypoint"]["launches"] == 1 and t["stages"]["descriptor"]["launches"] == 1
+        for chunks in (2, 3, 7, 16, 0):
+            ctx.set_tuning(built.TUNE_KP_CHUNKS, chunks)
+            for _ in range(2):
+                assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes(), chunks
+            if chunks:
+                assert ctx.timings()["stages"]["keypoint"]["launches"] == chunks
+        ctx.set_tuning(built.TUNE_KP_CHUNKS, 4)
+        ctx.enable_timing(1)
         assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
-    monkeypatch.setenv("SIFT3D_EARLY_KP", "1")
-    with built.Context(*dims) as ctx:                                   # fresh context: the early pass sizes the buffers itself
+        assert ctx.timings()["stages"]["descriptor"]["ms"] > 0
+        ctx.enable_timing(0)
+        ctx.set_tuning(built.TUNE_SAMPLER_CAP, 0)
+        assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
+    with built.Context(*dims) as ctx:                                   # fresh context, chunked from the first run
+        ctx.set_tuning(built.TUNE_KP_CHUNKS, 5)
         ctx.set_volume(vol)
         assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes()
-        assert ctx.timings()["stages"]["keypoint"]["launches"] == 2
+    tiny = vol_of(built, (24, 20, 18), 3)                               # fewer candidates than chunks
+    with built.Context(24, 20, 18) as ctx:
+        ctx.set_volume(tiny)
+        ctx.set_tuning(built.TUNE_KP_CHUNKS, 1)
+        w = ctx.extract()
+        ctx.set_tuning(built.TUNE_KP_CHUNKS, 16)
+        assert ctx.extract().tobytes() == w.tobytes()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims,noise", [((168, 164, 160), 0.0), ((96, 50, 67), 4.0), ((40, 36, 33), 0.0), ((9, 70, 64), 1.0)])
-def test_lazy_levels_give_the_same_candidates_and_records(built, oracle, dims, noise, monkeypatch):
+def test_lazy_levels_give_the_same_candidates_and_records(built, oracle, dims, noise):
     """The default pipeline stores neither D_0 nor D_4 nor L_5 (the level below D_1 is taken as L_0 - L_1 around the
     extrema, the level above D_3 is filtered only in the 27-voxel neighbourhood of what passed every other test);
-    SIFT3D_LAZY_LEVELS=0 stores and filters everything as the reference does.  Candidates (with the DoG values one level
+    sift3d_set_tuning(SIFT3D_TUNE_LAZY_LEVELS, 0) stores and filters everything as the reference does.  Candidates (with
+    the DoG values one level
     below and above) and records are the same bytes both ways, and the candidates are the oracle's."""
     vol = vol_of(built, dims, 29)
     if noise:
@@ -535,11 +540,11 @@ def test_lazy_levels_give_the_same_candidates_and_records(built, oracle, dims, n
         cand = ctx.detect()
         recs = ctx.extract()
         stages = ctx.timings()["stages"]
-        monkeypatch.setenv("SIFT3D_LAZY_LEVELS", "0")
+        ctx.set_tuning(built.TUNE_LAZY_LEVELS, 0)
         cand_full = ctx.detect()
         recs_full = ctx.extract()
         stages_full = ctx.timings()["stages"]
-        monkeypatch.delenv("SIFT3D_LAZY_LEVELS")
+        ctx.set_tuning(built.TUNE_LAZY_LEVELS, 1)
         assert ctx.extract().tobytes() == recs.tobytes()
     assert len(cand) > 5
     assert cand.tobytes() == cand_full.tobytes()
@@ -842,11 +847,11 @@ def _zslab_worker(rank, world, port, dims, seed, mode, q):
         vol = pkg.synth_blobs(*dims, seed=seed)
         plan = zs.SlabPlan(dims[0], dims[1], dims[2], world)
         i0, i1 = plan.input_range(rank)
-        ext = max(i1 - i0, 8)
-        ctx = pkg.Context(dims[0], dims[1], ext + 2 * zs.HALO, device=0)
+        ctx = pkg.Context(dims[0], dims[1], max(zs.slab_context_slices(plan, rank), 8 + 2 * zs.HALO), device=0, slab=True)
         be = zs.HipBackend(pkg, ctx, torch)
+        dgroup = dist.new_group(ranks=list(range(world)), backend="gloo")   # the deferred patch halos on a group of their own
         with be.stream_scope():
-            ex = zs.ZSlabExtractor(be, plan, rank, dist)
+            ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup)
             ex.run(vol[i0:i1], i0)
             recs, grp = ex.describe(desc_mode=mode)
         gathered = [None] * world

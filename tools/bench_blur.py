@@ -17,7 +17,7 @@ N = n ** 3
 print("N=%d^3  bytes/pass: %.3f GB" % (n, 8 * N / 1e9))
 cases = [(taps, s, True) for taps, s in sig.items()] + [(7, sig[7], False), (9, 1.5198684930801392, False)]   # level-only: L1 and the initial blur
 for taps, s, with_dog in cases:
-    outp = 0 if taps == 17 else b.data_ptr()   # the 17-tap level, when it is filtered in full (SIFT3D_LAZY_LEVELS=0), is not stored, only its DoG
+    outp = 0 if taps == 17 else b.data_ptr()   # the 17-tap level, when it is filtered in full (SIFT3D_TUNE_LAZY_LEVELS = 0), is not stored, only its DoG
     if not with_dog:
         for _ in range(2):
             ctx.gauss_blur_dev(a.data_ptr(), b.data_ptr(), n, n, n, s)

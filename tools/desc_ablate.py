@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""Development aid: time the descriptor kernel cut after stage N (SIFT3D_KP_STOP = 11..15)."""
-import importlib, os, subprocess, sys
-if len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    pkg = importlib.import_module("3d_sift_cuda_amd")
-    n = int(os.environ.get("ABL_N", "256"))
-    ctx = pkg.Context(n, n, n); ctx.set_volume(pkg.synth_blobs(n, n, n))
-    ctx.extract(); ctx.enable_timing(True); ctx.extract()
+"""Development aid (GPU box): time the descriptor kernel cut after stage N.  Needs the development build of the library
+(`make -C 3d_sift_cuda_amd/csrc DEV=1` -> csrc/_build_dev), whose kernels carry the ablation branches and which exports
+sift3d_dev_set_stop; the product library has neither.  usage: [ABL_N=256] [ABL_STOPS=...] python tools/desc_ablate.py"""
+import ctypes, importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("3d_sift_cuda_amd")
+pkg.LIB_HIP = os.path.join(pkg.CSRC, "_build_dev", "libsift3d_hip.so")
+L = pkg.hip_lib()
+L.sift3d_dev_set_stop.argtypes = [ctypes.c_void_p, ctypes.c_int]
+n = int(os.environ.get("ABL_N", "256"))
+ctx = pkg.Context(n, n, n)
+ctx.set_volume(pkg.synth_blobs(n, n, n))
+ctx.set_tuning(pkg.TUNE_KP_CHUNKS, 1)
+for stop in [int(v) for v in os.environ.get("ABL_STOPS", "21,11,12,13,14,0").split(",")]:
+    L.sift3d_dev_set_stop(ctx.handle, stop)
+    ctx.extract(); ctx.enable_timing(1); ctx.extract()
     log = ctx.launch_log(); sel = log[log["stage"] == 6]
-    print("stop=%s descriptor ms %.3f (records %s)" % (os.environ.get("SIFT3D_KP_STOP", "0"), sel["ms"].sum(), sel["nvox"].tolist()))
-else:
-    for stop in [int(v) for v in os.environ.get("ABL_STOPS", "21,11,12,13,14,0").split(",")]:
-        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, SIFT3D_KP_STOP=str(stop)))
+    ctx.enable_timing(0)
+    print("stop=%d descriptor ms %.3f (items %s)" % (stop, sel["ms"].sum(), sel["nvox"].tolist()))

@@ -18,7 +18,6 @@ def sweep(cases=60, seed=1, max_edge=112):
     """Returns the number of cases whose records differ from the oracle's."""
     rng = np.random.default_rng(seed)
     orc = _oracle.load()
-    saved = os.environ.get("SIFT3D_BLUR_FUSED")
     bad = 0
     t0 = time.time()
     fields = ("x", "y", "z", "scale", "ori", "eigs", "info", "desc")
@@ -30,11 +29,14 @@ def sweep(cases=60, seed=1, max_edge=112):
         mode = int(rng.integers(0, 4))
         init_scale = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
         noise = float(rng.choice([0.0, 0.0, 1.0, 8.0]))
-        os.environ["SIFT3D_BLUR_FUSED"] = str(int(rng.choice([1, 1, 2, 0])))   # 2: fused on every octave it supports
+        fused = int(rng.choice([1, 1, 2, 0]))   # 2: the fused blur on every octave it supports, 0: never
+        kp_chunks = int(rng.choice([0, 1, 3, 6]))   # the per-keypoint stage in chunks on two streams
         vol = pkg.synth_blobs(*dims, seed=vseed)
         if noise:
             vol = vol + (rng.standard_normal(vol.shape) * noise).astype(np.float32)
         with pkg.Context(*dims) as ctx:
+            ctx.set_tuning(pkg.TUNE_BLUR_FUSED, fused)
+            ctx.set_tuning(pkg.TUNE_KP_CHUNKS, kp_chunks)
             ctx.set_volume(vol)
             got = ctx.extract(initial_image_scale=init_scale, desc_mode=mode)
         want, _ = orc.extract(vol, init_scale=init_scale, desc_mode=mode)
@@ -44,13 +46,9 @@ def sweep(cases=60, seed=1, max_edge=112):
             where = "count" if len(got) != len(want) else ",".join(
                 f for f in fields if not (got[f].view(np.uint32) == want[f].view(np.uint32)).all())
             print("MISMATCH case %d dims %s seed %d mode %d init %.1f noise %.1f fused %s: %d / %d records, differs in %s"
-                  % (i, dims, vseed, mode, init_scale, noise, os.environ["SIFT3D_BLUR_FUSED"], len(got), len(want), where), flush=True)
+                  % (i, dims, vseed, mode, init_scale, noise, fused, len(got), len(want), where), flush=True)
         elif i % 10 == 0:
             print("case %d dims %s mode %d: %d records identical (%.0f s)" % (i, dims, mode, len(got), time.time() - t0), flush=True)
-    if saved is None:
-        os.environ.pop("SIFT3D_BLUR_FUSED", None)
-    else:
-        os.environ["SIFT3D_BLUR_FUSED"] = saved
     print("%d cases, %d mismatches, %.0f s" % (cases, bad, time.time() - t0))
     return bad
 

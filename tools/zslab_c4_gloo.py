@@ -18,7 +18,7 @@ dist.init_process_group(backend="gloo")
 vol = pkg.synth_blobs(*dims, seed=12345)
 plan = zs.SlabPlan(dims[0], dims[1], dims[2], world)
 i0, i1 = plan.input_range(rank)
-ctx = pkg.Context(dims[0], dims[1], (i1 - i0) + 2 * zs.HALO, device=0)
+ctx = pkg.Context(dims[0], dims[1], zs.slab_context_slices(plan, rank), device=0, slab=True)
 be = zs.HipBackend(pkg, ctx, torch)
 slab = torch.from_numpy(vol[i0:i1].copy()).cuda()
 torch.cuda.synchronize()

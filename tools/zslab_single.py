@@ -12,7 +12,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 vol = pkg.synth_blobs(n, n, n, seed=12345)
 dvol = torch.from_numpy(vol).cuda(); torch.cuda.synchronize()
 plan = zs.SlabPlan(n, n, n, 1)
-ctx = pkg.Context(n, n, n + 2 * zs.HALO)
+ctx = pkg.Context(n, n, n + 2 * zs.HALO, slab=True)
 be = zs.HipBackend(pkg, ctx, torch)
 
 
