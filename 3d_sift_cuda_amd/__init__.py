@@ -37,7 +37,7 @@ INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
 STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
 # sift3d_tuning (include/sift3d.h)
-TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS = range(7)
+TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST = range(8)
 
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),
@@ -109,6 +109,8 @@ def hip_lib():
     _sig(L.sift3d_gauss_blur, I, P, P, P, I64, I64, I64, F, F)
     _sig(L.sift3d_gauss_blur_dev, I, P, P, P, I64, I64, I64, F, F)
     _sig(L.sift3d_gauss_blur_dog_dev, I, P, P, P, P, I64, I64, I64, F, F)
+    _sig(L.sift3d_blur_window_supported, I, I64, I64, F, F)
+    _sig(L.sift3d_gauss_blur_dog_window_dev, I, P, P, P, P, I64, I64, I64, I64, I64, F, F)
     _sig(L.sift3d_dog, I, P, P, P, P, I64)
     _sig(L.sift3d_dog_dev, I, P, P, P, P, I64)
     _sig(L.sift3d_subsample2, I, P, P, I64, I64, I64, P)
@@ -168,7 +170,7 @@ class ZSlabStats(C.Structure):
     """sift3d_zslab_stats"""
     _fields_ = [("n_ranks", C.c_int32), ("sharded_octaves", C.c_int32), ("exchanges", C.c_int64), ("halo_bytes_critical", C.c_int64),
                 ("halo_bytes_deferred", C.c_int64), ("gather_bytes", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
-                ("n_records", C.c_int64), ("wall_ms", C.c_double)]
+                ("n_records", C.c_int64), ("wall_ms", C.c_double), ("halo_bytes_hidden", C.c_int64)]
 
 
 def extract_zslab(vol, devices, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
@@ -473,6 +475,15 @@ class Context:
     def gauss_blur_dev(self, d_in, d_out, nx, ny, nz, sigma, min_value=0.01):
         self._chk(self._L.sift3d_gauss_blur_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)), nx, ny, nz,
                                                 float(sigma), float(min_value)), "sift3d_gauss_blur_dev")
+
+    def blur_window_supported(self, nx, ny, sigma, min_value=0.01):
+        return bool(self._L.sift3d_blur_window_supported(nx, ny, float(sigma), float(min_value)))
+
+    def gauss_blur_dog_window_dev(self, d_in, d_out, d_dog, nx, ny, nz, z_lo, z_hi, sigma, min_value=0.01):
+        """sift3d_gauss_blur_dog_window_dev: only the output planes [z_lo, z_hi) are produced."""
+        self._chk(self._L.sift3d_gauss_blur_dog_window_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)) if d_out else None,
+                                                           C.c_void_p(int(d_dog)) if d_dog else None, nx, ny, nz, int(z_lo), int(z_hi),
+                                                           float(sigma), float(min_value)), "sift3d_gauss_blur_dog_window_dev")
 
     def dog_dev(self, d_a, d_b, d_out, n):
         self._chk(self._L.sift3d_dog_dev(self._h, C.c_void_p(int(d_a)), C.c_void_p(int(d_b)), C.c_void_p(int(d_out)), n),

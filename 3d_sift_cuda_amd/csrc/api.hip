@@ -286,6 +286,7 @@ static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bo
     c->tune[SIFT3D_TUNE_LAZY_LEVELS] = 1;
     c->tune[SIFT3D_TUNE_TINY_OCTAVE] = 1;
     c->tune[SIFT3D_TUNE_SAMPLER_CAP] = 4;
+    c->tune[SIFT3D_TUNE_BANDS_FIRST] = 1;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -347,7 +348,7 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -631,6 +632,33 @@ static int fence_out(sift3d_ctx *c)
     return SIFT3D_OK;
 }
 
+/* The blur restricted to output planes [zo0, zo1) of the volume (the input is read as far as the filter reaches): what a
+ * Z-slab rank uses to filter its two boundary bands before the interior.  Only the fused launch has that form. */
+static bool blur_window_supported(int64_t X, int64_t Y, float sigma, float min_value)
+{
+    float taps[SIFT3D_MAX_TAPS];
+    const int n = sift3d_gauss_taps(sigma, min_value, taps);
+    return n >= 3 && n <= 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X * Y < (1ll << 29);
+}
+
+static int blur_window_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
+                           float sigma, float min_value)
+{
+    float taps[SIFT3D_MAX_TAPS];
+    const int n = sift3d_gauss_taps(sigma, min_value, taps);
+    if (n < 3 || zo0 < 0 || zo1 > Z || zo1 <= zo0) return set_err(c, SIFT3D_ERR_ARG, "bad blur window [%lld, %lld) of %lld planes", (long long)zo0, (long long)zo1, (long long)Z);
+    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS]};
+    const double N = (double)X * Y * (double)(zo1 - zo0);
+    stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N);
+    hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, X, Y, Z, taps, n, &bt, zo0, zo1);
+    if (e == hipErrorNotSupported) {
+        sc.cancel();
+        return set_err(c, SIFT3D_ERR_ARG, "this shape or filter has no windowed blur (sift3d_blur_window_supported)");
+    }
+    HIPCHK(c, e);
+    return SIFT3D_OK;
+}
+
 /* runs op between the two fences */
 #define FENCED(c, op)                 \
     do {                              \
@@ -660,6 +688,21 @@ extern "C" int sift3d_gauss_blur_dog_dev(sift3d_ctx *c, const float *d_in, float
     if (nz < 2) return set_err(c, SIFT3D_ERR_ARG, "2-D images are outside this path (featExtract rejects z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
     FENCED(c, blur_dev(c, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value));
+}
+
+extern "C" int sift3d_blur_window_supported(int64_t nx, int64_t ny, float sigma, float min_value)
+{
+    return blur_window_supported(nx, ny, sigma, min_value) ? 1 : 0;
+}
+
+extern "C" int sift3d_gauss_blur_dog_window_dev(sift3d_ctx *c, const float *d_in, float *d_out, float *d_dog, int64_t nx, int64_t ny,
+                                                int64_t nz, int64_t z_lo, int64_t z_hi, float sigma, float min_value)
+{
+    int rc = check_shape(c, nx, ny, nz);
+    if (rc) return rc;
+    if (nz < 2 || (!d_out && !d_dog)) return set_err(c, SIFT3D_ERR_ARG, "bad windowed blur arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    FENCED(c, blur_window_dev(c, d_in, d_out, d_dog, nx, ny, nz, z_lo, z_hi, sigma, min_value));
 }
 
 extern "C" int sift3d_gauss_blur(sift3d_ctx *c, const float *in, float *out, int64_t nx, int64_t ny, int64_t nz,
@@ -1725,6 +1768,8 @@ struct zs_rank {
     sift3d_ctx *c = nullptr;
     int dev = 0;
     hipStream_t copy_stream = nullptr; /* the deferred patch-halo copies */
+    hipStream_t halo_stream = nullptr; /* the per-level halo copies into this rank, beside its interior launch */
+    hipEvent_t ev_halo = nullptr;      /* those copies are done */
     hipEvent_t ev_level = nullptr;     /* this rank's current level is complete (its own slices are final) */
     hipEvent_t ev_l3 = nullptr;        /* L1..L3 of the current octave are complete */
     hipEvent_t ev_patch = nullptr;     /* the patch-halo copies into this rank are done */
@@ -1798,6 +1843,7 @@ struct sift3d_zslab {
     std::vector<int> devices;
     std::vector<zs_rank> R; /* one per slab; a single one when the volume is too thin to shard */
     int lazy_levels = 1;    /* SIFT3D_TUNE_LAZY_LEVELS */
+    int bands_first = 1;    /* SIFT3D_TUNE_BANDS_FIRST */
     sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
 };
 
@@ -1809,6 +1855,8 @@ extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
         hipSetDevice(q.dev);
         hipStreamSynchronize(q.c->stream);
         if (q.copy_stream) { hipStreamSynchronize(q.copy_stream); hipStreamDestroy(q.copy_stream); }
+        if (q.halo_stream) { hipStreamSynchronize(q.halo_stream); hipStreamDestroy(q.halo_stream); }
+        if (q.ev_halo) hipEventDestroy(q.ev_halo);
         for (float *p : q.allocs) hipFree(p);
         hipFree(q.arena);
         if (q.ev_level) hipEventDestroy(q.ev_level);
@@ -1827,6 +1875,7 @@ extern "C" int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value)
         if (rc) return rc;
     }
     if (knob == SIFT3D_TUNE_LAZY_LEVELS) h->lazy_levels = value;
+    if (knob == SIFT3D_TUNE_BANDS_FIRST) h->bands_first = value;
     return SIFT3D_OK;
 }
 
@@ -1875,6 +1924,8 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
             goto done;
         }
         ZS_HIP(hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking));
+        ZS_HIP(hipStreamCreateWithFlags(&q.halo_stream, hipStreamNonBlocking));
+        ZS_HIP(hipEventCreateWithFlags(&q.ev_halo, hipEventDisableTiming));
         ZS_HIP(hipEventCreateWithFlags(&q.ev_level, hipEventDisableTiming));
         ZS_HIP(hipEventCreateWithFlags(&q.ev_l3, hipEventDisableTiming));
         ZS_HIP(hipEventCreateWithFlags(&q.ev_patch, hipEventDisableTiming));
@@ -1998,36 +2049,68 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
         }
         for (int j = 1; j <= nlev; j++) {
             const int64_t hb = (lazy && j == 4) ? ZS_BLUR + 1 : ZS_BLUR; /* slices of this level's halo refreshed from the neighbours */
-            /* every rank: level j on slab +- 8 (clipped to the buffer: at a face of the whole volume the buffer ends at the
-             * face, which is what makes the zero border exact), D_{j-1} fused */
+            /* Boundary bands first (round 3).  What a neighbour fetches of this level are a rank's own first and last hb
+             * slices.  Where the blur has a windowed form (the one-launch kernel: rows of whole 16-byte vectors, at most 17
+             * taps) a rank filters those two bands first, records the event its neighbours' copies wait for, and then filters
+             * its interior while the bands travel on the receivers' halo streams; its own halo slices are not computed at
+             * all, they arrive.  The next level's launches wait for the arrivals, which by then have had the whole interior
+             * launch to complete: no halo byte is waited for with an idle device unless the link is slower than the
+             * interior.  Without the windowed form (other row lengths): the level on slab +- 8 in one piece, then the
+             * exchange, as in round 2. */
+            const bool banded = sharded && blur_window_supported(X, Y, extras[j - 1], 0.01f) && h->bands_first;
             for (r = 0; r < nr; r++) {
                 zs_rank &q = R[(size_t)r];
                 const int64_t c0 = q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0, c1 = q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1;
-                const int64_t a = c0 - q.e0, b = c1 - q.e0;
+                const int64_t a = c0 - q.e0, b = c1 - q.e0, nzl = q.e1 - q.e0;
                 ZS_HIP(hipSetDevice(q.dev));
-                ZS_RC(blur_dev(q.c, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] ? q.D[j - 1] + a * XY : nullptr, X, Y, b - a, extras[j - 1], 0.01f));
-                ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
-                if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
+                if (banded && (q.lo || q.hi)) {
+                    if (q.lo) ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z0 - q.e0, q.z0 - q.e0 + hb, extras[j - 1], 0.01f));
+                    if (q.hi) ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z1 - q.e0 - hb, q.z1 - q.e0, extras[j - 1], 0.01f));
+                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream)); /* the bands are final: the neighbours may fetch them */
+                } else {
+                    /* level j on slab +- 8 (clipped to the buffer: at a face of the whole volume the buffer ends at the face,
+                     * which is what makes the zero border exact), D_{j-1} fused */
+                    ZS_RC(blur_dev(q.c, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] ? q.D[j - 1] + a * XY : nullptr, X, Y, b - a, extras[j - 1], 0.01f));
+                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
+                    if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
+                }
             }
-            /* the 8-slice halo of the new level from the two neighbours (their own slices, exact), queued on the receiver's
-             * stream behind the sender's event; then the fused DoG redone on the halo slices */
+            if (banded)
+                for (r = 0; r < nr; r++) { /* the interior, while the bands travel */
+                    zs_rank &q = R[(size_t)r];
+                    if (!q.lo && !q.hi) continue;
+                    const int64_t w0 = q.lo ? q.z0 - q.e0 + hb : 0, w1 = q.hi ? q.z1 - q.e0 - hb : q.e1 - q.e0;
+                    ZS_HIP(hipSetDevice(q.dev));
+                    ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, q.e1 - q.e0, w0, w1, extras[j - 1], 0.01f));
+                    if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
+                }
+            /* the hb-slice halo of the new level from the two neighbours (their own slices, exact), queued behind the
+             * sender's event -- on the receiver's halo stream beside its interior launch (bands first), or on its main
+             * stream; then the fused DoG redone on the halo slices */
             for (r = 0; r < nr; r++) {
                 zs_rank &q = R[(size_t)r];
                 ZS_HIP(hipSetDevice(q.dev));
                 const size_t bytes = sizeof(float) * (size_t)(hb * XY);
+                hipStream_t hs = banded ? q.halo_stream : q.c->stream;
                 if (q.lo) {
                     zs_rank &p = R[(size_t)r - 1];
-                    ZS_COMM(hipStreamWaitEvent(q.c->stream, p.ev_level, 0));
-                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z0 - hb - q.e0) * XY, q.dev, p.L[j] + (q.z0 - hb - p.e0) * XY, p.dev, bytes, q.c->stream));
+                    ZS_COMM(hipStreamWaitEvent(hs, p.ev_level, 0));
+                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z0 - hb - q.e0) * XY, q.dev, p.L[j] + (q.z0 - hb - p.e0) * XY, p.dev, bytes, hs));
                     st.halo_bytes_critical += (int64_t)bytes;
+                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
                     st.exchanges++;
                 }
                 if (q.hi) {
                     zs_rank &p = R[(size_t)r + 1];
-                    ZS_COMM(hipStreamWaitEvent(q.c->stream, p.ev_level, 0));
-                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z1 - q.e0) * XY, q.dev, p.L[j] + (q.z1 - p.e0) * XY, p.dev, bytes, q.c->stream));
+                    ZS_COMM(hipStreamWaitEvent(hs, p.ev_level, 0));
+                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z1 - q.e0) * XY, q.dev, p.L[j] + (q.z1 - p.e0) * XY, p.dev, bytes, hs));
                     st.halo_bytes_critical += (int64_t)bytes;
+                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
                     st.exchanges++;
+                }
+                if (banded && (q.lo || q.hi)) { /* the main stream goes on behind the arrivals */
+                    ZS_COMM(hipEventRecord(q.ev_halo, q.halo_stream));
+                    ZS_COMM(hipStreamWaitEvent(q.c->stream, q.ev_halo, 0));
                 }
                 const int64_t a = (q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0) - q.e0, b = (q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1) - q.e0;
                 if (q.D[j - 1] && q.lo && q.z0 - q.e0 > a)
@@ -2205,6 +2288,7 @@ done:
         hipSetDevice(q.dev);
         hipStreamSynchronize(q.c->stream);
         hipStreamSynchronize(q.copy_stream);
+        hipStreamSynchronize(q.halo_stream);
     }
     for (size_t i = 0; i < R.size(); i++) {
         hipSetDevice(R[i].dev);

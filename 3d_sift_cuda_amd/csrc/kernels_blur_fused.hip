@@ -119,8 +119,8 @@ struct fb_ring_cfg {
  * second plane in flight covers the latency the second workgroup covered. */
 template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
 __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
-    const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zlen, int tiles_x,
-    int tiles_y, long long total, fb_taps2 t)
+    const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen,
+    int tiles_x, int tiles_y, long long total, fb_taps2 t)
 {
     using C = fb_ring_cfg<R, BR, PF>;
     constexpr int U = 2 * R + 1, XO = C::XO;
@@ -143,8 +143,10 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
     const int ty = (int)((wi / tiles_x) % tiles_y);
     const int chunk = (int)(wi / ((long long)tiles_y * tiles_x));
     const int x0 = tx * FB_TX, y0 = ty * TY;
-    const int zc0 = chunk * zlen;
-    const int zc1 = zc0 + zlen < Z ? zc0 + zlen : Z;
+    /* output planes [zo0, zo1) of the volume (the whole of it, or a window: a Z-slab rank filters its boundary bands
+     * first); the input is read wherever the filter reaches, zeros outside [0, Z) */
+    const int zc0 = zo0 + chunk * zlen;
+    const int zc1 = zc0 + zlen < zo1 ? zc0 + zlen : zo1;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long XY = (long long)X * Y;
@@ -394,8 +396,8 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident, int for
 /* Returns false when the shape is outside the kernel (32-bit buffer offsets: a chunk with its lead-in planes must stay
  * below 4 GiB -- a volume whose planes are that large gets more z chunks, and only a plane pair beyond 4 GiB has none) */
 template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
-static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t,
-                          int forced_chunks)
+static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
+                          const fb_taps2 &t, int forced_chunks)
 {
     using C = fb_ring_cfg<R, BR, PF>;
     static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
@@ -409,23 +411,25 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     if (max_planes < 1) return false;
     const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + C::TY - 1) / C::TY);
     const long long tiles = (long long)tiles_x * tiles_y;
-    int n = fused_chunks(R, Z, tiles, resident, forced_chunks);
-    if ((Z + n - 1) / n > max_planes) n = (int)((Z + max_planes - 1) / max_planes);
-    const int zlen = (int)((Z + n - 1) / n);
-    const int nch = (int)((Z + zlen - 1) / zlen);
+    const int64_t Zo = zo1 - zo0; /* planes to produce */
+    int n = fused_chunks(R, Zo, tiles, resident, forced_chunks);
+    if ((Zo + n - 1) / n > max_planes) n = (int)((Zo + max_planes - 1) / max_planes);
+    const int zlen = (int)((Zo + n - 1) / n);
+    const int nch = (int)((Zo + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
     hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
-                       (int)Y, (int)Z, zlen, tiles_x, tiles_y, total, t);
+                       (int)Y, (int)Z, (int)zo0, (int)zo1, zlen, tiles_x, tiles_y, total, t);
     return true;
 }
 
 template <int R, int BR, int PF>
-static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t, int chunks)
+static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
+                           const fb_taps2 &t, int chunks)
 {
-    if (out && dog) return launch_ring_t<R, BR, true, true, PF>(s, in, out, dog, X, Y, Z, t, chunks);
-    if (out) return launch_ring_t<R, BR, true, false, PF>(s, in, out, dog, X, Y, Z, t, chunks);
-    return launch_ring_t<R, BR, false, true, PF>(s, in, out, dog, X, Y, Z, t, chunks);
+    if (out && dog) return launch_ring_t<R, BR, true, true, PF>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    if (out) return launch_ring_t<R, BR, true, false, PF>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    return launch_ring_t<R, BR, false, true, PF>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
 }
 
 /* The two mappings, by measurement at 512^3 and 256^3: two rows per thread, two planes of window
@@ -433,39 +437,42 @@ static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *do
  * and 17 taps, and for every filter below 2^22 voxels, where a volume has fewer tiles than the chip has CUs and sixteen
  * wavefronts per workgroup help.  tune->rows_per_thread forces one of the two (tests run both on every shape). */
 template <int R>
-static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, const fb_taps2 &t,
-                        const sift3d_blur_tuning *tune)
+static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
+                        const fb_taps2 &t, const sift3d_blur_tuning *tune)
 {
     const int forced = tune ? tune->rows_per_thread : 0;
-    const int br = forced == 1 || forced == 2 ? forced : ((R >= 7 || X * Y * Z < (1ll << 22)) ? 1 : 2);
+    const int br = forced == 1 || forced == 2 ? forced : ((R >= 7 || X * Y * (zo1 - zo0) < (1ll << 22)) ? 1 : 2);
     const int chunks = tune ? tune->z_chunks : 0;
-    if (br == 1) return launch_ring_pf<R, 1, 1>(s, in, out, dog, X, Y, Z, t, chunks);
-    return launch_ring_pf<R, 2, 2>(s, in, out, dog, X, Y, Z, t, chunks);
+    if (br == 1) return launch_ring_pf<R, 1, 1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    return launch_ring_pf<R, 2, 2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
 }
 
 /* Returns hipErrorNotSupported when the shape is outside this kernel (the caller then runs the three-pass path): rows
  * must be whole 16-byte vectors, the filter at most 17 taps and symmetric bit for bit -- the z pass shares the product of
  * taps j and 2R-j (sift3d_gauss_taps' always are: (j-R)^2 and the normalising sum are the same for both).  out or dog may
- * be NULL. */
+ * be NULL.  [zo0, zo1): the planes to produce (zo1 < 0: all of them); planes outside the window are not written, the input
+ * is read as far as the filter reaches. */
 hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z,
-                                    const float *taps, int ntaps, const sift3d_blur_tuning *tune)
+                                    const float *taps, int ntaps, const sift3d_blur_tuning *tune, int64_t zo0, int64_t zo1)
 {
     const int R = ntaps / 2;
+    if (zo1 < 0) zo1 = Z; /* the default window: the whole volume */
     if (R < 1 || R > SIFT3D_FAST_MAX_R || ntaps != 2 * R + 1 || X % 4 != 0 || X * Y >= (1ll << 29) || (!out && !dog)) return hipErrorNotSupported;
+    if (zo0 < 0 || zo1 > Z || zo1 <= zo0) return hipErrorInvalidValue;
     for (int j = 0; j < R; j++)
         if (__builtin_bit_cast(unsigned, taps[j]) != __builtin_bit_cast(unsigned, taps[2 * R - j])) return hipErrorNotSupported;
     fb_taps2 t;
     for (int i = 0; i < 2 * SIFT3D_FAST_MAX_R + 1; i++) t.f[i] = v2f(i < ntaps ? taps[i] : 0.0f);
     bool ok = false;
     switch (R) {
-    case 1: ok = launch_ring<1>(s, in, out, dog, X, Y, Z, t, tune); break;
-    case 2: ok = launch_ring<2>(s, in, out, dog, X, Y, Z, t, tune); break;
-    case 3: ok = launch_ring<3>(s, in, out, dog, X, Y, Z, t, tune); break;
-    case 4: ok = launch_ring<4>(s, in, out, dog, X, Y, Z, t, tune); break;
-    case 5: ok = launch_ring<5>(s, in, out, dog, X, Y, Z, t, tune); break;
-    case 6: ok = launch_ring<6>(s, in, out, dog, X, Y, Z, t, tune); break;
-    case 7: ok = launch_ring<7>(s, in, out, dog, X, Y, Z, t, tune); break;
-    default: ok = launch_ring<8>(s, in, out, dog, X, Y, Z, t, tune); break;
+    case 1: ok = launch_ring<1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    case 2: ok = launch_ring<2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    case 3: ok = launch_ring<3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    case 4: ok = launch_ring<4>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    case 5: ok = launch_ring<5>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    case 6: ok = launch_ring<6>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    case 7: ok = launch_ring<7>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    default: ok = launch_ring<8>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
     }
     if (!ok) return hipErrorNotSupported;
     return hipGetLastError();

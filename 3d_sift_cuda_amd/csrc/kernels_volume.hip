@@ -426,7 +426,33 @@ __device__ __forceinline__ float ex_min3(float a, float b, float c)
     return r;
 }
 
+/* the same shifts with a value of the lane's own for the lane that has no neighbour in the wavefront (lane 0 / lane 63) */
+__device__ __forceinline__ float dpp_from_lower_or(float v, float edge)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper_or(float v, float edge)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
 /* max / min over the x-triple of every element of a row: rmax/rmin include the element, l2max/l2min do not */
+__device__ __forceinline__ void row_extrema_v(const float (&v)[6], float (&rmax)[4], float (&rmin)[4], float (&l2max)[4], float (&l2min)[4])
+{
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        l2max[e] = ex_max(v[e], v[e + 2]);
+        l2min[e] = ex_min(v[e], v[e + 2]);
+        rmax[e] = ex_max3(v[e], v[e + 2], v[e + 1]);
+        rmin[e] = ex_min3(v[e], v[e + 2], v[e + 1]);
+    }
+}
+/* a wavefront covers all of its 256 x: the left neighbour of lane 0 and the right neighbour of lane 63 are `edge` */
+__device__ __forceinline__ void row_extrema_edge(v4f a, float edge, float (&rmax)[4], float (&rmin)[4], float (&l2max)[4], float (&l2min)[4])
+{
+    const float v[6] = {dpp_from_lower_or(a.w, edge), a.x, a.y, a.z, a.w, dpp_from_upper_or(a.x, edge)};
+    row_extrema_v(v, rmax, rmin, l2max, l2min);
+}
 __device__ __forceinline__ void row_extrema(v4f a, float (&rmax)[4], float (&rmin)[4], float (&l2max)[4], float (&l2min)[4])
 {
     const float v[6] = {dpp_from_lower(a.w), a.x, a.y, a.z, a.w, dpp_from_upper(a.x)};
@@ -531,8 +557,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
     }
 }
 
-/* First phase, marching form (used when the volume has enough planes).  A wavefront owns 248 x (64 lanes x float4; the
- * first and last lane only supply x-neighbours) by EXM_ROWS rows and walks a chunk of planes; every plane is loaded and
+/* First phase, marching form (used when the volume has enough planes).  A wavefront owns 256 x (64 lanes x float4) by EXM_ROWS rows and walks a chunk of planes; every plane is loaded and
  * reduced once.  Round 3 form.  What a lane carries from plane to plane is, per voxel, four floats:
  *   pm, pn    the 3x3 max / min (centre included) of the plane just below: the "26 neighbours" of the next plane's voxel
  *             that lie in that plane;
@@ -551,6 +576,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
 #define EXM_ROWS 4
 #endif
 #define EXM_LOAD (EXM_ROWS + 2)
+#define EXM_XOUT 256 /* x per wavefront: 64 lanes x float4, every lane an output lane */
 #define EXM_STAGE (64 + 4 * 64) /* a wavefront's staging buffer: flushed at 64 after every row, a row adds at most 4 per lane */
 
 __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restrict__ dcur, int X, int Xl, int Y, int Z, int z_first,
@@ -565,15 +591,21 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
     const int za = z_first + blockIdx.y * zchunk;
     const int zb = za + zchunk < z_last ? za + zchunk : z_last; /* output planes za .. zb-1; plane zb <= Z-1 exists */
     const bool idle = y0 >= Y - 1 || za >= z_last;             /* wave-uniform */
-    const int xv = xt * EX_XOUT - 4 + lane * 4;
-    const int xld = xv < 0 ? 0 : (xv > X - 4 ? X - 4 : xv);
+    /* all 64 lanes produce outputs: x = xv .. xv + 3.  The left neighbour of lane 0's first element and the right
+     * neighbour of lane 63's last one come from one extra 4-byte load per row in which only those two lanes carry an
+     * address inside the buffer (the others, and positions outside the row, are answered with zeros by the bounds check
+     * and cost no memory access).  The round-2 form gave up the outer two lanes instead (248 outputs per wavefront): three
+     * wavefronts for a 512-voxel row, i.e. 46 % more loads and arithmetic than the row has voxels. */
+    const int xv = xt * EXM_XOUT + lane * 4;
     const long long XY = (long long)X * Y;
-    unsigned roff[EXM_LOAD];
+    unsigned roff[EXM_LOAD], eoff[EXM_LOAD];
+    const int xe = lane == 0 ? xv - 1 : (lane == 63 ? xv + 4 : -1);
 #pragma unroll
     for (int r = 0; r < EXM_LOAD; r++) {
         int yy = y0 - 1 + r;
         yy = yy < Y ? yy : Y - 1;
-        roff[r] = (unsigned)(yy * X + xld) * 4u; /* X * Y < 2^29: a plane is below 2 GiB */
+        roff[r] = xv < X ? (unsigned)(yy * X + xv) * 4u : 0xFFFFFFFFu; /* X * Y < 2^29: a plane is below 2 GiB; X % 4 == 0 */
+        eoff[r] = (xe >= 0 && xe < X) ? (unsigned)(yy * X + xe) * 4u : 0xFFFFFFFFu;
     }
     const int seg = ex_segment_of_z_block();
     /* the chunk's planes za-1 .. zb through one descriptor: (zchunk + 2) planes stay below 4 GiB (the launcher sees to it) */
@@ -582,12 +614,14 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
     const unsigned plane_bytes = (unsigned)(XY * 4);
     /* za-1 <= z.  The plane offset travels in an SGPR, which the hardware's bounds check does not see: a plane past zb
      * (the prefetch runs two planes ahead; its data is never used) goes through a descriptor of no records instead */
-    auto load_plane = [&](v4f(&raw)[EXM_LOAD], int z) {
+    auto load_plane = [&](v4f(&raw)[EXM_LOAD], float(&edge)[EXM_LOAD], int z) {
         const bool ok = z <= zb; /* wave-uniform */
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)chunk_base, 0, ok ? chunk_bytes : 0, EX_RSRC_FLAGS);
         const int so = ok ? (int)((unsigned)(z - (za - 1)) * plane_bytes) : 0;
 #pragma unroll
         for (int r = 0; r < EXM_LOAD; r++) raw[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff[r], so, 0));
+#pragma unroll
+        for (int r = 0; r < EXM_LOAD; r++) edge[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)eoff[r], so, 0));
     };
     /* Own-level extrema go to a staging buffer of the wavefront in LDS (compacted with a ballot and a prefix count) and
      * from there to the list in batches: ONE returning atomic and a coalesced store per 64 or more of them (a returning
@@ -632,21 +666,20 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
             cmx[r][e] = NEG; /* plane za-1 has no candidates here: it is the chunk below's, or the volume's face */
             cmn[r][e] = POS;
         }
-    const bool xlane = lane >= 1 && lane <= 62;
     /* One plane: reduce it, finish the candidates of the plane below (plane z-1), start this plane's.  FIRST: plane za-1,
      * of which only the 3x3 max / min are wanted. */
-    auto step = [&](const v4f(&raw)[EXM_LOAD], int z, auto first_tag) {
+    auto step = [&](const v4f(&raw)[EXM_LOAD], const float(&edge)[EXM_LOAD], int z, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         /* a window of three reduced rows (slot = row % 3) and the in-row pair max / min of two (slot = row & 1) */
         float rmax[3][4], rmin[3][4], l2max[2][4], l2min[2][4];
-        row_extrema(raw[0], rmax[0], rmin[0], l2max[0], l2min[0]);
-        row_extrema(raw[1], rmax[1], rmin[1], l2max[1], l2min[1]);
+        row_extrema_edge(raw[0], edge[0], rmax[0], rmin[0], l2max[0], l2min[0]);
+        row_extrema_edge(raw[1], edge[1], rmax[1], rmin[1], l2max[1], l2min[1]);
 #pragma unroll
         for (int r = 0; r < EXM_ROWS; r++) {
             constexpr int dummy = 0;
             (void)dummy;
             const int a = r % 3, b = (r + 1) % 3, c2 = (r + 2) % 3; /* window slots of rows r, r+1 (the output row), r+2 */
-            row_extrema(raw[r + 2], rmax[c2], rmin[c2], l2max[r & 1], l2min[r & 1]);
+            row_extrema_edge(raw[r + 2], edge[r + 2], rmax[c2], rmin[c2], l2max[r & 1], l2min[r & 1]);
             const v4f cv = raw[r + 1];
             const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
             float oldx[4], oldn[4];
@@ -673,7 +706,7 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
             if constexpr (!FIRST) {
                 /* the rare part: extrema of plane z-1 in row y0 + r, inside the searched x and y range */
                 const int y = y0 + r;
-                const bool rowok = xlane && y < Y - 1;
+                const bool rowok = y < Y - 1;
                 if (__ballot(rowhit && rowok)) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -690,21 +723,22 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
     using T = std::true_type;
     using F = std::false_type;
     v4f w0[EXM_LOAD], w1[EXM_LOAD], w2[EXM_LOAD];
-    load_plane(w0, za - 1);
-    load_plane(w1, za);
-    load_plane(w2, za + 1);
-    step(w0, za - 1, T{});
+    float g0[EXM_LOAD], g1[EXM_LOAD], g2[EXM_LOAD];
+    load_plane(w0, g0, za - 1);
+    load_plane(w1, g1, za);
+    load_plane(w2, g2, za + 1);
+    step(w0, g0, za - 1, T{});
     /* planes za .. zb (zb only finishes zb-1).  Invariant at the top: w1 holds plane z, w2 plane z+1 (in flight), w0 is free;
      * the three register windows rotate without copies, two planes are always in flight */
     for (int z = za;;) {
-        load_plane(w0, z + 2);
-        step(w1, z, F{});
+        load_plane(w0, g0, z + 2);
+        step(w1, g1, z, F{});
         if (++z > zb) break;
-        load_plane(w1, z + 2);
-        step(w2, z, F{});
+        load_plane(w1, g1, z + 2);
+        step(w2, g2, z, F{});
         if (++z > zb) break;
-        load_plane(w2, z + 2);
-        step(w0, z, F{});
+        load_plane(w2, g2, z + 2);
+        step(w0, g0, z, F{});
         if (++z > zb) break;
     }
     if (pending > 0) flush();
@@ -1291,8 +1325,9 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
         /* marching form when chunks of >= 8 planes still give the chip a few thousand wavefronts (a wavefront of the march
          * takes EXM_ROWS rows, the four of a workgroup are neighbours in y); its buffer descriptor covers a chunk and the two
          * planes around it, which must stay below 4 GiB */
+        const int xtiles_m = (int)((X + EXM_XOUT - 1) / EXM_XOUT);
         const int ytiles_m = (int)((Y - 2 + EXM_ROWS - 1) / EXM_ROWS), ygroups = (ytiles_m + 3) / 4;
-        const long long waves_m = (long long)xtiles * ytiles_m;
+        const long long waves_m = (long long)xtiles_m * ytiles_m;
         const long long plane_bytes = X * Y * 4;
         int zchunk = 1;
         for (int zc = 64; zc >= 8; zc /= 2)
@@ -1304,8 +1339,8 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
         const int nseg = ex_segments_in_use(nz);
         const long long segcap = surv_cap / nseg; /* entries per segment of the own-level list */
         if (zchunk >= 2) {
-            dim3 grid((unsigned)(xtiles * ygroups), nz);
-            hipLaunchKernelGGL(extrema_march_kernel, grid, dim3(256), 0, s, dcur, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk, xtiles,
+            dim3 grid((unsigned)(xtiles_m * ygroups), nz);
+            hipLaunchKernelGGL(extrema_march_kernel, grid, dim3(256), 0, s, dcur, (int)X, (int)Xl, (int)Y, (int)Z, z0, z1, zchunk, xtiles_m,
                                ygroups, surv, surv_count, segcap);
         } else { /* reads the own level only: its neighbour-level arguments are unused */
             dim3 grid((unsigned)((waves_xy + 3) / 4), nz);

@@ -122,9 +122,10 @@ def slab_context_slices(plan, rank):
 class HipBackend:
     """Compute on torch CUDA tensors through the C-ABI *_dev operators."""
 
-    def __init__(self, pkg, ctx, torch, lazy_levels=True):
+    def __init__(self, pkg, ctx, torch, lazy_levels=True, bands_first=True):
         self.pkg, self.ctx, self.torch = pkg, ctx, torch
         self.lazy_levels = lazy_levels   # False: every level stored and filtered in full (the reference's schedule)
+        self.bands_first = bands_first   # False: a level in one piece, then its exchange (the round-2 schedule)
         # one non-default torch stream carries everything: torch allocations/copies, the library's kernels
         # (sift3d_set_stream) and the point where NCCL work is ordered against (its current stream)
         self.stream = torch.cuda.Stream(device=ctx.device)
@@ -151,6 +152,16 @@ class HipBackend:
 
     def dog(self, a, b, out):
         self.ctx.dog_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel())
+
+    # ---- the blur restricted to output planes [z_lo, z_hi) of the buffer: optional part of the backend interface ----
+    def window_ok(self, shape, sigma):
+        nz, ny, nx = shape
+        return self.bands_first and self.ctx.blur_window_supported(nx, ny, sigma)
+
+    def blur_dog_window(self, src, dst, dog, z_lo, z_hi, sigma):
+        nz, ny, nx = src.shape
+        self.ctx.gauss_blur_dog_window_dev(src.data_ptr(), dst.data_ptr(), dog.data_ptr() if dog is not None else 0, nx, ny, nz,
+                                           z_lo, z_hi, sigma)
 
     def subsample(self, src, dst):
         nz, ny, nx = src.shape
@@ -213,14 +224,15 @@ class ZSlabExtractor:
         self.level_ids = []
         # exchange_bytes: everything this rank received and sent; of that, deferred_bytes moved in the once-per-octave
         # patch-halo batch that overlaps L4 / L5 / extrema (critical = exchange_bytes - deferred_bytes)
-        self.stats = {"exchanges": 0, "exchange_bytes": 0, "deferred_exchanges": 0, "deferred_bytes": 0}
+        # hidden_bytes: the part of the per-level halos issued bands-first, i.e. moving while this rank filters its interior
+        self.stats = {"exchanges": 0, "exchange_bytes": 0, "deferred_exchanges": 0, "deferred_bytes": 0, "hidden_bytes": 0}
         # every DoG buffer an extrema pass was queued on: the library replays those passes from the recorded pointers when
         # a candidate list overflows (cand_finalize), so all five DoG levels of every octave -- not only the L1..L3 / D1..D3
         # the level table names -- must outlive candidates() / describe(); released by the next run()
         self._keepalive = []
 
     # ---- halo exchange of one level buffer -------------------------------------------------
-    def _exchange(self, bufs, z0, z1, e0, width, has_lo, has_hi, inner=0, defer=False):
+    def _exchange(self, bufs, z0, z1, e0, width, has_lo, has_hi, inner=0, defer=False, patch=True):
         """Refresh, in every buffer of `bufs`, the slices [z0-width, z0-inner) from the lower neighbour and
         [z1+inner, z1+width) from the upper one (and send it the mirror bands of this slab), as ONE batch of
         point-to-point operations.  defer=True returns a closure that completes the batch (for the caller to run later:
@@ -230,7 +242,7 @@ class ZSlabExtractor:
         if not isinstance(bufs, (list, tuple)):
             bufs = [bufs]
         d, ops, back = self.dist, [], []
-        grp = self.deferred_group if (defer and self.deferred_group is not None) else self.group
+        grp = self.deferred_group if (defer and patch and self.deferred_group is not None) else self.group
         self.be.before_exchange()
         # gloo cannot move device memory: stage through the host (the single-GPU rehearsals); with
         # nccl (= RCCL) the slices go GPU to GPU over xGMI
@@ -257,9 +269,11 @@ class ZSlabExtractor:
         nbytes = 2 * n * bufs[0].shape[1] * bufs[0].shape[2] * 4 * (int(has_lo) + int(has_hi)) * len(bufs)
         self.stats["exchanges"] += 1
         self.stats["exchange_bytes"] += nbytes
-        if defer:
+        if defer and patch:
             self.stats["deferred_exchanges"] += 1
             self.stats["deferred_bytes"] += nbytes
+        elif defer:
+            self.stats["hidden_bytes"] += nbytes
 
         def finish():
             for r in works:
@@ -294,12 +308,29 @@ class ZSlabExtractor:
         a, b = c0 - e0, c1 - e0
         patch_halos = lambda: None
         for j in range(1, nlev + 1):
-            if D[j - 1] is None:
-                be.blur(L[j - 1][a:b], L[j][a:b], extras[j - 1])
+            hb = BLUR_HALO + (1 if (lazy and j == 4) else 0)
+            # Boundary bands first (round 3): what a neighbour fetches of this level are this rank's own first and last hb
+            # slices, so where the blur has a windowed form they are filtered first and handed to the exchange, and the
+            # interior is filtered while they travel (an RCCL batch runs on the communicator's stream, behind the band
+            # launches it was issued after); this rank's own halo slices are not computed, they arrive.  Otherwise: the
+            # level on slab +- BLUR_HALO in one piece, then the exchange (round 2).
+            banded = (has_lo or has_hi) and hasattr(be, "window_ok") and be.window_ok(shape, extras[j - 1])
+            if banded:
+                if has_lo:
+                    be.blur_dog_window(L[j - 1], L[j], D[j - 1], z0 - e0, z0 - e0 + hb, extras[j - 1])
+                if has_hi:
+                    be.blur_dog_window(L[j - 1], L[j], D[j - 1], z1 - e0 - hb, z1 - e0, extras[j - 1])
+                arrived = self._exchange(L[j], z0, z1, e0, hb, has_lo, has_hi, defer=True, patch=False)
+                be.blur_dog_window(L[j - 1], L[j], D[j - 1], (z0 - e0 + hb) if has_lo else 0, (z1 - e0 - hb) if has_hi else nzl,
+                                   extras[j - 1])
+                arrived()
             else:
-                be.blur_dog(L[j - 1][a:b], L[j][a:b], D[j - 1][a:b], extras[j - 1])
-            # the next blur needs this level exact on slab +- BLUR_HALO: that, and no more, is exchanged here
-            self._exchange(L[j], z0, z1, e0, BLUR_HALO + (1 if (lazy and j == 4) else 0), has_lo, has_hi)
+                if D[j - 1] is None:
+                    be.blur(L[j - 1][a:b], L[j][a:b], extras[j - 1])
+                else:
+                    be.blur_dog(L[j - 1][a:b], L[j][a:b], D[j - 1][a:b], extras[j - 1])
+                # the next blur needs this level exact on slab +- BLUR_HALO: that, and no more, is exchanged here
+                self._exchange(L[j], z0, z1, e0, hb, has_lo, has_hi)
             # the fused DoG used the not-yet-exchanged margin of L[j]: redo it on the halo slices
             if has_lo and D[j - 1] is not None:
                 be.dog(L[j - 1][a:z0 - e0], L[j][a:z0 - e0], D[j - 1][a:z0 - e0])

@@ -15,6 +15,11 @@ section 6) then runs under a watchdog and is attached to the line as `zslab`
 (strong scaling: its own ms_per_step and records/s, and whether the merged
 records are the bytes of the single-GPU run).
 
+With N > 1 the line also carries, at top level, the strong-scaling result of the
+Z-slab run: `zslab_value` (keypoints/s of ONE 512^3 volume over all N GPUs),
+`zslab_ms_per_step`, `zslab_same_bytes_as_single_gpu` (null if that child job
+failed; details in `zslab`).  `value` itself stays the weak-scaling workload.
+
 Rank 0 prints ONE JSON line: metric = keypoints/s (.key records per second,
 whole job), plus
   roofline     the dominant pyramid kernel (the fused x+y+z+DoG blur, one launch per
@@ -128,9 +133,13 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
                "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"],
                "halo_bytes_critical_per_rank_per_step": ex.stats["exchange_bytes"] - ex.stats["deferred_bytes"],
                "halo_bytes_deferred_per_rank_per_step": ex.stats["deferred_bytes"],
-               "exchange_schedule": "per stored level (L1..L4: the 17-tap L5 is only evaluated around candidates, from L4): the 8-slice blur halo (what the next blur waits for; 9 slices of L4); per octave: one deferred "
-                                    "batch with the other 24 slices of the L1..L3 patch halos, issued when L3 is complete and "
-                                    "waited for after the extrema passes (rank 0's counts; interior ranks exchange on both sides)"}
+               "halo_bytes_hidden_per_rank_per_step": ex.stats["hidden_bytes"],
+               "exchange_schedule": "per stored level (L1..L4: the 17-tap L5 is only evaluated around candidates, from L4): the 8-slice blur halo "
+                                    "(what the next blur needs; 9 slices of L4), issued BANDS FIRST -- a rank filters its two boundary "
+                                    "bands, hands them to the exchange and filters its interior while they travel (`hidden` bytes); per "
+                                    "octave: one deferred batch with the other 24 slices of the L1..L3 patch halos on a communicator of "
+                                    "its own, issued when L3 is complete and waited for after the extrema passes (rank 0's counts; "
+                                    "interior ranks exchange on both sides)"}
         import hashlib
         res["records_sha256"] = hashlib.sha256(merged.tobytes()).hexdigest() if merged is not None else None
         if expect is not None:
@@ -151,7 +160,7 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
             "config": {k: res[k] for k in ("workload", "records", "sharded_octaves", "slab_bounds", "parallelism",
                                            "halo_exchanges_per_step", "halo_bytes_per_rank_per_step",
                                            "halo_bytes_critical_per_rank_per_step", "halo_bytes_deferred_per_rank_per_step",
-                                           "exchange_schedule", "records_sha256")}}))
+                                           "halo_bytes_hidden_per_rank_per_step", "exchange_schedule", "records_sha256")}}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -507,6 +516,12 @@ def main():
         if world > 1 and args.zslab_limit > 0:
             torch.cuda.empty_cache()
             out["zslab"] = zslab_child(args, world, expect, args.zslab_limit)
+            # the strong-scaling figures of the same line, as top-level keys (documented in the module docstring): ONE volume
+            # over all N GPUs -- what BASELINE.json's "1/2/4/8-GPU Z-slab scaling" asks for; null when the child job failed
+            z = out["zslab"]
+            out["zslab_value"] = z.get("value")
+            out["zslab_ms_per_step"] = z.get("ms_per_step")
+            out["zslab_same_bytes_as_single_gpu"] = z.get("same_bytes_as_single_gpu")
         print(json.dumps(out), flush=True)
 
 

@@ -124,6 +124,14 @@ int sift3d_gauss_blur_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, int6
  * (the pyramid does that for its sixth level); d_dog may be NULL. */
 int sift3d_gauss_blur_dog_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, float *d_dog, int64_t nx, int64_t ny,
                               int64_t nz, float sigma, float min_value);
+/* The same restricted to the output planes [z_lo, z_hi) of the volume: planes outside the window are not written, the
+ * input is read as far as the filter reaches (zeros beyond the volume).  A Z-slab rank filters its two boundary bands
+ * with it first, hands them to the halo exchange, and filters the interior while they travel.
+ * Only the one-launch form of the blur has a window: sift3d_blur_window_supported says whether this row length and
+ * filter take it (rows of whole 16-byte vectors, a plane below 2^29 voxels, at most 17 taps). */
+int sift3d_blur_window_supported(int64_t nx, int64_t ny, float sigma, float min_value);
+int sift3d_gauss_blur_dog_window_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, float *d_dog, int64_t nx, int64_t ny,
+                                     int64_t nz, int64_t z_lo, int64_t z_hi, float sigma, float min_value);
 /* fioMultSum_interleave(a, b, out, -1.0f) -> fioCudaMultSum
  * (SIFT_cuda_Tools.cuh:213-217, R/src_common/FeatureIO.cpp:1941-1943) */
 int sift3d_dog(sift3d_ctx *ctx, const float *a, const float *b, float *out, int64_t n);
@@ -191,6 +199,8 @@ typedef enum {
     SIFT3D_TUNE_KP_CHUNKS,      /* the per-keypoint stage in n chunks, the keypoint kernel of chunk i+1 on one stream beside the
                                  * descriptor kernel of chunk i on another: 0 or 1 = one launch of each, one after the other
                                  * (default: the overlap does not pay), up to 16 */
+    SIFT3D_TUNE_BANDS_FIRST,    /* Z-slab drivers: 1 (default) a rank filters the two boundary bands of a level first and the interior
+                                 * while they travel to its neighbours; 0: the level in one piece, then the exchange (round 2) */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);
@@ -260,11 +270,12 @@ int sift3d_describe_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_
 typedef struct {
     int32_t n_ranks, sharded_octaves;
     int64_t exchanges;            /* halo copies queued on the critical path + deferred batches */
-    int64_t halo_bytes_critical;  /* the 8-slice halo every level needs before the next blur, all ranks */
+    int64_t halo_bytes_critical;  /* the 8-slice halo every level needs before the next blur (9 of L4), all ranks */
     int64_t halo_bytes_deferred;  /* the rest of the L1..L3 patch halos, copied beside L4 / L5 / extrema */
     int64_t gather_bytes;         /* the first unsharded octave assembled on rank 0 */
     int64_t n_extrema, n_keypoints, n_records;
     double wall_ms;               /* host wall time of the extraction: upload of the slabs, pyramid, per-keypoint stage, download, merge */
+    int64_t halo_bytes_hidden;    /* the part of halo_bytes_critical issued bands-first: copied while the receiver filters its interior */
 } sift3d_zslab_stats;
 int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
                          float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,
@@ -280,6 +291,18 @@ int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_
 void sift3d_zslab_destroy(sift3d_zslab *h);
 /* sift3d_set_tuning on every slab's context (and the driver's own use of SIFT3D_TUNE_LAZY_LEVELS) */
 int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value);
+
+/* ---- matcher: exact nearest neighbours of 64-component descriptors ------------------
+ * The search step of featMatchMultiple (R/feat_common/featMatchUtilities.cpp:1612: flann_find_nearest_neighbors_index over
+ * a kd-tree forest built at :1559 with 8 trees, 64 checks -- approximate and randomised; FLANN is not part of
+ * /root/reference), done exactly on the matrix cores: squared Euclidean distances from an int8 Gram matrix.
+ * db / queries: n x 64 components, each 0..127 (the rank descriptors of a .key file are 0..63).  For every query the k
+ * (1..32) nearest database vectors, ascending by (distance, database index): idx and dist2 hold n_q x k entries (-1 /
+ * INT32_MAX past the end of a database smaller than k).  A vector that is in both sets finds itself at distance 0, as in
+ * the reference, whose vote stage drops the hits inside the query's own image.  repeats > 1 runs the search that many times
+ * and reports the mean device time of the runs after the first in *kernel_ms (may be NULL). */
+int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const int8_t *queries, int64_t n_q, int k, int32_t *idx,
+                 int32_t *dist2, int repeats, double *kernel_ms, char *err, int64_t err_len);
 
 /* ---- measurement ------------------------------------------------------------
  * Device time per stage of the last sift3d_detect/sift3d_extract call, from

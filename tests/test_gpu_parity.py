@@ -129,6 +129,60 @@ def test_dev_entry_points_are_ordered_with_the_default_stream(built, oracle):
             assert (bits(d_out.clone().cpu().numpy()) == bits(sw)).all(), it
 
 
+def test_slab_entry_points_are_ordered_with_the_default_stream(built):
+    """The same for the slab building blocks (round-2 advice): levels produced by queued work on the default stream,
+    sift3d_extrema_append_dev / _append_lazy_dev, then sift3d_describe_dev, with no synchronisation anywhere; the DoG levels
+    only the extrema passes read are overwritten on the default stream right after the appends (fence out), the level table's
+    buffers stay.  Expected: the first octave of the single-context extraction, byte for byte."""
+    import importlib
+    import torch
+    zs = importlib.import_module("3d_sift_cuda_amd.zslab")
+    dims = (96, 88, 80)
+    nx, ny, nz = dims
+    vol = vol_of(built, dims, 21)
+    extra0, extras, sig = zs.sigma_schedule(1.0)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        ctx.set_max_octaves(1)
+        want = ctx.extract()
+    assert len(want) > 100
+    for lazy in (False, True):
+        with built.Context(nx, ny, nz, slab=True) as ctx:
+            d_vol = torch.from_numpy(vol).cuda()
+            junk = torch.empty((64, 1024, 1024), dtype=torch.float32, device="cuda")
+            L = [torch.empty_like(d_vol) for _ in range(6)]
+            D = [torch.empty_like(d_vol) for _ in range(5)]
+            torch.cuda.synchronize()
+            for rnd in range(3):
+                for t in L + D:
+                    t.fill_(float("nan"))
+                for _ in range(3):
+                    junk.normal_()                                      # the default stream is busy ahead of everything
+                src = d_vol * 1.0                                       # the input itself is still being produced
+                ctx.gauss_blur_dev(src.data_ptr(), L[0].data_ptr(), nx, ny, nz, extra0)
+                for j in range(1, 6):
+                    ctx.gauss_blur_dog_dev(L[j - 1].data_ptr(), L[j].data_ptr(), D[j - 1].data_ptr(), nx, ny, nz, extras[j - 1])
+                ctx.candidates_reset()
+                if lazy:
+                    assert ctx.lazy_levels_supported(nx, ny, nz, extras[4])
+                    ctx.extrema_append_lazy_dev(0, L[0].data_ptr(), L[1].data_ptr(), D[1].data_ptr(), D[2].data_ptr(), 0, 0.0,
+                                                nx, ny, nz, 0, 0, nz)
+                    ctx.extrema_append_dev(D[1].data_ptr(), D[2].data_ptr(), D[3].data_ptr(), nx, ny, nz, 1, 0, nz)
+                    ctx.extrema_append_lazy_dev(D[2].data_ptr(), 0, 0, D[3].data_ptr(), 0, L[4].data_ptr(), extras[4],
+                                                nx, ny, nz, 2, 0, nz)
+                else:
+                    for l in range(3):
+                        ctx.extrema_append_dev(D[l].data_ptr(), D[l + 1].data_ptr(), D[l + 2].data_ptr(), nx, ny, nz, l, 0, nz)
+                D[0].fill_(-7.0); D[4].fill_(7.0); L[5].fill_(0.0)        # nothing after the appends reads them
+                if not lazy:
+                    L[0].fill_(3.0)
+                levels = [{"img": L[l + 1].data_ptr(), "dogc": D[l + 1].data_ptr(), "nx": nx, "ny": ny, "nz_local": nz,
+                           "nz_global": nz, "z_offset": 0, "sigma_h": sig[l], "sigma_c": sig[l + 1], "sigma_l": sig[l + 2],
+                           "octave_factor": 1.0} for l in range(3)]
+                got, _ = ctx.describe_dev(levels)
+                assert got.tobytes() == want.tobytes(), (lazy, rnd)
+
+
 def test_lds_float_atomic_add_rounds_like_the_alu(built):
     """The orientation-histogram splat adds with ds_add_f32: it must be the IEEE add the reference's CPU performs."""
     rng = np.random.default_rng(7)
@@ -726,7 +780,13 @@ def test_c_zslab_driver_matches_single_gpu(built, dims, seed, mode, devs, scale)
     assert c > 0 and 33 * d <= 72 * c <= 40 * d
     if all((dims[0] >> o) % 4 == 0 for o in range(st["sharded_octaves"])):
         assert 33 * d == 72 * c
+        assert st["halo_bytes_hidden"] == c                              # bands first: all of it travels beside the interior launch
     assert st["gather_bytes"] > 0
+    # the round-2 schedule (a level in one piece, then its exchange) gives the same bytes, with nothing hidden
+    with built.ZSlab(dims[0], dims[1], dims[2], devs) as h:
+        h.set_tuning(built.TUNE_BANDS_FIRST, 0)
+        got2, st2 = h.extract(vol, initial_image_scale=scale, desc_mode=mode, size_factor=scale)
+    assert got2.tobytes() == want.tobytes() and st2["halo_bytes_hidden"] == 0 and st2["halo_bytes_critical"] == c
 
 
 def test_c_zslab_handle_is_reusable(built):
@@ -765,7 +825,8 @@ def test_config_c5_shape_of_work_on_one_gpu(built):
     got, st = built.extract_zslab(vol, [0] * 8, desc_mode=built.DESC_NRRIEF)
     assert st["n_ranks"] == 8 and st["sharded_octaves"] == 3
     assert len(want) > 5000 and got.tobytes() == want.tobytes()
-    assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72   # 8 + 8 + 8 + 9 slices of L1..L4 on the critical path
+    assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72   # 8 + 8 + 8 + 9 slices of L1..L4 per level
+    assert st["halo_bytes_hidden"] == st["halo_bytes_critical"]              # all of them issued bands-first
 
 
 def test_config_c5_plane_size_on_one_gpu(built):
@@ -792,6 +853,7 @@ def test_config_c5_plane_size_on_one_gpu(built):
     assert st["n_ranks"] == 2 and st["sharded_octaves"] == 3
     assert len(got) == len(want) and got.tobytes() == want.tobytes()
     assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72
+    assert st["halo_bytes_hidden"] == st["halo_bytes_critical"]
 
 
 def test_c_zslab_driver_edge_cases(built):
@@ -895,8 +957,11 @@ def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
     assert stats["exchanges"] == sum(5 if z else 6 for z in lazy)
     if all(lazy):
         assert stats["deferred_bytes"] * 105 == stats["exchange_bytes"] * 72
+        # boundary bands first: every per-level halo was issued behind the band launches and moved beside the interior launch
+        assert stats["hidden_bytes"] == stats["exchange_bytes"] - stats["deferred_bytes"]
     elif not any(lazy):
         assert stats["deferred_bytes"] * 112 == stats["exchange_bytes"] * 72
+        assert stats["hidden_bytes"] == 0                                # no windowed blur for such rows: level, then exchange
     vol = vol_of(built, dims, seed)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)

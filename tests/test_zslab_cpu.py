@@ -19,9 +19,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 class OracleBackend:
     """numpy/oracle stand-in for HipBackend (CPU tensors; candidates kept as python lists)."""
 
-    def __init__(self, oracle, torch):
+    def __init__(self, oracle, torch, bands_first=False):
         self.o, self.torch = oracle, torch
         self.cands = []
+        self.bands_first = bands_first
+
+    # the windowed blur of the HIP backend (boundary bands first): only the output planes [z_lo, z_hi) are written
+    def window_ok(self, shape, sigma):
+        return self.bands_first
+
+    def blur_dog_window(self, src, dst, dog, z_lo, z_hi, sigma):
+        out = self.torch.from_numpy(self.o.blur(src.numpy(), sigma))
+        dst[z_lo:z_hi].copy_(out[z_lo:z_hi])
+        if dog is not None:
+            dog[z_lo:z_hi].copy_(self.torch.from_numpy(self.o.dog(src.numpy(), out.numpy()))[z_lo:z_hi])
 
     def empty(self, shape):
         return self.torch.zeros(shape, dtype=self.torch.float32)
@@ -98,7 +109,7 @@ def test_slab_plan_geometry():
     assert abs(extra0 - 1.5198684930801392) < 1e-12 and abs(extras[4] - 3.0900158882141113) < 1e-12
 
 
-def _worker(rank, world, port, dims, seed, q):
+def _worker(rank, world, port, dims, seed, q, bands_first=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -111,7 +122,8 @@ def _worker(rank, world, port, dims, seed, q):
         vol = pkg.synth_blobs(*dims, seed=seed)
         plan = zs.SlabPlan(dims[0], dims[1], dims[2], world)
         i0, i1 = plan.input_range(rank)
-        ex = zs.ZSlabExtractor(OracleBackend(_oracle.load(), torch), plan, rank, dist)
+        dgroup = dist.new_group(ranks=list(range(world)), backend="gloo") if bands_first else None
+        ex = zs.ZSlabExtractor(OracleBackend(_oracle.load(), torch, bands_first), plan, rank, dist, deferred_group=dgroup)
         ex.run(vol[i0:i1], i0)
         mine = ex.candidates()
         gathered = [None] * world
@@ -133,16 +145,19 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("dims,seed,world", [((40, 36, 160), 3, 2), ((36, 40, 130), 9, 2), ((28, 24, 208), 5, 3), ((24, 20, 272), 8, 4)])
-def test_gloo_ranks_match_serial_oracle(oracle, built, dims, seed, world):
+@pytest.mark.parametrize("dims,seed,world,bands", [((40, 36, 160), 3, 2, False), ((36, 40, 130), 9, 2, True), ((28, 24, 208), 5, 3, True),
+                                                   ((24, 20, 272), 8, 4, False), ((24, 20, 272), 8, 4, True)])
+def test_gloo_ranks_match_serial_oracle(oracle, built, dims, seed, world, bands):
     """World size 2, 3 and 4: from 3 on there are ranks with a neighbour on both sides (what every interior rank of an
     8-GPU run is).  The schedule under test exchanges 8 slices per level and defers the rest of the L1..L3 patch halos
-    to one batch per octave."""
+    to one batch per octave (on a process group of its own when given one).  bands: boundary bands first -- a rank filters
+    the two bands its neighbours fetch, issues the exchange, filters its interior and only then completes the exchange; its
+    own halo slices are never computed, they arrive."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, seed, q, bands)) for r in range(world)]
     for p in procs:
         p.start()
     n_sharded, merged, stats = q.get(timeout=600)
@@ -154,6 +169,8 @@ def test_gloo_ranks_match_serial_oracle(oracle, built, dims, seed, world):
     # other 24 slices of L1, L2, L3: 40 against 72 slices
     assert stats["deferred_exchanges"] == n_sharded and stats["exchanges"] == 6 * n_sharded
     assert stats["deferred_bytes"] * 112 == stats["exchange_bytes"] * 72
+    # bands first: every per-level halo (the 40 slices) was issued before the interior of its level was filtered
+    assert stats["hidden_bytes"] == (stats["exchange_bytes"] - stats["deferred_bytes"] if bands else 0)
     want = oracle.candidates(built.synth_blobs(*dims, seed=seed))
     assert len(want) > 20
     _same(merged, want)
