@@ -139,6 +139,7 @@ def hip_lib():
     _sig(L.sift3d_zslab_create, P, P, I, I64, I64, I64, C.c_char_p, I64)
     _sig(L.sift3d_zslab_extract, I, P, P, F, I, F, F, P, P, P, C.c_char_p, I64)
     _sig(L.sift3d_zslab_destroy, None, P)
+    _sig(L.sift3d_knn64, I, I, P, I64, P, I64, I, P, P, I, P, C.c_char_p, I64)
     _hip = L
     return L
 
@@ -160,6 +161,10 @@ def host_lib():
     _sig(L.sift3d_write_key, I, C.c_char_p, P, I64, F, I, P)
     _sig(L.sift3d_write_key_bin, I, C.c_char_p, P, I64, F)
     _sig(L.sift3d_read_key, I, C.c_char_p, P, P)
+    _sig(L.sift3d_match_filter, I64, P, I64, I, I)
+    _sig(L.sift3d_match_descriptors, I, P, I64, P)
+    _sig(L.sift3d_match_votes, I, P, P, I, P, I, P, P, I, P, P)
+    _sig(L.sift3d_match_write_votes, I, C.c_char_p, C.c_char_p, C.c_char_p, P, P, I, I, I)
     L.free_ptr = C.CDLL(None).free
     L.free_ptr.argtypes = [C.c_void_p]
     _host = L
@@ -246,6 +251,59 @@ class ZSlab:
 
 def device_count():
     return int(hip_lib().sift3d_device_count())
+
+
+# ---- matcher: exact nearest neighbours on the GPU, votes on the host ---------------------------
+FEATMATCH = os.path.join(CSRC, "_build", "featMatchMultiple")
+
+
+def knn64(db, queries, k, device=0, repeats=1):
+    """sift3d_knn64: for every row of `queries` (n_q x 64 int8, components 0..127) the k nearest rows of `db`, ascending
+    by (squared distance, index).  Returns (idx, dist2, kernel_ms), idx / dist2 of shape (n_q, k)."""
+    db = np.ascontiguousarray(db, np.int8)
+    queries = np.ascontiguousarray(queries, np.int8)
+    assert db.ndim == 2 and db.shape[1] == 64 and queries.ndim == 2 and queries.shape[1] == 64
+    idx = np.empty((len(queries), k), np.int32)
+    d2 = np.empty((len(queries), k), np.int32)
+    ms, err = C.c_double(0.0), C.create_string_buffer(256)
+    rc = hip_lib().sift3d_knn64(int(device), db.ctypes.data, len(db), queries.ctypes.data, len(queries), int(k), idx.ctypes.data,
+                                d2.ctypes.data, int(repeats), C.byref(ms), err, 256)
+    if rc != 0:
+        e = Sift3DError("sift3d_knn64 -> %d: %s" % (rc, err.value.decode(errors="replace")))
+        e.code = rc
+        raise e
+    return idx, d2, ms.value
+
+
+def match_filter(feats, reoriented=1, peaks=4):
+    """sift3d_match_filter: the reference matcher's feature filters; returns the kept records."""
+    f = np.ascontiguousarray(feats, FEATURE_DTYPE).copy()
+    n = host_lib().sift3d_match_filter(f.ctypes.data, len(f), int(reoriented), int(peaks))
+    return f[:n].copy()
+
+
+def match_descriptors(feats):
+    f = np.ascontiguousarray(feats, FEATURE_DTYPE)
+    out = np.empty((len(f), 64), np.int8)
+    if host_lib().sift3d_match_descriptors(f.ctypes.data, len(f), out.ctypes.data) != 0:
+        raise Sift3DError("a descriptor value is outside 0..127")
+    return out
+
+
+def match_votes(first, labels, n_labels, nn_idx, nn_dist2):
+    """sift3d_match_votes: (votes, counts), each n_images x n_labels."""
+    first = np.ascontiguousarray(first, np.int64)
+    labels = np.ascontiguousarray(labels, np.int32)
+    nn_idx = np.ascontiguousarray(nn_idx, np.int32)
+    nn_dist2 = np.ascontiguousarray(nn_dist2, np.int32)
+    n_img, k = len(first) - 1, nn_idx.shape[1]
+    votes = np.zeros((n_img, n_labels), np.float32)
+    counts = np.zeros((n_img, n_labels), np.int32)
+    rc = host_lib().sift3d_match_votes(None, first.ctypes.data, n_img, labels.ctypes.data, int(n_labels), nn_idx.ctypes.data,
+                                       nn_dist2.ctypes.data, k, votes.ctypes.data, counts.ctypes.data)
+    if rc != 0:
+        raise Sift3DError("sift3d_match_votes -> %d" % rc)
+    return votes, counts
 
 
 def gauss_taps(sigma, min_value=0.01):

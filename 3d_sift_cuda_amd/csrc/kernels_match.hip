@@ -128,9 +128,12 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
                     const long long idx = base + 8 * g4 + 4 * h + e;
                     if (d < bd[KK - 1] && idx < n_db) { /* rare: insert behind every entry with a distance <= d (indices arrive ascending) */
                         int cd = d, ci = (int)idx;
+                        bool shifting = false; /* once the new entry is in, everything behind it moves down one place (a displaced
+                                                * entry that ties with its successor must stay in front of it) */
 #pragma unroll
                         for (int j = 0; j < KK; j++) {
-                            const bool sw = cd < bd[j];
+                            const bool sw = shifting || cd < bd[j];
+                            shifting = sw;
                             const int td = bd[j], ti = bi[j];
                             bd[j] = sw ? cd : td;
                             bi[j] = sw ? ci : ti;

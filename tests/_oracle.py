@@ -75,6 +75,8 @@ class Oracle:
         sig("o3_octave_levels", I, P, I64, I64, I64, P, P)
         sig("o3_free", None, P)
         sig("o3_write_key", I, C.c_char_p, P, I64, F, I, P)
+        sig("o3_knn64", I, P, I64, P, I64, I, P, P)
+        sig("o3_match_votes", I, P, I, P, I, P, P, I, P, P)
 
     @staticmethod
     def _f(a):
@@ -164,6 +166,22 @@ class Oracle:
         G = np.empty((6, nz, ny, nx), np.float32); D = np.empty((5, nz, ny, nx), np.float32)
         self.L.o3_octave_levels(g0.ctypes.data, nx, ny, nz, G.ctypes.data, D.ctypes.data)
         return G, D
+
+    def knn64(self, db, queries, k):
+        """Brute-force nearest neighbours: (idx, dist2), each (n_q, k), ascending by (distance, index)."""
+        db = np.ascontiguousarray(db, np.int8); queries = np.ascontiguousarray(queries, np.int8)
+        idx = np.empty((len(queries), k), np.int32); d2 = np.empty((len(queries), k), np.int32)
+        assert self.L.o3_knn64(db.ctypes.data, len(db), queries.ctypes.data, len(queries), k, idx.ctypes.data, d2.ctypes.data) == 0
+        return idx, d2
+
+    def match_votes(self, first, labels, n_labels, nn_idx, nn_dist2):
+        first = np.ascontiguousarray(first, np.int64); labels = np.ascontiguousarray(labels, np.int32)
+        nn_idx = np.ascontiguousarray(nn_idx, np.int32); nn_dist2 = np.ascontiguousarray(nn_dist2, np.int32)
+        n_img = len(first) - 1
+        votes = np.zeros((n_img, n_labels), np.float32); counts = np.zeros((n_img, n_labels), np.int32)
+        assert self.L.o3_match_votes(first.ctypes.data, n_img, labels.ctypes.data, n_labels, nn_idx.ctypes.data, nn_dist2.ctypes.data,
+                                     nn_idx.shape[1], votes.ctypes.data, counts.ctypes.data) == 0
+        return votes, counts
 
     def write_key(self, path, recs, eig_thres=140.0, comments=()):
         recs = np.ascontiguousarray(recs, REC)
