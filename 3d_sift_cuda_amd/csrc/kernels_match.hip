@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
         bd[j] = KNN_BIG;
         bi[j] = -1;
     }
+    int gate = -KNN_BIG; /* a candidate enters the list iff 2 q.b - |b|^2 > gate = |q|^2 - (k-th distance) */
     /* staging: thread t carries 32 bytes of the tile (vector t / 2, half t & 1) and, for t < 128, one norm */
     const long long ntiles = (n_db + KNN_TILE - 1) / KNN_TILE;
     m_v4i st0, st1;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
         st1 = ok ? p[1] : m_v4i(0);
         if (tid < KNN_TILE) {
             const long long vn = t * KNN_TILE + tid;
-            stn = vn < n_db ? db_norm[vn] : KNN_BIG / 2; /* a vector past the end can never be among the nearest */
+            stn = vn < n_db ? -db_norm[vn] : -(KNN_BIG / 2); /* negated; a vector past the end can never be among the nearest */
         }
     };
     auto stash = [&](int buf) {
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
     for (long long t = 0; t < ntiles; t++) {
         const int buf = (int)(t & 1);
         if (t + 1 < ntiles) fetch(t + 1); /* in flight while this tile is multiplied */
-#pragma unroll 1
+#pragma unroll 2
         for (int sub = 0; sub < KNN_TILE / 32; sub++) {
             /* A operand: database vector (row) sub * 32 + r, bytes [32 s + 16 h, +16) */
             const signed char *row = &tile[buf][(sub * 32 + r) * KNN_DIM + 16 * h];
@@ -116,17 +117,29 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
             m_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1], acc, 0, 0, 0);
-            /* accumulator register g holds row (g & 3) + 8 (g >> 2) + 4 h of the subtile: four norms per 16-byte LDS read */
-            const long long base = t * KNN_TILE + sub * 32;
+            /* Accumulator register g holds row (g & 3) + 8 (g >> 2) + 4 h of the subtile.  The common case costs two vector
+             * operations per candidate: s = 2 q.b - |b|^2 (one shift-add on the negated norm: four norms per 16-byte LDS
+             * read), and the test d < kth, d = |q|^2 - s, as s > |q|^2 - kth -- the right-hand side a per-lane constant
+             * that only changes when the list does.  Only a wavefront with a hit somewhere enters the insertion code. */
+            int sv[16];
+            bool any = false;
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
-                const m_v4i nn = *reinterpret_cast<const m_v4i *>(&tnorm[buf][sub * 32 + 8 * g4 + 4 * h]);
+                const m_v4i nn = *reinterpret_cast<const m_v4i *>(&tnorm[buf][sub * 32 + 8 * g4 + 4 * h]); /* -|b|^2 */
                 const int nv[4] = {nn.x, nn.y, nn.z, nn.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int d = qn + nv[e] - 2 * acc[4 * g4 + e];
-                    const long long idx = base + 8 * g4 + 4 * h + e;
-                    if (d < bd[KK - 1] && idx < n_db) { /* rare: insert behind every entry with a distance <= d (indices arrive ascending) */
+                    sv[4 * g4 + e] = (acc[4 * g4 + e] << 1) + nv[e];
+                    any = any || sv[4 * g4 + e] > gate;
+                }
+            }
+            if (__ballot(any)) {
+                const long long base = t * KNN_TILE + sub * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const int d = qn - sv[g];
+                    const long long idx = base + (g & 3) + 8 * (g >> 2);
+                    if (d < bd[KK - 1] && idx < n_db) { /* insert behind every entry with a distance <= d (indices arrive ascending) */
                         int cd = d, ci = (int)idx;
                         bool shifting = false; /* once the new entry is in, everything behind it moves down one place (a displaced
                                                 * entry that ties with its successor must stay in front of it) */
@@ -142,6 +155,7 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
                         }
                     }
                 }
+                gate = bd[KK - 1] == KNN_BIG ? -KNN_BIG : qn - bd[KK - 1];
             }
         }
         if (t + 1 < ntiles) {
