@@ -52,6 +52,12 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 #define FB_TX 64
+/* Cache policy of the level / DoG stores (the aux operand of buffer_store): 2 = nt, non-temporal.  Measured at 512^3 against
+ * 0 (default), 3 (nt + sc0), 17 (sc0 + sc1) and 19 (nt + sc0 + sc1): launch times within 2 %, and the L2 read misses of the
+ * two instantiations that re-fetch part of their tile halo (7 and 9 taps with DoG: 4.9 and 5.4 B/voxel through the fabric
+ * against 4.2 - 4.4 for the others) stay where they are (4.8 - 5.3 / 5.2 - 6.0): the policy of the stores is not what
+ * evicts those lines (profiles/r03_store_policy.txt). */
+#define FB_STORE_AUX 2
 
 struct fb_taps2 {
     v2f f[2 * SIFT3D_FAST_MAX_R + 1]; /* (f[j], f[j]): a 64-bit scalar operand of the packed multiply */
@@ -259,12 +265,12 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
         if constexpr (HAS_OUT) {
             const __amdgpu_buffer_rsrc_t r = store_rsrc(out_base, live);
 #pragma unroll
-            for (int q = 0; q < BR; q++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, lv[q]), r, (int)soff[q], (int)so, 2 /* nt */);
+            for (int q = 0; q < BR; q++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, lv[q]), r, (int)soff[q], (int)so, FB_STORE_AUX);
         }
         if constexpr (HAS_DOG) {
             const __amdgpu_buffer_rsrc_t r = store_rsrc(dog_base, live);
 #pragma unroll
-            for (int q = 0; q < BR; q++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, dg[q]), r, (int)soff[q], (int)so, 2 /* nt */);
+            for (int q = 0; q < BR; q++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, dg[q]), r, (int)soff[q], (int)so, FB_STORE_AUX);
         }
     };
 

@@ -572,9 +572,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float *__restrict__ 
  * requests per voxel to L1/L2), two planes of prefetch in registers, and buffer loads (row offset in a VGPR, plane offset in
  * an SGPR: no 64-bit address arithmetic in the loop).  The four wavefronts of a workgroup are neighbours in y, so the halo
  * rows they share are L1 hits. */
-#ifndef EXM_ROWS
-#define EXM_ROWS 4
-#endif
+#define EXM_ROWS 4 /* by measurement: 2, 3 and 4 rows per wavefront (149 / 196 / 234 registers) take the same time; 4 loads least */
 #define EXM_LOAD (EXM_ROWS + 2)
 #define EXM_XOUT 256 /* x per wavefront: 64 lanes x float4, every lane an output lane */
 #define EXM_STAGE (64 + 4 * 64) /* a wavefront's staging buffer: flushed at 64 after every row, a row adds at most 4 per lane */

@@ -44,7 +44,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TABLE = "r02b_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
+PMC_TABLE = "r03_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
 BLUR_SOURCE = os.path.join("3d_sift_cuda_amd", "csrc", "kernels_blur_fused.hip")   # what the PMC table was measured on
 
 
@@ -57,7 +57,7 @@ def blur_source_hash():
 def kernel_name(stage, ntaps, dog, vec=4):
     r = ntaps // 2
     if stage == "blur_fused":
-        return "blur_fused_kernel<%d>" % r
+        return "blur_fused_ring_kernel<%d, rows per thread, has level, %s, prefetch planes>" % (r, "true" if dog else "false")
     if stage == "blur_x":
         return "blur_x_kernel<%d,%d>" % (r, vec)
     return "blur_col_kernel<%d,%d,%s>" % (r, vec, "true" if dog else "false")
@@ -285,7 +285,7 @@ def main():
     nrec = 0
     for _ in range(args.warmup):
         nrec = len(ctx.extract(desc_mode=args.desc, copy=False))
-    # Timed region: HIP events only around the dominant kernels (the blur launches on the full-size volume: six per
+    # Timed region: HIP events only around the dominant kernels (the blur launches on the full-size volume: five per
     # step).  Bracketing all ~170 launches of a step costs about 1 ms of the step; the full per-stage breakdown is
     # taken from extra steps after the timed region.
     ctx.enable_timing(2)
@@ -394,7 +394,7 @@ def main():
                 for pi in per_inst:
                     R = pi["taps"] // 2
                     with_dog = pi["alg_bytes_per_voxel"] > 9
-                    # template arguments: <R, rows per thread, has level, has DoG, prefetch planes, outputs per lane>
+                    # template arguments: <R, rows per thread, has level, has DoG, prefetch planes>
                     exact = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and
                              (", true, true," in k) == with_dog and (with_dog or ", true, false," in k)]
                     twin = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and ", true, true," in k]
