@@ -51,28 +51,28 @@ int main(int argc, char **argv)
     }
     int device = -1;
     int devices[64], n_devices = 0; /* -d0,1,2,3: one Z-slab per listed device */
-    int iArg = 1;
-    int bDoubleImageSize = 0;
+    int arg = 1;
+    int resize = 0;
     int desc_mode = SIFT3D_DESC_SIFT;
-    int bWorldCoordinates = 0;
-    const float fEigThres = 140;
-    while (iArg < argc && argv[iArg][0] == '-') {
-        switch (argv[iArg][1]) {
+    int world_mode = 0;
+    const float eig_thres = 140;
+    while (arg < argc && argv[arg][0] == '-') {
+        switch (argv[arg][1]) {
         case '2':
-            bDoubleImageSize = 1;
-            if (argv[iArg][2] == '-') bDoubleImageSize = -1;
-            iArg++;
+            resize = 1;
+            if (argv[arg][2] == '-') resize = -1;
+            arg++;
             break;
         case 'd':
-            if (argv[iArg][2] - '0' < 0 || argv[iArg][2] - '0' > sift3d_device_count()) {
-                printf("Error: unknown device: %d\n", argv[iArg][2] - '0');
+            if (argv[arg][2] - '0' < 0 || argv[arg][2] - '0' > sift3d_device_count()) {
+                printf("Error: unknown device: %d\n", argv[arg][2] - '0');
                 print_options();
                 return -1;
             }
-            device = argv[iArg][2] - '0';
+            device = argv[arg][2] - '0';
             /* beyond the reference: -d0,1,2,3 cuts the volume into one Z-slab per listed device (sift3d_extract_zslab) */
             n_devices = 0;
-            for (const char *p = argv[iArg] + 2; *p && n_devices < 64; p++) {
+            for (const char *p = argv[arg] + 2; *p && n_devices < 64; p++) {
                 if (*p == ',') continue;
                 if (*p < '0' || *p > '9' || *p - '0' >= sift3d_device_count()) {
                     printf("Error: unknown device: %d\n", *p - '0');
@@ -81,40 +81,40 @@ int main(int argc, char **argv)
                 }
                 devices[n_devices++] = *p - '0';
             }
-            iArg++;
+            arg++;
             break;
         case 'b':
-            desc_mode = argv[iArg][2] == 'r' ? SIFT3D_DESC_RRIEF : (argv[iArg][2] == 'n' ? SIFT3D_DESC_NRRIEF : SIFT3D_DESC_BRIEF);
-            iArg++;
+            desc_mode = argv[arg][2] == 'r' ? SIFT3D_DESC_RRIEF : (argv[arg][2] == 'n' ? SIFT3D_DESC_NRRIEF : SIFT3D_DESC_BRIEF);
+            arg++;
             break;
         case 'w':
         case 'W':
             /* world coordinates imply isotropic extraction (featExtract.cpp:330-342) */
-            bWorldCoordinates = 1;
-            if (argv[iArg][2] == 's' || argv[iArg][2] == 'S') bWorldCoordinates = 2;
-            iArg++;
+            world_mode = 1;
+            if (argv[arg][2] == 's' || argv[arg][2] == 'S') world_mode = 2;
+            arg++;
             break;
         default:
-            printf("Error: unknown command line argument: %s\n", argv[iArg]);
+            printf("Error: unknown command line argument: %s\n", argv[arg]);
             print_options();
             return -1;
         }
     }
-    if (argc - iArg < 2) {
+    if (argc - arg < 2) {
         print_options();
         return -1;
     }
-    printf("Extracting features: %s\n", argv[iArg]);
+    printf("Extracting features: %s\n", argv[arg]);
     const int times = getenv("SIFT3D_CLI_TIMES") != NULL;
     double t0 = now_s(), t1;
 
     nifti_min_image img;
-    if (nifti_min_read(argv[iArg], &img) < 0) {
-        printf("Error: could not read input file: %s\n", argv[iArg]);
+    if (nifti_min_read(argv[arg], &img) < 0) {
+        printf("Error: could not read input file: %s\n", argv[arg]);
         return -1;
     }
-    if (bWorldCoordinates && sift3d_world_make_isotropic(&img) < 0) {
-        printf("Error: could not read input file: %s\n", argv[iArg]);
+    if (world_mode && sift3d_world_make_isotropic(&img) < 0) {
+        printf("Error: could not read input file: %s\n", argv[arg]);
         return -1;
     }
     t1 = now_s();
@@ -127,22 +127,22 @@ int main(int argc, char **argv)
     }
     int64_t X = img.nx, Y = img.ny, Z = img.nz;
     int64_t PX = X, PY = Y, PZ = Z; /* processing size */
-    float fInitialBlurScale = 1.0f;
-    if (bDoubleImageSize == 1) {
+    float initial_scale = 1.0f;
+    if (resize == 1) {
         PX *= 2; PY *= 2; PZ *= 2;
-    } else if (bDoubleImageSize == -1) {
+    } else if (resize == -1) {
         PX /= 2; PY /= 2; PZ /= 2;
     }
     if (PZ <= 1 || PX <= 0 || PY <= 0) {
-        printf("Could not read volume: %s\n", argv[iArg]);
+        printf("Could not read volume: %s\n", argv[arg]);
         return -1;
     }
     int64_t cx = PX > X ? PX : X, cy = PY > Y ? PY : Y, cz = PZ > Z ? PZ : Z;
     /* several devices: the single-device context is only needed for the -2+ / -2- resize (a volume that needs several
      * GPUs would not fit it otherwise) */
     const int multi = n_devices > 1;
-    sift3d_ctx *ctx = (!multi || bDoubleImageSize != 0) ? sift3d_create(device, cx, cy, cz) : NULL;
-    if (!ctx && (!multi || bDoubleImageSize != 0)) {
+    sift3d_ctx *ctx = (!multi || resize != 0) ? sift3d_create(device, cx, cy, cz) : NULL;
+    if (!ctx && (!multi || resize != 0)) {
         printf("Error: could not extract features, insufficient memory.\n");
         return -1;
     }
@@ -150,12 +150,12 @@ int main(int argc, char **argv)
     if (times) fprintf(stderr, "# device context: %.3f s\n", t1 - t0);
     t0 = t1;
     /* -2+ / -2-: the resize happens on the device, between the upload and the pyramid */
-    if (bDoubleImageSize == 1) fInitialBlurScale *= 0.5;
+    if (resize == 1) initial_scale *= 0.5;
     printf("Input image: i=%d j=%d k=%d\n", (int)PX, (int)PY, (int)PZ);
 
-    float fSizeFactor = 1;
-    if (bDoubleImageSize > 0) fSizeFactor /= 2;
-    else if (bDoubleImageSize < 0) fSizeFactor *= 2;
+    float size_factor = 1;
+    if (resize > 0) size_factor /= 2;
+    else if (resize < 0) size_factor *= 2;
 
     sift3d_feature *feats = NULL;
     int64_t n = 0;
@@ -166,10 +166,10 @@ int main(int argc, char **argv)
         float *pv = img.data;
         char zerr[512] = "";
         sift3d_zslab_stats zst;
-        if (bDoubleImageSize != 0) {
+        if (resize != 0) {
             pv = (float *)malloc(sizeof(float) * (size_t)(PX * PY * PZ));
             if (!pv) rc = SIFT3D_ERR_MEMORY;
-            else rc = bDoubleImageSize > 0 ? sift3d_double_size(ctx, img.data, X, Y, Z, pv) : sift3d_halve_size(ctx, img.data, X, Y, Z, pv);
+            else rc = resize > 0 ? sift3d_double_size(ctx, img.data, X, Y, Z, pv) : sift3d_halve_size(ctx, img.data, X, Y, Z, pv);
             if (rc != SIFT3D_OK) snprintf(zerr, sizeof zerr, "%s", ctx ? sift3d_last_error(ctx) : "out of memory");
             sift3d_destroy(ctx);
             ctx = NULL;
@@ -178,7 +178,7 @@ int main(int argc, char **argv)
         if (times) fprintf(stderr, "# resize: %.3f s\n", t1 - t0);
         t0 = t1;
         if (rc == SIFT3D_OK)
-            rc = sift3d_extract_zslab(devices, n_devices, pv, PX, PY, PZ, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n,
+            rc = sift3d_extract_zslab(devices, n_devices, pv, PX, PY, PZ, initial_scale, desc_mode, eig_thres, size_factor, &feats, &n,
                                       &zst, zerr, sizeof zerr);
         if (pv != img.data) free(pv);
         if (rc != SIFT3D_OK) {
@@ -191,11 +191,11 @@ int main(int argc, char **argv)
                     (int)zst.n_ranks, (int)zst.sharded_octaves, (long long)zst.exchanges, zst.halo_bytes_critical / 1e6,
                     zst.halo_bytes_deferred / 1e6, zst.gather_bytes / 1e6);
     } else {
-        rc = sift3d_set_volume_resized(ctx, img.data, X, Y, Z, bDoubleImageSize);
+        rc = sift3d_set_volume_resized(ctx, img.data, X, Y, Z, resize);
         t1 = now_s();
         if (times) fprintf(stderr, "# upload: %.3f s\n", t1 - t0);
         t0 = t1;
-        if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, fInitialBlurScale, desc_mode, fEigThres, fSizeFactor, &feats, &n);
+        if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, initial_scale, desc_mode, eig_thres, size_factor, &feats, &n);
         if (rc != SIFT3D_OK) {
             fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
             printf("Error: could not extract features, insufficient memory.\n");
@@ -211,11 +211,11 @@ int main(int argc, char **argv)
     char c1[200], c2[256], c3[1024];
     snprintf(c1, sizeof c1, "Extraction Voxel Resolution (ijk) : %d %d %d", (int)PX, (int)PY, (int)PZ);
     snprintf(c2, sizeof c2, "Extraction Voxel Size (mm)  (ijk) : %f %f %f", 1.0f * img.dx, 1.0f * img.dy, 1.0f * img.dz);
-    if (bWorldCoordinates) {
+    if (world_mode) {
         /* featExtract.cpp:447-458, 548-564 */
         float(*m)[4] = img.qto_xyz;
         const char *name = "qto_xyz";
-        if (bWorldCoordinates == 2) {
+        if (world_mode == 2) {
             if (img.sform_code > 0) {
                 m = img.sto_xyz;
                 name = "sto_xyz";
@@ -231,8 +231,8 @@ int main(int argc, char **argv)
     } else
         snprintf(c3, sizeof c3, "Feature Coordinate Space: voxels: 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0");
     const char *cm[3] = {c1, c2, c3};
-    if (sift3d_write_key(argv[iArg + 1], feats, n, fEigThres, 3, cm) != 0) {
-        fprintf(stderr, "Error: could not write %s\n", argv[iArg + 1]);
+    if (sift3d_write_key(argv[arg + 1], feats, n, eig_thres, 3, cm) != 0) {
+        fprintf(stderr, "Error: could not write %s\n", argv[arg + 1]);
         return -1;
     }
     t1 = now_s();

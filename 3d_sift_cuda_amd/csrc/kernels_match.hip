@@ -15,7 +15,7 @@
  * integer operations on 64 (n_q + n_db) bytes.
  *
  * Mapping.  A workgroup of four wavefronts owns 128 queries (32 per wavefront: the B operand, loaded once, 2 x 16 bytes
- * per lane) and walks the database in tiles of 128 vectors staged through LDS (8 KB, double-buffered; the next tile is in
+ * per lane) and walks the database in tiles of 256 vectors staged through LDS (16 KB, double-buffered; the next tile is in
  * registers while this one is multiplied).  Per 32-vector subtile a wavefront issues two MFMAs (K = 2 x 32) with the
  * database vectors as rows: the 32 x 32 result has the QUERY on the lane (column = lane & 31) and sixteen database rows in
  * the lane's sixteen accumulator registers -- so a lane keeps the running top-k of ITS query in registers and never talks
@@ -30,7 +30,7 @@ typedef int m_v4i __attribute__((ext_vector_type(4)));
 typedef int m_v16i __attribute__((ext_vector_type(16)));
 
 #define KNN_DIM 64
-#define KNN_TILE 128    /* database vectors per LDS tile */
+#define KNN_TILE 256    /* database vectors per LDS tile: one per thread of the workgroup */
 #define KNN_QW 32       /* queries per wavefront */
 #define KNN_QWG 128     /* queries per workgroup */
 #define KNN_BIG 0x7fffffff
@@ -57,14 +57,17 @@ __global__ void knn_norms_kernel(const signed char *__restrict__ v, long long n,
     norms[i] = s;
 }
 
-/* KK: list length kept per lane (>= k).  part: [query][2][KK] pairs (dist2, index). */
-template <int KK>
+/* KK: list length kept per lane (>= k).  part: [query][2][KK] pairs (dist2, index).
+ * CN: every database vector has the same squared norm (rank descriptors: always 85 344) -- then the distance is a decreasing
+ * function of q.b alone and the common case needs no arithmetic on the candidates at all: the largest of a lane's sixteen
+ * dot products (a tree of eight three-operand maxima) against one per-lane threshold. */
+template <int KK, bool CN>
 __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__restrict__ db, const int *__restrict__ db_norm, long long n_db,
                                                          const signed char *__restrict__ q, const int *__restrict__ q_norm, long long n_q,
-                                                         int *__restrict__ part_d, int *__restrict__ part_i)
+                                                         int const_norm, int *__restrict__ part_d, int *__restrict__ part_i)
 {
     __shared__ __attribute__((aligned(16))) signed char tile[2][KNN_TILE * KNN_DIM];
-    __shared__ int tnorm[2][KNN_TILE];
+    __shared__ __attribute__((aligned(16))) int tnorm[2][KNN_TILE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -81,51 +84,50 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
         bd[j] = KNN_BIG;
         bi[j] = -1;
     }
-    int gate = -KNN_BIG; /* a candidate enters the list iff 2 q.b - |b|^2 > gate = |q|^2 - (k-th distance) */
-    /* staging: thread t carries 32 bytes of the tile (vector t / 2, half t & 1) and, for t < 128, one norm */
+    /* a candidate enters the list iff  2 q.b - |b|^2 > |q|^2 - (k-th distance)   (CN: iff q.b > gate, the same halved) */
+    int gate = -KNN_BIG;
+    /* staging: thread t carries 64 bytes of the tile (vector t) and one norm */
     const long long ntiles = (n_db + KNN_TILE - 1) / KNN_TILE;
-    m_v4i st0, st1;
+    m_v4i st[4];
     int stn = 0;
     auto fetch = [&](long long t) {
-        const long long v = t * KNN_TILE + (tid >> 1);
+        const long long v = t * KNN_TILE + tid;
         const bool ok = v < n_db;
-        const m_v4i *p = reinterpret_cast<const m_v4i *>(db + v * KNN_DIM + 32 * (tid & 1));
-        st0 = ok ? p[0] : m_v4i(0);
-        st1 = ok ? p[1] : m_v4i(0);
-        if (tid < KNN_TILE) {
-            const long long vn = t * KNN_TILE + tid;
-            stn = vn < n_db ? -db_norm[vn] : -(KNN_BIG / 2); /* negated; a vector past the end can never be among the nearest */
-        }
+        const m_v4i *p = reinterpret_cast<const m_v4i *>(db + v * KNN_DIM);
+#pragma unroll
+        for (int w = 0; w < 4; w++) st[w] = ok ? p[w] : m_v4i(0);
+        if (!CN) stn = ok ? -db_norm[v] : -(KNN_BIG / 2); /* negated; a vector past the end can never be among the nearest */
     };
     auto stash = [&](int buf) {
-        m_v4i *p = reinterpret_cast<m_v4i *>(&tile[buf][(tid >> 1) * KNN_DIM + 32 * (tid & 1)]);
-        p[0] = st0;
-        p[1] = st1;
-        if (tid < KNN_TILE) tnorm[buf][tid] = stn;
+        m_v4i *p = reinterpret_cast<m_v4i *>(&tile[buf][tid * KNN_DIM]);
+#pragma unroll
+        for (int w = 0; w < 4; w++) p[w] = st[w];
+        if (!CN) tnorm[buf][tid] = stn;
     };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (long long t = 0; t < ntiles; t++) {
-        const int buf = (int)(t & 1);
-        if (t + 1 < ntiles) fetch(t + 1); /* in flight while this tile is multiplied */
-#pragma unroll 2
-        for (int sub = 0; sub < KNN_TILE / 32; sub++) {
-            /* A operand: database vector (row) sub * 32 + r, bytes [32 s + 16 h, +16) */
-            const signed char *row = &tile[buf][(sub * 32 + r) * KNN_DIM + 16 * h];
-            const m_v4i a0 = *reinterpret_cast<const m_v4i *>(row), a1 = *reinterpret_cast<const m_v4i *>(row + 32);
-            m_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1], acc, 0, 0, 0);
-            /* Accumulator register g holds row (g & 3) + 8 (g >> 2) + 4 h of the subtile.  The common case costs two vector
-             * operations per candidate: s = 2 q.b - |b|^2 (one shift-add on the negated norm: four norms per 16-byte LDS
-             * read), and the test d < kth, d = |q|^2 - s, as s > |q|^2 - kth -- the right-hand side a per-lane constant
-             * that only changes when the list does.  Only a wavefront with a hit somewhere enters the insertion code. */
-            int sv[16];
-            bool any = false;
+    auto gram = [&](int buf, int sub) -> m_v16i { /* A operand: database vector (row) sub * 32 + r, bytes [32 s + 16 h, +16) */
+        const signed char *row = &tile[buf][(sub * 32 + r) * KNN_DIM + 16 * h];
+        const m_v4i a0 = *reinterpret_cast<const m_v4i *>(row), a1 = *reinterpret_cast<const m_v4i *>(row + 32);
+        m_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0], acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[1], acc, 0, 0, 0);
+    };
+    /* accumulator register g holds row (g & 3) + 8 (g >> 2) + 4 h of the subtile */
+    auto take = [&](const m_v16i &acc, int buf, int sub, long long t) {
+        int sv[16];
+        bool any;
+        if constexpr (CN) {
+#pragma unroll
+            for (int g = 0; g < 16; g++) sv[g] = acc[g];
+            int m[6];
+#pragma unroll
+            for (int u = 0; u < 5; u++) m[u] = max(max(sv[3 * u], sv[3 * u + 1]), sv[3 * u + 2]);
+            m[5] = sv[15];
+            any = max(max(max(m[0], m[1]), m[2]), max(max(m[3], m[4]), m[5])) > gate;
+        } else {
+            any = false;
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
-                const m_v4i nn = *reinterpret_cast<const m_v4i *>(&tnorm[buf][sub * 32 + 8 * g4 + 4 * h]); /* -|b|^2 */
+                const m_v4i nn = *reinterpret_cast<const m_v4i *>(&tnorm[buf][sub * 32 + 8 * g4 + 4 * h]); /* -|b|^2, four per read */
                 const int nv[4] = {nn.x, nn.y, nn.z, nn.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -133,34 +135,49 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const signed char *__re
                     any = any || sv[4 * g4 + e] > gate;
                 }
             }
-            if (__ballot(any)) {
-                const long long base = t * KNN_TILE + sub * 32 + 4 * h;
+        }
+        if (__ballot(any)) { /* only a wavefront with a hit somewhere enters the insertion code */
+            const long long base = t * KNN_TILE + sub * 32 + 4 * h;
 #pragma unroll
-                for (int g = 0; g < 16; g++) {
-                    const int d = qn - sv[g];
-                    const long long idx = base + (g & 3) + 8 * (g >> 2);
-                    if (d < bd[KK - 1] && idx < n_db) { /* insert behind every entry with a distance <= d (indices arrive ascending) */
-                        int cd = d, ci = (int)idx;
-                        bool shifting = false; /* once the new entry is in, everything behind it moves down one place (a displaced
-                                                * entry that ties with its successor must stay in front of it) */
+            for (int g = 0; g < 16; g++) {
+                const int d = CN ? qn + const_norm - 2 * sv[g] : qn - sv[g];
+                const long long idx = base + (g & 3) + 8 * (g >> 2);
+                if (d < bd[KK - 1] && idx < n_db) { /* insert behind every entry with a distance <= d (indices arrive ascending) */
+                    int cd = d, ci = (int)idx;
+                    bool shifting = false; /* once the new entry is in, everything behind it moves down one place (a displaced
+                                            * entry that ties with its successor must stay in front of it) */
 #pragma unroll
-                        for (int j = 0; j < KK; j++) {
-                            const bool sw = shifting || cd < bd[j];
-                            shifting = sw;
-                            const int td = bd[j], ti = bi[j];
-                            bd[j] = sw ? cd : td;
-                            bi[j] = sw ? ci : ti;
-                            cd = sw ? td : cd;
-                            ci = sw ? ti : ci;
-                        }
+                    for (int j = 0; j < KK; j++) {
+                        const bool sw = shifting || cd < bd[j];
+                        shifting = sw;
+                        const int td = bd[j], ti = bi[j];
+                        bd[j] = sw ? cd : td;
+                        bi[j] = sw ? ci : ti;
+                        cd = sw ? td : cd;
+                        ci = sw ? ti : ci;
                     }
                 }
-                gate = bd[KK - 1] == KNN_BIG ? -KNN_BIG : qn - bd[KK - 1];
             }
+            if (bd[KK - 1] == KNN_BIG) gate = -KNN_BIG;
+            else gate = CN ? (qn + const_norm - bd[KK - 1]) >> 1 : qn - bd[KK - 1]; /* CN: 2 q.b > x  <=>  q.b > floor(x / 2) */
         }
-        if (t + 1 < ntiles) {
-            stash(buf ^ 1); /* the other buffer was last read one iteration ago: every wavefront has passed the barrier below since */
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (long long t = 0; t < ntiles; t++) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < ntiles) fetch(t + 1); /* in flight while this tile is multiplied */
+        /* the matrix cores work on subtile s + 1 while the vector unit looks at the results of subtile s */
+        m_v16i acc0 = gram(buf, 0), acc1;
+#pragma unroll
+        for (int sub = 0; sub < KNN_TILE / 32; sub += 2) {
+            acc1 = gram(buf, sub + 1);
+            take(acc0, buf, sub, t);
+            if (sub + 2 < KNN_TILE / 32) acc0 = gram(buf, sub + 2);
+            take(acc1, buf, sub + 1, t);
         }
+        if (t + 1 < ntiles) stash(buf ^ 1); /* the other buffer was last read one iteration ago: every wavefront has passed the barrier below since */
         __syncthreads();
     }
     if (qok) {
@@ -212,16 +229,27 @@ hipError_t sift3d_launch_knn_norms(hipStream_t s, const signed char *v, int64_t 
 
 int sift3d_knn_list_length(int k) { return k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 0)); }
 
+/* const_norm >= 0: every database vector has this squared norm (the caller checked) */
 hipError_t sift3d_launch_knn(hipStream_t s, const signed char *db, const int *db_norm, int64_t n_db, const signed char *q, const int *q_norm,
-                             int64_t n_q, int k, int *part_d, int *part_i, int *out_i, int *out_d)
+                             int64_t n_q, int k, int const_norm, int *part_d, int *part_i, int *out_i, int *out_d)
 {
     if (n_q <= 0) return hipSuccess;
     const int KK = sift3d_knn_list_length(k);
     if (KK == 0 || k < 1) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n_q + KNN_QWG - 1) / KNN_QWG));
-    if (KK == 8) hipLaunchKernelGGL(knn_search_kernel<8>, grid, dim3(256), 0, s, db, db_norm, (long long)n_db, q, q_norm, (long long)n_q, part_d, part_i);
-    else if (KK == 16) hipLaunchKernelGGL(knn_search_kernel<16>, grid, dim3(256), 0, s, db, db_norm, (long long)n_db, q, q_norm, (long long)n_q, part_d, part_i);
-    else hipLaunchKernelGGL(knn_search_kernel<32>, grid, dim3(256), 0, s, db, db_norm, (long long)n_db, q, q_norm, (long long)n_q, part_d, part_i);
+#define KNN_LAUNCH(KK_, CN_)                                                                                                       \
+    hipLaunchKernelGGL((knn_search_kernel<KK_, CN_>), grid, dim3(256), 0, s, db, db_norm, (long long)n_db, q, q_norm, (long long)n_q, \
+                       const_norm, part_d, part_i)
+    if (const_norm >= 0) {
+        if (KK == 8) KNN_LAUNCH(8, true);
+        else if (KK == 16) KNN_LAUNCH(16, true);
+        else KNN_LAUNCH(32, true);
+    } else {
+        if (KK == 8) KNN_LAUNCH(8, false);
+        else if (KK == 16) KNN_LAUNCH(16, false);
+        else KNN_LAUNCH(32, false);
+    }
+#undef KNN_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, s, part_d, part_i, (long long)n_q, KK, k, out_i, out_d);

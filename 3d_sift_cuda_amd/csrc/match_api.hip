@@ -10,7 +10,7 @@
 
 hipError_t sift3d_launch_knn_norms(hipStream_t s, const signed char *v, int64_t n, int *norms);
 hipError_t sift3d_launch_knn(hipStream_t s, const signed char *db, const int *db_norm, int64_t n_db, const signed char *q, const int *q_norm,
-                             int64_t n_q, int k, int *part_d, int *part_i, int *out_i, int *out_d);
+                             int64_t n_q, int k, int const_norm, int *part_d, int *part_i, int *out_i, int *out_d);
 int sift3d_knn_list_length(int k);
 
 #define KCHK(call)                                                                                       \
@@ -38,12 +38,24 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
         if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments (1 <= k <= 32, 0 < n_db < 2^31)");
         return SIFT3D_ERR_ARG;
     }
-    /* the matrix cores take signed bytes: components must be 0..127 (rank descriptors are 0..63) */
-    for (int64_t i = 0; i < n_db * 64; i++)
-        if (db[i] < 0) {
-            if (err && err_len > 0) snprintf(err, (size_t)err_len, "database component %lld is outside 0..127", (long long)i);
-            return SIFT3D_ERR_ARG;
+    /* the matrix cores take signed bytes: components must be 0..127 (rank descriptors are 0..63).  While looking at every
+     * byte anyway: do all database vectors have one squared norm?  Rank descriptors do (every one a permutation of 0..63),
+     * and the search then needs no arithmetic on its candidates in the common case (knn_search_kernel<KK, true>). */
+    int const_norm = -1;
+    for (int64_t v = 0; v < n_db; v++) {
+        int nrm = 0;
+        for (int j = 0; j < 64; j++) {
+            const int c = db[v * 64 + j];
+            if (c < 0) {
+                if (err && err_len > 0) snprintf(err, (size_t)err_len, "database component %lld is outside 0..127", (long long)(v * 64 + j));
+                return SIFT3D_ERR_ARG;
+            }
+            nrm += c * c;
         }
+        if (v == 0) const_norm = nrm;
+        else if (nrm != const_norm) const_norm = -2;
+    }
+    if (const_norm < 0) const_norm = -1;
     for (int64_t i = 0; i < n_q * 64; i++)
         if (queries[i] < 0) {
             if (err && err_len > 0) snprintf(err, (size_t)err_len, "query component %lld is outside 0..127", (long long)i);
@@ -69,7 +81,7 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
         if (it == 0 && repeats > 1) { /* the first run is a warm-up; time the rest */ }
         KCHK(sift3d_launch_knn_norms(s, d_db, n_db, d_dbn));
         KCHK(sift3d_launch_knn_norms(s, d_q, n_q, d_qn));
-        KCHK(sift3d_launch_knn(s, d_db, d_dbn, n_db, d_q, d_qn, n_q, k, d_pd, d_pi, d_oi, d_od));
+        KCHK(sift3d_launch_knn(s, d_db, d_dbn, n_db, d_q, d_qn, n_q, k, const_norm, d_pd, d_pi, d_oi, d_od));
         if (it == 0 && repeats > 1) KCHK(hipEventRecord(e0, s)); /* timing starts behind the warm-up run */
     }
     KCHK(hipEventRecord(e1, s));
