@@ -1670,6 +1670,27 @@ extern "C" int sift3d_describe_dev(sift3d_ctx *c, const sift3d_level_desc *level
     return SIFT3D_OK;
 }
 
+/* One z-slice of a resident Gaussian level of the last run, dense (nx_o * ny_o floats of octave o): what the reference's
+ * debug output image.pgm shows (fioFeatureSliceXY of octave 0's first blurred level, R/src_common/MultiScale.cpp:373-384). */
+extern "C" int sift3d_get_level_slice(sift3d_ctx *c, int octave, int level, int64_t z, float *out, int64_t *nx_out, int64_t *ny_out)
+{
+    if (!c || !out) return SIFT3D_ERR_ARG;
+    NEED_LEVELS(c);
+    if (!c->has_volume) return set_err(c, SIFT3D_ERR_ARG, "no volume set (sift3d_set_volume)");
+    std::vector<octave_dims> oct = octave_list(c->nx, c->ny, c->nz);
+    if (octave < 0 || (size_t)octave >= oct.size() || level < 0 || level > 4 || !c->L[level])
+        return set_err(c, SIFT3D_ERR_ARG, "no level %d of octave %d", level, octave);
+    const octave_dims &d = oct[(size_t)octave];
+    if (z < 0 || z >= d.Z) return set_err(c, SIFT3D_ERR_ARG, "slice %lld outside 0..%lld", (long long)z, (long long)d.Z - 1);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(out, sizeof(float) * (size_t)d.X, c->L[level] + d.off + z * d.XP * d.Y, sizeof(float) * (size_t)d.XP,
+                               sizeof(float) * (size_t)d.X, (size_t)d.Y, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nx_out) *nx_out = d.X;
+    if (ny_out) *ny_out = d.Y;
+    return SIFT3D_OK;
+}
+
 extern "C" int sift3d_detect(sift3d_ctx *c, float initial_image_scale, sift3d_candidate **out, int64_t *n_out)
 {
     if (!c || !out || !n_out) return SIFT3D_ERR_ARG;

@@ -43,6 +43,66 @@ static int print_options(void)
     return 0;
 }
 
+/* What msGeneratePyramidDOG3D_efficient leaves behind besides its result (R/src_common/MultiScale.cpp): "\n#<microseconds>\n"
+ * after the initial blur (:296-302) and after the first blur of every octave (:386-388), "done.\n" at the end of every octave
+ * (:558), and ./image.pgm, the middle slice of octave 0's first blurred level scaled to 0..255 (:373-384, output_float in
+ * R/src_common/PpImageFloatOutput.cpp:136-166, the 8-bit branch of GenericImage::WriteToFile).  The durations printed here are
+ * the device times of the same blurs. */
+static void reference_side_effects(sift3d_ctx *ctx, int64_t X, int64_t Y, int64_t Z)
+{
+    sift3d_timings tm;
+    int64_t nlog = 0;
+    if (sift3d_get_timings(ctx, &tm) != SIFT3D_OK) return;
+    sift3d_get_launch_log(ctx, NULL, 0, &nlog);
+    sift3d_launch_record *log = (sift3d_launch_record *)calloc((size_t)(nlog > 0 ? nlog : 1), sizeof *log);
+    if (!log) return;
+    sift3d_get_launch_log(ctx, log, nlog, &nlog);
+    /* blur launches in issue order, grouped into filter calls: one fused launch, or an x, y, z triple; the octave of a
+     * call shows in its voxel count; an octave built whole by one workgroup is one call */
+    int printed_initial = 0, octaves_seen = 0;
+    int64_t last_vox = -1;
+    for (int64_t i = 0; i < nlog; i++) {
+        const int st = log[i].stage;
+        double us = 0;
+        int64_t vox = log[i].nvox;
+        if (st == SIFT3D_STAGE_BLUR_FUSED || st == SIFT3D_STAGE_OCTAVE_TINY) us = log[i].ms * 1e3;
+        else if (st == SIFT3D_STAGE_BLUR_X && i + 2 < nlog && log[i + 1].stage == SIFT3D_STAGE_BLUR_Y && log[i + 2].stage == SIFT3D_STAGE_BLUR_Z_DOG) {
+            us = (log[i].ms + log[i + 1].ms + log[i + 2].ms) * 1e3;
+            i += 2;
+        } else
+            continue;
+        if (!printed_initial) { /* the initial blur is the first call */
+            printf("\n#%lld\n", (long long)us);
+            printed_initial = 1;
+            continue;
+        }
+        if (vox != last_vox) { /* the first blur of an octave */
+            if (octaves_seen > 0) printf("done.\n");
+            printf("\n#%lld\n", (long long)us);
+            last_vox = vox;
+            octaves_seen++;
+        }
+    }
+    if (octaves_seen > 0) printf("done.\n");
+    free(log);
+    /* image.pgm */
+    float *slice = (float *)malloc(sizeof(float) * (size_t)(X * Y));
+    if (slice && sift3d_get_level_slice(ctx, 0, 1, Z / 2, slice, NULL, NULL) == SIFT3D_OK) {
+        float lo = slice[0], hi = slice[0];
+        for (int64_t i = 0; i < X * Y; i++) {
+            if (slice[i] > hi) hi = slice[i];
+            if (slice[i] < lo) lo = slice[i];
+        }
+        FILE *f = fopen("image.pgm", "wb");
+        if (f) {
+            fprintf(f, "P5\n%d %d\n%d\n", (int)X, (int)Y, 255);
+            for (int64_t i = 0; i < X * Y; i++) fputc((unsigned char)(((slice[i] - lo) * 255.0) / (hi - lo)), f);
+            fclose(f);
+        }
+    }
+    free(slice);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 3) {
@@ -195,12 +255,14 @@ int main(int argc, char **argv)
         t1 = now_s();
         if (times) fprintf(stderr, "# upload: %.3f s\n", t1 - t0);
         t0 = t1;
+        if (rc == SIFT3D_OK) rc = sift3d_enable_timing(ctx, 1); /* the reference prints how long its first blurs took */
         if (rc == SIFT3D_OK) rc = sift3d_extract(ctx, initial_scale, desc_mode, eig_thres, size_factor, &feats, &n);
         if (rc != SIFT3D_OK) {
             fprintf(stderr, "sift3d: %s\n", sift3d_last_error(ctx));
             printf("Error: could not extract features, insufficient memory.\n");
             return -1;
         }
+        reference_side_effects(ctx, PX, PY, PZ);
     }
 
     t1 = now_s();

@@ -180,6 +180,11 @@ int sift3d_detect(sift3d_ctx *ctx, float initial_image_scale, sift3d_candidate *
  * eig_thres: 140 in featExtract.cpp:297.  *out is malloc'ed (sift3d_free). */
 int sift3d_extract(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
                    sift3d_feature **out, int64_t *n_out);
+/* One z-slice of Gaussian level `level` (0..4) of octave `octave` as the last sift3d_detect / sift3d_extract left it, copied
+ * to the host as a dense nx_o * ny_o array (out must hold the octave's plane; *nx_out / *ny_out, which may be NULL, receive
+ * its size).  For the reference's debug output ./image.pgm: the middle slice of octave 0's first blurred level
+ * (R/src_common/MultiScale.cpp:373-384), which the featExtract command line of this build writes as the reference does. */
+int sift3d_get_level_slice(sift3d_ctx *ctx, int octave, int level, int64_t z, float *out, int64_t *nx_out, int64_t *ny_out);
 /* Beyond the reference: stop the pyramid after n octaves.  n = 0 restores the reference's only
  * rule -- halve until a dimension is <= 2 (R/src_common/MultiScale.cpp:337,359-360) -- which is also the default; the
  * command line has no such option and never sets it.  Records are ordered octave-major, so a limited run returns

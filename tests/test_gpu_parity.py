@@ -462,6 +462,32 @@ def test_cli_key_file_is_byte_identical(built, oracle, tmp_path):
     assert open(k1, "rb").read() == open(k2, "rb").read() and len(open(k1).readlines()) > 8
 
 
+def test_cli_side_effects_of_the_reference(built, oracle, tmp_path):
+    """What the reference's pyramid leaves behind besides its result (MultiScale.cpp:296-302,373-388,558): a '#<microseconds>'
+    line after the initial blur and after the first blur of every octave, 'done.' per octave, and ./image.pgm -- the middle
+    slice of octave 0's first blurred level, scaled to 0..255 (checked here against the oracle's level)."""
+    dims = (64, 56, 48)
+    vol = vol_of(built, dims, 17)
+    nii = str(tmp_path / "in.nii")
+    built.write_nifti(nii, vol)
+    r = subprocess.run([built.FEATEXTRACT, "-d0", nii, str(tmp_path / "o.key")], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.split("\n")
+    n_oct = 5                                                            # 64 x 56 x 48 halves to 4 x 3 x 3
+    timers = [l for l in lines if l.startswith("#")]
+    assert len(timers) == 1 + n_oct and all(l[1:].isdigit() for l in timers)
+    assert lines.count("done.") == n_oct
+    assert lines.index("Input image: i=64 j=56 k=48") < lines.index(timers[0]) and r.stdout.endswith("\nDone.\n")
+    pgm = open(tmp_path / "image.pgm", "rb").read()
+    head = b"P5\n64 56\n255\n"
+    assert pgm.startswith(head) and len(pgm) == len(head) + 64 * 56
+    l0 = oracle.blur(vol, 1.5198684930801392)
+    l1 = oracle.blur(l0, 1.2262736558914185)[dims[2] // 2]
+    lo, hi = np.float32(l1.min()), np.float32(l1.max())
+    want = (((l1 - lo).astype(np.float64) * 255.0) / np.float64(hi - lo)).astype(np.uint8)
+    assert (np.frombuffer(pgm[len(head):], np.uint8).reshape(56, 64) == want).all()
+
+
 @pytest.mark.parametrize("flag", ["-w", "-ws"])
 def test_cli_world_coordinates(built, tmp_path, flag):
     """-w / -ws on an anisotropic volume with distinct qform and sform: byte-identical to the oracle's .key."""
@@ -884,7 +910,10 @@ def test_cli_several_devices(built, tmp_path):
         r2 = subprocess.run([built.FEATEXTRACT, "-d0,0"] + flags + [src, k2], capture_output=True, text=True,
                             env=dict(os.environ, SIFT3D_CLI_TIMES="1"))
         assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
-        assert r1.stdout == r2.stdout and r2.stdout.endswith("\nDone.\n")
+        # the same lines but for the pyramid's debug output ('#<microseconds>' / 'done.' per octave), which only the
+        # single-device run has a pyramid of its own to print for
+        core = lambda out: [l for l in out.split("\n") if l and not l.startswith("#") and l != "done."]
+        assert core(r1.stdout) == core(r2.stdout) and r2.stdout.endswith("\nDone.\n")
         assert "# z-slabs: 2 ranks" in r2.stderr
         assert open(k1, "rb").read() == open(k2, "rb").read() and len(open(k1).readlines()) > 20
     r = subprocess.run([built.FEATEXTRACT, "-d0,7", nii, str(tmp_path / "x.key")], capture_output=True, text=True)
