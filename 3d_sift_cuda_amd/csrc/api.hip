@@ -5,13 +5,23 @@
  *
  * Schedule = msGeneratePyramidDOG3D_efficient (R/src_common/MultiScale.cpp:236-570,
  * R/ = /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/): initial
- * blur to sigma 1.6, then per octave five blurs L1..L5 (sigma ratio 2^(1/3)),
+ * blur to sigma 1.6, then per octave the levels L1..L5 (sigma ratio 2^(1/3)),
  * DoG k = L_k - L_{k+1} for k = 0..4, extrema in DoG 1..3, keypoints sampled
  * from L_k, next octave seeded by the 2x2x2 mean of L_3.  The reference
- * recycles five buffers and validates "on the fly"; here all six Gaussians
- * and five DoGs of an octave stay resident in HBM (13.1 N floats in total:
- * 288 GB holds a 1024^3 volume four times over), so each level is produced by
- * exactly one x, one y and one z(+DoG) pass and read by one extrema pass.
+ * recycles five buffers and validates "on the fly"; here the levels something
+ * reads in full -- L0..L4 and D1..D3 of every octave -- stay resident in HBM
+ * (13.4 N floats with the intermediates: 288 GB holds a 1024^3 volume five
+ * times over), each produced by one fused x + y + z + DoG launch where the
+ * volume fills the chip (three launches on coarse octaves) and read by one
+ * extrema pass; D0, D4 and L5 are evaluated only around the candidates
+ * (DESIGN.md section 4).  Nothing leaves the device between the upload of the
+ * volume and the records, which the descriptor kernel stores straight into
+ * pinned host memory.
+ *
+ * Layout of this file: context and tuning; timing; operator-level entry points;
+ * candidate lists (reset / append / finalize); the per-keypoint stage in three
+ * phases (describe_queue / _launch / _finish); run_pipeline; the slab building
+ * blocks of the C-ABI; the one-process Z-slab driver (sift3d_zslab_*).
  */
 #include <algorithm>
 #include <chrono>
@@ -63,7 +73,6 @@ struct octave_dims {
 struct sift3d_ctx {
     int device;
     hipStream_t stream;
-    hipStream_t copy_stream;   /* record download, overlapped with the descriptor launches */
     hipStream_t ex_stream;     /* extrema detection of an octave, overlapped with the blurs of the coarser octaves */
     hipStream_t cand_stream;   /* where cand_append launches: stream, or ex_stream inside run_pipeline */
     hipStream_t ex_stream2;    /* extrema of the octaves after the first */
@@ -253,7 +262,7 @@ static int alloc_cands(sift3d_ctx *c, int64_t cap)
 
 static void destroy_sync_objects(sift3d_ctx *c)
 {
-    hipStream_t streams[] = {c->copy_stream, c->ex_stream, c->ex_stream2, c->kp_stream};
+    hipStream_t streams[] = {c->ex_stream, c->ex_stream2, c->kp_stream};
     for (hipStream_t st : streams)
         if (st) {
             hipStreamSynchronize(st);
@@ -290,7 +299,7 @@ static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bo
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    hipStream_t *streams[] = {&c->copy_stream, &c->ex_stream, &c->ex_stream2, &c->kp_stream};
+    hipStream_t *streams[] = {&c->ex_stream, &c->ex_stream2, &c->kp_stream};
     for (hipStream_t *st : streams) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
     hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1]};
     for (hipEvent_t *e : events) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
