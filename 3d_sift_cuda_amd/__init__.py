@@ -140,6 +140,7 @@ def hip_lib():
     _sig(L.sift3d_zslab_extract, I, P, P, F, I, F, F, P, P, P, C.c_char_p, I64)
     _sig(L.sift3d_zslab_destroy, None, P)
     _sig(L.sift3d_knn64, I, I, P, I64, P, I64, I, P, P, I, P, C.c_char_p, I64)
+    _sig(L.sift3d_get_level_slice, I, P, I, I, I64, P, P, P)
     _hip = L
     return L
 

@@ -80,6 +80,44 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows):
         assert (log["stage"] == built.STAGES.index("blur_fused")).all()   # the fused kernel is what ran
 
 
+@pytest.mark.parametrize("dims", [(64, 48, 40), (132, 70, 33), (256, 8, 24)])
+def test_windowed_blur_writes_exactly_its_planes(built, oracle, dims):
+    """sift3d_gauss_blur_dog_window_dev (what a Z-slab rank filters its boundary bands with): the planes of the window are the
+    full blur's planes bit for bit -- level and DoG -- for windows at the faces, in the middle, of one plane and of the whole
+    volume, with one and several z chunks and both thread mappings; every plane outside the window keeps what it held."""
+    import torch
+    nx, ny, nz = dims
+    vol = vol_of(built, dims, 9) - np.float32(2.0)
+    with built.Context(*dims) as ctx:
+        d_in = torch.from_numpy(vol).cuda()
+        torch.cuda.synchronize()
+        for sigma in (SIGMAS[2], SIGMAS[4], SIGMAS[6], SIGMAS[7]):        # 7, 9, 13, 17 taps
+            assert ctx.blur_window_supported(nx, ny, sigma)
+            want = oracle.blur(vol, sigma)
+            want_dog = oracle.dog(vol, want)
+            for (lo, hi), chunks, rows in (((0, 5), 0, 0), ((nz - 3, nz), 2, 1), ((7, 8), 0, 2), ((4, nz - 6), 3, 0), ((0, nz), 0, 0)):
+                ctx.set_tuning(built.TUNE_FUSED_CHUNKS, chunks)
+                ctx.set_tuning(built.TUNE_FUSED_ROWS, rows)
+                d_out = torch.full_like(d_in, 123.0)
+                d_dog = torch.full_like(d_in, -321.0)
+                torch.cuda.synchronize()
+                ctx.gauss_blur_dog_window_dev(d_in.data_ptr(), d_out.data_ptr(), d_dog.data_ptr(), nx, ny, nz, lo, hi, sigma)
+                ctx.sync()
+                o, g = d_out.cpu().numpy(), d_dog.cpu().numpy()
+                assert (bits(o[lo:hi]) == bits(want[lo:hi])).all() and (bits(g[lo:hi]) == bits(want_dog[lo:hi])).all(), (sigma, lo, hi)
+                assert (o[:lo] == 123.0).all() and (o[hi:] == 123.0).all() and (g[:lo] == -321.0).all() and (g[hi:] == -321.0).all()
+        assert not ctx.blur_window_supported(nx + 1, ny, SIGMAS[2])        # rows that are not whole 16-byte vectors
+        with pytest.raises(built.Sift3DError):
+            ctx.gauss_blur_dog_window_dev(d_in.data_ptr(), d_in.data_ptr(), 0, nx, ny, nz, 3, 3, SIGMAS[2])
+        # the slice accessor of the command line's image.pgm
+        ctx.set_volume(vol)
+        ctx.detect()
+        sl = np.empty((ny, nx), np.float32)
+        from ctypes import c_void_p
+        rc = built.hip_lib().sift3d_get_level_slice(c_void_p(ctx.handle), 0, 0, nz // 2, c_void_p(sl.ctypes.data), None, None)
+        assert rc == 0 and (bits(sl) == bits(oracle.blur(vol, SIGMAS[3])[nz // 2])).all()
+
+
 def test_dev_entry_points_are_ordered_with_the_default_stream(built, oracle):
     """A caller on the default stream (torch's, and the reference's own) needs no synchronisation around the *_dev entry
     points: the input is still being produced by queued torch kernels when sift3d_gauss_blur_dog_dev is called, and torch
