@@ -1327,12 +1327,15 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
         const int ytiles_m = (int)((Y - 2 + EXM_ROWS - 1) / EXM_ROWS), ygroups = (ytiles_m + 3) / 4;
         const long long waves_m = (long long)xtiles_m * ytiles_m;
         const long long plane_bytes = X * Y * 4;
+        /* the longest chunk that still gives the chip 2 048 wavefronts (two per SIMD: what the kernel's registers allow) --
+         * 512^3: 64 planes, 256^3: 8 --, else the longest that gives 512 (128^3: 8); below that the plane-per-block form */
         int zchunk = 1;
-        for (int zc = 64; zc >= 8; zc /= 2)
-            if (waves_m * ((z1 - z0 + zc - 1) / zc) >= 4096 && (zc + 2) * plane_bytes < (1ll << 32)) {
-                zchunk = zc;
-                break;
-            }
+        for (int need = 2048; need >= 512 && zchunk == 1; need /= 4)
+            for (int zc = 64; zc >= 8; zc /= 2)
+                if (waves_m * ((z1 - z0 + zc - 1) / zc) >= need && (zc + 2) * plane_bytes < (1ll << 32)) {
+                    zchunk = zc;
+                    break;
+                }
         const unsigned nz = (unsigned)((z1 - z0 + zchunk - 1) / zchunk);
         const int nseg = ex_segments_in_use(nz);
         const long long segcap = surv_cap / nseg; /* entries per segment of the own-level list */
