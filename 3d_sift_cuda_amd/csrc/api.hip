@@ -1383,6 +1383,15 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         c->cand_stream = exs;
         c->surv_sel = (exs != c->stream && which == 1) ? 1 : 0;
         int rc_ = SIFT3D_OK;
+        /* an octave one workgroup built whole (at most 4 096 voxels, every DoG level stored): its three detection levels in one
+         * launch; the per-level jobs are recorded all the same, for a replay after a list overflow */
+        const bool small_octave = pl.tiny_done && pl.d4tiny;
+        if (small_octave) {
+            const float *dl[5] = {c->D[0] + d.off, c->D[1] + d.off, c->D[2] + d.off, c->D[3] + d.off, pl.d4tiny};
+            stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 12.0 * (double)d.XP * d.Y * d.Z, 0, d.XP * d.Y * d.Z, exs);
+            HIPCHK(c, sift3d_launch_extrema_octave_small(exs, dl, d.XP, d.X, d.Y, d.Z, (int)o * 3, c->keys_a, c->vals_a, c->d_count, c->cand_cap));
+            c->count_queued = false;
+        }
         for (int l = 0; l < 3 && !rc_; l++) {
             const int id = (int)o * 3 + l;
             const float *dnext = l < 2 ? c->D[l + 2] + d.off : (pl.tiny_done ? pl.d4tiny : (pl.lazy_next ? nullptr : c->D[4] + d.off));
@@ -1397,7 +1406,8 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 job.next_ntaps = pl.next_ntaps;
                 for (int q = 0; q < pl.next_ntaps; q++) job.next_taps[q] = pl.next_taps[q];
             }
-            rc_ = cand_append(c, job, true);
+            if (small_octave) c->jobs.push_back(job);
+            else rc_ = cand_append(c, job, true);
             sift3d_level &lv = levels[(size_t)id];
             lv.img = c->L[l + 1] + d.off;
             lv.dogc = c->D[l + 1] + d.off;

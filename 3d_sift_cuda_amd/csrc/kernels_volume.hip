@@ -988,16 +988,41 @@ __global__ __launch_bounds__(64) void extrema_validate_lazy_kernel(const float *
 }
 
 /* Fallback for row lengths that are not a multiple of 4 (no aligned 16-byte rows) and for tiny volumes:
- * lanes along x, 27 direct loads per voxel, wavefront-wide early-out. */
+ * lanes along x, 27 direct loads per voxel, wavefront-wide early-out.  The body serves one detection level; the second
+ * kernel below runs the three detection levels of an octave in one launch (blockIdx.z = level * planes + plane). */
+__device__ __forceinline__ void extrema_generic_body(const float *__restrict__ dprev, const float *__restrict__ dcur,
+                                                     const float *__restrict__ dnext, int X, int Xl, int Y, int z, int lvl_id,
+                                                     unsigned long long *__restrict__ keys, sift3d_cval *__restrict__ vals,
+                                                     unsigned long long *count, long long cap);
+
 __global__ __launch_bounds__(256) void extrema_generic_kernel(const float *__restrict__ dprev, const float *__restrict__ dcur,
                                                       const float *__restrict__ dnext, int X, int Xl, int Y, int Z, int z_first,
                                                       int lvl_id, unsigned long long *__restrict__ keys,
                                                       sift3d_cval *__restrict__ vals, unsigned long long *count,
                                                       long long cap)
 {
+    extrema_generic_body(dprev, dcur, dnext, X, Xl, Y, (int)blockIdx.z + z_first, lvl_id, keys, vals, count, cap);
+}
+
+struct ex_octave5 {
+    const float *d[5]; /* the five DoG levels of an octave: detection level l tests d[l + 1] against d[l] and d[l + 2] */
+};
+__global__ __launch_bounds__(256) void extrema_generic_octave_kernel(ex_octave5 o, int X, int Xl, int Y, int Z, int lvl_id0,
+                                                                     unsigned long long *__restrict__ keys,
+                                                                     sift3d_cval *__restrict__ vals, unsigned long long *count,
+                                                                     long long cap)
+{
+    const int planes = Z - 2, l = (int)blockIdx.z / planes, z = 1 + (int)blockIdx.z % planes;
+    extrema_generic_body(o.d[l], o.d[l + 1], o.d[l + 2], X, Xl, Y, z, lvl_id0 + l, keys, vals, count, cap);
+}
+
+__device__ __forceinline__ void extrema_generic_body(const float *__restrict__ dprev, const float *__restrict__ dcur,
+                                                     const float *__restrict__ dnext, int X, int Xl, int Y, int z, int lvl_id,
+                                                     unsigned long long *__restrict__ keys, sift3d_cval *__restrict__ vals,
+                                                     unsigned long long *count, long long cap)
+{
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z + z_first;
     const bool inside = (x >= 1 && x < Xl - 1 && y >= 1 && y < Y - 1);
     const long long XY = (long long)X * Y;
     const long long idx = (long long)z * XY + (long long)y * X + x;
@@ -1315,6 +1340,22 @@ static void launch_validate_lazy(hipStream_t s, const sift3d_extrema_lazy &lz, i
     if (wgs > lz.list2_cap) wgs = lz.list2_cap;
     hipLaunchKernelGGL(extrema_validate_lazy_kernel<R>, dim3((unsigned)wgs), dim3(64), 0, s, lz.next_g, (int)X, (int)Xl, (int)Y, (int)Z,
                        lz.list2, lz.list2_count, (long long)(lz.list2_cap / nseg), lvl_id, keys, vals, count, (long long)cap, t);
+}
+
+/* The three detection levels of an octave of at most SIFT3D_TINY_VOX voxels, all five DoG levels stored, in one launch
+ * (the per-level path is two to three launches per level: fifteen small launches at the very end of the pyramid's chain
+ * for the three smallest octaves of a 512^3 volume). */
+hipError_t sift3d_launch_extrema_octave_small(hipStream_t s, const float *const d[5], int64_t X, int64_t Xl, int64_t Y, int64_t Z,
+                                              int lvl_id0, unsigned long long *keys, sift3d_cval *vals, unsigned long long *count,
+                                              int64_t cap)
+{
+    if (Xl < 3 || Y < 3 || Z < 3) return hipSuccess;
+    ex_octave5 o;
+    for (int i = 0; i < 5; i++) o.d[i] = d[i];
+    dim3 grid((unsigned)((X + 63) / 64), (unsigned)((Y + 3) / 4), (unsigned)(3 * (Z - 2)));
+    hipLaunchKernelGGL(extrema_generic_octave_kernel, grid, dim3(256), 0, s, o, (int)X, (int)Xl, (int)Y, (int)Z, lvl_id0, keys, vals, count,
+                       (long long)cap);
+    return hipGetLastError();
 }
 
 hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float *dcur, const float *dnext, int64_t X,

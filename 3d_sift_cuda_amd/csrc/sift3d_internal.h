@@ -111,6 +111,10 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
                                  unsigned long long *surv_count /* SIFT3D_SURV_COUNTERS words */,
                                  unsigned long long *surv_overflow, int64_t surv_cap, bool zero_counters,
                                  const sift3d_extrema_lazy *lazy = nullptr);
+/* the three detection levels of an octave of at most SIFT3D_TINY_VOX voxels (d[0..4]: its five stored DoG levels) in one launch */
+hipError_t sift3d_launch_extrema_octave_small(hipStream_t s, const float *const d[5], int64_t X, int64_t Xl, int64_t Y, int64_t Z,
+                                              int lvl_id0, unsigned long long *keys, sift3d_cval *vals, unsigned long long *count,
+                                              int64_t cap);
 #define SIFT3D_SURV_SETS 96 /* one counter set per extrema pass of a pipeline run, zeroed together */
 #define SIFT3D_SURV_COUNTERS (64 * 32)
 #define SIFT3D_LIST2_COUNTERS 64
