@@ -742,10 +742,22 @@ def test_config_c3_flags_bit_exact(built, oracle):
     assert _compare_records(got, want)
 
 
+def _oracle_on_all_cores():
+    """The OpenMP build of the CPU restatement, for the full-size configurations: its records are the serial library's byte
+    for byte (tests/test_oracle_pins.py holds it to that), and it finishes a 2^30-voxel volume in about a minute where the
+    serial build needs three.  None when the box has less than 80 GB of free host memory."""
+    import psutil
+    if psutil.virtual_memory().available < 80 * 2 ** 30:
+        return None
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
+    import _oracle
+    return _oracle.load_omp()
+
+
 def test_config_c3_full_size(built):
-    """BASELINE config C3 at its own size: 512^3 float32, -2+ (processing size 1024^3 = 2^30 voxels), BRIEF, one GPU.
-    The oracle needs minutes and 30 GB for this, so: size-independent properties, idempotence, and the octave-0 volume
-    checked against the doubling rule on a sample of voxels."""
+    """BASELINE config C3 at its own size: 512^3 float32, -2+ (processing size 1024^3 = 2^30 voxels), BRIEF, one GPU:
+    size-independent properties, idempotence, and -- round 3 -- every record against the CPU restatement run on all host
+    cores (about a minute and 40 GB of host memory)."""
     import torch
     free, _ = torch.cuda.mem_get_info()
     if free < 90 * 2 ** 30:
@@ -758,6 +770,10 @@ def test_config_c3_full_size(built):
         t = ctx.timings()
         assert t["n_octaves"] == 9 and t["n_extrema"] > 50000 and len(f) > 200000
         _record_properties(f, (n, n, n))
+        orc = _oracle_on_all_cores()
+        if orc is not None:
+            want, _ = orc.extract(orc.double_size(vol), init_scale=0.5, desc_mode=1, size_factor=0.5)
+            assert _compare_records(f, want), "float fields are within 1e-4 but not bit-identical"
         again = ctx.extract(initial_image_scale=0.5, desc_mode=built.DESC_BRIEF, size_factor=0.5)
         assert (again.view(np.uint8) == f.view(np.uint8)).all()             # idempotent
         # the SIFT-rank run of the same volume finds the same keypoints (the descriptor mode only changes desc)
@@ -769,8 +785,9 @@ def test_config_c3_full_size(built):
 
 
 def test_config_c4_volume_single_gpu(built):
-    """The volume of BASELINE config C4 (1024 x 1024 x 512, 2^29 voxels) on one GPU: properties and idempotence.  The
-    four-slab split of the same volume is the next test; its merged records must be these bytes."""
+    """The volume of BASELINE config C4 (1024 x 1024 x 512, 2^29 voxels) on one GPU: properties, idempotence and -- round 3 --
+    every record against the CPU restatement run on all host cores.  The four-slab split of the same volume is the next test;
+    its merged records must be these bytes."""
     import torch
     free, _ = torch.cuda.mem_get_info()
     if free < 60 * 2 ** 30:
@@ -783,6 +800,10 @@ def test_config_c4_volume_single_gpu(built):
         t = ctx.timings()
         assert t["n_octaves"] == 8 and len(f) > 500000
         _record_properties(f, dims)
+        orc = _oracle_on_all_cores()
+        if orc is not None:
+            want, _ = orc.extract(vol)
+            assert _compare_records(f, want), "float fields are within 1e-4 but not bit-identical"
         again = ctx.extract()
         assert (again.view(np.uint8) == f.view(np.uint8)).all()
         cands = ctx.detect()
@@ -911,6 +932,11 @@ def test_config_c5_plane_size_on_one_gpu(built):
         t = ctx.timings()
     assert t["n_octaves"] == 7 and len(want) > 500000
     _record_properties(want, dims, rank_desc=False)
+    orc = _oracle_on_all_cores()
+    if orc is not None:                                                     # and the CPU restatement agrees, record by record
+        cpu, _ = orc.extract(vol, desc_mode=3)
+        assert _compare_records(want, cpu), "float fields are within 1e-4 but not bit-identical"
+        del cpu
     # keypoints in the far corner of the volume exist (indices beyond 2^31 bytes into a level were addressed)
     assert ((want["z"] > 200) & (want["y"] > 1800) & (want["x"] > 1800)).any()
     got, st = built.extract_zslab(vol, [0, 0], desc_mode=built.DESC_NRRIEF)
