@@ -105,11 +105,11 @@ struct fb_ring_cfg {
     static constexpr int XW = (NR + RPW - 1) / RPW;             /* wavefronts with an x-pass role */
     static constexpr int P1ROWS = XW * RPW;                     /* rows those wavefronts write (>= NR; the surplus rows are never read) */
     static constexpr int S = R + 2;                /* DoG-input ring: written for plane z+1 while plane z-R is read */
-    /* SINGLE: the configuration meant to run one workgroup per CU (two rows per thread, two planes of prefetch).  Its
+    /* SINGLE: the configuration meant to run one workgroup per CU (two rows per thread, two or three planes of prefetch).  Its
      * LDS request is padded past half of the CU's 160 KiB so that a second workgroup can never become resident, also on
      * volumes with more tiles than CUs: two resident workgroups with two planes in flight each stream markedly slower
      * (0.38 against 0.315 ms per 7-tap launch at 512^3). */
-    static constexpr bool SINGLE = PF == 2 && BR == 2;
+    static constexpr bool SINGLE = PF >= 2 && BR == 2;
     static constexpr int LDS_NEEDED = 2 * P1ROWS * FB_TX + S * TY * FB_TX;
     static constexpr int LDS_FLOATS = (SINGLE && LDS_NEEDED < 21 * 1024) ? 21 * 1024 : LDS_NEEDED;
     /* workgroups per CU the LDS allows (160 KiB), capped at what 32 wavefronts per CU allow */
@@ -286,11 +286,16 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
      * giving them issue priority over the wavefronts that share their SIMD, s_setprio 2, changed nothing: 0.390 against
      * 0.387 - 0.395 ms at 17 taps.  They are not short of issue slots.) */
     using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, PF - 1>;
-    if (xrole) {
+    using B1 = std::integral_constant<int, 1 % PF>;
+    using B2 = std::integral_constant<int, 2 % PF>;
+    if (xrole) { /* plane zfirst + k lives in window buffer k % PF */
         load_window(zfirst, B0{});
         x_pass(P1b, pvb, B0{});        /* plane zfirst (zeros when it lies before the volume) */
-        if constexpr (PF == 2) {
+        if constexpr (PF == 3) {
+            load_window(zfirst + 1, B1{});
+            load_window(zfirst + 2, B2{});
+            load_window(zfirst + 3, B0{});
+        } else if constexpr (PF == 2) {
             load_window(zfirst + 1, B1{});
             load_window(zfirst + 2, B0{});
         } else {
@@ -366,7 +371,16 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
         lds_barrier(); /* the other P1 buffer and the ring slot are complete, every wavefront has read this P1 buffer */
     };
     /* the first 2R steps are lead-in: their stores are dropped */
-    if constexpr (PF == 2) {
+    if constexpr (PF == 3) {
+        int zin = zfirst;
+        for (; zin + 2 <= zlast; zin += 3) {
+            step(zin, B1{});
+            step(zin + 1, B2{});
+            step(zin + 2, B0{});
+        }
+        if (zin <= zlast) step(zin, B1{});
+        if (zin + 1 <= zlast) step(zin + 1, B2{});
+    } else if constexpr (PF == 2) {
         int zin = zfirst;
         for (; zin + 1 <= zlast; zin += 2) {
             step(zin, B1{});     /* plane zfirst + 1 went to buffer 1 */
@@ -450,6 +464,11 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     const int br = forced == 1 || forced == 2 ? forced : ((R >= 7 || X * Y * (zo1 - zo0) < (1ll << 22)) ? 1 : 2);
     const int chunks = tune ? tune->z_chunks : 0;
     if (br == 1) return launch_ring_pf<R, 1, 1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    /* three planes of window prefetch where the registers are there and only one array is stored (7 and 9 taps, level
+     * only: 0.213 / 0.224 ms at 512^3 against 0.225 - 0.232 / 0.233 - 0.237 with two; with the DoG store beside it three planes
+     * change nothing: 0.324 / 0.338 against 0.328 / 0.334 - 0.342; four planes, level only: 0.225 / 0.220, no better than three) */
+    if constexpr (R <= 4)
+        if (!(out && dog)) return launch_ring_pf<R, 2, 3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
     return launch_ring_pf<R, 2, 2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
 }
 
