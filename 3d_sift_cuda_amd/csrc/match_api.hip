@@ -10,8 +10,9 @@
 
 hipError_t sift3d_launch_knn_norms(hipStream_t s, const signed char *v, int64_t n, int *norms);
 hipError_t sift3d_launch_knn(hipStream_t s, const signed char *db, const int *db_norm, int64_t n_db, const signed char *q, const int *q_norm,
-                             int64_t n_q, int k, int const_norm, int *part_d, int *part_i, int *out_i, int *out_d);
+                             int64_t n_q, int k, int const_norm, int groups, int segments, int *part_d, int *part_i, int *out_i, int *out_d);
 int sift3d_knn_list_length(int k);
+void sift3d_knn_plan(int64_t n_db, int64_t n_q, int k, int *groups, int *segments);
 
 #define KCHK(call)                                                                                       \
     do {                                                                                                 \
@@ -34,6 +35,7 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
     if (err && err_len > 0) err[0] = 0;
     if (kernel_ms) *kernel_ms = 0.0;
     const int KK = sift3d_knn_list_length(k);
+    int groups = 1, segments = 1;
     if (!db || !queries || !idx || !dist2 || n_db <= 0 || n_q <= 0 || k < 1 || KK == 0 || n_db >= (1ll << 31)) {
         if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments (1 <= k <= 32, 0 < n_db < 2^31)");
         return SIFT3D_ERR_ARG;
@@ -62,6 +64,7 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
             return SIFT3D_ERR_ARG;
         }
     if (repeats < 1) repeats = 1;
+    sift3d_knn_plan(n_db, n_q, k, &groups, &segments);
     KCHK(hipSetDevice(device));
     KCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     KCHK(hipEventCreate(&e0));
@@ -70,8 +73,8 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
     KCHK(hipMalloc((void **)&d_q, (size_t)n_q * 64));
     KCHK(hipMalloc((void **)&d_dbn, sizeof(int) * (size_t)n_db));
     KCHK(hipMalloc((void **)&d_qn, sizeof(int) * (size_t)n_q));
-    KCHK(hipMalloc((void **)&d_pd, sizeof(int) * (size_t)n_q * 2 * KK));
-    KCHK(hipMalloc((void **)&d_pi, sizeof(int) * (size_t)n_q * 2 * KK));
+    KCHK(hipMalloc((void **)&d_pd, sizeof(int) * (size_t)n_q * 2 * segments * KK));
+    KCHK(hipMalloc((void **)&d_pi, sizeof(int) * (size_t)n_q * 2 * segments * KK));
     KCHK(hipMalloc((void **)&d_oi, sizeof(int) * (size_t)n_q * k));
     KCHK(hipMalloc((void **)&d_od, sizeof(int) * (size_t)n_q * k));
     KCHK(hipMemcpyAsync(d_db, db, (size_t)n_db * 64, hipMemcpyHostToDevice, s));
@@ -81,7 +84,7 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
         if (it == 0 && repeats > 1) { /* the first run is a warm-up; time the rest */ }
         KCHK(sift3d_launch_knn_norms(s, d_db, n_db, d_dbn));
         KCHK(sift3d_launch_knn_norms(s, d_q, n_q, d_qn));
-        KCHK(sift3d_launch_knn(s, d_db, d_dbn, n_db, d_q, d_qn, n_q, k, const_norm, d_pd, d_pi, d_oi, d_od));
+        KCHK(sift3d_launch_knn(s, d_db, d_dbn, n_db, d_q, d_qn, n_q, k, const_norm, groups, segments, d_pd, d_pi, d_oi, d_od));
         if (it == 0 && repeats > 1) KCHK(hipEventRecord(e0, s)); /* timing starts behind the warm-up run */
     }
     KCHK(hipEventRecord(e1, s));

@@ -354,6 +354,9 @@ int sift3d_get_launch_log(const sift3d_ctx *ctx, sift3d_launch_record *out, int6
 /* Development builds only (make DEV=1; tools/kp_ablate.py, tools/desc_ablate.py): the per-keypoint kernels return after
  * stage n (0 = run everything).  Not compiled into the product library. */
 int sift3d_dev_set_stop(sift3d_ctx *ctx, int n);
+/* Development builds only (tools/bench_match.py with KNN_PLAN=groups,segments): overrides how sift3d_knn64 cuts a search
+ * (0 = the library's own choice). */
+void sift3d_dev_knn_plan(int groups, int segments);
 #endif
 
 #ifdef __cplusplus
