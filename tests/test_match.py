@@ -83,6 +83,62 @@ def test_knn_is_exact(built, oracle, n_db, n_q, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [3, 8, 20])
+def test_knn_when_every_row_is_a_candidate(built, oracle, k):
+    """The order a search likes least: every database row is nearer to the queries than all rows before it, so every row beats
+    the running k-th distance (the lanes' queues are full all the time and candidates go straight into the lists); the
+    second half of the database repeats rows of the first (ties between the two lanes of a pair, resolved by index)."""
+    rng = np.random.default_rng(77 + k)
+    base = np.argsort(rng.random(64)).astype(np.int8)
+    rows = []
+    for i in range(1500):
+        v = base.copy()
+        for _ in range((1500 - i) // 30):                                  # fewer transpositions as the file goes on
+            a, b = rng.integers(0, 64, 2)
+            v[a], v[b] = v[b], v[a]
+        rows.append(v)
+    db = np.stack(rows + [rows[i] for i in rng.integers(0, 1500, 1300)])   # 2 800 rows: not a multiple of the tile
+    q = np.stack([base] + [db[i] for i in rng.integers(0, 2800, 199)])
+    want_i, want_d = oracle.knn64(db, q, k)
+    got_i, got_d, _ = built.knn64(db, q, k)
+    assert (got_d == want_d).all() and (got_i == want_i).all()
+
+
+@pytest.mark.gpu
+def test_knn_few_queries_against_a_long_database(built, oracle):
+    """Few queries: the database is cut into segments searched by different workgroups (sift3d_knn_plan) and the merge
+    kernel joins 2 x segments lists per query -- same neighbours, same order on ties (every vector is there four times)."""
+    rng = np.random.default_rng(4242)
+    quarter = clustered(rng, 10_100, 37, 5)
+    db = np.concatenate([quarter, quarter, quarter, quarter])             # 40 400 rows = 158 tiles: 4 segments for one block of queries
+    q = np.concatenate([quarter[:40], clustered(rng, 30, 37, 5)])
+    for k in (5, 12):
+        want_i, want_d = oracle.knn64(db, q, k)
+        got_i, got_d, _ = built.knn64(db, q, k)
+        assert (got_d == want_d).all() and (got_i == want_i).all()
+    assert (got_d[:40, :4] == 0).all() and (np.diff(got_i[:40, :4], axis=1) > 0).all()         # the copies, lowest index first
+
+
+@pytest.mark.gpu
+def test_knn_extreme_components(built, oracle):
+    """The largest distances the byte range allows (64 x 127^2): the lists' keys (distance x 2^31 + index, held in doubles)
+    must stay exact, and rows past the end of the database (zero vectors inside the last tile) must stay out."""
+    rng = np.random.default_rng(9)
+    db = np.zeros((700, 64), np.int8)
+    db[::2] = 127                                                          # all-127 and all-zero rows: norms 1 032 256 and 0
+    db[5::7, :32] = 0
+    db[100:140] = rng.integers(0, 128, (40, 64))
+    q = np.concatenate([db[:70], np.zeros((3, 64), np.int8), np.full((3, 64), 127, np.int8), rng.integers(0, 128, (60, 64)).astype(np.int8)])
+    for k in (1, 6, 32):
+        want_i, want_d = oracle.knn64(db, q, k)
+        got_i, got_d, _ = built.knn64(db, q, k)
+        assert (got_d == want_d).all() and (got_i == want_i).all()
+    same = np.full((260, 64), 9, np.int8)                                  # one norm for all (the constant-norm kernel), all distances 0
+    gi, gd, _ = built.knn64(same, same[:5], 8)
+    assert (gd == 0).all() and (gi == np.arange(8)[None, :]).all()
+
+
+@pytest.mark.gpu
 def test_knn_general_int8_vectors_and_errors(built, oracle):
     rng = np.random.default_rng(5)
     db = rng.integers(0, 128, (900, 64)).astype(np.int8)                  # not permutations: the norms differ
