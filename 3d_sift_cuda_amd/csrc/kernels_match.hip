@@ -61,6 +61,10 @@ typedef int m_v16i __attribute__((ext_vector_type(16)));
 #define KNN_PAD_NORM (1 << 21)          /* "squared norm" of the rows past the end of the database: above every real one, and
                                          * their distances still below 2^22 */
 #define KNN_MAX_SEGMENTS 8
+/* wavefronts per SIMD the register allocation is asked to allow (the matrix instructions take their VGPR form at two or more) */
+#ifndef KNN_WAVES
+#define KNN_WAVES(KK, CN, G) 2
+#endif
 
 /* |v|^2 per vector (one thread per vector) */
 __global__ void knn_norms_kernel(const signed char *__restrict__ v, long long n, int *__restrict__ norms)
@@ -103,13 +107,13 @@ __device__ __forceinline__ void knn_dispatch_rank(int k, F &&f)
  * function of q.b alone and the common case needs no arithmetic on the candidates at all: the largest of a lane's sixteen
  * dot products (a tree of eight three-operand maxima) against one per-lane threshold. */
 template <int KK, bool CN, int G>
-__global__ __launch_bounds__(256, 2) void knn_search_kernel(const signed char *__restrict__ db, const int *__restrict__ db_norm, long long n_db,
+__global__ __launch_bounds__(256, KNN_WAVES(KK, CN, G)) void knn_search_kernel(const signed char *__restrict__ db, const int *__restrict__ db_norm, long long n_db,
                                                          const signed char *__restrict__ q, const int *__restrict__ q_norm, long long n_q,
                                                          int const_norm, int k, long long tiles_per_segment, int *__restrict__ part_d,
                                                          int *__restrict__ part_i)
 {
     __shared__ __attribute__((aligned(256))) signed char tile[2][KNN_TILE * KNN_DIM];
-    __shared__ __attribute__((aligned(16))) int tnorm[2][KNN_TILE];
+    __shared__ __attribute__((aligned(16))) int tnorm[2][CN ? 4 : KNN_TILE]; /* CN: unused -- two 16 KB tiles are then all of a workgroup's LDS, five of them fit a CU */
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(256, 2) void knn_search_kernel(const signed char *_
         }
         int mall = max(max(m[0], m[1]), max(m[2], m[3]));
         if constexpr (NG == 6) mall = max(max(mall, m[4]), m[5]);
-        if (__ballot(mall > gate[g])) { /* only a wavefront with a candidate somewhere leaves the common path */
+        if (__builtin_expect(__ballot(mall > gate[g]) != 0, 0)) { /* only a wavefront with a candidate somewhere leaves the common path (which
+                                                                   * falls through: a taken branch costs the wavefront an instruction fetch) */
             /* the row's index less 4 h: the same for every lane, so it costs the common path nothing (kept in scalar
              * registers); the lane's 4 h is added when the lists are written */
             const int base = __builtin_amdgcn_readfirstlane((int)(t * KNN_TILE) + sub * 32);
@@ -265,31 +270,35 @@ __global__ __launch_bounds__(256, 2) void knn_search_kernel(const signed char *_
         /* One subtile ahead: the matrix cores work on subtile s + 1 while the vector unit looks at the results of s.  Two
          * subtiles per trip, so that the two accumulator sets keep their registers.  (Asking for the A operand another
          * subtile earlier costs 14 - 60 registers and gains nothing: four wavefronts per SIMD cover the LDS latency.) */
-        auto operand = [&](int sub, int off) __attribute__((always_inline)) {
-            return *reinterpret_cast<const m_v4i *>(tb + (sub & (KNN_TILE / 32 - 1)) * 32 * KNN_DIM + off); /* past the last subtile: the first again (unused) */
-        };
+        /* the two operand addresses march with the loop (one add each per trip); the subtile inside a trip is an immediate */
+        const signed char *p0 = tb + a_off0, *p1 = tb + a_off1;
         m_v16i acc_a[G], acc_b[G];
         {
-            const m_v4i x0 = operand(0, a_off0), x1 = operand(0, a_off1);
+            const m_v4i x0 = *reinterpret_cast<const m_v4i *>(p0), x1 = *reinterpret_cast<const m_v4i *>(p1);
 #pragma unroll
             for (int g = 0; g < G; g++) acc_a[g] = gram(x0, x1, g);
         }
 #pragma unroll 1
         for (int sub = 0; sub < KNN_TILE / 32; sub += 2) {
             {
-                const m_v4i x0 = operand(sub + 1, a_off0), x1 = operand(sub + 1, a_off1);
+                const m_v4i x0 = *reinterpret_cast<const m_v4i *>(p0 + 32 * KNN_DIM), x1 = *reinterpret_cast<const m_v4i *>(p1 + 32 * KNN_DIM);
 #pragma unroll
                 for (int g = 0; g < G; g++) acc_b[g] = gram(x0, x1, g);
             }
 #pragma unroll
             for (int g = 0; g < G; g++) take(acc_a[g], g, buf, sub, t);
             if (sub + 2 < KNN_TILE / 32) {
-                const m_v4i x0 = operand(sub + 2, a_off0), x1 = operand(sub + 2, a_off1);
+                const m_v4i x0 = *reinterpret_cast<const m_v4i *>(p0 + 64 * KNN_DIM), x1 = *reinterpret_cast<const m_v4i *>(p1 + 64 * KNN_DIM);
 #pragma unroll
                 for (int g = 0; g < G; g++) acc_a[g] = gram(x0, x1, g);
             }
 #pragma unroll
             for (int g = 0; g < G; g++) take(acc_b[g], g, buf, sub + 1, t);
+            p0 += 64 * KNN_DIM;
+            p1 += 64 * KNN_DIM;
+#ifdef KNN_EXTRA_BARRIER /* experiment: what a workgroup barrier costs here */
+            if (sub == 2) __syncthreads();
+#endif
         }
         if (t + 1 < t_end) stash(buf ^ 1); /* the other buffer was last read one iteration ago: every wavefront has passed the barrier below since */
         __syncthreads();

@@ -18,7 +18,7 @@ import _oracle
 plan = os.environ.get("KNN_PLAN")
 if plan:
     import ctypes
-    pkg.LIB_HIP = os.path.join(pkg.CSRC, "_build_dev", "libsift3d_hip.so")
+    pkg.LIB_HIP = os.path.join(pkg.CSRC, os.environ.get("KNN_BUILD", "_build_dev"), "libsift3d_hip.so")   # KNN_BUILD: another development build
     pkg.hip_lib().sift3d_dev_knn_plan(*[ctypes.c_int(int(v)) for v in plan.split(",")])
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
