@@ -14,7 +14,7 @@
  * per-lane running top-k.  Unlike every other kernel of this library this one IS matrix-shaped: 2 * 64 * n_q * n_db
  * integer operations on 64 (n_q + n_db) bytes.
  *
- * Mapping.  A workgroup of four wavefronts owns 128 G queries: a wavefront keeps G groups of 32 as B operands in registers
+ * Mapping.  A workgroup of four wavefronts owns 128 G queries (G = 1 in the product): a wavefront keeps G groups of 32 as B operands in registers
  * (loaded once, 2 x 16 bytes per lane and group) and every workgroup walks its segment of the database in tiles of 256
  * vectors staged through LDS (16 KB, double-buffered; the next tile is in registers while this one is multiplied).  Per
  * 32-vector subtile a wavefront reads the A operand once (two ds_read_b128) and issues two MFMAs per group (K = 2 x 32) with
@@ -374,7 +374,7 @@ void sift3d_knn_plan(int64_t n_db, int64_t n_q, int k, int *groups, int *segment
     const int64_t ntiles = (n_db + KNN_TILE - 1) / KNN_TILE, qblocks = (n_q + 127) / 128;
     int sg = 1;
     while (sg < KNN_MAX_SEGMENTS && qblocks * sg < 1024 && ntiles / (sg + 1) >= 32) sg++;
-    *groups = g_knn_dev_groups > 0 && g_knn_dev_groups <= 2 ? g_knn_dev_groups : 1;
+    *groups = g_knn_dev_groups > 0 && g_knn_dev_groups <= 2 ? g_knn_dev_groups : 1; /* 2: development builds only, lists of 8 */
     *segments = g_knn_dev_segments > 0 && g_knn_dev_segments <= KNN_MAX_SEGMENTS ? g_knn_dev_segments : sg;
 }
 
@@ -386,6 +386,11 @@ hipError_t sift3d_launch_knn(hipStream_t s, const signed char *db, const int *db
     if (n_q <= 0) return hipSuccess;
     const int KK = sift3d_knn_list_length(k);
     if (KK == 0 || k < 1 || segments < 1 || segments > KNN_MAX_SEGMENTS || groups < 1 || groups > 2) return hipErrorInvalidValue;
+#ifndef SIFT3D_DEV
+    if (groups != 1) return hipErrorInvalidValue;
+#else
+    if (groups == 2 && KK != 8) return hipErrorInvalidValue;
+#endif
     const int64_t ntiles = (n_db + KNN_TILE - 1) / KNN_TILE;
     const long long tps = (long long)((ntiles + segments - 1) / segments);
     const dim3 grid((unsigned)((n_q + 128 * groups - 1) / (128 * groups)), (unsigned)segments);
@@ -393,13 +398,19 @@ hipError_t sift3d_launch_knn(hipStream_t s, const signed char *db, const int *db
     hipLaunchKernelGGL((knn_search_kernel<KK_, CN_, G_>), grid, dim3(256), 0, s, db, db_norm, (long long)n_db, q, q_norm, (long long)n_q, \
                        const_norm, k, tps, part_d, part_i)
     if (const_norm >= 0) {
+#ifdef SIFT3D_DEV /* two groups per wavefront: measured slower at every size; development builds keep it */
         if (KK == 8 && groups == 2) KNN_LAUNCH(8, true, 2);
-        else if (KK == 8) KNN_LAUNCH(8, true, 1);
+        else
+#endif
+        if (KK == 8) KNN_LAUNCH(8, true, 1);
         else if (KK == 16) KNN_LAUNCH(16, true, 1);
         else KNN_LAUNCH(32, true, 1);
     } else {
+#ifdef SIFT3D_DEV
         if (KK == 8 && groups == 2) KNN_LAUNCH(8, false, 2);
-        else if (KK == 8) KNN_LAUNCH(8, false, 1);
+        else
+#endif
+        if (KK == 8) KNN_LAUNCH(8, false, 1);
         else if (KK == 16) KNN_LAUNCH(16, false, 1);
         else KNN_LAUNCH(32, false, 1);
     }
