@@ -379,14 +379,33 @@ __device__ __forceinline__ void wave_sample_patch(float *patch, const float *__r
     const float rad = 2.0f * scale;
     const int sr = PD / 2;
     const float sc = rad / (float)(sr);
+    /* Which sample a lane takes changes no value, only which memory lines the 64 gathers of one instruction touch: the
+     * lanes walk the patch axis that runs closest to the volume's x first (then the one closest to y), so that
+     * neighbouring lanes read neighbouring voxels of a row wherever the frame allows it (descriptor kernel at 512^3:
+     * 4.12 -> 3.97 ms; the patch in Z-curve blocks of 4 x 4 x 4 instead of lines: no better). */
+    int ax_fast = 0, ax_mid = 1, ax_slow = 2;
+    {
+        const float f0 = fabsf(inv[0]), f1 = fabsf(inv[1]), f2 = fabsf(inv[2]);
+        ax_fast = f0 >= f1 && f0 >= f2 ? 0 : (f1 >= f2 ? 1 : 2);
+        const int r0 = ax_fast == 0 ? 1 : 0, r1 = ax_fast == 2 ? 1 : 2;
+        const bool first = fabsf(inv[3 + r0]) >= fabsf(inv[3 + r1]);
+        ax_mid = first ? r0 : r1;
+        ax_slow = first ? r1 : r0;
+    }
+    const int st_fast = ax_fast == 0 ? 1 : (ax_fast == 1 ? PD : PD * PD), st_mid = ax_mid == 0 ? 1 : (ax_mid == 1 ? PD : PD * PD),
+              st_slow = ax_slow == 0 ? 1 : (ax_slow == 1 ? PD : PD * PD);
     /* three samples per lane per trip: the 24 gathers of a trip are issued together */
     for (int s0 = threadIdx.x; s0 < PV; s0 += 3 * NT) {
         float pix[3];
+        int sidx[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-            const int s = s0 + NT * u;
+            const int t = s0 + NT * u;
             pix[u] = 0;
-            if (s < PV) {
+            sidx[u] = 0;
+            if (t < PV) {
+                const int s = (t % PD) * st_fast + ((t / PD) % PD) * st_mid + (t / (PD * PD)) * st_slow; /* the patch voxel this lane samples */
+                sidx[u] = s;
                 const int xx = s % PD - sr, yy = (s / PD) % PD - sr, zz = s / (PD * PD) - sr;
                 float in3[3] = {(float)xx, (float)yy, (float)zz};
                 float o[3];
@@ -405,7 +424,7 @@ __device__ __forceinline__ void wave_sample_patch(float *patch, const float *__r
         }
 #pragma unroll
         for (int u = 0; u < 3; u++)
-            if (s0 + NT * u < PV) patch[s0 + NT * u] = pix[u];
+            if (s0 + NT * u < PV) patch[sidx[u]] = pix[u];
     }
     __syncthreads();
 }
