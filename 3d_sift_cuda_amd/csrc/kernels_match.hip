@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, KNN_WAVES(KK, CN, G)) void knn_search_kernel(c
                                                          int *__restrict__ part_i)
 {
     __shared__ __attribute__((aligned(256))) signed char tile[2][KNN_TILE * KNN_DIM];
-    __shared__ __attribute__((aligned(16))) int tnorm[2][CN ? 4 : KNN_TILE]; /* CN: unused -- two 16 KB tiles are then all of a workgroup's LDS, five of them fit a CU */
+    __shared__ __attribute__((aligned(16))) int tnorm[2][CN ? 4 : KNN_TILE]; /* CN: unused */
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
