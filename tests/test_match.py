@@ -117,6 +117,11 @@ def test_knn_few_queries_against_a_long_database(built, oracle):
         got_i, got_d, _ = built.knn64(db, q, k)
         assert (got_d == want_d).all() and (got_i == want_i).all()
     assert (got_d[:40, :4] == 0).all() and (np.diff(got_i[:40, :4], axis=1) > 0).all()         # the copies, lowest index first
+    gen = rng.integers(0, 128, (40_100, 64)).astype(np.int8)              # norms differ: the general kernel, segments again, a ragged last tile
+    gq = np.concatenate([gen[100:130], rng.integers(0, 128, (25, 64)).astype(np.int8)])
+    want_i, want_d = oracle.knn64(gen, gq, 9)
+    got_i, got_d, _ = built.knn64(gen, gq, 9)
+    assert (got_d == want_d).all() and (got_i == want_i).all()
 
 
 @pytest.mark.gpu
