@@ -365,15 +365,16 @@ extern "C" void sift3d_dev_knn_plan(int groups, int segments)
 
 /* How a search is cut.  One group of 32 queries per wavefront (two were slower at every size tried: the insertion path, not
  * the LDS reads, is what a wavefront spends its time on, and half as many workgroups fill the chip worse).  Database
- * segments only where the queries alone give the chip too few workgroups (under 1 024 = 256 CUs x 4): every segment fills
- * its lists from empty, which costs insertions (200 000 x 200 000: two segments 5 - 7 % slower than one), so a segment
- * is at least 32 tiles. */
+ * segments only where the queries alone give the chip few workgroups: every segment fills its lists from empty, which costs
+ * insertions, so segments are added only up to about 600 workgroups and never below 16 tiles each (measured, k = 5:
+ * 20 000 x 20 000 best with 4 segments, 0.167 against 0.231 ms with one; 50 000^2 with 2, 0.369 against 0.430;
+ * 100 000^2 and 200 000^2 with one). */
 void sift3d_knn_plan(int64_t n_db, int64_t n_q, int k, int *groups, int *segments)
 {
     (void)k;
     const int64_t ntiles = (n_db + KNN_TILE - 1) / KNN_TILE, qblocks = (n_q + 127) / 128;
     int sg = 1;
-    while (sg < KNN_MAX_SEGMENTS && qblocks * sg < 1024 && ntiles / (sg + 1) >= 32) sg++;
+    while (sg < KNN_MAX_SEGMENTS && qblocks * sg < 600 && ntiles / (sg + 1) >= 16) sg++;
     *groups = g_knn_dev_groups > 0 && g_knn_dev_groups <= 2 ? g_knn_dev_groups : 1; /* 2: development builds only, lists of 8 */
     *segments = g_knn_dev_segments > 0 && g_knn_dev_segments <= KNN_MAX_SEGMENTS ? g_knn_dev_segments : sg;
 }
