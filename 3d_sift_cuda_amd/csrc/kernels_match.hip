@@ -66,26 +66,44 @@ typedef int m_v16i __attribute__((ext_vector_type(16)));
 #define KNN_WAVES(KK, CN, G) 2
 #endif
 
-/* |v|^2 per vector (one thread per vector) */
-__global__ void knn_norms_kernel(const signed char *__restrict__ v, long long n, int *__restrict__ norms)
+/* |v|^2 per vector (one thread per vector), and what the host used to find by reading every byte itself: stats[0] = the
+ * lowest flat index of a component outside 0..127 (the matrix cores take signed bytes), stats[1] / stats[2] = the smallest
+ * and the largest squared norm (equal: the constant-norm kernel applies).  The caller presets {~0, ~0, 0}. */
+__global__ void knn_norms_kernel(const signed char *__restrict__ v, long long n, int *__restrict__ norms, unsigned long long *__restrict__ stats)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const m_v4i *p = reinterpret_cast<const m_v4i *>(v + i * KNN_DIM);
     int s = 0;
+    unsigned long long bad = ~0ull;
+    if (i < n) {
+        const m_v4i *p = reinterpret_cast<const m_v4i *>(v + i * KNN_DIM);
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const m_v4i x = p[w];
-        const int xs[4] = {x.x, x.y, x.z, x.w};
+        for (int w = 3; w >= 0; w--) {
+            const m_v4i x = p[w];
+            const int xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int e = 0; e < 4; e++)
+            for (int e = 3; e >= 0; e--)
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int c = (int)(signed char)((xs[e] >> (8 * b)) & 0xff);
-                s += c * c;
-            }
+                for (int b = 3; b >= 0; b--) {
+                    const int c = (int)(signed char)((xs[e] >> (8 * b)) & 0xff);
+                    s += c * c;
+                    if (c < 0) bad = (unsigned long long)(i * KNN_DIM + 16 * w + 4 * e + b); /* descending: the lowest index stays */
+                }
+        }
+        norms[i] = s;
     }
-    norms[i] = s;
+    unsigned long long lo = i < n ? (unsigned long long)s : ~0ull, hi = i < n ? (unsigned long long)s : 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { /* one set of atomics per wavefront */
+        const unsigned long long ob = __shfl_xor(bad, d), ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        bad = ob < bad ? ob : bad;
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad != ~0ull) atomicMin(stats, bad);
+        atomicMin(stats + 1, lo);
+        atomicMax(stats + 2, hi);
+    }
 }
 
 /* f(integral_constant<int, k>) for a wave-uniform 1 <= k <= KK (k above KK: KK) */
@@ -345,10 +363,11 @@ __global__ void knn_merge_kernel(const int *__restrict__ part_d, const int *__re
         if (best >= 0) pos[best]++;
     }
 }
-hipError_t sift3d_launch_knn_norms(hipStream_t s, const signed char *v, int64_t n, int *norms)
+/* stats: three words the caller has preset to {~0, ~0, 0} (knn_norms_kernel) */
+hipError_t sift3d_launch_knn_norms(hipStream_t s, const signed char *v, int64_t n, int *norms, unsigned long long *stats)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, (long long)n, norms);
+    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, (long long)n, norms, stats);
     return hipGetLastError();
 }
 
