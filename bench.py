@@ -450,6 +450,19 @@ def main():
         pyramid["exclusive_frac_of_peak"] = round(pyramid["exclusive_alg_GBs"] / HBM_PEAK_GBS, 4)
         pyramid["accounting"] += ("; ms_per_step / frac_of_peak: blur launches timed while the finer octave's extrema share the chip "
                                   "(the production schedule); exclusive_*: the same launches timed alone")
+        # BASELINE.md section 4 / SURVEY.md section 8d state the pyramid's budget in the bytes of the separable three-pass design
+        # the north star names: 24N per blur + 8N per fused DoG = 176N for octave 0, 152N for every later octave (N / 8 each):
+        # 197.7N = 26.5 GB at 512^3, "70 % target => <= 4.7 ms for Gaussian + DoG".  The same time priced that way, for
+        # comparison with that target only (roofline.* and pyramid.frac_of_peak stay on the compulsory bytes of what is launched):
+        n_vox = float(n) ** 3
+        b8d = n_vox * (176.0 + 152.0 / 7.0)
+        pyramid["survey_8d_accounting"] = {
+            "alg_bytes_per_step": b8d, "target_ms_at_70_percent_of_peak": round(b8d / (0.7 * HBM_PEAK_GBS * 1e9) * 1e3, 3),
+            "ms_per_step": pyramid["ms_per_step"], "exclusive_ms_per_step": pyramid["exclusive_ms_per_step"],
+            "equivalent_GBs": round(b8d / (pyramid["ms_per_step"] * 1e-3) / 1e9, 1),
+            "met": bool(pyramid["ms_per_step"] <= b8d / (0.7 * HBM_PEAK_GBS * 1e9) * 1e3),
+            "note": "three-pass bytes of SURVEY.md 8d (24N per blur, +8N per DoG, all octaves) over the time the pyramid's blur launches take here; "
+                    "the fused launches move a third of those bytes, which is why this figure may exceed the HBM peak"}
         out = {
             "metric": "keypoints/s (.key records per second; Gauss-pyramid GB/s vs HBM roofline in `pyramid`/`roofline`)",
             "value": round(total_records / (ms_per_step * 1e-3), 1),
