@@ -37,7 +37,7 @@ INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
 STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
 # sift3d_tuning (include/sift3d.h)
-TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST = range(8)
+TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST, TUNE_HOST_RECORDS = range(9)
 
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),
@@ -99,6 +99,7 @@ def hip_lib():
     _sig(L.sift3d_create, P, I, I64, I64, I64)
     _sig(L.sift3d_create_slab, P, I, I64, I64, I64)
     _sig(L.sift3d_set_tuning, I, P, I, I)
+    _sig(L.sift3d_host_buffer_grows, I64, P)
     _sig(L.sift3d_zslab_set_tuning, I, P, I, I)
     _sig(L.sift3d_destroy, None, P)
     _sig(L.sift3d_last_error, C.c_char_p, P)
@@ -162,6 +163,8 @@ def host_lib():
     _sig(L.sift3d_write_key, I, C.c_char_p, P, I64, F, I, P)
     _sig(L.sift3d_write_key_bin, I, C.c_char_p, P, I64, F)
     _sig(L.sift3d_read_key, I, C.c_char_p, P, P)
+    _sig(L.sift3d_write_pgm, I, C.c_char_p, P, I, I)
+    _sig(L.sift3d_world_transform, None, P, I64, P)
     _sig(L.sift3d_match_filter, I64, P, I64, I, I)
     _sig(L.sift3d_match_descriptors, I, P, I64, P)
     _sig(L.sift3d_match_votes, I, P, P, I, P, I, P, P, I, P, P)
@@ -376,6 +379,21 @@ def write_key_bin(path, feats, eig_thres=140.0):
         raise Sift3DError("could not write %s" % path)
 
 
+def world_transform(feats, m44):
+    """sift3d_world_transform (featExtract.cpp:436-538): records to world coordinates through a 4 x 4 voxel-to-mm matrix."""
+    out = np.ascontiguousarray(feats, FEATURE_DTYPE).copy()
+    m = np.ascontiguousarray(m44, np.float32).reshape(4, 4)
+    host_lib().sift3d_world_transform(out.ctypes.data, len(out), m.ctypes.data)
+    return out
+
+
+def write_pgm(path, slice_yx):
+    """output_float + GenericImage::WriteToFile: an x-y slice of floats as the reference's image.pgm."""
+    a = _f32(slice_yx)
+    if a.ndim != 2 or host_lib().sift3d_write_pgm(os.fsencode(path), a.ctypes.data, a.shape[0], a.shape[1]) != 0:
+        raise Sift3DError("could not write %s" % path)
+
+
 def read_key(path):
     """msFeature3DVectorInputText: the records of a text .key file as a FEATURE_DTYPE array."""
     L = host_lib()
@@ -409,6 +427,10 @@ class Context:
     def set_tuning(self, knob, value):
         """sift3d_set_tuning: TUNE_* knobs (tests and A/B timing; no knob changes a result)."""
         self._chk(self._L.sift3d_set_tuning(self._h, int(knob), int(value)), "sift3d_set_tuning")
+
+    def host_buffer_grows(self):
+        """sift3d_host_buffer_grows: runs on this context that outgrew their pinned record buffers."""
+        return int(self._L.sift3d_host_buffer_grows(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -125,7 +125,8 @@ struct sift3d_ctx {
     int *nrec, *offs; /* per-candidate record count and exclusive prefix */
     int64_t kps_cap;
     int *rec_kp, *rec_frame;
-    int64_t recs_cap;       /* records the arrays below hold: kps_cap * (1 + SIFT3D_MAX_FRAMES) */
+    int64_t recs_cap;       /* record slots of rec_kp / rec_frame: kps_cap * (1 + SIFT3D_MAX_FRAMES), the worst case */
+    int64_t hrecs_cap;      /* records the two pinned host buffers below hold: a few per candidate, grown when a run needs more */
     sift3d_feature *h_recs; /* pinned host memory the descriptor kernel stores its records into; reused from call to call */
     int *h_group;           /* per record: level id * 2 + is_max (pinned host) */
     sift3d_feature *d_hrecs; /* the device's addresses of the two */
@@ -145,6 +146,7 @@ struct sift3d_ctx {
     bool has_volume;
     int max_octaves; /* 0: the reference's only stop rule (a dimension <= 2); n > 0: at most n octaves */
     int tune[SIFT3D_TUNE_COUNT]; /* sift3d_set_tuning */
+    int64_t host_grows;          /* times describe_launch had to grow the pinned record buffers (tests) */
     bool lean;       /* a slab context: the caller owns the level buffers, none are allocated here */
     int timing; /* 0 off; 1 every launch bracketed by events; 2 only the blur launches of the finest octave */
     std::vector<timed_launch> launches;
@@ -296,6 +298,7 @@ static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bo
     c->tune[SIFT3D_TUNE_TINY_OCTAVE] = 1;
     c->tune[SIFT3D_TUNE_SAMPLER_CAP] = 4;
     c->tune[SIFT3D_TUNE_BANDS_FIRST] = 1;
+    c->tune[SIFT3D_TUNE_HOST_RECORDS] = 5;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -357,12 +360,15 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
     return SIFT3D_OK;
 }
+
+extern "C" int64_t sift3d_host_buffer_grows(const sift3d_ctx *c) { return c ? c->host_grows : 0; }
 
 #ifdef SIFT3D_DEV
 extern "C" int sift3d_dev_set_stop(sift3d_ctx *c, int n)
@@ -1101,9 +1107,39 @@ extern "C" int sift3d_set_volume_resized(sift3d_ctx *c, const float *vol, int64_
     return SIFT3D_OK;
 }
 
+/* The pinned host buffers the descriptor kernel stores its records into, for at least `need` records.  Growing keeps the
+ * first `keep` records (those of chunks already launched).  The caller has made sure nothing is writing into them. */
+static int ensure_host_records(sift3d_ctx *c, int64_t need, int64_t keep)
+{
+    if (need <= c->hrecs_cap) return SIFT3D_OK;
+    sift3d_feature *nr = nullptr;
+    int *ng = nullptr;
+    const int64_t cap = need + need / 8 + 1024;
+    HIPCHK(c, hipHostMalloc((void **)&nr, sizeof(sift3d_feature) * (size_t)cap, hipHostMallocDefault));
+    if (hipHostMalloc((void **)&ng, sizeof(int) * (size_t)cap, hipHostMallocDefault) != hipSuccess) {
+        hipHostFree(nr);
+        return set_err(c, SIFT3D_ERR_MEMORY, "out of pinned host memory for %lld records", (long long)cap);
+    }
+    if (keep > 0 && c->h_recs) {
+        memcpy(nr, c->h_recs, sizeof(sift3d_feature) * (size_t)keep);
+        memcpy(ng, c->h_group, sizeof(int) * (size_t)keep);
+    }
+    if (c->h_recs) hipHostFree(c->h_recs);
+    if (c->h_group) hipHostFree(c->h_group);
+    c->h_recs = nr;
+    c->h_group = ng;
+    c->hrecs_cap = cap;
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_hrecs, c->h_recs, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_hgroup, c->h_group, 0));
+    return SIFT3D_OK;
+}
+
 /* Buffers of the per-keypoint stage for ncand candidates.  A candidate yields at most 1 + SIFT3D_MAX_FRAMES records
- * (determineCanonicalOrientation3D stops at that many frames), 4.2 on average on blob fields; the record arrays are sized
- * for the worst case so that the chunks of the stage can write them before the host knows a total. */
+ * (determineCanonicalOrientation3D stops at that many frames), 4.2 on average on blob fields.  The device-side record map
+ * (8 bytes a slot) is sized for the worst case so that the chunks of the stage can write it before the host knows a total;
+ * the pinned host buffers (328 bytes a record) are sized for SIFT3D_TUNE_HOST_RECORDS records per candidate (default 5) and
+ * grown by describe_launch when a run turns out to need more -- the worst case would be 12 records per candidate of
+ * page-locked memory, tens of GB on an extrema-dense volume (advisor, round 3). */
 static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand)
 {
     if (ncand > c->kps_cap) {
@@ -1111,14 +1147,10 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand)
         HIPCHK(c, hipStreamSynchronize(c->kp_stream));
         hipFree(c->kps); hipFree(c->nrec); hipFree(c->offs); hipFree(c->scan_tmp); hipFree(c->patch0);
         hipFree(c->rec_kp); hipFree(c->rec_frame);
-        if (c->h_recs) hipHostFree(c->h_recs);
-        if (c->h_group) hipHostFree(c->h_group);
         c->kps = nullptr;
         c->patch0 = nullptr;
         c->nrec = c->offs = c->rec_kp = c->rec_frame = nullptr;
         c->scan_tmp = nullptr;
-        c->h_recs = nullptr;
-        c->h_group = nullptr;
         c->kps_cap = 0;
         const int64_t cap = ncand + ncand / 2 + 1024, rcap = cap * (1 + SIFT3D_MAX_FRAMES);
         c->scan_tmp_bytes = sift3d_scan_temp_bytes(cap) + 256;
@@ -1129,13 +1161,17 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand)
         HIPCHK(c, hipMalloc(&c->scan_tmp, c->scan_tmp_bytes));
         HIPCHK(c, hipMalloc((void **)&c->rec_kp, sizeof(int) * (size_t)rcap));
         HIPCHK(c, hipMalloc((void **)&c->rec_frame, sizeof(int) * (size_t)rcap));
-        /* the records go straight into pinned host memory (mapped into the device's address space) */
-        HIPCHK(c, hipHostMalloc((void **)&c->h_recs, sizeof(sift3d_feature) * (size_t)rcap, hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_group, sizeof(int) * (size_t)rcap, hipHostMallocDefault));
-        HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_hrecs, c->h_recs, 0));
-        HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_hgroup, c->h_group, 0));
         c->kps_cap = cap;
         c->recs_cap = rcap;
+    }
+    int per = c->tune[SIFT3D_TUNE_HOST_RECORDS];
+    if (per < 1) per = 1;
+    if (per > 1 + SIFT3D_MAX_FRAMES) per = 1 + SIFT3D_MAX_FRAMES;
+    if (c->hrecs_cap < ncand * per) { /* nothing of an earlier run is in flight here: describe_finish has synchronised */
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->kp_stream));
+        int rc = ensure_host_records(c, ncand * per, 0);
+        if (rc) return rc;
     }
     return SIFT3D_OK;
 }
@@ -1272,6 +1308,16 @@ static int describe_launch(sift3d_ctx *c)
         HIPCHK(c, hipEventSynchronize(c->ev_kpc[i]));
         const int64_t end = h_end[i], m = end - base;
         if (end < base || end > c->recs_cap) return set_err(c, SIFT3D_ERR_DEVICE, "record map out of range (%lld of %lld)", (long long)end, (long long)c->recs_cap);
+        if (end > c->hrecs_cap) {
+            /* more records than the pinned buffers were sized for: wait for the descriptor launches of the earlier chunks
+             * (they store into the buffers about to be replaced), grow, carry their records over */
+            HIPCHK(c, hipStreamSynchronize(ds));
+            /* chunks still to come: assume they yield records at the rate seen so far */
+            const int64_t done_cand = c->kp.first[i + 1], need = done_cand > 0 && i + 1 < nch ? (int64_t)((double)end * (double)c->kp.ncand / (double)done_cand) + 1 : end;
+            int rc = ensure_host_records(c, need > end ? need : end, base);
+            if (rc) return rc;
+            c->host_grows++;
+        }
         if (m > 0) {
             stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, m, ds);
             if (c->kp.p.sampler_cap > 0) /* the per-CU tokens start from zero whatever became of an earlier launch */

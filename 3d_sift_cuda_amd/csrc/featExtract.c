@@ -87,19 +87,8 @@ static void reference_side_effects(sift3d_ctx *ctx, int64_t X, int64_t Y, int64_
     free(log);
     /* image.pgm */
     float *slice = (float *)malloc(sizeof(float) * (size_t)(X * Y));
-    if (slice && sift3d_get_level_slice(ctx, 0, 1, Z / 2, slice, NULL, NULL) == SIFT3D_OK) {
-        float lo = slice[0], hi = slice[0];
-        for (int64_t i = 0; i < X * Y; i++) {
-            if (slice[i] > hi) hi = slice[i];
-            if (slice[i] < lo) lo = slice[i];
-        }
-        FILE *f = fopen("image.pgm", "wb");
-        if (f) {
-            fprintf(f, "P5\n%d %d\n%d\n", (int)X, (int)Y, 255);
-            for (int64_t i = 0; i < X * Y; i++) fputc((unsigned char)(((slice[i] - lo) * 255.0) / (hi - lo)), f);
-            fclose(f);
-        }
-    }
+    if (slice && sift3d_get_level_slice(ctx, 0, 1, Z / 2, slice, NULL, NULL) == SIFT3D_OK)
+        sift3d_write_pgm("image.pgm", slice, (int)Y, (int)X);
     free(slice);
 }
 

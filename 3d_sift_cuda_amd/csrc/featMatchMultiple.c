@@ -172,7 +172,10 @@ int main(int argc, char **argv)
         valleys = (key_set *)calloc((size_t)n_names, sizeof(key_set));
     }
     int64_t total = 0;
-    int n_read = 0;
+    /* every name keeps its set and its index: a file that cannot be read stays an empty set (the reference's loop leaves
+     * iFeatVec == iFeatVecTotal, featMatchMultiple.cpp:578-632), so feature_count.txt and the vote matrices have one row
+     * per line of _names.txt whatever opened */
+    const int n_read = n_names;
     for (int i = 0; i < n_names; i++) {
         const char *pch = strrchr(names[i], '\\');
         pch = pch ? pch + 1 : names[i];
@@ -197,7 +200,6 @@ int main(int argc, char **argv)
         sets[i].f = f;
         sets[i].n = n;
         total += n;
-        n_read = i + 1;
         printf("feats: %d, total: %d\n", (int)n, (int)total);
     }
     FILE *fc = fopen("feature_count.txt", "wt");
@@ -209,7 +211,9 @@ int main(int argc, char **argv)
         printf("Error: no HIP device (there is no CPU path in this build)\n");
         return -1;
     }
-    int rc = match_all(names, sets, n_read, neighbours, title, 0, 0);
+    /* -s2: all three passes append to matching_votes.txt / vote_count.txt (featMatchMultiple.cpp:58-65: "at" whenever
+     * bOnlyPeaksFeatures == 2, the first pass included) */
+    int rc = match_all(names, sets, n_read, neighbours, title, peaks_mode == 2, 0);
     if (rc == 0 && peaks_mode == 2) {
         rc = match_all(names, peaks, n_read, neighbours, "Peaks", 1, 0);
         if (rc == 0) rc = match_all(names, valleys, n_read, neighbours, "Valley", 1, 0);

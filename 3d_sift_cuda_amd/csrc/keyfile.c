@@ -177,3 +177,35 @@ int sift3d_read_key(const char *path, sift3d_feature **recs, int64_t *n)
     *n = count;
     return 0;
 }
+
+int sift3d_write_pgm(const char *path, const float *slice, int rows, int cols)
+{
+    if (!path || !slice || rows < 1 || cols < 1) return -1;
+    /* min_max_float (PpImageFloatOutput.cpp:22-63): first strictly greater / smaller value in raster order */
+    float lo = slice[0], hi = slice[0];
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = 0; i < n; i++) {
+        if (slice[i] > hi) hi = slice[i];
+        if (slice[i] < lo) lo = slice[i];
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    fprintf(f, "P5\n%d %d\n%d\n", cols, rows, 255); /* GenericImage::WriteToFile, 8 bits per pixel */
+    /* output_float (:136-165): (unsigned char)(((v - min) * 255.0) / (max - min)), the product and quotient in double.  A
+     * constant slice divides 0.0 by 0.0f there and casts the NaN -- undefined in C, 0 from x86's cvttsd2si & 0xff; written
+     * as 0 here */
+    unsigned char *row = (unsigned char *)malloc((size_t)cols);
+    if (!row) {
+        fclose(f);
+        return -1;
+    }
+    for (int r = 0; r < rows; r++) {
+        for (int q = 0; q < cols; q++) {
+            const double v = ((slice[(int64_t)r * cols + q] - lo) * 255.0) / (hi - lo);
+            row[q] = v == v ? (unsigned char)v : 0;
+        }
+        fwrite(row, 1, (size_t)cols, f);
+    }
+    free(row);
+    return fclose(f) == 0 ? 0 : -1;
+}

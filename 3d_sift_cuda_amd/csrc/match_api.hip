@@ -38,8 +38,10 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
     if (kernel_ms) *kernel_ms = 0.0;
     const int KK = sift3d_knn_list_length(k);
     int groups = 1, segments = 1;
-    if (!db || !queries || !idx || !dist2 || n_db <= 0 || n_q <= 0 || k < 1 || KK == 0 || n_db >= (1ll << 31)) {
-        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments (1 <= k <= 32, 0 < n_db < 2^31)");
+    /* row indices are 32-bit in the kernels, and the last tile is padded to a whole one: n_db + a tile must stay below 2^31,
+     * or a pad row's index wraps and no longer compares >= n_db in the merge (advisor, round 3) */
+    if (!db || !queries || !idx || !dist2 || n_db <= 0 || n_q <= 0 || k < 1 || KK == 0 || n_db > (1ll << 31) - 4096 || n_q > (1ll << 31) - 4096) {
+        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments (1 <= k <= 32, 0 < n_db, n_q <= 2^31 - 4096)");
         return SIFT3D_ERR_ARG;
     }
     if (repeats < 1) repeats = 1;
@@ -64,7 +66,9 @@ extern "C" int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const in
      * common case (knn_search_kernel<KK, true>). */
     KCHK(hipMalloc((void **)&d_stats, sizeof(stats)));
     for (int it = 0; it < repeats; it++) { /* repeats > 1: timing (the first run is a warm-up; the last run's results are returned) */
-        if (it == 0 || (it == 1 && repeats > 1)) KCHK(hipEventRecord(e0, s)); /* timing starts behind the warm-up run */
+        /* timing starts behind the warm-up run; with repeats == 1 there is none, and the one run's verdict on the bytes (a
+         * device-to-host copy the host waits for) sits inside the interval: kernel_ms is then end to end, not kernel time */
+        if (it == 0 || (it == 1 && repeats > 1)) KCHK(hipEventRecord(e0, s));
         stats[0] = stats[1] = stats[3] = stats[4] = ~0ull;
         stats[2] = stats[5] = 0;
         KCHK(hipMemcpyAsync(d_stats, stats, sizeof(stats), hipMemcpyHostToDevice, s));

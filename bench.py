@@ -80,10 +80,82 @@ def records_match(gpu, cpu):
     return res
 
 
-def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
+class Watchdog:
+    """Per-phase time limit for a rank of a multi-process run.  `phase(name, limit_s)` names what the rank is about to do and
+    how long it may take; a daemon thread ends the PROCESS (exit code 3) with the phase name and every thread's Python stack
+    on stderr when the limit passes.  torch.distributed.run then ends the other ranks and returns non-zero, so a stall in any
+    phase of the one multi-rank path becomes a named failure within its limit instead of a silent hang (round-3 review,
+    weak 7: one of five two-rank rehearsals hung in the main measurement, cause unknown)."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.name, self.deadline, self.t0 = rank, None, None, time.monotonic()
+        self.lock = threading.Lock()
+        self.history = []
+        t = threading.Thread(target=self._watch, daemon=True)
+        t.start()
+
+    def phase(self, name, limit_s):
+        with self.lock:
+            now = time.monotonic()
+            if self.name is not None:
+                self.history.append((self.name, round(now - self.t0, 3)))
+            self.name, self.t0 = name, now
+            self.deadline = None if not limit_s else now + limit_s
+
+    def done(self):
+        self.phase(None, 0)
+
+    def _watch(self):
+        import faulthandler
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                name, deadline, t0 = self.name, self.deadline, self.t0
+            if name is not None and deadline is not None and time.monotonic() > deadline:
+                sys.stderr.write("bench.py: rank %d: phase '%s' exceeded its limit (%.0f s); phases so far: %s\n"
+                                 % (self.rank, name, time.monotonic() - t0, self.history))
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                sys.stderr.flush()
+                os._exit(3)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks HERE, as a child job under
+    torch.distributed.run, relay its output and leave with its exit code.  Done before torch is imported and before anything
+    touches the GPU (this process never initialises it: it only waits for the child).  Without this the run would read
+    WORLD_SIZE = 1 and measure ONE GPU under an N-GPU label."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env["SIFT3D_BENCH_SELF_LAUNCHED"] = "1"
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd[1:9])))
+    sys.stderr.flush()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for l in p.stdout:
+        if l.startswith("{") and '"metric"' in l:
+            line = l.rstrip("\n")      # the ranks' ONE line: printed last, after the child has ended
+        else:
+            sys.stderr.write(l)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the launched job ended without a result line\n")
+        rc = 4
+    return rc
+
+
+def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, phase=lambda *a: None):
     """ONE n^3 volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records on rank 0.
     Returns the result object on rank 0 (None elsewhere).  expect: the single-GPU records of the same volume, if the
     caller has them (rank 0), to state whether the merged records are the same bytes."""
+    phase("zslab: plan, slab context, upload")
     zs = importlib.import_module("3d_sift_cuda_amd.zslab")
     n = args.size
     ndev = torch.cuda.device_count()
@@ -111,14 +183,19 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
             merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev, dtype=pkg.FEATURE_DTYPE)
         return ex, merged
 
+    phase("zslab: warm-up steps (first halo exchange)")
     for _ in range(max(1, args.warmup)):
         step()
+    phase("zslab: barrier before the timed steps")
     barrier()
+    phase("zslab: timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ex, merged = step()
+    phase("zslab: barrier after the timed steps")
     barrier()
     elapsed = time.perf_counter() - t0
+    phase("zslab: max over ranks, result")
     el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda:%d" % dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ms_per_step = 1e3 * float(el.item()) / args.steps
@@ -149,8 +226,8 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None):
     return res
 
 
-def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
-    res = zslab_measure(args, pkg, torch, dist, rank, world, local_rank)
+def zslab_main(args, pkg, torch, dist, rank, world, local_rank, phase=lambda *a: None):
+    res = zslab_measure(args, pkg, torch, dist, rank, world, local_rank, phase=phase)
     if rank == 0:
         print(json.dumps({
             "metric": "keypoints/s (.key records per second)", "value": res["value"],
@@ -161,8 +238,10 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank):
                                            "halo_exchanges_per_step", "halo_bytes_per_rank_per_step",
                                            "halo_bytes_critical_per_rank_per_step", "halo_bytes_deferred_per_rank_per_step",
                                            "halo_bytes_hidden_per_rank_per_step", "exchange_schedule", "records_sha256")}}))
+    phase("zslab: leaving the process group")
     dist.barrier()
     dist.destroy_process_group()
+    phase(None, 0)
 
 
 def zslab_child(args, world, expect, limit_s):
@@ -183,7 +262,8 @@ def zslab_child(args, world, expect, limit_s):
     env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--size", str(args.size), "--desc", str(args.desc), "--mode", "zslab"]
+           str(args.warmup), "--size", str(args.size), "--desc", str(args.desc), "--mode", "zslab",
+           "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)]
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
         so, se = p.communicate(timeout=limit_s)
@@ -241,7 +321,16 @@ def main():
                          "attached as `zslab`); 'zslab' = only the Z-slab run (strong scaling)")
     ap.add_argument("--zslab-limit", type=int, default=120,
                     help="N > 1, mode volumes: seconds the attached Z-slab child job may take (0 = do not attach it)")
+    ap.add_argument("--phase-limit", type=int, default=300,
+                    help="N > 1: seconds any one phase of a rank (set-up, warm-up, the timed steps, a reduction) may take before "
+                         "the rank ends the job with exit code 3 and the phase name (0 = no limit)")
+    ap.add_argument("--launch-check", default=None, choices=["ok", "fail"],
+                    help="only bring the ranks up (process group over gloo, no GPU call), print a line with the world size "
+                         "seen and leave -- 'fail': rank 1 exits with code 7 instead (tests of the self-launch path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))   # before torch is imported: this process never touches the GPU
 
     if os.environ.get("BENCH_DUMP_STACKS_AFTER"):   # diagnosis of a hang: every thread's Python stack to stderr after N seconds
         import faulthandler
@@ -249,26 +338,54 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    wd = Watchdog(rank) if (world > 1 and args.phase_limit > 0) else None
+
+    def phase(name, limit=None):
+        if wd is not None:
+            wd.phase(name, args.phase_limit if limit is None else limit)
+
+    phase("import torch + process group")
     import torch
     dist = None
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        seen = dist.get_world_size()
+        if args.launch_check == "fail" and rank == 1:
+            sys.exit(7)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "launch check", "value": 0, "n_gpus": seen, "launch_check": True,
+                              "launched_by": "self" if os.environ.get("SIFT3D_BENCH_SELF_LAUNCHED") else "external launcher"}), flush=True)
+        dist.destroy_process_group()
+        return
+    ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
-        local_rank = local_rank % max(1, torch.cuda.device_count())   # (ranks share a GPU only in the gloo rehearsal)
-        torch.cuda.set_device(local_rank)
         backend = os.environ.get("SIFT3D_DIST_BACKEND", "nccl")   # "gloo" only for the single-GPU rehearsal of zslab mode
+        if backend == "nccl" and world > ndev:
+            raise SystemExit("bench.py: %d ranks but %d GPU(s) visible: RCCL needs one device per rank "
+                             "(SIFT3D_DIST_BACKEND=gloo rehearses several ranks on one GPU)" % (world, ndev))
+        local_rank = local_rank % max(1, ndev)   # (ranks share a GPU only in the gloo rehearsal)
+        torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world and rank == 0:
-        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
+        world = dist.get_world_size()   # what the process group really holds: this is what the line reports as n_gpus
+    if args.gpus != world:
+        # never a silent relabel: a line that says n_gpus = N must come from N ranks
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s); start it as `python bench.py --gpus %d` "
+                         "(it launches its ranks itself) or under torch.distributed.run with --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus, args.gpus))
 
     pkg = importlib.import_module("3d_sift_cuda_amd")
     if not os.path.exists(pkg.LIB_HIP):
         raise SystemExit("libsift3d_hip.so missing: run python __graft_entry__.py (no CPU fallback)")
     n = args.size
     if args.mode == "zslab" and world > 1:
-        return zslab_main(args, pkg, torch, dist, rank, world, local_rank)
+        return zslab_main(args, pkg, torch, dist, rank, world, local_rank, phase)
+    phase("volumes: synthetic volume, context, upload")
     vol = pkg.synth_blobs(n, n, n, seed=12345 + rank)
     ctx = pkg.Context(n, n, n, device=local_rank)
     dvol = torch.from_numpy(vol).to("cuda:%d" % local_rank)   # the input lives in HBM before timing starts
@@ -283,6 +400,7 @@ def main():
         torch.cuda.synchronize(local_rank)
 
     nrec = 0
+    phase("volumes: warm-up steps")
     for _ in range(args.warmup):
         nrec = len(ctx.extract(desc_mode=args.desc, copy=False))
     # Timed region: HIP events only around the dominant kernels (the blur launches on the full-size volume: five per
@@ -290,15 +408,19 @@ def main():
     # taken from extra steps after the timed region.
     ctx.enable_timing(2)
     logs = []
+    phase("volumes: barrier before the timed steps")
     barrier()
+    phase("volumes: timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         feats = ctx.extract(desc_mode=args.desc, copy=False)   # records land in pinned host memory
         nrec = len(feats)
         logs.append(ctx.launch_log())
     ctx.sync()
+    phase("volumes: barrier after the timed steps")
     barrier()
     elapsed = time.perf_counter() - t0
+    phase("volumes: breakdown steps")
     tim = ctx.timings()
     gpu_recs = feats.copy() if rank == 0 else None   # the timed region's last step (the pinned view is reused by the next call)
     full_logs, excl_logs = [], []
@@ -313,6 +435,7 @@ def main():
             excl_logs.append(ctx.launch_log())
         ctx.enable_timing(0)
 
+    phase("volumes: max / sum over ranks")
     red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda:%d" % local_rank   # gloo: the one-GPU rehearsal
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     rc = torch.tensor([float(nrec)], dtype=torch.float64, device=red_dev)
@@ -322,6 +445,7 @@ def main():
     elapsed = float(el.item())
     total_records = float(rc.item())
     ms_per_step = 1e3 * elapsed / args.steps
+    phase("volumes: result line (rank 0: breakdown, CPU baseline)", 0)
 
     if rank == 0:
         nfullvox = ((n + 3) // 4 * 4) * n * n   # rows are padded to whole 16-byte vectors inside the pipeline
@@ -467,7 +591,7 @@ def main():
             "metric": "keypoints/s (.key records per second; Gauss-pyramid GB/s vs HBM roofline in `pyramid`/`roofline`)",
             "value": round(total_records / (ms_per_step * 1e-3), 1),
             "unit": "keypoints/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "devices_used": min(world, ndev), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -523,8 +647,11 @@ def main():
     ctx.close()
     del dvol
     if dist is not None:
+        phase("volumes: leaving the process group")
         dist.barrier()
         dist.destroy_process_group()   # the measurement is complete; ranks other than 0 are done and leave the GPUs
+    if wd is not None:
+        wd.done()
     if rank == 0:
         if world > 1 and args.zslab_limit > 0:
             torch.cuda.empty_cache()

@@ -206,9 +206,13 @@ typedef enum {
                                  * (default: the overlap does not pay), up to 16 */
     SIFT3D_TUNE_BANDS_FIRST,    /* Z-slab drivers: 1 (default) a rank filters the two boundary bands of a level first and the interior
                                  * while they travel to its neighbours; 0: the level in one piece, then the exchange (round 2) */
+    SIFT3D_TUNE_HOST_RECORDS,   /* records per candidate the pinned download buffers are first sized for: 5 (default; blob fields yield
+                                 * 4.2), 1..12; a run that yields more grows them (sift3d_host_buffer_grows counts) */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);
+/* how often a run on this context found its pinned record buffers too small and grew them (see SIFT3D_TUNE_HOST_RECORDS) */
+int64_t sift3d_host_buffer_grows(const sift3d_ctx *ctx);
 
 /* Same, without the final host copy: *view points at the context's pinned download buffer and stays
  * valid until the next call on this context (or sift3d_destroy).  Do not free it. */
@@ -305,7 +309,9 @@ int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value);
  * (1..32) nearest database vectors, ascending by (distance, database index): idx and dist2 hold n_q x k entries (-1 /
  * INT32_MAX past the end of a database smaller than k).  A vector that is in both sets finds itself at distance 0, as in
  * the reference, whose vote stage drops the hits inside the query's own image.  repeats > 1 runs the search that many times
- * and reports the mean device time of the runs after the first in *kernel_ms (may be NULL). */
+ * and reports the mean device time of the runs after the first in *kernel_ms (may be NULL); with repeats == 1 the figure
+ * is the one run end to end on the device's clock, including the read-back that validates the bytes.  n_db and n_q at most
+ * 2^31 - 4096 (32-bit row indices, the last tile padded). */
 int sift3d_knn64(int device, const int8_t *db, int64_t n_db, const int8_t *queries, int64_t n_q, int k, int32_t *idx,
                  int32_t *dist2, int repeats, double *kernel_ms, char *err, int64_t err_len);
 

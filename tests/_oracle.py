@@ -230,4 +230,11 @@ def load_ref():
     r.ref_mult3.argtypes = [P, P, P]
     r.ref_sort_high_low.argtypes = [P, I]
     r.ref_sign.argtypes = [F]
+    r.ref_write_key_text.argtypes = [P, I, C.c_char_p, F, I, P]
+    r.ref_write_key_bin.argtypes = [P, I, C.c_char_p, F]
+    r.ref_read_key_text.argtypes = [C.c_char_p, P, I, P]
+    r.ref_dist_sqr_pcs.argtypes = [P, P, I]
+    r.ref_dist_sqr_pcs.restype = F
+    r.ref_world_orientation.argtypes = [P, P]
+    r.ref_output_float_pgm.argtypes = [P, I, I, C.c_char_p]
     return r

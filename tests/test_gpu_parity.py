@@ -604,6 +604,31 @@ def test_config_c2_against_the_oracle(built, oracle):
         assert (bits(cands[f]) == bits(wc[f])).all(), f
 
 
+def test_pinned_record_buffers_grow_when_a_run_needs_more(built):
+    """advisor, round 3: the pinned download buffers are sized for a few records per candidate (5; blob fields yield 4.2), not
+    for the worst case of 12.  A run that yields more grows them between the keypoint and the descriptor kernel -- forced here
+    by sizing them for ONE record per candidate -- and returns the same bytes, in one chunk and in several (where records of
+    chunks already described are carried over), on a fresh and on a reused context."""
+    dims = (96, 80, 72)
+    vol = vol_of(built, dims, 13)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract()
+        assert len(want) > 1000 and ctx.host_buffer_grows() == 0
+        assert len(want) > 2 * ctx.timings()["n_extrema"]                # more than two records per candidate: 1 per candidate cannot hold them
+    for chunks in (1, 3, 8):
+        with built.Context(*dims) as ctx:
+            ctx.set_tuning(built.TUNE_HOST_RECORDS, 1)
+            ctx.set_tuning(built.TUNE_KP_CHUNKS, chunks)
+            ctx.set_volume(vol)
+            got = ctx.extract()
+            assert ctx.host_buffer_grows() >= 1 and got.tobytes() == want.tobytes(), chunks
+            grown = ctx.host_buffer_grows()
+            assert ctx.extract().tobytes() == want.tobytes() and ctx.host_buffer_grows() == grown   # now large enough
+            assert ctx.extract(copy=False).tobytes() == want.tobytes()
+
+
+
 @pytest.mark.parametrize("dims,mode", [((168, 164, 160), 0), ((200, 120, 96), 2)])
 def test_chunked_keypoint_stage_gives_the_same_records(built, dims, mode):
     """The per-keypoint stage cut into chunks (keypoint kernel of chunk i+1 beside the descriptor kernel of chunk i, on two
@@ -742,13 +767,17 @@ def test_config_c3_flags_bit_exact(built, oracle):
     assert _compare_records(got, want)
 
 
-def _oracle_on_all_cores():
+def _oracle_on_all_cores(done="the properties above"):
     """The OpenMP build of the CPU restatement, for the full-size configurations: its records are the serial library's byte
     for byte (tests/test_oracle_pins.py holds it to that), and it finishes a 2^30-voxel volume in about a minute where the
-    serial build needs three.  None when the box has less than 80 GB of free host memory."""
+    serial build needs three.  On a box with less than 80 GB of free host memory the test is reported as SKIPPED with the
+    reason (round-3 review: it used to pass silently without the oracle comparison) -- the callers therefore make this
+    their last step, after every property that needs no oracle."""
     import psutil
-    if psutil.virtual_memory().available < 80 * 2 ** 30:
-        return None
+    avail = psutil.virtual_memory().available
+    if avail < 80 * 2 ** 30:
+        pytest.skip("oracle comparison NOT run: %.0f GB of free host memory, the full-size CPU restatement needs 80 "
+                    "(%s passed)" % (avail / 2 ** 30, done))
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
     import _oracle
     return _oracle.load_omp()
@@ -770,10 +799,7 @@ def test_config_c3_full_size(built):
         t = ctx.timings()
         assert t["n_octaves"] == 9 and t["n_extrema"] > 50000 and len(f) > 200000
         _record_properties(f, (n, n, n))
-        orc = _oracle_on_all_cores()
-        if orc is not None:
-            want, _ = orc.extract(orc.double_size(vol), init_scale=0.5, desc_mode=1, size_factor=0.5)
-            assert _compare_records(f, want), "float fields are within 1e-4 but not bit-identical"
+        f = f.copy()
         again = ctx.extract(initial_image_scale=0.5, desc_mode=built.DESC_BRIEF, size_factor=0.5)
         assert (again.view(np.uint8) == f.view(np.uint8)).all()             # idempotent
         # the SIFT-rank run of the same volume finds the same keypoints (the descriptor mode only changes desc)
@@ -782,6 +808,9 @@ def test_config_c3_full_size(built):
         for k in ("x", "y", "z", "scale", "ori", "eigs", "info"):
             assert np.ascontiguousarray(g[k]).tobytes() == np.ascontiguousarray(f[k]).tobytes(), k
         assert (g["desc"] != f["desc"]).any()
+    orc = _oracle_on_all_cores("size-independent properties, idempotence and the descriptor-mode check")   # last: may skip
+    want, _ = orc.extract(orc.double_size(vol), init_scale=0.5, desc_mode=1, size_factor=0.5)
+    assert _compare_records(f, want), "float fields are within 1e-4 but not bit-identical"
 
 
 def test_config_c4_volume_single_gpu(built):
@@ -800,10 +829,7 @@ def test_config_c4_volume_single_gpu(built):
         t = ctx.timings()
         assert t["n_octaves"] == 8 and len(f) > 500000
         _record_properties(f, dims)
-        orc = _oracle_on_all_cores()
-        if orc is not None:
-            want, _ = orc.extract(vol)
-            assert _compare_records(f, want), "float fields are within 1e-4 but not bit-identical"
+        f = f.copy()
         again = ctx.extract()
         assert (again.view(np.uint8) == f.view(np.uint8)).all()
         cands = ctx.detect()
@@ -811,6 +837,9 @@ def test_config_c4_volume_single_gpu(built):
         lin = (cands["z"].astype(np.int64) * 1024 + cands["y"]) * 1024 + cands["x"]
         assert (np.lexsort((lin, key)) == np.arange(len(cands))).all()      # the reference's order
         assert len(cands) == t["n_extrema"]
+    orc = _oracle_on_all_cores("size-independent properties, idempotence and the order of the candidates")   # last: may skip
+    want, _ = orc.extract(vol)
+    assert _compare_records(f, want), "float fields are within 1e-4 but not bit-identical"
 
 
 def _tool(name):
@@ -932,11 +961,6 @@ def test_config_c5_plane_size_on_one_gpu(built):
         t = ctx.timings()
     assert t["n_octaves"] == 7 and len(want) > 500000
     _record_properties(want, dims, rank_desc=False)
-    orc = _oracle_on_all_cores()
-    if orc is not None:                                                     # and the CPU restatement agrees, record by record
-        cpu, _ = orc.extract(vol, desc_mode=3)
-        assert _compare_records(want, cpu), "float fields are within 1e-4 but not bit-identical"
-        del cpu
     # keypoints in the far corner of the volume exist (indices beyond 2^31 bytes into a level were addressed)
     assert ((want["z"] > 200) & (want["y"] > 1800) & (want["x"] > 1800)).any()
     got, st = built.extract_zslab(vol, [0, 0], desc_mode=built.DESC_NRRIEF)
@@ -944,6 +968,10 @@ def test_config_c5_plane_size_on_one_gpu(built):
     assert len(got) == len(want) and got.tobytes() == want.tobytes()
     assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72
     assert st["halo_bytes_hidden"] == st["halo_bytes_critical"]
+    del got
+    orc = _oracle_on_all_cores("properties and the two-slab run against the single context")   # last: may skip
+    cpu, _ = orc.extract(vol, desc_mode=3)                                  # the CPU restatement agrees, record by record
+    assert _compare_records(want, cpu), "float fields are within 1e-4 but not bit-identical"
 
 
 def test_c_zslab_driver_edge_cases(built):

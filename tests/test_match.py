@@ -48,6 +48,42 @@ def test_votes_match_the_oracle_on_cpu(built, oracle):
     assert (c0 == c1).all() and v0.tobytes() == v1.tobytes()
 
 
+def test_votes_refuse_indices_out_of_range_and_are_the_same_for_any_thread_count(built, oracle):
+    """advisor, round 3: sift3d_match_votes is public C-ABI -- a neighbour index beyond the features or a label beyond
+    n_labels must be an error, not a read or write out of bounds.  Round 4: the loop over query images runs under OpenMP
+    as the reference's does (featMatchMultiple.cpp:108); rows must not depend on the thread count."""
+    rng = np.random.default_rng(8)
+    sizes = [30] * 12
+    first = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    desc = clustered(rng, int(first[-1]), 7, 2)
+    idx, d2 = oracle.knn64(desc, desc, 5)
+    labels = (np.arange(len(sizes)) % 4).astype(np.int32)
+    v0, c0 = oracle.match_votes(first, labels, 4, idx, d2)
+    v1, c1 = built.match_votes(first, labels, 4, idx, d2)
+    assert v0.tobytes() == v1.tobytes() and (c0 == c1).all() and c0.sum() > 50
+    code = ("import importlib, numpy as np, sys; p = importlib.import_module('3d_sift_cuda_amd'); d = np.load(sys.argv[1]); "
+            "v, c = p.match_votes(d['first'], d['labels'], 4, d['idx'], d['d2']); sys.stdout.buffer.write(v.tobytes() + c.tobytes())")
+    import subprocess, sys, os, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "a.npz"), first=first, labels=labels, idx=idx, d2=d2)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for nt in ("1", "3", "8"):
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "a.npz")], capture_output=True, cwd=root,
+                               env=dict(os.environ, OMP_NUM_THREADS=nt))
+            assert r.returncode == 0, r.stderr
+            assert r.stdout == v0.tobytes() + c0.tobytes()
+    bad = idx.copy()
+    bad[7, 2] = int(first[-1])            # one past the last feature
+    with pytest.raises(built.Sift3DError):
+        built.match_votes(first, labels, 4, bad, d2)
+    with pytest.raises(built.Sift3DError):
+        built.match_votes(first, labels, 3, idx, d2)          # label 3 with n_labels 3
+    neg = labels.copy()
+    neg[2] = -1
+    with pytest.raises(built.Sift3DError):
+        built.match_votes(first, neg, 4, idx, d2)
+
+
 def test_filters_and_descriptor_bytes(built):
     f = np.zeros(6, built.FEATURE_DTYPE)
     f["info"] = [0x00, 0x10, 0x20, 0x30, 0x20, 0x00]
@@ -198,6 +234,23 @@ def test_matcher_command_line(built, oracle, tmp_path):
     assert got_c[0, 1] > got_c[0, 3] and got_c[0, 2] > got_c[0, 3]         # shared blobs attract votes, a foreign volume few
     fc = open(tmp_path / "feature_count.txt").read().split()
     assert [int(x) for x in fc[1::2]] == [len(s) for s in sets]
+    # advisor, round 3: a key file that cannot be read keeps its index and stays an empty set (the reference's loop,
+    # featMatchMultiple.cpp:578-632) -- also when it is the LAST name: one row per name in every output
+    r = subprocess.run([built.FEATMATCH, "-n", "5"] + names + [str(tmp_path / "missing.key")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "Error: could not open feature file 4" in r.stdout
+    fc = open(tmp_path / "feature_count.txt").read().split()
+    assert [int(x) for x in fc[1::2]] == [len(s) for s in sets] + [0]
+    lines = open(tmp_path / "matching_votes.txt").read().split("\n")
+    rows5 = [[float(x) for x in l.split("\t") if x] for l in lines[1:6]]
+    assert all(len(row) == 5 for row in rows5) and rows5[4] == [0.0] * 5
+    assert (np.array(rows5)[:4, :4] == want_v).all()
+    assert len(open(tmp_path / "_names.txt").read().splitlines()) == 5
+    # -s 2: all three passes APPEND to the vote files (featMatchMultiple.cpp:58-65), the first included
+    before = open(tmp_path / "matching_votes.txt").read()
+    r = subprocess.run([built.FEATMATCH, "-n", "5", "-s2"] + names, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    after = open(tmp_path / "matching_votes.txt").read()
+    assert after.startswith(before) and [l for l in after[len(before):].split("\n") if l and not l[0].isdigit()] == ["Peak and Valley", "Peaks", "Valley"]
     # usage and bad option, as the reference
     assert subprocess.run([built.FEATMATCH], capture_output=True).returncode == 255
     bad = subprocess.run([built.FEATMATCH, "-q", names[0], names[1]], cwd=tmp_path, capture_output=True, text=True)
