@@ -126,6 +126,7 @@ struct sift3d_ctx {
     int64_t kps_cap;
     int *rec_kp, *rec_frame;
     int64_t recs_cap;       /* record slots of rec_kp / rec_frame: kps_cap * (1 + SIFT3D_MAX_FRAMES), the worst case */
+    int64_t capT;           /* floats each of T[0], T[1] holds */
     int64_t hrecs_cap;      /* records the two pinned host buffers below hold: a few per candidate, grown when a run needs more */
     sift3d_feature *h_recs; /* pinned host memory the descriptor kernel stores its records into; reused from call to call */
     int *h_group;           /* per record: level id * 2 + is_max (pinned host) */
@@ -320,7 +321,14 @@ static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bo
         ok = ok && hipMalloc((void **)&c->D4tiny, sizeof(float) * SIFT3D_D4TINY_FLOATS) == hipSuccess &&
              hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream) == hipSuccess;
     }
-    for (int i = 0; i < 2 && ok; i++) ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
+    /* the two pass intermediates of the three-launch blur: allocated here for the volumes the numbers are quoted on; a
+     * context beyond 2^31 voxels allocates them when a blur first takes that form, sized for it (its full-size levels go
+     * through the one-launch kernel, the coarse octaves need an eighth) -- 2 x 17 GB less at config C5's 2^32 voxels */
+    if (c->capN <= SIFT3D_EAGER_T_FLOATS)
+        for (int i = 0; i < 2 && ok; i++) {
+            ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
+            if (ok) c->capT = c->capN;
+        }
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
@@ -360,8 +368,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -563,6 +571,30 @@ extern "C" int sift3d_get_launch_log(const sift3d_ctx *c, sift3d_launch_record *
     return *n > cap ? SIFT3D_ERR_CAPACITY : SIFT3D_OK;
 }
 
+/* T[0], T[1] hold at least `floats` floats each (see ctx_create).  Growing waits for the stream: a blur queued earlier may
+ * still be using the old pair. */
+static int ensure_T(sift3d_ctx *c, int64_t floats)
+{
+    if (floats <= c->capT) return SIFT3D_OK;
+    if (floats > c->capN) return set_err(c, SIFT3D_ERR_ARG, "pass intermediates of %lld floats asked of a context of %lld", (long long)floats, (long long)c->capN);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(c->T[0]);
+    hipFree(c->T[1]);
+    c->T[0] = c->T[1] = nullptr;
+    c->capT = 0;
+    /* at least the second octave (capN / 8 and its row padding), so that the coarse octaves of one extraction grow it once */
+    int64_t want = c->capN / 8 + c->capN / 64 + 4096;
+    if (want < floats) want = floats;
+    if (want > c->capN) want = c->capN;
+    for (int i = 0; i < 2; i++)
+        if (hipMalloc((void **)&c->T[i], sizeof(float) * (size_t)want) != hipSuccess) {
+            (void)hipGetLastError();
+            return set_err(c, SIFT3D_ERR_MEMORY, "out of device memory for the pass intermediates (%lld floats)", (long long)want);
+        }
+    c->capT = want;
+    return SIFT3D_OK;
+}
+
 /* ---- device-level building blocks -------------------------------------- */
 /* out = blur(in); if dog != NULL also dog = in - out.  out may be NULL when only the DoG is wanted.  Uses T[0], T[1]. */
 static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma,
@@ -583,7 +615,7 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     /* One fused launch per level where the volume fills the chip (it marches along z with few, fat workgroups);
      * coarse octaves keep the three-pass path.  SIFT3D_TUNE_BLUR_FUSED: 0 never / 2 always (tests, A/B timing). */
     const int fmode = c->tune[SIFT3D_TUNE_BLUR_FUSED];
-    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS]};
+    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE]};
     /* measured standalone (tools/bench_blur_ab.sh 128 / 64): below 2^22 voxels the one launch still beats the three for 7 and
      * 9 taps (0.020 / 0.026 against 0.042 / 0.043 ms at 128^3), ties at 11-13 and loses at 17 */
     if (fmode == 2 || (fmode == 1 && (N >= (double)(1 << 22) || (N >= (double)(1 << 18) && n <= 9)))) {
@@ -595,10 +627,14 @@ static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     }
     /* the three-pass form goes through the context's two intermediates: a volume beyond them (a gathered octave on a slab
      * context sized for its slab) must not overrun them */
-    float *const T0 = c->T[0], *const T1 = c->T[1];
     if ((int64_t)N > c->capN)
         return set_err(c, SIFT3D_ERR_ARG, "a %lldx%lldx%lld blur needs pass intermediates of %lld floats, the context has %lld", (long long)X,
                        (long long)Y, (long long)Z, (long long)N, (long long)c->capN);
+    {
+        int rc_t = ensure_T(c, (int64_t)N);
+        if (rc_t) return rc_t;
+    }
+    float *const T0 = c->T[0], *const T1 = c->T[1];
     {
         stage_scope sc(c, SIFT3D_STAGE_BLUR_X, 8.0 * N, n, (int64_t)N, ws);
         HIPCHK(c, sift3d_launch_blur_x(ws, in, T0, X, Y, Z, taps, n, c->d_taps));
@@ -662,7 +698,7 @@ static int blur_window_dev(sift3d_ctx *c, const float *in, float *out, float *do
     float taps[SIFT3D_MAX_TAPS];
     const int n = sift3d_gauss_taps(sigma, min_value, taps);
     if (n < 3 || zo0 < 0 || zo1 > Z || zo1 <= zo0) return set_err(c, SIFT3D_ERR_ARG, "bad blur window [%lld, %lld) of %lld planes", (long long)zo0, (long long)zo1, (long long)Z);
-    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS]};
+    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE]};
     const double N = (double)X * Y * (double)(zo1 - zo0);
     stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N);
     hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, X, Y, Z, taps, n, &bt, zo0, zo1);
@@ -1096,6 +1132,8 @@ extern "C" int sift3d_set_volume_resized(sift3d_ctx *c, const float *vol, int64_
     if (oz <= 1) return set_err(c, SIFT3D_ERR_ARG, "Could not read volume (z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
     /* T[0], T[1]: the dense scratch volumes of the three-pass blur, free until the pyramid runs */
+    rc = ensure_T(c, ox * oy * oz > nx * ny * nz ? ox * oy * oz : nx * ny * nz);
+    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->T[0], vol, sizeof(float) * (size_t)(nx * ny * nz), hipMemcpyHostToDevice, c->stream));
     if (resize > 0) HIPCHK(c, sift3d_launch_double_size(c->stream, c->T[0], nx, ny, nz, c->T[1]));
     else HIPCHK(c, sift3d_launch_halve_size(c->stream, c->T[0], nx, ny, nz, c->T[1]));

@@ -94,13 +94,20 @@ typedef int v2i __attribute__((ext_vector_type(2)));
  * wavefronts' worth.  (4 outputs per lane -- 10 to 12 wavefronts, three per SIMD instead of an uneven two / one -- was
  * built for the 1024-thread mapping in round 2: bit-identical, and no faster: 0.402 against 0.401 ms at 17 taps.) */
 #define FB_XO 8
-template <int R, int BR, int PF = 1>
+/* TXv x TYv: the (x, y) tile, 2 048 voxels either way.  64 x 32 is the shape of rounds 1 - 3; 128 x 16 (round 4) makes the row
+ * segment a workgroup reads and writes 512 bytes instead of 256 -- the zero-arithmetic march streams 6 - 8 % better on such
+ * tiles ("Tile shapes") -- and pays for it with a taller relative y halo: the x pass filters 16 + 2R rows
+ * for 16 instead of 32 + 2R for 32. */
+template <int R, int BR, int PF = 1, int TXv = FB_TX, int TYv = 32>
 struct fb_ring_cfg {
     static constexpr int XO = FB_XO;
-    static constexpr int TY = 32;
+    static constexpr int TX = TXv;
+    static constexpr int TY = TYv;
+    static constexpr int CP = TX / 2;                           /* column pairs of the tile: the y / z pass's lanes along x */
     static constexpr int NT = 1024 / BR;
+    static_assert(CP * (TY / BR) == NT, "every thread owns a 2 x BR block of the tile");
     static constexpr int NR = TY + 2 * R;
-    static constexpr int LPR = FB_TX / XO;                      /* lanes per row of the x pass */
+    static constexpr int LPR = TX / XO;                         /* lanes per row of the x pass */
     static constexpr int RPW = 64 / LPR;                        /* rows per x-pass wavefront */
     static constexpr int XW = (NR + RPW - 1) / RPW;             /* wavefronts with an x-pass role */
     static constexpr int P1ROWS = XW * RPW;                     /* rows those wavefronts write (>= NR; the surplus rows are never read) */
@@ -110,7 +117,7 @@ struct fb_ring_cfg {
      * volumes with more tiles than CUs: two resident workgroups with two planes in flight each stream markedly slower
      * (0.38 against 0.315 ms per 7-tap launch at 512^3). */
     static constexpr bool SINGLE = PF >= 2 && BR == 2;
-    static constexpr int LDS_NEEDED = 2 * P1ROWS * FB_TX + S * TY * FB_TX;
+    static constexpr int LDS_NEEDED = 2 * P1ROWS * TX + S * TY * TX;
     static constexpr int LDS_FLOATS = (SINGLE && LDS_NEEDED < 21 * 1024) ? 21 * 1024 : LDS_NEEDED;
     /* workgroups per CU the LDS allows (160 KiB), capped at what 32 wavefronts per CU allow */
     static constexpr int WG_LDS = (160 * 1024) / (LDS_FLOATS * 4);
@@ -123,19 +130,20 @@ struct fb_ring_cfg {
  * wavefronts per SIMD, up to 256 registers) -- a zero-arithmetic march of the same tiles streams 5.4-5.8 TB/s with one
  * workgroup per CU and two z chunks against 4.4-4.9 with two per CU and four chunks (tools/stream_roof.hip), and the
  * second plane in flight covers the latency the second workgroup covered. */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
-__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32>
+__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
     const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen,
     int tiles_x, int tiles_y, long long total, fb_taps2 t)
 {
-    using C = fb_ring_cfg<R, BR, PF>;
+    using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
     constexpr int U = 2 * R + 1, XO = C::XO;
+    constexpr int TX = C::TX, CP = C::CP;
     constexpr int TY = C::TY, NR = C::NR, XW = C::XW, P1ROWS = C::P1ROWS, S = C::S;
     constexpr int H4 = ((R + 3) / 4) * 4; /* window halo, whole 16-byte vectors */
     constexpr int WIN = XO + 2 * H4, NV = WIN / 4;
     constexpr int LPR = C::LPR;
     static_assert(XO == 8, "a lane filters two 16-byte vectors of a row");
-    constexpr int P1PL = P1ROWS * FB_TX, PVPL = TY * FB_TX;
+    constexpr int P1PL = P1ROWS * TX, PVPL = TY * TX;
     static_assert(XW * 64 <= C::NT, "the x-pass wavefronts are wavefronts of the workgroup");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     float *const P1b = lds;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
     const int tx = (int)(wi % tiles_x);
     const int ty = (int)((wi / tiles_x) % tiles_y);
     const int chunk = (int)(wi / ((long long)tiles_y * tiles_x));
-    const int x0 = tx * FB_TX, y0 = ty * TY;
+    const int x0 = tx * TX, y0 = ty * TY;
     /* output planes [zo0, zo1) of the volume (the whole of it, or a window: a Z-slab rank filters its boundary bands
      * first); the input is read wherever the filter reaches, zeros outside [0, Z) */
     const int zc0 = zo0 + chunk * zlen;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
     const bool prow = ar >= R && ar < R + TY; /* a row of the tile itself: its centre 8 floats go to the DoG-input ring */
 
     /* stage B/C role: column pair bcp, BR rows starting at row brow of the tile */
-    const int bcp = tid & 31, brow = (tid >> 5) * BR;
+    const int bcp = tid % CP, brow = (tid / CP) * BR;
     const int bx = x0 + 2 * bcp;
     unsigned soff[BR];
 #pragma unroll
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
         }
         if (HAS_DOG && prow) {
 #pragma unroll
-            for (int q = 0; q < XO / 4; q++) *reinterpret_cast<v4f *>(&pvs[(ar - R) * FB_TX + axs + 4 * q]) = win[B][H4 / 4 + q];
+            for (int q = 0; q < XO / 4; q++) *reinterpret_cast<v4f *>(&pvs[(ar - R) * TX + axs + 4 * q]) = win[B][H4 / 4 + q];
         }
         /* tap loop outside, output pairs inside: per tap XO/2 independent products, then XO/2 adds, none of which depends
          * on its immediate predecessor (a packed operation that consumes the result of the instruction right before it
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
         for (int q = 0; q < XO / 4; q++) {
             v4f r0;
             r0.x = o[2 * q].x; r0.y = o[2 * q].y; r0.z = o[2 * q + 1].x; r0.w = o[2 * q + 1].y;
-            *reinterpret_cast<v4f *>(&P1[ar * FB_TX + axs + 4 * q]) = r0;
+            *reinterpret_cast<v4f *>(&P1[ar * TX + axs + 4 * q]) = r0;
         }
     };
 
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
         const float *P1 = P1b + cur * P1PL;
         v2f p[U + BR - 1];
 #pragma unroll
-        for (int q = 0; q < U + BR - 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(brow + q) * FB_TX + 2 * bcp]);
+        for (int q = 0; q < U + BR - 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(brow + q) * TX + 2 * bcp]);
         v2f g[BR];
 #pragma unroll
         for (int r = 0; r < BR; r++) {
@@ -357,9 +365,9 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF>::WAVES_PER_SIMD)
             v2f dg[BR];
             if constexpr (HAS_DOG) {
                 const int rslot = wslot + 1 == S ? 0 : wslot + 1;
-                const float *pvp = pvb + rslot * PVPL + brow * FB_TX + 2 * bcp;
+                const float *pvp = pvb + rslot * PVPL + brow * TX + 2 * bcp;
 #pragma unroll
-                for (int r = 0; r < BR; r++) dg[r] = *reinterpret_cast<const v2f *>(pvp + r * FB_TX) - a[r];
+                for (int r = 0; r < BR; r++) dg[r] = *reinterpret_cast<const v2f *>(pvp + r * TX) - a[r];
             } else {
 #pragma unroll
                 for (int r = 0; r < BR; r++) dg[r] = v2f(0.0f);
@@ -415,21 +423,21 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident, int for
 
 /* Returns false when the shape is outside the kernel (32-bit buffer offsets: a chunk with its lead-in planes must stay
  * below 4 GiB -- a volume whose planes are that large gets more z chunks, and only a plane pair beyond 4 GiB has none) */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF>
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32>
 static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
                           const fb_taps2 &t, int forced_chunks)
 {
-    using C = fb_ring_cfg<R, BR, PF>;
+    using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
     static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
     if (resident == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF>, C::NT, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv>, C::NT, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     const int64_t plane_bytes = X * Y * 4;
     const int64_t max_planes = (int64_t)0xFFFFFFF0ll / plane_bytes - 2 * R - 2; /* planes per chunk the offsets can address */
     if (max_planes < 1) return false;
-    const int tiles_x = (int)((X + FB_TX - 1) / FB_TX), tiles_y = (int)((Y + C::TY - 1) / C::TY);
+    const int tiles_x = (int)((X + C::TX - 1) / C::TX), tiles_y = (int)((Y + C::TY - 1) / C::TY);
     const long long tiles = (long long)tiles_x * tiles_y;
     const int64_t Zo = zo1 - zo0; /* planes to produce */
     int n = fused_chunks(R, Zo, tiles, resident, forced_chunks);
@@ -438,18 +446,18 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     const int nch = (int)((Zo + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
-    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
+    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
                        (int)Y, (int)Z, (int)zo0, (int)zo1, zlen, tiles_x, tiles_y, total, t);
     return true;
 }
 
-template <int R, int BR, int PF>
+template <int R, int BR, int PF, int TXv = FB_TX, int TYv = 32>
 static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
                            const fb_taps2 &t, int chunks)
 {
-    if (out && dog) return launch_ring_t<R, BR, true, true, PF>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
-    if (out) return launch_ring_t<R, BR, true, false, PF>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
-    return launch_ring_t<R, BR, false, true, PF>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    if (out && dog) return launch_ring_t<R, BR, true, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    if (out) return launch_ring_t<R, BR, true, false, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    return launch_ring_t<R, BR, false, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
 }
 
 /* The two mappings, by measurement at 512^3 and 256^3: two rows per thread, two planes of window
@@ -464,6 +472,20 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     const int br = forced == 1 || forced == 2 ? forced : ((R >= 7 || X * Y * (zo1 - zo0) < (1ll << 22)) ? 1 : 2);
     const int chunks = tune ? tune->z_chunks : 0;
     if (br == 1) return launch_ring_pf<R, 1, 1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    /* tile shape of the two-rows-per-thread mapping: tune->tile 0 = by measurement (below), 1 = 64 x 32, 2 = 128 x 16 */
+    /* by measurement at 512^3 (profiles/r04_tile_ab.txt, dense random data, ms per launch 64 x 32 -> 128 x 16): 7 taps level only
+     * 0.217 -> 0.201 - 0.207, 9 taps level + DoG 0.333 - 0.337 -> 0.318 - 0.323, 7 taps level + DoG 0.329 - 0.331 -> 0.321 - 0.326; no
+     * gain at 11 taps (0.356 - 0.358 both) and a loss where the taller y halo meets more arithmetic or three planes of prefetch:
+     * 13 taps 0.364 - 0.368 -> 0.370 - 0.375, 9 taps level only 0.216 - 0.220 -> 0.225 - 0.234 */
+    const int tile = tune ? tune->tile : 0;
+    const bool both = out && dog;
+    const bool wide = tile == 2 || (tile == 0 && ((R == 3) || (R == 4 && both)));
+    if constexpr (R <= 6)
+        if (wide && X >= 128) {
+            if constexpr (R <= 4)
+                if (!(out && dog)) return launch_ring_pf<R, 2, 3, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+            return launch_ring_pf<R, 2, 2, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+        }
     /* three planes of window prefetch where the registers are there and only one array is stored (7 and 9 taps, level
      * only: 0.213 / 0.224 ms at 512^3 against 0.225 - 0.232 / 0.233 - 0.237 with two; with the DoG store beside it three planes
      * change nothing: 0.324 / 0.338 against 0.328 / 0.334 - 0.342; four planes, level only: 0.225 / 0.220, no better than three) */

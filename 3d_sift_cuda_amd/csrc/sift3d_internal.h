@@ -69,6 +69,7 @@ hipError_t sift3d_launch_blur_z(hipStream_t s, const float *in, float *out, cons
 struct sift3d_blur_tuning {
     int z_chunks;        /* SIFT3D_TUNE_FUSED_CHUNKS */
     int rows_per_thread; /* SIFT3D_TUNE_FUSED_ROWS: 2 = 512 threads, two planes of prefetch; 1 = 1024 threads, one plane */
+    int tile;            /* SIFT3D_TUNE_FUSED_TILE: 1 = 64 x 32, 2 = 128 x 16 (two-rows-per-thread mapping, up to 13 taps) */
 };
 hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z,
                                     const float *taps, int ntaps, const sift3d_blur_tuning *tune, int64_t zo0 = 0, int64_t zo1 = -1);
@@ -79,6 +80,8 @@ hipError_t sift3d_launch_zero_pad(hipStream_t s, float *a, float *b, int64_t X, 
 /* levels 1..5 (L[4] may be NULL) and DoGs 0..4 of an octave of at most SIFT3D_TINY_VOX voxels from its level 0, rows of
  * pitch XP; hipErrorNotSupported outside that */
 #define SIFT3D_TINY_VOX 4096
+/* contexts of at most this many floats allocate the two pass intermediates of the three-launch blur when they are created */
+#define SIFT3D_EAGER_T_FLOATS (1ll << 31)
 struct sift3d_octave_out {
     float *L[5];
     float *D[5];

@@ -3,11 +3,14 @@
 
 #include <math.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
-void sift3d_synth_blobs(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t seed)
+/* the blobs of the generator, in generation order, accumulated into planes [za, zb) only */
+static void blobs_into_planes(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t seed, int64_t za, int64_t zb)
 {
     const int64_t N = X * Y * Z;
-    memset(vol, 0, sizeof(float) * (size_t)N);
     uint32_t s = seed;
 #define NEXT_U() (s = s * 1664525u + 1013904223u, (float)(s >> 8) / 16777216.0f)
     const int64_t nblobs = N / 2048;
@@ -27,6 +30,8 @@ void sift3d_synth_blobs(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t se
         if (x1 > X - 1) x1 = X - 1;
         if (y1 > Y - 1) y1 = Y - 1;
         if (z1 > Z - 1) z1 = Z - 1;
+        if (z0 < za) z0 = za;
+        if (z1 > zb - 1) z1 = zb - 1;
         for (int64_t z = z0; z <= z1; z++) {
             float dz = (float)z - cz;
             for (int64_t y = y0; y <= y1; y++) {
@@ -41,4 +46,25 @@ void sift3d_synth_blobs(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t se
         }
     }
 #undef NEXT_U
+}
+
+void sift3d_synth_blobs(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t seed)
+{
+    /* A voxel's value is the float sum of its blobs in generation order.  Each thread walks the whole blob sequence (five
+     * draws a blob) and adds only into its own range of planes, so every voxel still sees its blobs in that order: the
+     * same bits for any thread count (a 2048 x 2048 x 1024 volume takes minutes on one core). */
+#ifdef _OPENMP
+    int nt = omp_get_max_threads();
+    if (nt > Z) nt = (int)Z;
+    if (X * Y * Z < (1ll << 22) || nt < 1) nt = 1;
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < nt; t++) {
+        const int64_t za = Z * t / nt, zb = Z * (t + 1) / nt;
+        memset(vol + za * Y * X, 0, sizeof(float) * (size_t)((zb - za) * Y * X));
+        blobs_into_planes(vol, X, Y, Z, seed, za, zb);
+    }
+#else
+    memset(vol, 0, sizeof(float) * (size_t)(X * Y * Z));
+    blobs_into_planes(vol, X, Y, Z, seed, 0, Z);
+#endif
 }

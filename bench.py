@@ -324,6 +324,9 @@ def main():
     ap.add_argument("--phase-limit", type=int, default=300,
                     help="N > 1: seconds any one phase of a rank (set-up, warm-up, the timed steps, a reduction) may take before "
                          "the rank ends the job with exit code 3 and the phase name (0 = no limit)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="sift3d_set_tuning on the context before the run, e.g. FUSED_TILE=2 (A/B measurements; no knob changes a "
+                         "result; the line records what was set)")
     ap.add_argument("--launch-check", default=None, choices=["ok", "fail"],
                     help="only bring the ranks up (process group over gloo, no GPU call), print a line with the world size "
                          "seen and leave -- 'fail': rank 1 exits with code 7 instead (tests of the self-launch path)")
@@ -388,6 +391,9 @@ def main():
     phase("volumes: synthetic volume, context, upload")
     vol = pkg.synth_blobs(n, n, n, seed=12345 + rank)
     ctx = pkg.Context(n, n, n, device=local_rank)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ctx.set_tuning(getattr(pkg, "TUNE_" + k.upper()), int(v))
     dvol = torch.from_numpy(vol).to("cuda:%d" % local_rank)   # the input lives in HBM before timing starts
     torch.cuda.synchronize(local_rank)
     ctx.set_volume_dev(dvol.data_ptr(), n, n, n)
@@ -600,6 +606,7 @@ def main():
                        "records_per_volume": int(nrec), "octaves": int(tim["n_octaves"]), "extrema": int(tim["n_extrema"]),
                        "keypoints": int(tim["n_keypoints"]),
                        "parallelism": "1 volume per GPU (independent volumes, no collective)" if world > 1 else "single GPU",
+                       "tuning": args.tune or "defaults",
                        "descriptor_parity": ("SIFT-rank: pinned against the reference (see DESIGN.md section 2)" if args.desc == 0 else
                                              "BRIEF / RRIEF / NRRIEF exist in the reference only as commented alternatives "
                                              "(MultiScale.cpp:1037-1045): HIP == oracle bit for bit, but the oracle rows are unpinned "

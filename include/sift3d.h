@@ -208,6 +208,8 @@ typedef enum {
                                  * while they travel to its neighbours; 0: the level in one piece, then the exchange (round 2) */
     SIFT3D_TUNE_HOST_RECORDS,   /* records per candidate the pinned download buffers are first sized for: 5 (default; blob fields yield
                                  * 4.2), 1..12; a run that yields more grows them (sift3d_host_buffer_grows counts) */
+    SIFT3D_TUNE_FUSED_TILE,     /* (x, y) tile of the fused launch's two-rows-per-thread mapping: 0 = by measurement (default), 1 = 64 x 32,
+                                 * 2 = 128 x 16 */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);

@@ -39,12 +39,12 @@ def test_blur_bit_exact(built, oracle, dims):
             assert (bits(got) == bits(want)).all(), (dims, s, np.abs(got - want).max())
 
 
-FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37, 45), (68, 17, 3), (128, 64, 70)]
+FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37, 45), (68, 17, 3), (128, 64, 70), (260, 50, 21)]
 
 
 @pytest.mark.parametrize("dims", FUSED_SHAPES)
-@pytest.mark.parametrize("chunks,rows", [(0, 0), (3, 1), (2, 2), (3, 2), (1, 1), (5, 0)])
-def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows):
+@pytest.mark.parametrize("chunks,rows,tile", [(0, 0, 0), (3, 1, 0), (2, 2, 1), (3, 2, 1), (1, 1, 0), (5, 0, 0), (0, 2, 2), (3, 2, 2)])
+def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows, tile):
     """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up, 2^18 for narrow filters):
     partial tiles in x and y, volumes thinner than the filter, one or several z chunks, both thread mappings (one row per
     thread with one plane of window prefetch; two rows with two planes) on every shape and filter: level and DoG
@@ -56,6 +56,7 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows):
         ctx.set_tuning(built.TUNE_BLUR_FUSED, 2)
         ctx.set_tuning(built.TUNE_FUSED_CHUNKS, chunks)
         ctx.set_tuning(built.TUNE_FUSED_ROWS, rows)
+        ctx.set_tuning(built.TUNE_FUSED_TILE, tile)   # 2: the 128 x 16 tile (rows of at least 128 voxels; round 4)
         d_in = torch.from_numpy(vol).cuda()
         d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
         torch.cuda.synchronize()
@@ -609,13 +610,13 @@ def test_pinned_record_buffers_grow_when_a_run_needs_more(built):
     for the worst case of 12.  A run that yields more grows them between the keypoint and the descriptor kernel -- forced here
     by sizing them for ONE record per candidate -- and returns the same bytes, in one chunk and in several (where records of
     chunks already described are carried over), on a fresh and on a reused context."""
-    dims = (96, 80, 72)
+    dims = (192, 176, 160)
     vol = vol_of(built, dims, 13)
     with built.Context(*dims) as ctx:
         ctx.set_volume(vol)
         want = ctx.extract()
-        assert len(want) > 1000 and ctx.host_buffer_grows() == 0
-        assert len(want) > 2 * ctx.timings()["n_extrema"]                # more than two records per candidate: 1 per candidate cannot hold them
+        assert len(want) > 4000 and ctx.host_buffer_grows() == 0
+        assert len(want) > 1.125 * ctx.timings()["n_extrema"] + 1024     # 1 per candidate (plus the allocation's slack) cannot hold them
     for chunks in (1, 3, 8):
         with built.Context(*dims) as ctx:
             ctx.set_tuning(built.TUNE_HOST_RECORDS, 1)
@@ -972,6 +973,73 @@ def test_config_c5_plane_size_on_one_gpu(built):
     orc = _oracle_on_all_cores("properties and the two-slab run against the single context")   # last: may skip
     cpu, _ = orc.extract(vol, desc_mode=3)                                  # the CPU restatement agrees, record by record
     assert _compare_records(want, cpu), "float fields are within 1e-4 but not bit-identical"
+
+
+def test_config_c5_at_its_own_size(built):
+    """BASELINE config C5 ITSELF: 2048 x 2048 x 1024 = 2^32 voxels, NRRIEF -- a size the reference cannot address at all (its
+    element count is an unsigned int: R/src_common/FeatureIO.cpp:381; its CUDA path indexes with int:
+    R/cuda_common/SIFT_cuda_Tools.cu:187).  On ONE 288 GB GPU: (1) the single-context extraction (a pyramid of 11.4 floats a
+    voxel, 208 GB -- the pass intermediates of the three-launch blur are allocated on demand above 2^31 voxels);
+    (2) properties no oracle is needed for: record invariants, idempotence, the reference's raster order of the candidates,
+    keypoints whose linear index is next to 2^32; (3) C5's slab geometry -- Z-slabs of 128 slices of 2048 x 2048, three sharded
+    octaves -- through the C slab driver: FOUR of them (2048 x 2048 x 512: eight would need 310 GB on the one device), byte for
+    byte the single-context records of that half;
+    (4) the translation property of tools/big_volume_check.py at this size: a blob block in the far corner gives the
+    candidates of the same block in a small volume, shifted, with bit-identical DoG values (that small volume is one the
+    oracle-checked tests cover).  The CPU restatement itself would need 160 GB of host memory and minutes here."""
+    import time
+    import psutil
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 245 * 2 ** 30:
+        pytest.skip("C5 at its own size NOT run: needs about 235 GB of free HBM, this device has %.0f" % (free / 2 ** 30))
+    avail = psutil.virtual_memory().available
+    if avail < 48 * 2 ** 30:
+        pytest.skip("C5 at its own size NOT run: needs about 40 GB of free host memory (the 17 GB volume, its records), found %.0f" % (avail / 2 ** 30))
+    dims = (2048, 2048, 1024)
+    t0 = time.time()
+    vol = vol_of(built, dims, 2027)
+    print("C5: volume generated in %.1f s" % (time.time() - t0), flush=True)
+    with built.Context(*dims) as ctx:
+        t0 = time.time()
+        ctx.set_volume(vol)
+        want = ctx.extract(desc_mode=built.DESC_NRRIEF)
+        t = ctx.timings()
+        print("C5: single context: upload + first extraction %.1f s, %d records, %d extrema, %d octaves" %
+              (time.time() - t0, len(want), t["n_extrema"], t["n_octaves"]), flush=True)
+        t0 = time.time()
+        again = ctx.extract(desc_mode=built.DESC_NRRIEF, copy=False)
+        print("C5: second extraction (resident volume) %.3f s" % (time.time() - t0), flush=True)
+        assert len(again) == len(want) and (again.view(np.uint8) == want.view(np.uint8)).all()      # idempotent
+        cands = ctx.detect()
+    assert t["n_octaves"] == 9 and len(want) > 4000000 and len(cands) == t["n_extrema"] > 1000000
+    _record_properties(want, dims, rank_desc=False)
+    key = (cands["octave"].astype(np.int64) << 44) + (cands["level"].astype(np.int64) << 42) + (cands["is_max"].astype(np.int64) << 41)
+    lin = ((cands["z"].astype(np.int64) * (dims[1] >> cands["octave"]) + cands["y"]) * (dims[0] >> cands["octave"])) + cands["x"]
+    assert lin.max() > 2 ** 32 - 2 ** 27                                        # candidates at the far end of the 2^32 indices
+    order = key + lin
+    assert (order[1:] > order[:-1]).all()                                       # octave, level, minima first, raster z-y-x: the reference's order
+    assert ((want["z"] > 1000) & (want["y"] > 2000) & (want["x"] > 2000)).any()  # keypoints in the far corner
+    del cands, again
+    del want
+    # C5's own eight slabs keep 128 + 2 x 32 slices of every level each: 1.5 x the pyramid, 310 GB -- more than the ONE device
+    # of this box holds (on eight devices: 39 GB each).  Half the volume in FOUR slabs of the same 128 slices (two interior
+    # ranks, three sharded octaves) is what fits: byte for byte the single-context records of that half.
+    half = vol[:512]
+    with built.Context(2048, 2048, 512) as ctx:
+        ctx.set_volume(half)
+        want = ctx.extract(desc_mode=built.DESC_NRRIEF)
+    t0 = time.time()
+    got, st = built.extract_zslab(half, [0] * 4, desc_mode=built.DESC_NRRIEF)
+    print("C5: 2048 x 2048 x 512 in four Z-slabs of 128 slices on one device: %.1f s, %d records" % (time.time() - t0, len(got)), flush=True)
+    assert st["n_ranks"] == 4 and st["sharded_octaves"] == 3
+    assert len(got) == len(want) > 2000000 and got.tobytes() == want.tobytes()
+    assert st["halo_bytes_deferred"] * 33 == st["halo_bytes_critical"] * 72
+    assert st["halo_bytes_hidden"] == st["halo_bytes_critical"]
+    del got, want, vol, half
+    t0 = time.time()
+    assert _tool("big_volume_check").check(dims)
+    print("C5: translation property at 2048 x 2048 x 1024: %.1f s" % (time.time() - t0), flush=True)
 
 
 def test_c_zslab_driver_edge_cases(built):
