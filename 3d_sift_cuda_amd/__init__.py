@@ -137,6 +137,8 @@ def hip_lib():
     _sig(L.sift3d_describe_dev, I, P, P, I, I, F, F, P, P, P)
     _sig(L.sift3d_set_max_octaves, I, P, I)
     _sig(L.sift3d_extract_zslab, I, P, I, P, I64, I64, I64, F, I, F, F, P, P, P, C.c_char_p, I64)
+    _sig(L.sift3d_extract_zslab_over, I, I, P, I, P, I64, I64, I64, F, I, F, F, P, P, P, C.c_char_p, I64)
+    _sig(L.sift3d_zslab_set_transport_library, None, C.c_char_p)
     _sig(L.sift3d_zslab_create, P, P, I, I64, I64, I64, C.c_char_p, I64)
     _sig(L.sift3d_zslab_extract, I, P, P, F, I, F, F, P, P, P, C.c_char_p, I64)
     _sig(L.sift3d_zslab_destroy, None, P)
@@ -179,18 +181,27 @@ class ZSlabStats(C.Structure):
     """sift3d_zslab_stats"""
     _fields_ = [("n_ranks", C.c_int32), ("sharded_octaves", C.c_int32), ("exchanges", C.c_int64), ("halo_bytes_critical", C.c_int64),
                 ("halo_bytes_deferred", C.c_int64), ("gather_bytes", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
-                ("n_records", C.c_int64), ("wall_ms", C.c_double), ("halo_bytes_hidden", C.c_int64)]
+                ("n_records", C.c_int64), ("wall_ms", C.c_double), ("halo_bytes_hidden", C.c_int64), ("transport", C.c_int32),
+                ("transport_fell_back", C.c_int32), ("rccl_version", C.c_int32), ("reserved", C.c_int32)]
 
 
-def extract_zslab(vol, devices, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
-    """sift3d_extract_zslab: the volume cut into one Z-slab per entry of `devices`, one process, halos by peer copies.
-    Returns (records, stats dict)."""
+ZSLAB_TRANSPORT, TRANSPORT_PEER_COPY, TRANSPORT_RCCL = 1000, 0, 1   # sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, ...)
+
+
+def zslab_set_transport_library(path):
+    """sift3d_zslab_set_transport_library: the RCCL build the slab driver loads (None: librccl.so.1)."""
+    hip_lib().sift3d_zslab_set_transport_library(None if path is None else os.fsencode(path))
+
+
+def extract_zslab(vol, devices, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0, transport=TRANSPORT_PEER_COPY):
+    """sift3d_extract_zslab_over: the volume cut into one Z-slab per entry of `devices`, one process, halos by peer copies
+    or RCCL.  Returns (records, stats dict)."""
     vol = _f32(vol)
     nz, ny, nx = vol.shape
     dev = (C.c_int * len(devices))(*[int(d) for d in devices])
     out, n, st, err = C.c_void_p(), C.c_int64(0), ZSlabStats(), C.create_string_buffer(512)
-    rc = hip_lib().sift3d_extract_zslab(dev, len(devices), vol.ctypes.data, nx, ny, nz, float(initial_image_scale), int(desc_mode),
-                                        float(eig_thres), float(size_factor), C.byref(out), C.byref(n), C.byref(st), err, 512)
+    rc = hip_lib().sift3d_extract_zslab_over(int(transport), dev, len(devices), vol.ctypes.data, nx, ny, nz, float(initial_image_scale),
+                                             int(desc_mode), float(eig_thres), float(size_factor), C.byref(out), C.byref(n), C.byref(st), err, 512)
     if rc != 0:
         e = Sift3DError("sift3d_extract_zslab -> %d: %s" % (rc, err.value.decode(errors="replace")))
         e.code = rc

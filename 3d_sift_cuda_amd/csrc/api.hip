@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "sift3d_internal.h"
+#include "zslab_transport.h"
 
 #define SIFT3D_KP_MAX_CHUNKS 16
 /* One chunk by default: measured at 512^3 (tools/kp_chunks.py, profiles/r03_kp_chunks.txt) 1: 10.33, 2: 10.31, 3: 10.47, 4: 10.47,
@@ -1952,6 +1953,14 @@ struct zs_rank {
             goto done;                                                                                                 \
         }                                                                                                              \
     } while (0)
+#define ZS_X(call) /* a step of the exchange through the handle's transport (peer copies or RCCL) */                 \
+    do {                                                                                                               \
+        if ((call) != 0) {                                                                                             \
+            snprintf(errbuf, sizeof errbuf, "%s", zs_transport_error(h->tr));                                          \
+            rc = SIFT3D_ERR_COMM;                                                                                      \
+            goto done;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
 #define ZS_RC(call)                                                                                  \
     do {                                                                                             \
         rc = (call);                                                                                 \
@@ -1968,12 +1977,23 @@ struct sift3d_zslab {
     std::vector<zs_rank> R; /* one per slab; a single one when the volume is too thin to shard */
     int lazy_levels = 1;    /* SIFT3D_TUNE_LAZY_LEVELS */
     int bands_first = 1;    /* SIFT3D_TUNE_BANDS_FIRST */
+    int transport_want = ZS_TRANSPORT_PEER; /* SIFT3D_ZSLAB_TRANSPORT */
+    zs_transport *tr = nullptr;             /* created by the first extraction after the choice (zslab_transport.hip) */
     sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
 };
 
 extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
 {
     if (!h) return;
+    for (zs_rank &q : h->R) /* nothing of an exchange may be in flight when its communicators go */
+        if (q.c) {
+            hipSetDevice(q.dev);
+            hipStreamSynchronize(q.c->stream);
+            if (q.copy_stream) hipStreamSynchronize(q.copy_stream);
+            if (q.halo_stream) hipStreamSynchronize(q.halo_stream);
+        }
+    zs_transport_destroy(h->tr);
+    h->tr = nullptr;
     for (zs_rank &q : h->R) {
         if (!q.c) continue;
         hipSetDevice(q.dev);
@@ -1994,6 +2014,15 @@ extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
 extern "C" int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value)
 {
     if (!h) return SIFT3D_ERR_ARG;
+    if (knob == SIFT3D_ZSLAB_TRANSPORT) { /* the driver's own: how a block of slices travels between two ranks */
+        if (value != SIFT3D_TRANSPORT_PEER_COPY && value != SIFT3D_TRANSPORT_RCCL) return SIFT3D_ERR_ARG;
+        if (h->tr && value != h->transport_want) { /* replaced at the next extraction; nothing is in flight between two */
+            zs_transport_destroy(h->tr);
+            h->tr = nullptr;
+        }
+        h->transport_want = value;
+        return SIFT3D_OK;
+    }
     for (zs_rank &q : h->R) {
         const int rc = sift3d_set_tuning(q.c, knob, value);
         if (rc) return rc;
@@ -2094,6 +2123,19 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
     memset(&st, 0, sizeof st);
     st.n_ranks = S;
     st.sharded_octaves = S > 1 ? K : 0;
+    if (!h->tr) {
+        std::vector<int> devs((size_t)S);
+        for (int i = 0; i < S; i++) devs[(size_t)i] = R[(size_t)i].dev;
+        char terr[400];
+        h->tr = zs_transport_create(h->transport_want == SIFT3D_TRANSPORT_RCCL ? ZS_TRANSPORT_RCCL : ZS_TRANSPORT_PEER, devs.data(), S, terr, sizeof terr);
+        if (!h->tr) {
+            if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", terr);
+            return SIFT3D_ERR_COMM;
+        }
+    }
+    st.transport = zs_transport_kind(h->tr) == ZS_TRANSPORT_RCCL ? SIFT3D_TRANSPORT_RCCL : SIFT3D_TRANSPORT_PEER_COPY;
+    st.transport_fell_back = zs_transport_fell_back(h->tr);
+    st.rccl_version = zs_transport_version(h->tr);
     std::vector<std::vector<sift3d_feature>> recs((size_t)S);
     std::vector<std::vector<int>> grps((size_t)S);
     const auto wall0 = std::chrono::steady_clock::now();
@@ -2211,27 +2253,32 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
             /* the hb-slice halo of the new level from the two neighbours (their own slices, exact), queued behind the
              * sender's event -- on the receiver's halo stream beside its interior launch (bands first), or on its main
              * stream; then the fused DoG redone on the halo slices */
+            ZS_X(zs_xfer_begin(h->tr));
+            for (r = 0; r < nr; r++) {
+                zs_rank &q = R[(size_t)r];
+                const size_t bytes = sizeof(float) * (size_t)(hb * XY);
+                hipStream_t hs = banded ? q.halo_stream : q.c->stream;
+                if (q.lo) { /* global slices [z0 - hb, z0): the lower neighbour's last own slices */
+                    zs_rank &p = R[(size_t)r - 1];
+                    ZS_X(zs_xfer(h->tr, 0, r - 1, p.L[j] + (q.z0 - hb - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
+                                 q.L[j] + (q.z0 - hb - q.e0) * XY, hs, (size_t)(hb * XY)));
+                    st.halo_bytes_critical += (int64_t)bytes;
+                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
+                    st.exchanges++;
+                }
+                if (q.hi) { /* global slices [z1, z1 + hb): the upper neighbour's first own slices */
+                    zs_rank &p = R[(size_t)r + 1];
+                    ZS_X(zs_xfer(h->tr, 0, r + 1, p.L[j] + (q.z1 - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
+                                 q.L[j] + (q.z1 - q.e0) * XY, hs, (size_t)(hb * XY)));
+                    st.halo_bytes_critical += (int64_t)bytes;
+                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
+                    st.exchanges++;
+                }
+            }
+            ZS_X(zs_xfer_end(h->tr)); /* RCCL queues the step's sends and receives here: what follows is behind them */
             for (r = 0; r < nr; r++) {
                 zs_rank &q = R[(size_t)r];
                 ZS_HIP(hipSetDevice(q.dev));
-                const size_t bytes = sizeof(float) * (size_t)(hb * XY);
-                hipStream_t hs = banded ? q.halo_stream : q.c->stream;
-                if (q.lo) {
-                    zs_rank &p = R[(size_t)r - 1];
-                    ZS_COMM(hipStreamWaitEvent(hs, p.ev_level, 0));
-                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z0 - hb - q.e0) * XY, q.dev, p.L[j] + (q.z0 - hb - p.e0) * XY, p.dev, bytes, hs));
-                    st.halo_bytes_critical += (int64_t)bytes;
-                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
-                    st.exchanges++;
-                }
-                if (q.hi) {
-                    zs_rank &p = R[(size_t)r + 1];
-                    ZS_COMM(hipStreamWaitEvent(hs, p.ev_level, 0));
-                    ZS_COMM(hipMemcpyPeerAsync(q.L[j] + (q.z1 - q.e0) * XY, q.dev, p.L[j] + (q.z1 - p.e0) * XY, p.dev, bytes, hs));
-                    st.halo_bytes_critical += (int64_t)bytes;
-                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
-                    st.exchanges++;
-                }
                 if (banded && (q.lo || q.hi)) { /* the main stream goes on behind the arrivals */
                     ZS_COMM(hipEventRecord(q.ev_halo, q.halo_stream));
                     ZS_COMM(hipStreamWaitEvent(q.c->stream, q.ev_halo, 0));
@@ -2245,17 +2292,17 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
             if (j == 3) {
                 /* L1..L3 are final: the other 24 slices of their patch halos, on the copy stream, while L4, L5 and the
                  * extrema passes run on the main one */
+                ZS_X(zs_xfer_begin(h->tr));
                 for (r = 0; r < nr; r++) {
                     zs_rank &q = R[(size_t)r];
                     if (!q.lo && !q.hi) continue;
-                    ZS_HIP(hipSetDevice(q.dev));
                     for (int l = 1; l <= 3; l++) {
                         if (q.lo) {
                             zs_rank &p = R[(size_t)r - 1];
                             const int64_t s0 = std::max(q.e0, q.z0 - ZS_HALO), s1 = q.z0 - ZS_BLUR;
                             if (s1 > s0) {
-                                ZS_COMM(hipStreamWaitEvent(q.copy_stream, p.ev_l3, 0));
-                                ZS_COMM(hipMemcpyPeerAsync(q.L[l] + (s0 - q.e0) * XY, q.dev, p.L[l] + (s0 - p.e0) * XY, p.dev, sizeof(float) * (size_t)((s1 - s0) * XY), q.copy_stream));
+                                ZS_X(zs_xfer(h->tr, 1, r - 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
+                                             (size_t)((s1 - s0) * XY)));
                                 st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
                             }
                         }
@@ -2263,14 +2310,20 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
                             zs_rank &p = R[(size_t)r + 1];
                             const int64_t s0 = q.z1 + ZS_BLUR, s1 = std::min(q.e1, q.z1 + ZS_HALO);
                             if (s1 > s0) {
-                                ZS_COMM(hipStreamWaitEvent(q.copy_stream, p.ev_l3, 0));
-                                ZS_COMM(hipMemcpyPeerAsync(q.L[l] + (s0 - q.e0) * XY, q.dev, p.L[l] + (s0 - p.e0) * XY, p.dev, sizeof(float) * (size_t)((s1 - s0) * XY), q.copy_stream));
+                                ZS_X(zs_xfer(h->tr, 1, r + 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
+                                             (size_t)((s1 - s0) * XY)));
                                 st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
                             }
                         }
                     }
-                    ZS_HIP(hipEventRecord(q.ev_patch, q.copy_stream));
                     st.exchanges++;
+                }
+                ZS_X(zs_xfer_end(h->tr));
+                for (r = 0; r < nr; r++) {
+                    zs_rank &q = R[(size_t)r];
+                    if (!q.lo && !q.hi) continue;
+                    ZS_HIP(hipSetDevice(q.dev));
+                    ZS_HIP(hipEventRecord(q.ev_patch, q.copy_stream));
                 }
             }
         }
@@ -2324,6 +2377,8 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
             float *full = root.alloc(zn * XYn);
             if (!full) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank 0: out of device memory"); goto done; }
             int64_t at = 0;
+            struct gather_part { int rank; const float *src; int64_t at, t; };
+            std::vector<gather_part> parts;
             for (r = 0; r < S; r++) {
                 zs_rank &q = R[(size_t)r];
                 const int64_t t = std::min<int64_t>((q.z1 - q.z0) / 2, zn - at); /* an odd last slice of the whole volume is dropped, as in the serial code */
@@ -2334,13 +2389,17 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
                 ZS_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (q.z0 - q.e0) * XY, X, X, Y, 2 * t, part, Xn));
                 if (r > 0) {
                     ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
-                    ZS_HIP(hipSetDevice(root.dev));
-                    ZS_COMM(hipStreamWaitEvent(root.c->stream, q.ev_level, 0));
-                    ZS_COMM(hipMemcpyPeerAsync(full + at * XYn, root.dev, part, q.dev, sizeof(float) * (size_t)(t * XYn), root.c->stream));
-                    st.gather_bytes += (int64_t)sizeof(float) * t * XYn;
+                    parts.push_back({r, part, at, t});
                 }
                 at += t;
             }
+            ZS_X(zs_xfer_begin(h->tr)); /* every rank's part of the octave to rank 0, ordered in rank 0's main stream */
+            for (const gather_part &g : parts) {
+                zs_rank &q = R[(size_t)g.rank];
+                ZS_X(zs_xfer(h->tr, 0, g.rank, g.src, q.c->stream, q.ev_level, 0, full + g.at * XYn, root.c->stream, (size_t)(g.t * XYn)));
+                st.gather_bytes += (int64_t)sizeof(float) * g.t * XYn;
+            }
+            ZS_X(zs_xfer_end(h->tr));
             if (at != zn) { rc = SIFT3D_ERR_ARG; snprintf(errbuf, sizeof errbuf, "slab plan does not tile octave %d (%lld of %lld slices)", o + 1, (long long)at, (long long)zn); goto done; }
             next0[0] = full;
         } else { /* unsharded: rank 0 alone */
@@ -2424,20 +2483,32 @@ done:
     return rc;
 }
 
-extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
-                                    float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
-                                    sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
+extern "C" int sift3d_extract_zslab_over(int transport, const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
+                                         float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                                         sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
 {
     if (out) *out = nullptr;
     if (n_out) *n_out = 0;
-    if (!vol || !out || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) {
+    if (!vol || !out || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF ||
+        (transport != SIFT3D_TRANSPORT_PEER_COPY && transport != SIFT3D_TRANSPORT_RCCL)) {
         if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
         return SIFT3D_ERR_ARG;
     }
     int status = SIFT3D_ERR_ARG;
     sift3d_zslab *h = zslab_create_impl(devices, n_devices, nx, ny, nz, err, err_len, &status);
     if (!h) return status != SIFT3D_OK ? status : SIFT3D_ERR_MEMORY;
+    h->transport_want = transport;
     const int rc = sift3d_zslab_extract(h, vol, initial_image_scale, desc_mode, eig_thres, size_factor, out, n_out, stats, err, err_len);
     sift3d_zslab_destroy(h);
     return rc;
 }
+
+extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
+                                    float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                                    sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
+{
+    return sift3d_extract_zslab_over(SIFT3D_TRANSPORT_PEER_COPY, devices, n_devices, vol, nx, ny, nz, initial_image_scale, desc_mode, eig_thres,
+                                     size_factor, out, n_out, stats, err, err_len);
+}
+
+extern "C" void sift3d_zslab_set_transport_library(const char *path) { zs_transport_set_library(path); }

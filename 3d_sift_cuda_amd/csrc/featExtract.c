@@ -100,6 +100,7 @@ int main(int argc, char **argv)
     }
     int device = -1;
     int devices[64], n_devices = 0; /* -d0,1,2,3: one Z-slab per listed device */
+    int transport = SIFT3D_TRANSPORT_PEER_COPY; /* -d0,1,2,3:rccl */
     int arg = 1;
     int resize = 0;
     int desc_mode = SIFT3D_DESC_SIFT;
@@ -123,6 +124,15 @@ int main(int argc, char **argv)
             n_devices = 0;
             for (const char *p = argv[arg] + 2; *p && n_devices < 64; p++) {
                 if (*p == ',') continue;
+                if (*p == ':') { /* -d0,1,2,3:rccl -- the slabs' halos over RCCL instead of peer copies */
+                    if (strcmp(p, ":rccl") == 0) transport = SIFT3D_TRANSPORT_RCCL;
+                    else if (strcmp(p, ":peer") != 0) {
+                        printf("Error: unknown slab transport: %s\n", p + 1);
+                        print_options();
+                        return -1;
+                    }
+                    break;
+                }
                 if (*p < '0' || *p > '9' || *p - '0' >= sift3d_device_count()) {
                     printf("Error: unknown device: %d\n", *p - '0');
                     print_options();
@@ -227,8 +237,8 @@ int main(int argc, char **argv)
         if (times) fprintf(stderr, "# resize: %.3f s\n", t1 - t0);
         t0 = t1;
         if (rc == SIFT3D_OK)
-            rc = sift3d_extract_zslab(devices, n_devices, pv, PX, PY, PZ, initial_scale, desc_mode, eig_thres, size_factor, &feats, &n,
-                                      &zst, zerr, sizeof zerr);
+            rc = sift3d_extract_zslab_over(transport, devices, n_devices, pv, PX, PY, PZ, initial_scale, desc_mode, eig_thres, size_factor,
+                                           &feats, &n, &zst, zerr, sizeof zerr);
         if (pv != img.data) free(pv);
         if (rc != SIFT3D_OK) {
             fprintf(stderr, "sift3d: %s\n", zerr);
@@ -236,8 +246,9 @@ int main(int argc, char **argv)
             return -1;
         }
         if (times)
-            fprintf(stderr, "# z-slabs: %d ranks, %d sharded octaves, %lld halo copies, %.1f MB on the critical path, %.1f MB deferred, %.1f MB gathered\n",
-                    (int)zst.n_ranks, (int)zst.sharded_octaves, (long long)zst.exchanges, zst.halo_bytes_critical / 1e6,
+            fprintf(stderr, "# z-slabs: %d ranks, %d sharded octaves, %lld halo transfers over %s%s, %.1f MB on the critical path, %.1f MB deferred, %.1f MB gathered\n",
+                    (int)zst.n_ranks, (int)zst.sharded_octaves, (long long)zst.exchanges, zst.transport == SIFT3D_TRANSPORT_RCCL ? "RCCL" : "peer copies",
+                    zst.transport_fell_back ? " (RCCL asked for, but a device is listed twice)" : "", zst.halo_bytes_critical / 1e6,
                     zst.halo_bytes_deferred / 1e6, zst.gather_bytes / 1e6);
     } else {
         rc = sift3d_set_volume_resized(ctx, img.data, X, Y, Z, resize);

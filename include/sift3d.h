@@ -287,10 +287,30 @@ typedef struct {
     int64_t n_extrema, n_keypoints, n_records;
     double wall_ms;               /* host wall time of the extraction: upload of the slabs, pyramid, per-keypoint stage, download, merge */
     int64_t halo_bytes_hidden;    /* the part of halo_bytes_critical issued bands-first: copied while the receiver filters its interior */
+    int32_t transport;            /* what moved the slices between ranks: SIFT3D_TRANSPORT_PEER_COPY or SIFT3D_TRANSPORT_RCCL */
+    int32_t transport_fell_back;  /* 1: RCCL was asked for, but a device is listed more than once (not something RCCL ranks can
+                                   * be): peer copies were used */
+    int32_t rccl_version;         /* ncclGetVersion() of the library that was loaded (0 with peer copies) */
+    int32_t reserved;
 } sift3d_zslab_stats;
+/* How a block of slices travels from one rank's device to another's (sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, v),
+ * sift3d_extract_zslab_over): peer copies -- hipMemcpyPeerAsync on the receiver's stream behind the sender's event, the
+ * default -- or RCCL: ncclSend / ncclRecv on the ranks' halo streams inside one ncclGroupStart / ncclGroupEnd per exchange
+ * step, one communicator set for the halos a launch waits for and one for the deferred patch halos.  RCCL is loaded at run
+ * time (librccl.so.1; sift3d_zslab_set_transport_library names another build, NULL restores the default); a failure to load
+ * it or to create the communicators is SIFT3D_ERR_COMM with the reason in err.  NEITHER transport has moved a byte between
+ * two GPUs yet (one-GPU development box). */
+#define SIFT3D_ZSLAB_TRANSPORT 1000
+#define SIFT3D_TRANSPORT_PEER_COPY 0
+#define SIFT3D_TRANSPORT_RCCL 1
+void sift3d_zslab_set_transport_library(const char *path);
 int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
                          float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,
                          int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len);
+/* sift3d_extract_zslab with the transport named (SIFT3D_TRANSPORT_*); sift3d_extract_zslab uses peer copies */
+int sift3d_extract_zslab_over(int transport, const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
+                              float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,
+                              int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len);
 /* The same with the contexts, streams and events of the slabs kept between volumes of one shape: create once, extract any
  * number of volumes (the level buffers of a run come from one arena per slab, sized after the first run), destroy.
  * sift3d_extract_zslab is create + extract + destroy; creating the contexts dominates its wall time. */

@@ -1058,6 +1058,48 @@ def test_c_zslab_driver_edge_cases(built):
     assert ei.value.code == -1 and "no HIP device 99" in str(ei.value)
 
 
+def test_c_zslab_driver_rccl_transport_selection(built):
+    """RCCL as the slab driver's transport (round-3 review, item 7; BASELINE north star: "halo exchange over RCCL/xGMI").  What
+    one GPU can show: (1) a device listed twice cannot be two RCCL ranks -- the driver falls back to peer copies, says so in
+    its stats and returns the single-GPU bytes; (2) with one distinct device the library IS loaded at run time and both
+    communicator sets are created and destroyed (ncclCommInitAll over one device; nothing to exchange); (3) a library that
+    cannot be loaded is SIFT3D_ERR_COMM with the reason, and leaves the peer-copy transport usable.  Sends and receives between
+    two GPUs have never run."""
+    dims = (96, 80, 160)
+    vol = vol_of(built, dims, 7)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract()
+    got, st = built.extract_zslab(vol, [0, 0], transport=built.TRANSPORT_RCCL)
+    assert got.tobytes() == want.tobytes() and st["n_ranks"] == 2
+    assert st["transport"] == built.TRANSPORT_PEER_COPY and st["transport_fell_back"] == 1 and st["rccl_version"] == 0
+    got, st = built.extract_zslab(vol, [0, 0])
+    assert st["transport"] == built.TRANSPORT_PEER_COPY and st["transport_fell_back"] == 0 and got.tobytes() == want.tobytes()
+    got, st = built.extract_zslab(vol, [0], transport=built.TRANSPORT_RCCL)
+    assert got.tobytes() == want.tobytes() and st["n_ranks"] == 1
+    assert st["transport"] == built.TRANSPORT_RCCL and st["transport_fell_back"] == 0 and st["rccl_version"] >= 20000
+    with built.ZSlab(dims[0], dims[1], dims[2], [0, 0]) as h:           # through the handle: chosen, changed, chosen again
+        h.set_tuning(built.ZSLAB_TRANSPORT, built.TRANSPORT_RCCL)
+        got, st = h.extract(vol)
+        assert got.tobytes() == want.tobytes() and st["transport_fell_back"] == 1
+        h.set_tuning(built.ZSLAB_TRANSPORT, built.TRANSPORT_PEER_COPY)
+        got, st = h.extract(vol)
+        assert got.tobytes() == want.tobytes() and st["transport_fell_back"] == 0
+        with pytest.raises(built.Sift3DError):
+            h.set_tuning(built.ZSLAB_TRANSPORT, 7)
+    built.zslab_set_transport_library("/nonexistent/librccl-none.so")
+    try:
+        with pytest.raises(built.Sift3DError) as ei:
+            built.extract_zslab(vol, [0], transport=built.TRANSPORT_RCCL)
+        assert ei.value.code == -5 and "cannot load the RCCL library /nonexistent/librccl-none.so" in str(ei.value)
+        got, st = built.extract_zslab(vol, [0])                            # peer copies need no library
+        assert got.tobytes() == want.tobytes()
+    finally:
+        built.zslab_set_transport_library(None)
+    got, st = built.extract_zslab(vol, [0], transport=built.TRANSPORT_RCCL)
+    assert st["transport"] == built.TRANSPORT_RCCL and got.tobytes() == want.tobytes()
+
+
 def test_cli_several_devices(built, tmp_path):
     """featExtract -d0,0 (one Z-slab per listed device) writes the .key of featExtract -d0, with and without -2+."""
     nii = str(tmp_path / "in.nii")
@@ -1078,6 +1120,15 @@ def test_cli_several_devices(built, tmp_path):
         assert open(k1, "rb").read() == open(k2, "rb").read() and len(open(k1).readlines()) > 20
     r = subprocess.run([built.FEATEXTRACT, "-d0,7", nii, str(tmp_path / "x.key")], capture_output=True, text=True)
     assert r.returncode == 255 and "Error: unknown device: 7" in r.stdout
+    # the transport by name: -d0,0:rccl (one device twice: falls back to peer copies and says so), unknown names refused
+    k3 = str(tmp_path / "three.key")
+    r3 = subprocess.run([built.FEATEXTRACT, "-d0,0:rccl", nii, k3], capture_output=True, text=True, env=dict(os.environ, SIFT3D_CLI_TIMES="1"))
+    assert r3.returncode == 0 and "over peer copies (RCCL asked for, but a device is listed twice)" in r3.stderr
+    k1 = str(tmp_path / "one.key")
+    subprocess.run([built.FEATEXTRACT, "-d0", nii, k1], check=True, capture_output=True)
+    assert open(k3, "rb").read() == open(k1, "rb").read()
+    r = subprocess.run([built.FEATEXTRACT, "-d0,0:smoke", nii, k3], capture_output=True, text=True)
+    assert r.returncode == 255 and "Error: unknown slab transport: smoke" in r.stdout
 
 
 # ---------------------------------------------------------------------------------------------------
