@@ -98,13 +98,6 @@ struct sift3d_ctx {
     float *D[5];  /* DoG levels, same layout; D[4] is only allocated when an octave has to store its last DoG level in full
                    * (ensure_level_buffer): by default that level is evaluated around the candidates only */
     float *D4tiny; /* the last DoG level of the octaves that one workgroup builds whole (at most SIFT3D_TINY_VOX voxels each) */
-    /* the coarse octaves in one persistent launch (kernels_chain.hip): their last DoG level, pass intermediates of their own
-     * (the main stream's three-launch blurs use T[] at the same time), the barrier words, a stream and two events */
-    float *chainD4, *chainT[2];
-    int64_t chainD4_cap, chainT_cap;
-    unsigned *chain_sync;
-    hipStream_t chain_stream;
-    hipEvent_t ev_chain[2];
     float *T[2];  /* x- and y-pass intermediates */
     float *d_taps;
     /* extrema as (key, value) pairs, unsorted (a) and sorted (b) */
@@ -208,10 +201,6 @@ static void free_dev(sift3d_ctx *c)
     for (int i = 0; i < 6; i++) hipFree(c->L[i]);
     for (int i = 0; i < 5; i++) hipFree(c->D[i]);
     hipFree(c->D4tiny);
-    hipFree(c->chainD4);
-    hipFree(c->chainT[0]);
-    hipFree(c->chainT[1]);
-    hipFree(c->chain_sync);
     hipFree(c->T[0]);
     hipFree(c->T[1]);
     hipFree(c->d_taps);
@@ -277,14 +266,13 @@ static int alloc_cands(sift3d_ctx *c, int64_t cap)
 
 static void destroy_sync_objects(sift3d_ctx *c)
 {
-    hipStream_t streams[] = {c->ex_stream, c->ex_stream2, c->kp_stream, c->chain_stream};
+    hipStream_t streams[] = {c->ex_stream, c->ex_stream2, c->kp_stream};
     for (hipStream_t st : streams)
         if (st) {
             hipStreamSynchronize(st);
             hipStreamDestroy(st);
         }
-    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1],
-                           c->ev_chain[0], c->ev_chain[1]};
+    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1]};
     for (hipEvent_t e : events)
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_kpc)
@@ -313,14 +301,12 @@ static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bo
     c->tune[SIFT3D_TUNE_SAMPLER_CAP] = 4;
     c->tune[SIFT3D_TUNE_BANDS_FIRST] = 1;
     c->tune[SIFT3D_TUNE_HOST_RECORDS] = 5;
-    c->tune[SIFT3D_TUNE_COARSE_CHAIN] = 1;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    hipStream_t *streams[] = {&c->ex_stream, &c->ex_stream2, &c->kp_stream, &c->chain_stream};
+    hipStream_t *streams[] = {&c->ex_stream, &c->ex_stream2, &c->kp_stream};
     for (hipStream_t *st : streams) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1],
-                            &c->ev_chain[0], &c->ev_chain[1]};
+    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1]};
     for (hipEvent_t *e : events) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t &e : c->ev_kpc) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * (8 + SIFT3D_KP_MAX_CHUNKS), hipHostMallocDefault) == hipSuccess;
@@ -350,7 +336,6 @@ static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bo
     ok = ok && hipMalloc((void **)&c->sampler_tokens, sizeof(int) * SIFT3D_CU_SLOTS) == hipSuccess &&
          hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_rec_base, sizeof(int) * (SIFT3D_KP_MAX_CHUNKS + 1)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->chain_sync, sizeof(unsigned) * 4) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
     c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
     ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
@@ -384,8 +369,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 256};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -1523,140 +1508,12 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         c->surv_sel = 0;
         return rc_;
     };
-    /* ---- the coarse octaves as ONE persistent launch (kernels_chain.hip; round-3 review, item 4): every octave from the first
-     * one of at most 2^21 voxels on (never octave 0) -- levels, DoG levels (all five stored), subsamples and the extrema test.
-     * It starts on a stream of its own as soon as its first level 0 exists (the subsample after level 3 of the octave in
-     * front), beside that octave's last levels and every extrema pass of the finer octaves.  SIFT3D_TUNE_COARSE_CHAIN: 0 =
-     * launch by launch as in rounds 1 - 3, 1 = on with the default number of workgroups, n > 1 = n workgroups. ---- */
-    size_t oc = oct.size(); /* first octave the chain builds (== size: none) */
-    sift3d_chain_params cp;
-    memset(&cp, 0, sizeof cp);
-    double chain_bytes = 0;
-    int64_t chain_vox = 0;
-    if (c->tune[SIFT3D_TUNE_COARSE_CHAIN] > 0) {
-        for (size_t o = 1; o < oct.size() && oc == oct.size(); o++)
-            if (oct[o].XP * oct[o].Y * oct[o].Z <= SIFT3D_CHAIN_FIRST_VOX) oc = o;
-        if (oct.size() - oc > SIFT3D_CHAIN_MAX_OCT) oc = oct.size();
-        float sg = 1.6f;
-        for (int j = 0; j < 5 && oc < oct.size(); j++) {
-            float taps[SIFT3D_MAX_TAPS];
-            const int n = sift3d_gauss_taps(sg * sqrtf(factor * factor - 1.0f), 0.01f, taps);
-            if (n < 3 || n > 2 * SIFT3D_FAST_MAX_R + 1) oc = oct.size(); /* a filter the kernel has no form for: launch by launch */
-            else {
-                cp.ntaps[j] = n;
-                for (int q = 0; q < n; q++) cp.taps[j][q] = taps[q];
-            }
-            sg *= factor;
-        }
-    }
-    if (oc < oct.size()) {
-        const int64_t first = oct[oc].off, tot = oct.back().off + oct.back().XP * oct.back().Y * oct.back().Z - first;
-        const int64_t tfl = oct[oc].XP * oct[oc].Y * oct[oc].Z;
-        if (tot > c->chainD4_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->chain_stream));
-            hipFree(c->chainD4);
-            c->chainD4 = nullptr;
-            c->chainD4_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->chainD4, sizeof(float) * (size_t)tot));
-            c->chainD4_cap = tot;
-        }
-        if (tfl > c->chainT_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->chain_stream));
-            for (int i = 0; i < 2; i++) {
-                hipFree(c->chainT[i]);
-                c->chainT[i] = nullptr;
-            }
-            c->chainT_cap = 0;
-            for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void **)&c->chainT[i], sizeof(float) * (size_t)tfl));
-            c->chainT_cap = tfl;
-        }
-        cp.n_oct = (int)(oct.size() - oc);
-        for (size_t o = oc; o < oct.size(); o++) {
-            const octave_dims &d = oct[o];
-            sift3d_chain_octave &q = cp.oct[o - oc];
-            for (int j = 0; j < 5; j++) q.L[j] = c->L[j] + d.off;
-            for (int j = 0; j < 4; j++) q.D[j] = c->D[j] + d.off;
-            q.D[4] = c->chainD4 + (d.off - first);
-            q.next_L0 = o + 1 < oct.size() ? c->L[0] + oct[o + 1].off : nullptr;
-            q.next_XP = o + 1 < oct.size() ? (int)oct[o + 1].XP : 0;
-            q.X = (int)d.X; q.XP = (int)d.XP; q.Y = (int)d.Y; q.Z = (int)d.Z;
-            q.lvl_id0 = (int)o * 3;
-            if (d.XP * d.Y * d.Z > SIFT3D_CHAIN_SOLO_VOX) cp.n_grid = (int)(o - oc) + 1;
-            chain_bytes += (5 * 32.0 + 12.0 * 3 + 4.5) * (double)(d.XP * d.Y * d.Z); /* five levels in three passes with DoG, three extrema levels, a subsample */
-            chain_vox += d.XP * d.Y * d.Z;
-        }
-        cp.T0 = c->chainT[0];
-        cp.T1 = c->chainT[1];
-        cp.sync = c->chain_sync;
-        cp.keys = c->keys_a;
-        cp.vals = c->vals_a;
-        cp.count = c->d_count;
-        cp.cap = c->cand_cap;
-    }
-    bool chain_launched = false;
-    /* called right after the subsample that produced level 0 of octave o + 1 */
-    auto after_subsample = [&](size_t o) -> int {
-        if (o + 1 != oc || oc >= oct.size()) return SIFT3D_OK;
-        int wgs = c->tune[SIFT3D_TUNE_COARSE_CHAIN];
-        if (wgs <= 1) wgs = SIFT3D_CHAIN_DEFAULT_WGS;
-        /* timing mode 3 times every launch alone: the chain then stays on the main stream */
-        hipStream_t cs = c->timing == 3 ? c->stream : c->chain_stream;
-        if (cs != c->stream) {
-            HIPCHK(c, hipEventRecord(c->ev_chain[0], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(cs, c->ev_chain[0], 0));
-        }
-        if (cs != c->ex_stream) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_reset, 0)); /* it appends to the candidate list */
-        {
-            stage_scope sc(c, SIFT3D_STAGE_COARSE_CHAIN, chain_bytes, 0, chain_vox, cs);
-            HIPCHK(c, sift3d_launch_coarse_chain(cs, cp, wgs));
-        }
-        /* the abort word of its barriers comes back with the candidate counts */
-        HIPCHK(c, hipMemcpyAsync(c->h_cnt0 + 7, c->chain_sync + 2, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
-        if (cs != c->stream) HIPCHK(c, hipEventRecord(c->ev_chain[1], cs));
-        chain_launched = true;
-        c->count_queued = false;
-        return SIFT3D_OK;
-    };
-    c->h_cnt0[7] = 0;
     for (size_t o = 0; o < oct.size(); o++) {
         const octave_dims &d = oct[o];
         const double N = (double)d.X * d.Y * d.Z;
         hipStream_t ws = c->stream;
         sigma = 1.6f;
         sig[0] = sigma;
-        if (o >= oc) {
-            /* built by the chain kernel: what is left to do here is the bookkeeping -- the level table of the per-keypoint
-             * stage and the jobs a replay after a list overflow would run (stored levels: the standard extrema launches) */
-            for (int j = 1; j < 6; j++) {
-                sigma *= factor;
-                sig[j] = sigma;
-            }
-            ex_plan &pl = plans[o];
-            pl.tiny_done = false;
-            pl.d4tiny = nullptr;
-            pl.lazy = pl.lazy_next = false;
-            pl.next_ntaps = 0;
-            for (int q = 0; q < 7; q++) pl.sig[q] = sig[q];
-            pl.fscale = fscale;
-            const sift3d_chain_octave &q = cp.oct[o - oc];
-            for (int l = 0; l < 3; l++) {
-                const int id = (int)o * 3 + l;
-                c->jobs.push_back(level_job{q.D[l], q.D[l + 1], q.D[l + 2], d.XP, d.Y, d.Z, 0, (int)d.Z, id, d.X});
-                sift3d_level &lv = levels[(size_t)id];
-                lv.img = c->L[l + 1] + d.off;
-                lv.dogc = c->D[l + 1] + d.off;
-                lv.X = (int)d.X; lv.Y = (int)d.Y; lv.Z = (int)d.Z;
-                lv.XP = (int)d.XP;
-                lv.sigma_h = pl.sig[l]; lv.sigma_c = pl.sig[l + 1]; lv.sigma_l = pl.sig[l + 2];
-                lv.octave_factor = pl.fscale;
-                lv.Zl = (int)d.Z;
-                lv.z_off = 0;
-                lv.pad = 0;
-            }
-            fscale *= 2.0f;
-            c->last.n_octaves++;
-            continue;
-        }
         /* an octave of at most 4096 voxels: all five levels in one single-workgroup launch instead of fifteen */
         bool tiny_done = false;
         /* the last DoG level of such an octave lives in a small buffer of its own, at the octave's offset from the first of them */
@@ -1712,8 +1569,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                      * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
                     if (oct[o + 1].XP != oct[o + 1].X)
                         HIPCHK(c, sift3d_launch_zero_pad(ws, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
-                    rc = after_subsample(o);
-                    if (rc) return rc;
                 }
                 sigma *= factor;
                 sig[j] = sigma;
@@ -1742,8 +1597,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                  * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
                 if (oct[o + 1].XP != oct[o + 1].X)
                     HIPCHK(c, sift3d_launch_zero_pad(ws, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
-                rc = after_subsample(o);
-                if (rc) return rc;
             }
             sigma *= factor;
             sig[j] = sigma;
@@ -1764,7 +1617,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
          * they do not queue up behind octave 0's.  (Started right after octave 0's own levels they shared the chip with
          * octave 1's blurs -- both three to ten times slower for it -- and the chain of octaves 2.. ran alone afterwards,
          * a millisecond of mostly idle chip: 10.75 against 10.50 ms per extraction.) */
-        if (o == 0 && (oct.size() == 1 || oc == 1)) { /* no finer-grained octave follows on the main stream */
+        if (o == 0 && oct.size() == 1) {
             rc = enqueue_extrema(0, 0);
             if (rc) return rc;
         } else if (o >= 1) {
@@ -1784,7 +1637,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         HIPCHK(c, hipEventRecord(c->ev_ex2[1], c->ex_stream2));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ex2[1], 0));
     }
-    if (chain_launched && c->timing != 3) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_chain[1], 0));
     /* the level table goes to the device now, behind the pyramid, not after the host has waited for the extrema count */
     const bool levels_early = extract && levels.size() <= 96;
     if (levels_early)
@@ -1792,8 +1644,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     int64_t ncand = 0;
     rc = cand_finalize(c, &ncand);
     if (rc) return rc;
-    if (chain_launched && (unsigned)c->h_cnt0[7] != 0u)
-        return set_err(c, SIFT3D_ERR_DEVICE, "the coarse-octave launch gave up at a grid barrier (a workgroup never arrived)");
     c->last.n_extrema = ncand;
     if (!extract) return candidates_to_host(c, levels, ncand, cands_out, n_out);
     rc = describe_sorted(c, levels, ncand, desc_mode, eig_thres, size_factor, n_out, levels_early);

@@ -118,34 +118,6 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
 hipError_t sift3d_launch_extrema_octave_small(hipStream_t s, const float *const d[5], int64_t X, int64_t Xl, int64_t Y, int64_t Z,
                                               int lvl_id0, unsigned long long *keys, sift3d_cval *vals, unsigned long long *count,
                                               int64_t cap);
-/* ---- the coarse octaves in one persistent launch (kernels_chain.hip) ---- */
-#define SIFT3D_CHAIN_MAX_OCT 12
-#define SIFT3D_CHAIN_FIRST_VOX (1ll << 21)  /* the chain starts at the first octave (after octave 0) of at most this many voxels */
-#define SIFT3D_CHAIN_DEFAULT_WGS 96
-#define SIFT3D_CHAIN_SOLO_VOX 8192          /* octaves of at most this many voxels are built by one workgroup alone */
-#define SIFT3D_CHAIN_SPIN_LIMIT (1u << 22)  /* polls of a grid barrier before the launch gives up (seconds) */
-struct sift3d_chain_octave {
-    float *L[5];    /* L_0 (the input: the previous octave's subsampled L_3) .. L_4 */
-    float *D[5];    /* D_0 .. D_4, every one stored */
-    float *next_L0; /* level 0 of the next octave (NULL for the last) */
-    int X, XP, Y, Z; /* logical row length, row pitch (a multiple of 4), rows, planes */
-    int next_XP;
-    int lvl_id0;    /* level id of D_1: octave * 3 */
-};
-struct sift3d_chain_params {
-    sift3d_chain_octave oct[SIFT3D_CHAIN_MAX_OCT];
-    int n_oct, n_grid; /* octaves [0, n_grid) are shared by the grid, [n_grid, n_oct) built by workgroup 0 alone */
-    float taps[5][2 * SIFT3D_FAST_MAX_R + 1];
-    int ntaps[5];
-    float *T0, *T1;    /* pass intermediates, each as large as the first octave */
-    unsigned *sync;    /* 4 words: arrivals, generation, abort, unused */
-    unsigned long long *keys;
-    sift3d_cval *vals;
-    unsigned long long *count;
-    long long cap;
-};
-hipError_t sift3d_launch_coarse_chain(hipStream_t s, const sift3d_chain_params &p, int workgroups);
-
 #define SIFT3D_SURV_SETS 96 /* one counter set per extrema pass of a pipeline run, zeroed together */
 #define SIFT3D_SURV_COUNTERS (64 * 32)
 #define SIFT3D_LIST2_COUNTERS 64

@@ -407,36 +407,23 @@ def test_context_reuse_pitched_coarse_octaves(built, oracle, dims):
         assert (bits(gc["value"]) == bits(wc["value"])).all()
 
 
-@pytest.mark.parametrize("chain", [0, 1, 5])
 @pytest.mark.parametrize("dims", [(168, 164, 160), (166, 165, 161)])
-def test_pipeline_records_through_the_fused_blur(built, oracle, dims, chain):
+def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
     """A volume of more than 2^22 voxels: its finest octave is built by the one-launch ring kernel (two rows per thread;
     the 17-tap level is never filtered in full: test_lazy_levels_*), the 7- and 9-tap levels of the next octave (2^18
     voxels or more) too, with one row per thread; everything else by the three-pass kernels and the single-workgroup
     octave kernel.  The second shape has rows
-    that are not whole 16-byte vectors (pitched rows).  Records against the oracle.  chain = 0: that launch-by-launch form of
-    the coarse octaves (rounds 1 - 3); chain = 1 / 5 (round 4): every octave after the first in ONE persistent launch
-    (coarse_chain_kernel, default number of workgroups / five), whose octaves here have pitched rows in the second shape
-    (83 -> pitch 84, 41 -> 44, 20, 10 -> 12, 5 -> 8)."""
+    that are not whole 16-byte vectors (pitched rows).  Records against the oracle."""
     vol = vol_of(built, dims, 9)
     with built.Context(*dims) as ctx:
-        ctx.set_tuning(built.TUNE_COARSE_CHAIN, chain)
         ctx.set_volume(vol)
         ctx.enable_timing(True)
         got = ctx.extract()
         log = ctx.launch_log()
-        again = ctx.extract()                 # the barrier words, lists and buffers of the chain are reusable
-        assert again.tobytes() == got.tobytes()
     fused = log[log["stage"] == built.STAGES.index("blur_fused")]
-    nchain = int((log["stage"] == built.STAGES.index("coarse_chain")).sum())
+    assert len(fused) == 7                    # octave 0: initial blur + four levels; octave 1: its 7- and 9-tap levels
     assert fused["ntaps"][:5].tolist() == [9, 7, 9, 11, 13]
-    if chain == 0:
-        assert len(fused) == 7                # octave 0: initial blur + four levels; octave 1: its 7- and 9-tap levels
-        assert sorted(fused["ntaps"][5:].tolist()) == [7, 9] and (fused["nvox"][5:] < fused["nvox"][0]).all()
-        assert nchain == 0
-    else:
-        assert len(fused) == 5 and nchain == 1
-        assert not (log["stage"] == built.STAGES.index("octave_tiny")).any()     # the small octaves are the chain's too
+    assert sorted(fused["ntaps"][5:].tolist()) == [7, 9] and (fused["nvox"][5:] < fused["nvox"][0]).all()
     want, _ = oracle.extract(vol)
     assert len(want) > 200 and _compare_records(got, want)
 
