@@ -21,7 +21,8 @@
  * Layout of this file: context and tuning; timing; operator-level entry points;
  * candidate lists (reset / append / finalize); the per-keypoint stage in three
  * phases (describe_queue / _launch / _finish); run_pipeline; the slab building
- * blocks of the C-ABI; the one-process Z-slab driver (sift3d_zslab_*).
+ * blocks of the C-ABI.  The one-process Z-slab driver (sift3d_zslab_*) is
+ * zslab_driver.hip; what the two share is pipeline.h.
  */
 #include <algorithm>
 #include <chrono>
@@ -33,133 +34,10 @@
 #include <vector>
 
 #include "sift3d_internal.h"
-#include "zslab_transport.h"
 
-#define SIFT3D_KP_MAX_CHUNKS 16
-/* One chunk by default: measured at 512^3 (tools/kp_chunks.py, profiles/r03_kp_chunks.txt) 1: 10.33, 2: 10.31, 3: 10.47, 4: 10.47,
- * 6: 10.73, 8: 10.99, 16: 11.20 ms per extraction -- seven keypoint workgroups fill a CU's LDS (7 x 23 KB), so a descriptor
- * workgroup only becomes resident where a keypoint workgroup has retired, and the two kernels take turns instead of sharing. */
-#define SIFT3D_KP_DEFAULT_CHUNKS 1
-#define SIFT3D_D4TINY_FLOATS 32768 /* room for the octaves of at most SIFT3D_TINY_VOX voxels of one volume, pitched rows included */
+#include "pipeline.h"
 
-struct timed_launch {
-    int stage;
-    hipEvent_t e0, e1;
-    int ntaps;
-    int64_t nvox;
-    double bytes;
-    float ms;
-    float start_ms;
-};
-
-/* One detection level: which buffers, which dims, which slices to keep */
-struct level_job {
-    const float *dp, *dc, *dn;
-    int64_t X, Y, Z; /* X is the row pitch of the buffers */
-    int z_lo, z_hi;
-    int lvl_id;
-    int64_t Xl;      /* logical row length (0: same as X) */
-    /* neighbour levels that are not stored (sift3d_extrema_lazy): the level below is dp - prev_b; the level above is
-     * next_g - blur(next_g, next_taps), evaluated around the candidates only (dn is NULL then) */
-    const float *prev_b = nullptr, *next_g = nullptr;
-    float next_taps[2 * SIFT3D_FAST_MAX_R + 1] = {};
-    int next_ntaps = 0;
-};
-
-struct octave_dims {
-    int64_t X, Y, Z, off; /* dims and float offset of this octave inside every level buffer */
-    int64_t XP;           /* row pitch: X rounded up to whole 16-byte vectors (the pad columns stay zero) */
-};
-
-struct sift3d_ctx {
-    int device;
-    hipStream_t stream;
-    hipStream_t ex_stream;     /* extrema detection of an octave, overlapped with the blurs of the coarser octaves */
-    hipStream_t cand_stream;   /* where cand_append launches: stream, or ex_stream inside run_pipeline */
-    hipStream_t ex_stream2;    /* extrema of the octaves after the first */
-    hipEvent_t ev_ex2[2];      /* levels of such an octave complete / its extrema launches complete */
-    hipEvent_t ev_reset;       /* the counters of the extrema passes have been cleared (on ex_stream) */
-    sift3d_survivor *surv2;    /* own-level list of that stream (the passes of one stream share a list, one after the other) */
-    int64_t surv2_cap;
-    int surv_sel;              /* which list cand_append uses: 0 = surv, 1 = surv2 */
-    hipStream_t kp_stream;     /* descriptor launches of the chunked per-keypoint stage, beside the keypoint kernel of the next chunk */
-    hipEvent_t ev_kpc[SIFT3D_KP_MAX_CHUNKS]; /* chunk i's keypoint kernel, scan and record map are complete */
-    hipEvent_t ev_desc;        /* the descriptor launches on kp_stream are complete */
-    unsigned long long *h_cnt0; /* pinned, 8 + SIFT3D_KP_MAX_CHUNKS words: [4..7] the small read-backs the host waits for (extrema counts,
-                                 * keypoint count), [8..] the record totals of the chunks: a copy into pageable memory goes through a
-                                 * staging buffer and costs tens of microseconds more */
-    hipEvent_t ev_oct[2];      /* octave's DoG levels complete / extrema launches complete */
-    hipEvent_t ev_fence[2];    /* ordering of the *_dev entry points with the legacy default stream (fence_in / fence_out) */
-    bool own_stream;
-    int64_t capN;   /* voxels of the largest volume */
-    int64_t capTot; /* floats per level buffer: all octaves of a capN volume back to back */
-    float *vol;   /* input volume */
-    float *L[6];  /* Gaussian levels, every octave resident (octave o at offset off_o); L[5] is never stored and stays NULL */
-    float *D[5];  /* DoG levels, same layout; D[4] is only allocated when an octave has to store its last DoG level in full
-                   * (ensure_level_buffer): by default that level is evaluated around the candidates only */
-    float *D4tiny; /* the last DoG level of the octaves that one workgroup builds whole (at most SIFT3D_TINY_VOX voxels each) */
-    float *T[2];  /* x- and y-pass intermediates */
-    float *d_taps;
-    /* extrema as (key, value) pairs, unsorted (a) and sorted (b) */
-    unsigned long long *keys_a, *keys_b;
-    sift3d_cval *vals_a, *vals_b;
-    int64_t cand_cap;
-    unsigned long long *d_count; /* [0] validated extrema, [1] own-level survivors of the level in flight, [2] survivor overflow high-water mark */
-    sift3d_survivor *surv;
-    sift3d_survivor2 *list2[2];      /* extrema that passed the level below, waiting for the lazily evaluated level above: one list
-                                      * per extrema stream (surv_sel) */
-    int64_t list2_cap[2];
-    unsigned long long *list2_counts; /* one length word per extrema pass (SIFT3D_SURV_SETS), zeroed with surv_counts */
-    unsigned long long *surv_counts; /* segment counters of the own-level list: SIFT3D_SURV_SETS sets */
-    int surv_set;                    /* next unused set since the last reset */
-    int64_t surv_cap;
-    int surv_div; /* own-level extrema expected per level: voxels / surv_div (+ slack); 1 after an overflow */
-    void *sort_tmp;
-    size_t sort_tmp_bytes;
-    void *scan_tmp;
-    size_t scan_tmp_bytes;
-    sift3d_level *d_levels;
-    sift3d_dkp *kps;
-    float *patch0; /* identity-frame patches of the extrema, kps_cap x 1331 floats */
-    int *sampler_tokens; /* per-CU counters of the descriptor kernel's sampling phase (zero whenever no kernel runs) */
-    int *d_rec_base;     /* chunked per-keypoint stage: first record of chunk i (SIFT3D_KP_MAX_CHUNKS + 1 ints; [n] = total) */
-    int *nrec, *offs; /* per-candidate record count and exclusive prefix */
-    int64_t kps_cap;
-    int *rec_kp, *rec_frame;
-    int64_t recs_cap;       /* record slots of rec_kp / rec_frame: kps_cap * (1 + SIFT3D_MAX_FRAMES), the worst case */
-    int64_t capT;           /* floats each of T[0], T[1] holds */
-    int64_t hrecs_cap;      /* records the two pinned host buffers below hold: a few per candidate, grown when a run needs more */
-    sift3d_feature *h_recs; /* pinned host memory the descriptor kernel stores its records into; reused from call to call */
-    int *h_group;           /* per record: level id * 2 + is_max (pinned host) */
-    sift3d_feature *d_hrecs; /* the device's addresses of the two */
-    int *d_hgroup;
-    struct {                /* the per-keypoint stage in flight (describe_queue / _launch / _finish) */
-        sift3d_kp_params p;
-        float taps5[SIFT3D_MAX_TAPS];
-        int64_t ncand, nrec;
-        int nchunks, launched;
-        int64_t first[SIFT3D_KP_MAX_CHUNKS + 1];
-    } kp;
-    int dev_stop;           /* -DSIFT3D_DEV builds: sift3d_dev_set_stop */
-    bool count_queued;      /* cand_count_queue ran and nothing was appended since */
-    std::vector<struct level_job> jobs; /* extrema launches since the last reset (replayed if the buffer must grow) */
-    int64_t nx, ny, nz;
-    int64_t pad_nx, pad_ny, pad_nz; /* geometry the pad columns of the level buffers were last cleared for */
-    bool has_volume;
-    int max_octaves; /* 0: the reference's only stop rule (a dimension <= 2); n > 0: at most n octaves */
-    int tune[SIFT3D_TUNE_COUNT]; /* sift3d_set_tuning */
-    int64_t host_grows;          /* times describe_launch had to grow the pinned record buffers (tests) */
-    bool lean;       /* a slab context: the caller owns the level buffers, none are allocated here */
-    int timing; /* 0 off; 1 every launch bracketed by events; 2 only the blur launches of the finest octave */
-    std::vector<timed_launch> launches;
-    std::vector<hipEvent_t> pool;
-    size_t pool_used;
-    size_t resolved; /* launches whose events have been read */
-    sift3d_timings last;
-    char err[512];
-};
-
-static int set_err(sift3d_ctx *c, int code, const char *fmt, ...)
+int set_err(sift3d_ctx *c, int code, const char *fmt, ...)
 {
     if (c) {
         va_list ap;
@@ -169,14 +47,6 @@ static int set_err(sift3d_ctx *c, int code, const char *fmt, ...)
     }
     return code;
 }
-
-#define HIPCHK(c, call)                                                                                        \
-    do {                                                                                                       \
-        hipError_t e_ = (call);                                                                                \
-        if (e_ != hipSuccess)                                                                                  \
-            return set_err((c), SIFT3D_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
-                           __LINE__);                                                                          \
-    } while (0)
 
 /* entry points that work in the context's own level buffers: not on a slab context, which has none */
 #define NEED_LEVELS(c)                                                                                                  \
@@ -231,7 +101,6 @@ static void free_dev(sift3d_ctx *c)
 }
 
 /* octave list of a volume: halve while every dimension stays above 2 (MultiScale.cpp:359-360,546-556) */
-static inline int64_t pitch_of(int64_t X) { return (X + 3) / 4 * 4; }
 
 /* Inside the pipeline every octave is stored with rows padded to whole 16-byte vectors; the pad columns hold zeros
  * (what the blur reads outside the volume), so the vector kernels serve any row length. */
@@ -283,7 +152,7 @@ static void destroy_sync_objects(sift3d_ctx *c)
 
 /* lean: a slab context (sift3d_create_slab) -- the caller owns the level buffers; only the pass intermediates, the
  * candidate lists and the per-keypoint buffers live here */
-static sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean)
+sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean)
 {
     if (nx <= 0 || ny <= 0 || nz <= 0) return nullptr;
     int n = sift3d_device_count();
@@ -508,7 +377,7 @@ struct stage_scope {
     }
 };
 
-static void timing_begin(sift3d_ctx *c)
+void timing_begin(sift3d_ctx *c)
 {
     memset(&c->last, 0, sizeof(c->last));
     c->launches.clear();
@@ -598,7 +467,7 @@ static int ensure_T(sift3d_ctx *c, int64_t floats)
 
 /* ---- device-level building blocks -------------------------------------- */
 /* out = blur(in); if dog != NULL also dog = in - out.  out may be NULL when only the DoG is wanted.  Uses T[0], T[1]. */
-static int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma,
+int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma,
                     float min_value)
 {
     float taps[SIFT3D_MAX_TAPS];
@@ -686,14 +555,14 @@ static int fence_out(sift3d_ctx *c)
 
 /* The blur restricted to output planes [zo0, zo1) of the volume (the input is read as far as the filter reaches): what a
  * Z-slab rank uses to filter its two boundary bands before the interior.  Only the fused launch has that form. */
-static bool blur_window_supported(int64_t X, int64_t Y, float sigma, float min_value)
+bool blur_window_supported(int64_t X, int64_t Y, float sigma, float min_value)
 {
     float taps[SIFT3D_MAX_TAPS];
     const int n = sift3d_gauss_taps(sigma, min_value, taps);
     return n >= 3 && n <= 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X * Y < (1ll << 29);
 }
 
-static int blur_window_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
+int blur_window_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
                            float sigma, float min_value)
 {
     float taps[SIFT3D_MAX_TAPS];
@@ -868,7 +737,7 @@ extern "C" int sift3d_halve_size(sift3d_ctx *c, const float *in, int64_t nx, int
  * replay of the recorded launches into a bigger buffer if it overflowed (the DoG levels stay
  * resident), and the device radix sort. */
 /* on: the stream the clears are queued on (the caller orders the extrema passes behind it) */
-static int cand_reset(sift3d_ctx *c, hipStream_t on = nullptr)
+int cand_reset(sift3d_ctx *c, hipStream_t on)
 {
     if (!on) on = c->stream;
     c->jobs.clear();
@@ -880,7 +749,7 @@ static int cand_reset(sift3d_ctx *c, hipStream_t on = nullptr)
     return SIFT3D_OK;
 }
 
-static int cand_append(sift3d_ctx *c, const level_job &j, bool record)
+int cand_append(sift3d_ctx *c, const level_job &j, bool record)
 {
     c->count_queued = false;
     if (record) c->jobs.push_back(j);
@@ -952,7 +821,7 @@ static int cand_replay(sift3d_ctx *c)
 /* The count of validated extrema comes back in two steps so that a driver with several contexts can queue the read-back
  * on all of them before it waits for the first: cand_count_queue (asynchronous), cand_finalize (waits, replays the extrema
  * launches into bigger lists if one overflowed, sorts). */
-static int cand_count_queue(sift3d_ctx *c)
+int cand_count_queue(sift3d_ctx *c)
 {
     unsigned long long *cnt = c->h_cnt0 + 4; /* validated extrema, survivors of the last level, survivor overflow */
     cnt[0] = cnt[1] = cnt[2] = 0;
@@ -961,7 +830,7 @@ static int cand_count_queue(sift3d_ctx *c)
     return SIFT3D_OK;
 }
 
-static int cand_finalize(sift3d_ctx *c, int64_t *count_out)
+int cand_finalize(sift3d_ctx *c, int64_t *count_out)
 {
     for (int attempt = 0; attempt < 4; attempt++) {
         const unsigned long long *cnt = c->h_cnt0 + 4;
@@ -1290,7 +1159,7 @@ static int kp_chunks_for(const sift3d_ctx *c, int64_t ncand)
     return n;
 }
 
-static int describe_queue(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode, float eig_thres,
+int describe_queue(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode, float eig_thres,
                           float size_factor, bool levels_on_device)
 {
     float taps3[SIFT3D_MAX_TAPS];
@@ -1332,7 +1201,7 @@ static int describe_queue(sift3d_ctx *c, const std::vector<sift3d_level> &levels
     return SIFT3D_OK;
 }
 
-static int describe_launch(sift3d_ctx *c)
+int describe_launch(sift3d_ctx *c)
 {
     const int nch = c->kp.nchunks;
     if (nch <= 0) return SIFT3D_OK;
@@ -1375,7 +1244,7 @@ static int describe_launch(sift3d_ctx *c)
     return SIFT3D_OK;
 }
 
-static int describe_finish(sift3d_ctx *c, int64_t *n_out)
+int describe_finish(sift3d_ctx *c, int64_t *n_out)
 {
     unsigned long long &nkp = c->h_cnt0[6]; /* pinned */
     nkp = 0;
@@ -1825,690 +1694,3 @@ extern "C" int sift3d_extract(sift3d_ctx *c, float initial_image_scale, int desc
     return SIFT3D_OK;
 }
 
-/* ======================================================================================================================
- * Z-slab extraction driven from C: ONE process, one context per device, halos moved with hipMemcpyPeerAsync (xGMI between
- * the GPUs of a node).  The reference has no multi-GPU code; the partitioning is the one of
- * 3d_sift_cuda_amd/zslab.py (which runs one process per GPU over RCCL for bench.py): slabs along z with boundaries that are
- * multiples of 2^K, every level recomputed on slab +- 8 slices and its 8-slice halo refreshed from the two neighbours, the
- * other 24 slices of the L1..L3 patch halos copied once per octave on a second stream while L4, L5 and the extrema passes
- * run, the first unsharded octave assembled on rank 0.  A halo copy is queued on the RECEIVER's stream behind an event the
- * sender records when the level is complete, so no host thread ever waits inside the pyramid; the host enqueues the work
- * of all devices round-robin.  The same device may be listed several times (a rehearsal of the slab logic on one GPU).
- * ====================================================================================================================== */
-namespace {
-const int64_t ZS_HALO = 32; /* slices of L1..L3 kept around a slab: an 11^3 patch reaches < 29 slices from its keypoint */
-const int64_t ZS_BLUR = 8;  /* slices recomputed / exchanged for the next blur (largest filter half-width) */
-
-struct zs_plan {
-    int64_t nx, ny, nz;
-    int S;
-    std::vector<std::vector<int64_t>> oct; /* {X, Y, Z} per octave */
-    int K;                                 /* sharded octaves */
-    std::vector<int64_t> bounds;           /* S + 1 */
-    zs_plan(int64_t nx_, int64_t ny_, int64_t nz_, int S_) : nx(nx_), ny(ny_), nz(nz_), S(S_), K(0)
-    {
-        int64_t x = nx, y = ny, z = nz;
-        while (x > 2 && y > 2 && z > 2 && oct.size() < 32) {
-            oct.push_back({x, y, z});
-            x /= 2; y /= 2; z /= 2;
-        }
-        bounds.assign((size_t)S + 1, 0);
-        bounds[(size_t)S] = nz;
-        if (S <= 1) return;
-        /* K = number of sharded octaves: boundaries multiples of 2^K, every slab of octave K-1 at least ZS_HALO thick */
-        for (int k = (int)oct.size(); k >= 1; k--) {
-            const int64_t align = 1ll << k;
-            std::vector<int64_t> b((size_t)S + 1);
-            for (int r = 0; r < S; r++) b[(size_t)r] = (int64_t)llround((double)r * (double)nz / S / (double)align) * align;
-            b[(size_t)S] = nz;
-            bool ok = true;
-            for (int r = 0; r < S && ok; r++) ok = b[(size_t)r + 1] > b[(size_t)r];
-            for (int o = 0; o < k && ok; o++)
-                for (int r = 0; r < S && ok; r++) {
-                    const int64_t lo = b[(size_t)r] >> o, hi = r == S - 1 ? oct[(size_t)o][2] : b[(size_t)r + 1] >> o;
-                    ok = hi - lo >= ZS_HALO;
-                }
-            if (ok) {
-                K = k;
-                bounds = b;
-                break;
-            }
-        }
-    }
-    void slab(int r, int o, int64_t &z0, int64_t &z1) const
-    {
-        z0 = bounds[(size_t)r] >> o;
-        z1 = r == S - 1 ? oct[(size_t)o][2] : bounds[(size_t)r + 1] >> o;
-    }
-    void input_range(int r, int64_t &i0, int64_t &i1) const
-    {
-        int64_t z0, z1;
-        slab(r, 0, z0, z1);
-        i0 = std::max<int64_t>(0, z0 - 2 * ZS_BLUR);
-        i1 = std::min<int64_t>(nz, z1 + 2 * ZS_BLUR);
-    }
-};
-
-struct zs_rank {
-    sift3d_ctx *c = nullptr;
-    int dev = 0;
-    hipStream_t copy_stream = nullptr; /* the deferred patch-halo copies */
-    hipStream_t halo_stream = nullptr; /* the per-level halo copies into this rank, beside its interior launch */
-    hipEvent_t ev_halo = nullptr;      /* those copies are done */
-    hipEvent_t ev_level = nullptr;     /* this rank's current level is complete (its own slices are final) */
-    hipEvent_t ev_l3 = nullptr;        /* L1..L3 of the current octave are complete */
-    hipEvent_t ev_patch = nullptr;     /* the patch-halo copies into this rank are done */
-    std::vector<float *> allocs;       /* what this run had to allocate beside the arena */
-    float *arena = nullptr;            /* one block reused from run to run (sized after the first run of a handle) */
-    int64_t arena_cap = 0, arena_used = 0, need = 0; /* floats */
-    float *L[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *D[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    int64_t z0 = 0, z1 = 0, e0 = 0, e1 = 0; /* current octave: own slices [z0, z1), buffer extent [e0, e1) */
-    bool lo = false, hi = false;
-    std::vector<sift3d_level> levels;
-    float *alloc(int64_t nfloats)
-    {
-        nfloats = ((nfloats > 0 ? nfloats : 1) + 63) / 64 * 64; /* 256-byte granules */
-        need += nfloats;
-        if (arena && arena_used + nfloats <= arena_cap) {
-            float *p = arena + arena_used;
-            arena_used += nfloats;
-            return p;
-        }
-        float *p = nullptr;
-        if (hipMalloc((void **)&p, sizeof(float) * (size_t)nfloats) != hipSuccess) return nullptr;
-        allocs.push_back(p);
-        return p;
-    }
-    /* end of a run: drop what was allocated beside the arena and make the arena big enough for a run like this one */
-    void recycle()
-    {
-        for (float *p : allocs) hipFree(p);
-        allocs.clear();
-        if (need > arena_cap) {
-            hipFree(arena);
-            arena = nullptr;
-            arena_cap = 0;
-            if (hipMalloc((void **)&arena, sizeof(float) * (size_t)need) == hipSuccess) arena_cap = need;
-        }
-        arena_used = need = 0;
-    }
-};
-
-
-#define ZS_HIP(call)                                                                                                   \
-    do {                                                                                                               \
-        hipError_t e_ = (call);                                                                                        \
-        if (e_ != hipSuccess) {                                                                                        \
-            snprintf(errbuf, sizeof errbuf, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            rc = SIFT3D_ERR_DEVICE;                                                                                    \
-            goto done;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
-#define ZS_COMM(call)                                                                                                  \
-    do {                                                                                                               \
-        hipError_t e_ = (call);                                                                                        \
-        if (e_ != hipSuccess) {                                                                                        \
-            snprintf(errbuf, sizeof errbuf, "slab exchange: %s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            rc = SIFT3D_ERR_COMM;                                                                                      \
-            goto done;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
-#define ZS_X(call) /* a step of the exchange through the handle's transport (peer copies or RCCL) */                 \
-    do {                                                                                                               \
-        if ((call) != 0) {                                                                                             \
-            snprintf(errbuf, sizeof errbuf, "%s", zs_transport_error(h->tr));                                          \
-            rc = SIFT3D_ERR_COMM;                                                                                      \
-            goto done;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
-#define ZS_RC(call)                                                                                  \
-    do {                                                                                             \
-        rc = (call);                                                                                 \
-        if (rc != SIFT3D_OK) {                                                                       \
-            snprintf(errbuf, sizeof errbuf, "rank %d: %s", r, sift3d_last_error(R[(size_t)r].c));    \
-            goto done;                                                                               \
-        }                                                                                            \
-    } while (0)
-} // namespace
-
-struct sift3d_zslab {
-    zs_plan plan;
-    std::vector<int> devices;
-    std::vector<zs_rank> R; /* one per slab; a single one when the volume is too thin to shard */
-    int lazy_levels = 1;    /* SIFT3D_TUNE_LAZY_LEVELS */
-    int bands_first = 1;    /* SIFT3D_TUNE_BANDS_FIRST */
-    int transport_want = ZS_TRANSPORT_PEER; /* SIFT3D_ZSLAB_TRANSPORT */
-    zs_transport *tr = nullptr;             /* created by the first extraction after the choice (zslab_transport.hip) */
-    sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
-};
-
-extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
-{
-    if (!h) return;
-    for (zs_rank &q : h->R) /* nothing of an exchange may be in flight when its communicators go */
-        if (q.c) {
-            hipSetDevice(q.dev);
-            hipStreamSynchronize(q.c->stream);
-            if (q.copy_stream) hipStreamSynchronize(q.copy_stream);
-            if (q.halo_stream) hipStreamSynchronize(q.halo_stream);
-        }
-    zs_transport_destroy(h->tr);
-    h->tr = nullptr;
-    for (zs_rank &q : h->R) {
-        if (!q.c) continue;
-        hipSetDevice(q.dev);
-        hipStreamSynchronize(q.c->stream);
-        if (q.copy_stream) { hipStreamSynchronize(q.copy_stream); hipStreamDestroy(q.copy_stream); }
-        if (q.halo_stream) { hipStreamSynchronize(q.halo_stream); hipStreamDestroy(q.halo_stream); }
-        if (q.ev_halo) hipEventDestroy(q.ev_halo);
-        for (float *p : q.allocs) hipFree(p);
-        hipFree(q.arena);
-        if (q.ev_level) hipEventDestroy(q.ev_level);
-        if (q.ev_l3) hipEventDestroy(q.ev_l3);
-        if (q.ev_patch) hipEventDestroy(q.ev_patch);
-        sift3d_destroy(q.c);
-    }
-    delete h;
-}
-
-extern "C" int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value)
-{
-    if (!h) return SIFT3D_ERR_ARG;
-    if (knob == SIFT3D_ZSLAB_TRANSPORT) { /* the driver's own: how a block of slices travels between two ranks */
-        if (value != SIFT3D_TRANSPORT_PEER_COPY && value != SIFT3D_TRANSPORT_RCCL) return SIFT3D_ERR_ARG;
-        if (h->tr && value != h->transport_want) { /* replaced at the next extraction; nothing is in flight between two */
-            zs_transport_destroy(h->tr);
-            h->tr = nullptr;
-        }
-        h->transport_want = value;
-        return SIFT3D_OK;
-    }
-    for (zs_rank &q : h->R) {
-        const int rc = sift3d_set_tuning(q.c, knob, value);
-        if (rc) return rc;
-    }
-    if (knob == SIFT3D_TUNE_LAZY_LEVELS) h->lazy_levels = value;
-    if (knob == SIFT3D_TUNE_BANDS_FIRST) h->bands_first = value;
-    return SIFT3D_OK;
-}
-
-/* status_out (may be NULL) receives the sift3d_status behind a NULL result */
-static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_t nx, int64_t ny, int64_t nz, char *err, int64_t err_len,
-                                       int *status_out)
-{
-    char errbuf[512] = "";
-    int rc = SIFT3D_OK;
-    if (err && err_len > 0) err[0] = 0;
-    if (status_out) *status_out = SIFT3D_ERR_ARG;
-    auto fail = [&](const char *msg) -> sift3d_zslab * {
-        if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", msg);
-        return nullptr;
-    };
-    if (!devices || n_devices < 1 || n_devices > 64 || nx <= 0 || ny <= 0 || nz <= 1) return fail("bad arguments");
-    const int ndev = sift3d_device_count();
-    for (int i = 0; i < n_devices; i++)
-        if (devices[i] < 0 || devices[i] >= ndev) {
-            snprintf(errbuf, sizeof errbuf, "no HIP device %d", devices[i]);
-            return fail(errbuf);
-        }
-    sift3d_zslab *h = new sift3d_zslab(nx, ny, nz, n_devices);
-    const int S = h->plan.K > 0 ? n_devices : 1; /* too thin to shard: the whole volume on the first device */
-    h->devices.assign(devices, devices + n_devices);
-    h->R.resize((size_t)S);
-    for (int r = 0; r < S; r++) {
-        zs_rank &q = h->R[(size_t)r];
-        q.dev = devices[r];
-        int64_t i0 = 0, i1 = nz;
-        if (S > 1) h->plan.input_range(r, i0, i1);
-        ZS_HIP(hipSetDevice(q.dev));
-        /* a slab context owns no level buffers (they come from the rank's arena); its pass intermediates must hold the
-         * largest volume the rank ever blurs: its slab with halos, and on rank 0 the first unsharded octave, which is
-         * gathered there (nz / 2^K slices of a plane a 4^K-th the size: smaller than the slab unless the slabs are many) */
-        int64_t ctx_nz = (i1 - i0) + 2 * ZS_HALO;
-        if (r == 0 && S > 1 && (size_t)h->plan.K < h->plan.oct.size()) {
-            const std::vector<int64_t> &g = h->plan.oct[(size_t)h->plan.K];
-            const int64_t need = (pitch_of(g[0]) * g[1] * g[2] + pitch_of(nx) * ny - 1) / (pitch_of(nx) * ny);
-            ctx_nz = std::max(ctx_nz, need);
-        }
-        q.c = ctx_create(q.dev, nx, ny, ctx_nz, S > 1);
-        if (!q.c) {
-            snprintf(errbuf, sizeof errbuf, "rank %d: no context on device %d (memory?)", r, q.dev);
-            rc = SIFT3D_ERR_MEMORY;
-            goto done;
-        }
-        ZS_HIP(hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking));
-        ZS_HIP(hipStreamCreateWithFlags(&q.halo_stream, hipStreamNonBlocking));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_halo, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_level, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_l3, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_patch, hipEventDisableTiming));
-        for (int p = 0; p < S; p++) /* direct copies between the devices where the fabric allows (errors: already on, or same device) */
-            if (devices[p] != q.dev) (void)hipDeviceEnablePeerAccess(devices[p], 0);
-        (void)hipGetLastError();
-    }
-done:
-    if (status_out) *status_out = rc;
-    if (rc != SIFT3D_OK) {
-        sift3d_zslab_destroy(h);
-        return fail(errbuf);
-    }
-    return h;
-}
-
-extern "C" sift3d_zslab *sift3d_zslab_create(const int *devices, int n_devices, int64_t nx, int64_t ny, int64_t nz, char *err, int64_t err_len)
-{
-    return zslab_create_impl(devices, n_devices, nx, ny, nz, err, err_len, nullptr);
-}
-
-extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_scale, int desc_mode, float eig_thres,
-                                    float size_factor, sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
-                                    int64_t err_len)
-{
-    char errbuf[512] = "";
-    int rc = SIFT3D_OK;
-    int r = 0;
-    if (err && err_len > 0) err[0] = 0;
-    if (!h || !vol || !out || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) {
-        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
-        return SIFT3D_ERR_ARG;
-    }
-    *out = nullptr;
-    *n_out = 0;
-    const zs_plan &plan = h->plan;
-    const int64_t nx = plan.nx, ny = plan.ny, nz = plan.nz;
-    std::vector<zs_rank> &R = h->R;
-    const int S = (int)R.size();
-    const int K = plan.K;
-    sift3d_zslab_stats st;
-    memset(&st, 0, sizeof st);
-    st.n_ranks = S;
-    st.sharded_octaves = S > 1 ? K : 0;
-    if (!h->tr) {
-        std::vector<int> devs((size_t)S);
-        for (int i = 0; i < S; i++) devs[(size_t)i] = R[(size_t)i].dev;
-        char terr[400];
-        h->tr = zs_transport_create(h->transport_want == SIFT3D_TRANSPORT_RCCL ? ZS_TRANSPORT_RCCL : ZS_TRANSPORT_PEER, devs.data(), S, terr, sizeof terr);
-        if (!h->tr) {
-            if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", terr);
-            return SIFT3D_ERR_COMM;
-        }
-    }
-    st.transport = zs_transport_kind(h->tr) == ZS_TRANSPORT_RCCL ? SIFT3D_TRANSPORT_RCCL : SIFT3D_TRANSPORT_PEER_COPY;
-    st.transport_fell_back = zs_transport_fell_back(h->tr);
-    st.rccl_version = zs_transport_version(h->tr);
-    std::vector<std::vector<sift3d_feature>> recs((size_t)S);
-    std::vector<std::vector<int>> grps((size_t)S);
-    const auto wall0 = std::chrono::steady_clock::now();
-
-    /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
-    float sigma_init = 0.5f;
-    if (initial_image_scale > 0) sigma_init /= initial_image_scale;
-    const float factor = (float)pow(2.0, 1.0 / (double)3);
-    const float extra0 = sqrtf(1.6f * 1.6f - sigma_init * sigma_init);
-    float extras[5], sig[6];
-    {
-        float sg = 1.6f;
-        sig[0] = sg;
-        for (int j = 0; j < 5; j++) {
-            extras[j] = sg * sqrtf(factor * factor - 1.0f);
-            sg *= factor;
-            sig[j + 1] = sg;
-        }
-    }
-    float *next0[64]; /* level 0 of the next octave per rank */
-    for (int i = 0; i < 64; i++) next0[i] = nullptr;
-    float fscale = 1.0f;
-
-    /* ---- input slabs, level 0 of octave 0 ---- */
-    for (r = 0; r < S; r++) {
-        zs_rank &q = R[(size_t)r];
-        int64_t i0 = 0, i1 = nz;
-        if (S > 1) plan.input_range(r, i0, i1);
-        ZS_HIP(hipSetDevice(q.dev));
-        q.levels.assign(plan.oct.size() * 3, sift3d_level());
-        ZS_RC(cand_reset(q.c));
-        timing_begin(q.c);
-        /* level 0 = initial blur of the input, on slab +- 8 from input slab +- 16 */
-        const int64_t XY = nx * ny;
-        float *din = q.alloc((i1 - i0) * XY), *tmp = q.alloc((i1 - i0) * XY);
-        if (!din || !tmp) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-        ZS_HIP(hipMemcpyAsync(din, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream));
-        ZS_RC(blur_dev(q.c, din, tmp, nullptr, nx, ny, i1 - i0, extra0, 0.01f));
-        int64_t z0 = 0, z1 = nz;
-        if (S > 1) plan.slab(r, 0, z0, z1);
-        const bool lo = S > 1 && r > 0, hi = S > 1 && r < S - 1;
-        const int64_t e0 = lo ? std::max<int64_t>(0, z0 - ZS_HALO) : z0, e1 = hi ? std::min<int64_t>(nz, z1 + ZS_HALO) : z1;
-        const int64_t c0 = lo ? std::max(e0, z0 - ZS_BLUR) : e0, c1 = hi ? std::min(e1, z1 + ZS_BLUR) : e1;
-        float *l0 = q.alloc((e1 - e0) * XY);
-        if (!l0) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-        ZS_HIP(hipMemcpyAsync(l0 + (c0 - e0) * XY, tmp + (c0 - i0) * XY, sizeof(float) * (size_t)((c1 - c0) * XY), hipMemcpyDeviceToDevice, q.c->stream));
-        next0[r] = l0;
-    }
-
-    /* ---- octaves ---- */
-    for (int o = 0; o < (int)plan.oct.size(); o++) {
-        const int64_t X = plan.oct[(size_t)o][0], Y = plan.oct[(size_t)o][1], zo = plan.oct[(size_t)o][2], XY = X * Y;
-        const bool sharded = S > 1 && o < K;
-        const int nr = sharded ? S : 1; /* the gathered octaves live on rank 0 */
-        /* As on one device (run_pipeline): D_0 is read as L_0 - L_1 around the extrema of D_1, and L_5 -- hence D_4 -- is
-         * filtered only around the candidates of D_3, from L_4.  A slab then blurs four levels instead of five and exchanges
-         * four halos per octave instead of five; the third extrema phase reads L_4 nine slices beyond a candidate, so L_4's
-         * halo is refreshed nine slices deep instead of eight.  Rows that are not whole 16-byte vectors keep every level
-         * stored (the extrema kernels of such rows take stored levels only), as does sift3d_zslab_set_tuning(SIFT3D_TUNE_LAZY_LEVELS, 0). */
-        float taps5[SIFT3D_MAX_TAPS];
-        const int ntaps5 = sift3d_gauss_taps(extras[4], 0.01f, taps5);
-        const bool lazy = ntaps5 == 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X >= 8 && XY < (1ll << 29) && Y >= 3 && zo >= 3 && h->lazy_levels;
-        const int nlev = lazy ? 4 : 5;
-        for (r = 0; r < nr; r++) {
-            zs_rank &q = R[(size_t)r];
-            if (sharded) plan.slab(r, o, q.z0, q.z1); else { q.z0 = 0; q.z1 = zo; }
-            q.lo = sharded && r > 0;
-            q.hi = sharded && r < S - 1;
-            q.e0 = q.lo ? std::max<int64_t>(0, q.z0 - ZS_HALO) : q.z0;
-            q.e1 = q.hi ? std::min<int64_t>(zo, q.z1 + ZS_HALO) : q.z1;
-            ZS_HIP(hipSetDevice(q.dev));
-            q.L[0] = next0[r];
-            for (int j = 1; j < 6; j++) q.L[j] = j <= nlev ? q.alloc((q.e1 - q.e0) * XY) : nullptr;
-            for (int j = 0; j < 5; j++) q.D[j] = (lazy && (j == 0 || j == 4)) ? nullptr : q.alloc((q.e1 - q.e0) * XY);
-            for (int j = 1; j <= nlev; j++)
-                if (!q.L[j] || (!q.D[j - 1] && !(lazy && j == 1))) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-        }
-        for (int j = 1; j <= nlev; j++) {
-            const int64_t hb = (lazy && j == 4) ? ZS_BLUR + 1 : ZS_BLUR; /* slices of this level's halo refreshed from the neighbours */
-            /* Boundary bands first (round 3).  What a neighbour fetches of this level are a rank's own first and last hb
-             * slices.  Where the blur has a windowed form (the one-launch kernel: rows of whole 16-byte vectors, at most 17
-             * taps) a rank filters those two bands first, records the event its neighbours' copies wait for, and then filters
-             * its interior while the bands travel on the receivers' halo streams; its own halo slices are not computed at
-             * all, they arrive.  The next level's launches wait for the arrivals, which by then have had the whole interior
-             * launch to complete: no halo byte is waited for with an idle device unless the link is slower than the
-             * interior.  Without the windowed form (other row lengths): the level on slab +- 8 in one piece, then the
-             * exchange, as in round 2. */
-            const bool banded = sharded && blur_window_supported(X, Y, extras[j - 1], 0.01f) && h->bands_first;
-            for (r = 0; r < nr; r++) {
-                zs_rank &q = R[(size_t)r];
-                const int64_t c0 = q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0, c1 = q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1;
-                const int64_t a = c0 - q.e0, b = c1 - q.e0, nzl = q.e1 - q.e0;
-                ZS_HIP(hipSetDevice(q.dev));
-                if (banded && (q.lo || q.hi)) {
-                    if (q.lo) ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z0 - q.e0, q.z0 - q.e0 + hb, extras[j - 1], 0.01f));
-                    if (q.hi) ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z1 - q.e0 - hb, q.z1 - q.e0, extras[j - 1], 0.01f));
-                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream)); /* the bands are final: the neighbours may fetch them */
-                } else {
-                    /* level j on slab +- 8 (clipped to the buffer: at a face of the whole volume the buffer ends at the face,
-                     * which is what makes the zero border exact), D_{j-1} fused */
-                    ZS_RC(blur_dev(q.c, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] ? q.D[j - 1] + a * XY : nullptr, X, Y, b - a, extras[j - 1], 0.01f));
-                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
-                    if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
-                }
-            }
-            if (banded)
-                for (r = 0; r < nr; r++) { /* the interior, while the bands travel */
-                    zs_rank &q = R[(size_t)r];
-                    if (!q.lo && !q.hi) continue;
-                    const int64_t w0 = q.lo ? q.z0 - q.e0 + hb : 0, w1 = q.hi ? q.z1 - q.e0 - hb : q.e1 - q.e0;
-                    ZS_HIP(hipSetDevice(q.dev));
-                    ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, q.e1 - q.e0, w0, w1, extras[j - 1], 0.01f));
-                    if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
-                }
-            /* the hb-slice halo of the new level from the two neighbours (their own slices, exact), queued behind the
-             * sender's event -- on the receiver's halo stream beside its interior launch (bands first), or on its main
-             * stream; then the fused DoG redone on the halo slices */
-            ZS_X(zs_xfer_begin(h->tr));
-            for (r = 0; r < nr; r++) {
-                zs_rank &q = R[(size_t)r];
-                const size_t bytes = sizeof(float) * (size_t)(hb * XY);
-                hipStream_t hs = banded ? q.halo_stream : q.c->stream;
-                if (q.lo) { /* global slices [z0 - hb, z0): the lower neighbour's last own slices */
-                    zs_rank &p = R[(size_t)r - 1];
-                    ZS_X(zs_xfer(h->tr, 0, r - 1, p.L[j] + (q.z0 - hb - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
-                                 q.L[j] + (q.z0 - hb - q.e0) * XY, hs, (size_t)(hb * XY)));
-                    st.halo_bytes_critical += (int64_t)bytes;
-                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
-                    st.exchanges++;
-                }
-                if (q.hi) { /* global slices [z1, z1 + hb): the upper neighbour's first own slices */
-                    zs_rank &p = R[(size_t)r + 1];
-                    ZS_X(zs_xfer(h->tr, 0, r + 1, p.L[j] + (q.z1 - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
-                                 q.L[j] + (q.z1 - q.e0) * XY, hs, (size_t)(hb * XY)));
-                    st.halo_bytes_critical += (int64_t)bytes;
-                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
-                    st.exchanges++;
-                }
-            }
-            ZS_X(zs_xfer_end(h->tr)); /* RCCL queues the step's sends and receives here: what follows is behind them */
-            for (r = 0; r < nr; r++) {
-                zs_rank &q = R[(size_t)r];
-                ZS_HIP(hipSetDevice(q.dev));
-                if (banded && (q.lo || q.hi)) { /* the main stream goes on behind the arrivals */
-                    ZS_COMM(hipEventRecord(q.ev_halo, q.halo_stream));
-                    ZS_COMM(hipStreamWaitEvent(q.c->stream, q.ev_halo, 0));
-                }
-                const int64_t a = (q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0) - q.e0, b = (q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1) - q.e0;
-                if (q.D[j - 1] && q.lo && q.z0 - q.e0 > a)
-                    ZS_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] + a * XY, (q.z0 - q.e0 - a) * XY));
-                if (q.D[j - 1] && q.hi && b > q.z1 - q.e0)
-                    ZS_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + (q.z1 - q.e0) * XY, q.L[j] + (q.z1 - q.e0) * XY, q.D[j - 1] + (q.z1 - q.e0) * XY, (b - (q.z1 - q.e0)) * XY));
-            }
-            if (j == 3) {
-                /* L1..L3 are final: the other 24 slices of their patch halos, on the copy stream, while L4, L5 and the
-                 * extrema passes run on the main one */
-                ZS_X(zs_xfer_begin(h->tr));
-                for (r = 0; r < nr; r++) {
-                    zs_rank &q = R[(size_t)r];
-                    if (!q.lo && !q.hi) continue;
-                    for (int l = 1; l <= 3; l++) {
-                        if (q.lo) {
-                            zs_rank &p = R[(size_t)r - 1];
-                            const int64_t s0 = std::max(q.e0, q.z0 - ZS_HALO), s1 = q.z0 - ZS_BLUR;
-                            if (s1 > s0) {
-                                ZS_X(zs_xfer(h->tr, 1, r - 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
-                                             (size_t)((s1 - s0) * XY)));
-                                st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
-                            }
-                        }
-                        if (q.hi) {
-                            zs_rank &p = R[(size_t)r + 1];
-                            const int64_t s0 = q.z1 + ZS_BLUR, s1 = std::min(q.e1, q.z1 + ZS_HALO);
-                            if (s1 > s0) {
-                                ZS_X(zs_xfer(h->tr, 1, r + 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
-                                             (size_t)((s1 - s0) * XY)));
-                                st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
-                            }
-                        }
-                    }
-                    st.exchanges++;
-                }
-                ZS_X(zs_xfer_end(h->tr));
-                for (r = 0; r < nr; r++) {
-                    zs_rank &q = R[(size_t)r];
-                    if (!q.lo && !q.hi) continue;
-                    ZS_HIP(hipSetDevice(q.dev));
-                    ZS_HIP(hipEventRecord(q.ev_patch, q.copy_stream));
-                }
-            }
-        }
-        /* extrema of the rank's own slices; the level table in whole-volume terms */
-        for (r = 0; r < nr; r++) {
-            zs_rank &q = R[(size_t)r];
-            ZS_HIP(hipSetDevice(q.dev));
-            for (int l = 0; l < 3; l++) {
-                const int id = o * 3 + l;
-                level_job jb = {q.D[l], q.D[l + 1], q.D[l + 2], X, Y, q.e1 - q.e0, (int)(q.z0 - q.e0), (int)(q.z1 - q.e0), id, 0};
-                if (lazy && l == 0) { /* the level below D_1 is L_0 - L_1 */
-                    jb.dp = q.L[0];
-                    jb.prev_b = q.L[1];
-                }
-                if (lazy && l == 2) { /* the level above D_3 is L_4 - blur(L_4) */
-                    jb.dn = nullptr;
-                    jb.next_g = q.L[4];
-                    jb.next_ntaps = ntaps5;
-                    for (int t = 0; t < ntaps5; t++) jb.next_taps[t] = taps5[t];
-                }
-                ZS_RC(cand_append(q.c, jb, true));
-                sift3d_level &lv = q.levels[(size_t)id];
-                lv.img = q.L[l + 1]; lv.dogc = q.D[l + 1];
-                lv.X = (int)X; lv.Y = (int)Y; lv.Z = (int)zo; lv.XP = (int)X;
-                lv.sigma_h = sig[l]; lv.sigma_c = sig[l + 1]; lv.sigma_l = sig[l + 2];
-                lv.octave_factor = fscale;
-                lv.Zl = (int)(q.e1 - q.e0); lv.z_off = (int)q.e0; lv.pad = 0;
-            }
-            if (q.lo || q.hi) ZS_HIP(hipStreamWaitEvent(q.c->stream, q.ev_patch, 0)); /* before the subsample reads L3 beyond +- 8 */
-        }
-        fscale *= 2.0f;
-        if (o + 1 >= (int)plan.oct.size()) break;
-        /* ---- level 0 of the next octave ---- */
-        const int64_t Xn = plan.oct[(size_t)o + 1][0], Yn = plan.oct[(size_t)o + 1][1], zn = plan.oct[(size_t)o + 1][2], XYn = Xn * Yn;
-        if (sharded && o + 1 < K) { /* next octave sharded too: slab +- 16 of L3 -> next slab +- 8 */
-            for (r = 0; r < S; r++) {
-                zs_rank &q = R[(size_t)r];
-                int64_t n0, n1;
-                plan.slab(r, o + 1, n0, n1);
-                const int64_t ne0 = q.lo ? std::max<int64_t>(0, n0 - ZS_HALO) : n0, ne1 = q.hi ? std::min<int64_t>(zn, n1 + ZS_HALO) : n1;
-                const int64_t s0 = q.lo ? std::max(ne0, n0 - ZS_BLUR) : ne0, s1 = q.hi ? std::min(ne1, n1 + ZS_BLUR) : ne1;
-                ZS_HIP(hipSetDevice(q.dev));
-                float *nx0 = q.alloc((ne1 - ne0) * XYn);
-                if (!nx0) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-                ZS_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (2 * s0 - q.e0) * XY, X, X, Y, 2 * (s1 - s0), nx0 + (s0 - ne0) * XYn, Xn));
-                next0[r] = nx0;
-            }
-        } else if (sharded) { /* last sharded octave: every rank subsamples exactly its slab, rank 0 assembles the whole octave */
-            zs_rank &root = R[0];
-            ZS_HIP(hipSetDevice(root.dev));
-            float *full = root.alloc(zn * XYn);
-            if (!full) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank 0: out of device memory"); goto done; }
-            int64_t at = 0;
-            struct gather_part { int rank; const float *src; int64_t at, t; };
-            std::vector<gather_part> parts;
-            for (r = 0; r < S; r++) {
-                zs_rank &q = R[(size_t)r];
-                const int64_t t = std::min<int64_t>((q.z1 - q.z0) / 2, zn - at); /* an odd last slice of the whole volume is dropped, as in the serial code */
-                if (t <= 0) continue;
-                ZS_HIP(hipSetDevice(q.dev));
-                float *part = r == 0 ? full + at * XYn : q.alloc(t * XYn);
-                if (!part) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-                ZS_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (q.z0 - q.e0) * XY, X, X, Y, 2 * t, part, Xn));
-                if (r > 0) {
-                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
-                    parts.push_back({r, part, at, t});
-                }
-                at += t;
-            }
-            ZS_X(zs_xfer_begin(h->tr)); /* every rank's part of the octave to rank 0, ordered in rank 0's main stream */
-            for (const gather_part &g : parts) {
-                zs_rank &q = R[(size_t)g.rank];
-                ZS_X(zs_xfer(h->tr, 0, g.rank, g.src, q.c->stream, q.ev_level, 0, full + g.at * XYn, root.c->stream, (size_t)(g.t * XYn)));
-                st.gather_bytes += (int64_t)sizeof(float) * g.t * XYn;
-            }
-            ZS_X(zs_xfer_end(h->tr));
-            if (at != zn) { rc = SIFT3D_ERR_ARG; snprintf(errbuf, sizeof errbuf, "slab plan does not tile octave %d (%lld of %lld slices)", o + 1, (long long)at, (long long)zn); goto done; }
-            next0[0] = full;
-        } else { /* unsharded: rank 0 alone */
-            zs_rank &q = R[0];
-            ZS_HIP(hipSetDevice(q.dev));
-            float *nx0 = q.alloc(zn * XYn);
-            if (!nx0) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank 0: out of device memory"); goto done; }
-            ZS_HIP(sift3d_launch_subsample(q.c->stream, q.L[3], X, X, Y, zo, nx0, Xn));
-            next0[0] = nx0;
-        }
-    }
-
-    /* ---- per-keypoint stage on every rank, phase by phase across the ranks so that no device waits for another's host
-     * round trip: (1) every rank's extrema count is requested; (2) rank by rank the count is awaited, the candidates are
-     * sorted and the keypoint side of the stage is queued -- the devices before it are already computing; (3) rank by rank
-     * the descriptor launches follow the keypoint chunks; (4) one synchronisation per rank at the end. ---- */
-    {
-        std::vector<int64_t> ncands((size_t)S, 0);
-        for (r = 0; r < S; r++) {
-            zs_rank &q = R[(size_t)r];
-            ZS_HIP(hipSetDevice(q.dev));
-            /* (the main stream already waits for the deferred patch halos of every sharded octave: ev_patch above) */
-            ZS_RC(cand_count_queue(q.c));
-        }
-        for (r = 0; r < S; r++) {
-            zs_rank &q = R[(size_t)r];
-            ZS_HIP(hipSetDevice(q.dev));
-            ZS_RC(cand_finalize(q.c, &ncands[(size_t)r]));
-            st.n_extrema += ncands[(size_t)r];
-            ZS_RC(describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false));
-        }
-        for (r = 0; r < S; r++) {
-            ZS_HIP(hipSetDevice(R[(size_t)r].dev));
-            ZS_RC(describe_launch(R[(size_t)r].c));
-        }
-        for (r = 0; r < S; r++) {
-            zs_rank &q = R[(size_t)r];
-            int64_t nrec = 0;
-            ZS_HIP(hipSetDevice(q.dev));
-            ZS_RC(describe_finish(q.c, &nrec));
-            recs[(size_t)r].assign(q.c->h_recs, q.c->h_recs + nrec);
-            grps[(size_t)r].assign(q.c->h_group, q.c->h_group + nrec);
-            st.n_keypoints += q.c->last.n_keypoints;
-        }
-    }
-    {
-        /* merge: within a group (level, is_max) slabs are in z order, so rank order is the serial raster order */
-        int64_t total = 0;
-        for (r = 0; r < S; r++) total += (int64_t)recs[(size_t)r].size();
-        sift3d_feature *res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));
-        if (!res) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "out of host memory"); goto done; }
-        std::vector<int64_t> count(2 * 96 + 2, 0);
-        for (r = 0; r < S; r++)
-            for (int g : grps[(size_t)r]) count[(size_t)(g < 0 || g >= 192 ? 192 : g) + 1]++;
-        for (size_t g = 1; g < count.size(); g++) count[g] += count[g - 1];
-        for (r = 0; r < S; r++)
-            for (size_t i = 0; i < recs[(size_t)r].size(); i++) {
-                const int g = grps[(size_t)r][i];
-                res[count[(size_t)(g < 0 || g >= 192 ? 192 : g)]++] = recs[(size_t)r][i];
-            }
-        *out = res;
-        *n_out = total;
-        st.n_records = total;
-    }
-
-done:
-    for (size_t i = 0; i < R.size(); i++) { /* everything queued has to be done before the buffers go back */
-        zs_rank &q = R[i];
-        hipSetDevice(q.dev);
-        hipStreamSynchronize(q.c->stream);
-        hipStreamSynchronize(q.copy_stream);
-        hipStreamSynchronize(q.halo_stream);
-    }
-    for (size_t i = 0; i < R.size(); i++) {
-        hipSetDevice(R[i].dev);
-        R[i].recycle();
-    }
-    st.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    if (stats) *stats = st;
-    if (rc != SIFT3D_OK && err && err_len > 0) snprintf(err, (size_t)err_len, "%s", errbuf);
-    return rc;
-}
-
-extern "C" int sift3d_extract_zslab_over(int transport, const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
-                                         float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
-                                         sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
-{
-    if (out) *out = nullptr;
-    if (n_out) *n_out = 0;
-    if (!vol || !out || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF ||
-        (transport != SIFT3D_TRANSPORT_PEER_COPY && transport != SIFT3D_TRANSPORT_RCCL)) {
-        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
-        return SIFT3D_ERR_ARG;
-    }
-    int status = SIFT3D_ERR_ARG;
-    sift3d_zslab *h = zslab_create_impl(devices, n_devices, nx, ny, nz, err, err_len, &status);
-    if (!h) return status != SIFT3D_OK ? status : SIFT3D_ERR_MEMORY;
-    h->transport_want = transport;
-    const int rc = sift3d_zslab_extract(h, vol, initial_image_scale, desc_mode, eig_thres, size_factor, out, n_out, stats, err, err_len);
-    sift3d_zslab_destroy(h);
-    return rc;
-}
-
-extern "C" int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
-                                    float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
-                                    sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
-{
-    return sift3d_extract_zslab_over(SIFT3D_TRANSPORT_PEER_COPY, devices, n_devices, vol, nx, ny, nz, initial_image_scale, desc_mode, eig_thres,
-                                     size_factor, out, n_out, stats, err, err_len);
-}
-
-extern "C" void sift3d_zslab_set_transport_library(const char *path) { zs_transport_set_library(path); }

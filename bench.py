@@ -44,7 +44,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TABLE = "r03_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
+PMC_TABLE = "r04_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
 BLUR_SOURCE = os.path.join("3d_sift_cuda_amd", "csrc", "kernels_blur_fused.hip")   # what the PMC table was measured on
 
 
@@ -507,7 +507,7 @@ def main():
             accounting = "8 B/voxel per x or y pass, 16 B/voxel for the z pass with fused DoG store"
         big_ms, big_bytes = float(sel["ms"].sum()), float(sel["alg_bytes"].sum())
         achieved = big_bytes / (big_ms * 1e-3) / 1e9
-        traffic, traffic_note = None, None
+        traffic, traffic_note, traffic_when = None, None, ""
         pmc = os.path.join(ROOT, "profiles", PMC_TABLE)
         if not os.path.exists(pmc):
             traffic_note = "no PMC table profiles/%s" % PMC_TABLE
@@ -536,6 +536,8 @@ def main():
                         raise LookupError("no PMC entry for %d taps" % pi["taps"])
                     tot += w * pi["launches"]; cnt += pi["launches"]
                 traffic = tot / cnt
+                m = tab.get("_measured") or {}
+                traffic_when = "measured %s UTC on %s (%s) by %s" % (m.get("date_utc", "?"), m.get("host", "?"), m.get("gpu", "?"), m.get("by", "?"))
             except Exception as e:
                 traffic, traffic_note = None, "dropped: %s" % (e,)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -550,7 +552,9 @@ def main():
                     "all_launches": {"launches": int(len(dom_all)), "avg_launch_ms": round(float(dom_all["ms"].mean()), 4),
                                      "achieved": round(float(dom_all["alg_bytes"].sum()) / (float(dom_all["ms"].sum()) * 1e-3) / 1e9, 1),
                                      "note": "every octave the kernel runs on, from the two breakdown steps after the timed region; compare with the per-kernel averages of rocprofv3 --stats"},
-                    "traffic_source": "profiles/" + PMC_TABLE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md), averaged over the launches" if traffic else traffic_note}
+                    "traffic_source": ("profiles/" + PMC_TABLE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per "
+                                       "MI355X_MICROARCH.md), averaged over the launches; a table committed with the source it was measured on "
+                                       "(hash-checked), NOT counters of this run: " + traffic_when) if traffic else traffic_note}
         pyr_ms = sum(v["ms"] for v in blur_groups.values())
         pyr_bytes = sum(v["bytes"] for v in blur_groups.values())
         pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
