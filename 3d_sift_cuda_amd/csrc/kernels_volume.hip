@@ -901,7 +901,17 @@ __global__ __launch_bounds__(64) void extrema_validate_lazy_kernel(const float *
     before -= len;
     const long long XY = (long long)X * Y;
     const int plane_bytes = (int)(XY * 4); /* the launcher keeps X * Y below 2^29 */
-    for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+    /* Which candidates a workgroup takes.  The list is in slabs of z (its segments, in order), and consecutive workgroups
+     * land on consecutive XCDs: handing out candidate i to workgroup i mod gridDim spreads every slab over all eight L2s,
+     * each of which then fetches the same lines of the level.  Instead XCD x (workgroups x, x + 8, ...) walks the x-th
+     * eighth of the list in order: its L2 holds one slab's neighbourhood at a time.  (SIFT3D_LAZY_ORDER 0: the round-2 order.) */
+#ifndef SIFT3D_LAZY_ORDER
+#define SIFT3D_LAZY_ORDER 1
+#endif
+    const long long nxcd = (gridDim.x & 7u) == 0 && SIFT3D_LAZY_ORDER ? 8 : 1;
+    const long long share = (n + nxcd - 1) / nxcd, first_i = (long long)(blockIdx.x % nxcd) * share;
+    const long long last_i = first_i + share < n ? first_i + share : n;
+    for (long long i = first_i + blockIdx.x / nxcd; i < last_i; i += gridDim.x / nxcd) {
         const int sg = __popcll(__ballot(before <= i)) - 1; /* before[] ascends: the last segment that starts at or before i */
         const long long first = __shfl(before, sg, 64);
         const sift3d_survivor2 e = list[(long long)sg * list_cap + (i - first)];
@@ -1338,6 +1348,7 @@ static void launch_validate_lazy(hipStream_t s, const sift3d_extrema_lazy &lz, i
     long long wgs = X * Y * Z / 2048; /* the finest octaves fill the chip; a coarse one does not pay for 4096 idle workgroups */
     wgs = wgs < 64 ? 64 : (wgs > 4096 ? 4096 : wgs);
     if (wgs > lz.list2_cap) wgs = lz.list2_cap;
+    if (wgs >= 8) wgs = wgs / 8 * 8; /* whole rounds of the eight XCDs: the kernel gives each an eighth of the list */
     hipLaunchKernelGGL(extrema_validate_lazy_kernel<R>, dim3((unsigned)wgs), dim3(64), 0, s, lz.next_g, (int)X, (int)Xl, (int)Y, (int)Z,
                        lz.list2, lz.list2_count, (long long)(lz.list2_cap / nseg), lvl_id, keys, vals, count, (long long)cap, t);
 }

@@ -6,6 +6,8 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 pkg = importlib.import_module("3d_sift_cuda_amd")
+if os.environ.get("SIFT3D_BUILD"):   # an A/B build of the library beside the product's: csrc/<SIFT3D_BUILD>/libsift3d_hip.so
+    pkg.LIB_HIP = os.path.join(pkg.CSRC, os.environ["SIFT3D_BUILD"], "libsift3d_hip.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 vol = pkg.synth_blobs(n, n, n)
