@@ -584,7 +584,14 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const float *__restr
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* wave-uniform by construction: say so, or every buffer descriptor below lands in vector registers */
-    const int xt = blockIdx.x % xtiles, yg = blockIdx.x / xtiles;
+    /* consecutive workgroups land on consecutive XCDs: XCD x takes the x-th eighth of the (x tile, y group) list, so that the
+     * two halo rows a y group shares with each neighbour are fetched into ONE L2 (SIFT3D_MARCH_ORDER 0: the round-3 order) */
+#ifndef SIFT3D_MARCH_ORDER
+#define SIFT3D_MARCH_ORDER 1
+#endif
+    const unsigned gx = gridDim.x;
+    const unsigned bx = (SIFT3D_MARCH_ORDER && (gx & 7u) == 0) ? (blockIdx.x & 7u) * (gx >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int xt = (int)(bx % (unsigned)xtiles), yg = (int)(bx / (unsigned)xtiles);
     const int y0 = 1 + (yg * 4 + wave) * EXM_ROWS;   /* first output row of this wavefront */
     const int za = z_first + blockIdx.y * zchunk;
     const int zb = za + zchunk < z_last ? za + zchunk : z_last; /* output planes za .. zb-1; plane zb <= Z-1 exists */
