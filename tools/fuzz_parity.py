@@ -31,12 +31,16 @@ def sweep(cases=60, seed=1, max_edge=112):
         noise = float(rng.choice([0.0, 0.0, 1.0, 8.0]))
         fused = int(rng.choice([1, 1, 2, 0]))   # 2: the fused blur on every octave it supports, 0: never
         kp_chunks = int(rng.choice([0, 1, 3, 6]))   # the per-keypoint stage in chunks on two streams
+        tile = int(rng.choice([0, 0, 1, 2]))        # round 4: the fused blur's tile (64 x 32 / 128 x 16)
+        host_recs = int(rng.choice([5, 5, 1, 12]))  # round 4: records per candidate the pinned buffers start with (1: they grow)
         vol = pkg.synth_blobs(*dims, seed=vseed)
         if noise:
             vol = vol + (rng.standard_normal(vol.shape) * noise).astype(np.float32)
         with pkg.Context(*dims) as ctx:
             ctx.set_tuning(pkg.TUNE_BLUR_FUSED, fused)
             ctx.set_tuning(pkg.TUNE_KP_CHUNKS, kp_chunks)
+            ctx.set_tuning(pkg.TUNE_FUSED_TILE, tile)
+            ctx.set_tuning(pkg.TUNE_HOST_RECORDS, host_recs)
             ctx.set_volume(vol)
             got = ctx.extract(initial_image_scale=init_scale, desc_mode=mode)
         want, _ = orc.extract(vol, init_scale=init_scale, desc_mode=mode)

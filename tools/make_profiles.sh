@@ -45,7 +45,9 @@ def _gpu_name():
         out = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
         names = [l.split(":", 1)[1].strip() for l in out.splitlines() if "Marketing Name" in l]
         gpus = [n for n in names if "MI3" in n or "Instinct" in n or "gfx" in n.lower()]
-        return (gpus or names or ["unknown"])[-1] if (gpus or names) else "unknown"
+        if not gpus:   # boxes whose GPU agent has an empty marketing name: its ISA name (gfx950) says what it is
+            gpus = [l.split(":", 1)[1].strip() for l in out.splitlines() if l.strip().startswith("Name:") and "gfx" in l]
+        return (gpus or [n for n in names if n] or ["unknown"])[-1]
     except Exception as e:
         return "unknown (%r)" % (e,)
 res = {"_measured": {"date_utc": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M"), "host": platform.node(), "gpu": _gpu_name(),
