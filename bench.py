@@ -166,6 +166,13 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     be = zs.HipBackend(pkg, ctx, torch)
     # the deferred patch-halo batch on a communicator of its own, so that it cannot queue in front of a level's halo
     dgroup = dist.new_group(ranks=list(range(world)), backend=dist.get_backend())
+    # one collective on each group before the first halo: with RCCL that creates both communicators here, on every rank at
+    # the same point, instead of inside the first point-to-point batch (where a rank talks to one or two neighbours only
+    # and the ranks would be setting up connections in different orders)
+    phase("zslab: first collective on both process groups")
+    warm = torch.zeros(1, device="cpu" if dist.get_backend() == "gloo" else "cuda:%d" % dev)
+    dist.all_reduce(warm)
+    dist.all_reduce(warm, group=dgroup)
     # the rank's input slices live in HBM before timing starts, as the volume of the per-GPU run does
     slab = torch.from_numpy(pkg.synth_blobs(n, n, n, seed=12345)[i0:i1].copy()).to("cuda:%d" % dev)
     torch.cuda.synchronize(dev)
@@ -561,7 +568,8 @@ def main():
                    "ms_per_step": round(pyr_ms / nfull, 3), "alg_bytes_per_step": pyr_bytes / nfull,
                    "accounting": "fused launches (volumes >= 2^22 voxels): 12 B/voxel with DoG, 8 without; three-pass launches "
                                  "(coarse octaves): 8 B/voxel per x or y pass, 16 for the z pass with fused DoG; octaves of at "
-                                 "most 4096 voxels: one launch, 40 B/voxel (level 0 in, four levels and five DoGs out)"}
+                                 "most 4096 voxels: one launch, 40 B/voxel (level 0 in, four levels and five DoGs out); the coarse octaves' levels as one "
+                                 "persistent launch (blur_chain): per octave 8 + 3 x 12 B/voxel for its four fused levels and 4.5 for the subsample"}
         stages = {}
         for i, s in enumerate(stage_names):
             sel = full[full["stage"] == i]
@@ -578,7 +586,7 @@ def main():
             sel = excl[excl["stage"] == i]
             if len(sel) and sname in stages:
                 stages[sname]["exclusive_ms_per_step"] = round(float(sel["ms"].sum()) / len(excl_logs), 3)
-        eb = excl[np.isin(excl["stage"], [stage_names.index(q) for q in ("blur_x", "blur_y", "blur_z_dog", "blur_fused", "octave_tiny")])]
+        eb = excl[np.isin(excl["stage"], [stage_names.index(q) for q in ("blur_x", "blur_y", "blur_z_dog", "blur_fused", "octave_tiny", "blur_chain") if q in stage_names])]
         pyramid["exclusive_ms_per_step"] = round(float(eb["ms"].sum()) / len(excl_logs), 3)
         pyramid["exclusive_alg_GBs"] = round(float(eb["alg_bytes"].sum()) / (float(eb["ms"].sum()) * 1e-3) / 1e9, 1)
         pyramid["exclusive_frac_of_peak"] = round(pyramid["exclusive_alg_GBs"] / HBM_PEAK_GBS, 4)
