@@ -71,7 +71,6 @@ static void free_dev(sift3d_ctx *c)
     for (int i = 0; i < 6; i++) hipFree(c->L[i]);
     for (int i = 0; i < 5; i++) hipFree(c->D[i]);
     hipFree(c->D4tiny);
-    hipFree(c->chain_sync);
     hipFree(c->T[0]);
     hipFree(c->T[1]);
     hipFree(c->d_taps);
@@ -136,14 +135,13 @@ static int alloc_cands(sift3d_ctx *c, int64_t cap)
 
 static void destroy_sync_objects(sift3d_ctx *c)
 {
-    hipStream_t streams[] = {c->ex_stream, c->ex_stream2, c->kp_stream, c->chain_stream};
+    hipStream_t streams[] = {c->ex_stream, c->ex_stream2, c->kp_stream};
     for (hipStream_t st : streams)
         if (st) {
             hipStreamSynchronize(st);
             hipStreamDestroy(st);
         }
-    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1],
-                           c->ev_chain[0], c->ev_chain[1]};
+    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1]};
     for (hipEvent_t e : events)
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_kpc)
@@ -172,14 +170,12 @@ sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean
     c->tune[SIFT3D_TUNE_SAMPLER_CAP] = 4;
     c->tune[SIFT3D_TUNE_BANDS_FIRST] = 1;
     c->tune[SIFT3D_TUNE_HOST_RECORDS] = 5;
-    c->tune[SIFT3D_TUNE_BLUR_CHAIN] = 1;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    hipStream_t *streams[] = {&c->ex_stream, &c->ex_stream2, &c->kp_stream, &c->chain_stream};
+    hipStream_t *streams[] = {&c->ex_stream, &c->ex_stream2, &c->kp_stream};
     for (hipStream_t *st : streams) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1],
-                            &c->ev_chain[0], &c->ev_chain[1]};
+    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1]};
     for (hipEvent_t *e : events) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t &e : c->ev_kpc) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * (8 + SIFT3D_KP_MAX_CHUNKS), hipHostMallocDefault) == hipSuccess;
@@ -209,7 +205,6 @@ sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean
     ok = ok && hipMalloc((void **)&c->sampler_tokens, sizeof(int) * SIFT3D_CU_SLOTS) == hipSuccess &&
          hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_rec_base, sizeof(int) * (SIFT3D_KP_MAX_CHUNKS + 1)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->chain_sync, sizeof(unsigned) * 4) == hipSuccess;
     ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
     c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
     ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
@@ -243,8 +238,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 256};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -1382,100 +1377,18 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         c->surv_sel = 0;
         return rc_;
     };
-    /* ---- the levels of the coarse octaves as ONE persistent launch (blur_chain_kernel, kernels_blur_fused.hip; round-3
-     * review item 4): every octave from the first one of at most 2^21 voxels on (never octave 0).  It starts on a stream of
-     * its own as soon as its first level 0 exists (the subsample after level 3 of the octave in front) and runs beside that
-     * octave's last level and the extrema passes of the finer octaves; the extrema passes of its own octaves are queued
-     * behind it, as launches.  Taken only where every one of those octaves has the shape the kernel is built for: dense
-     * rows of whole 16-byte vectors, the pyramid's own filters (7, 9, 11, 13 taps; 17 for the level that is never stored),
-     * lazy levels (or, for an octave of at most 4 096 voxels, the single-workgroup form with every level stored).
-     * SIFT3D_TUNE_BLUR_CHAIN: 0 = launch by launch as in rounds 1 - 3, 1 = on, n > 1 = with n workgroups. ---- */
-    size_t oc = oct.size(); /* first octave the chain builds (== size: none) */
-    sift3d_blur_chain_params cp;
-    memset(&cp, 0, sizeof cp);
-    double chain_bytes = 0;
-    int64_t chain_vox = 0;
-    auto chain_tiny = [&](const octave_dims &d) {
-        return d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && tiny_base >= 0 && d.off >= tiny_base &&
-               d.off - tiny_base + d.XP * d.Y * d.Z <= SIFT3D_D4TINY_FLOATS && c->tune[SIFT3D_TUNE_TINY_OCTAVE];
-    };
-    if (c->tune[SIFT3D_TUNE_BLUR_CHAIN] > 0 && c->tune[SIFT3D_TUNE_LAZY_LEVELS]) {
-        for (size_t o = 1; o < oct.size() && oc == oct.size(); o++)
-            if (oct[o].XP * oct[o].Y * oct[o].Z <= SIFT3D_CHAIN_FIRST_VOX) oc = o;
-        if (oct.size() - oc > SIFT3D_CHAIN_MAX_OCT) oc = oct.size();
-        float sg = 1.6f;
-        for (int j = 0; j < 5 && oc < oct.size(); j++) {
-            float taps[SIFT3D_MAX_TAPS];
-            const int n = sift3d_gauss_taps(sg * sqrtf(factor * factor - 1.0f), 0.01f, taps);
-            if (j < 4 ? (n / 2 < 3 || n / 2 > 6 || !(n & 1)) : n != 2 * SIFT3D_FAST_MAX_R + 1) oc = oct.size(); /* not the pyramid's own filters */
-            else {
-                cp.ntaps[j] = n;
-                for (int q = 0; q < n; q++) cp.taps[j][q] = taps[q];
-            }
-            sg *= factor;
-        }
-        bool seen_tiny = false;
-        for (size_t o = oc; o < oct.size(); o++) { /* every octave of the chain in a shape the kernel takes */
-            const octave_dims &d = oct[o];
-            const bool tiny = chain_tiny(d);
-            if (d.XP != d.X || (!tiny && (seen_tiny || d.XP < 8 || d.Y < 3 || d.Z < 3 || d.XP * d.Y >= (1ll << 29)))) oc = oct.size();
-            seen_tiny = seen_tiny || tiny;
-        }
-    }
-    if (oc < oct.size()) {
-        cp.n_oct = (int)(oct.size() - oc);
-        for (size_t o = oc; o < oct.size(); o++) {
-            const octave_dims &d = oct[o];
-            sift3d_blur_chain_octave &q = cp.oct[o - oc];
-            const bool tiny = chain_tiny(d);
-            for (int j = 0; j < 5; j++) q.L[j] = c->L[j] + d.off;
-            for (int j = 0; j < 4; j++) q.D[j] = c->D[j] + d.off;
-            q.D[4] = tiny ? c->D4tiny + (d.off - tiny_base) : nullptr;
-            q.next_L0 = o + 1 < oct.size() ? c->L[0] + oct[o + 1].off : nullptr;
-            q.X = (int)d.X; q.Y = (int)d.Y; q.Z = (int)d.Z;
-            if (!tiny) cp.n_grid = (int)(o - oc) + 1;
-            chain_bytes += (tiny ? 40.0 : 8.0 + 3 * 12.0 + 4.5) * (double)(d.X * d.Y * d.Z);
-            chain_vox += d.X * d.Y * d.Z;
-        }
-        cp.sync = c->chain_sync;
-    }
-    bool chain_launched = false, chain_joined = false;
-    /* called right after the subsample that produced level 0 of octave o + 1 */
-    auto after_subsample = [&](size_t o) -> int {
-        if (o + 1 != oc || oc >= oct.size()) return SIFT3D_OK;
-        int wgs = c->tune[SIFT3D_TUNE_BLUR_CHAIN];
-        if (wgs <= 1) wgs = SIFT3D_CHAIN_DEFAULT_WGS;
-        /* timing mode 3 times every launch alone: the chain then stays on the main stream */
-        hipStream_t cs = c->timing == 3 ? c->stream : c->chain_stream;
-        if (cs != c->stream) {
-            HIPCHK(c, hipEventRecord(c->ev_chain[0], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(cs, c->ev_chain[0], 0));
-        }
-        {
-            stage_scope sc(c, SIFT3D_STAGE_BLUR_CHAIN, chain_bytes, cp.n_oct, chain_vox, cs);
-            hipError_t e = sift3d_launch_blur_chain(cs, cp, wgs);
-            if (e != hipSuccess) return set_err(c, SIFT3D_ERR_DEVICE, "the coarse-octave launch failed: %s", hipGetErrorString(e));
-        }
-        /* the abort word of its barriers comes back with the candidate counts */
-        HIPCHK(c, hipMemcpyAsync(c->h_cnt0 + 7, c->chain_sync + 2, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
-        if (cs != c->stream) HIPCHK(c, hipEventRecord(c->ev_chain[1], cs));
-        chain_launched = true;
-        return SIFT3D_OK;
-    };
-    c->h_cnt0[7] = 0;
     for (size_t o = 0; o < oct.size(); o++) {
         const octave_dims &d = oct[o];
         const double N = (double)d.X * d.Y * d.Z;
         hipStream_t ws = c->stream;
         sigma = 1.6f;
         sig[0] = sigma;
-        const bool in_chain = o >= oc; /* its levels are the persistent launch's: only the bookkeeping and the extrema passes are left */
         /* an octave of at most 4096 voxels: all five levels in one single-workgroup launch instead of fifteen */
-        bool tiny_done = in_chain && chain_tiny(d);
+        bool tiny_done = false;
         /* the last DoG level of such an octave lives in a small buffer of its own, at the octave's offset from the first of them */
         float *const d4tiny = (tiny_base >= 0 && d.off >= tiny_base && d.off - tiny_base + d.XP * d.Y * d.Z <= SIFT3D_D4TINY_FLOATS)
                                   ? c->D4tiny + (d.off - tiny_base) : nullptr;
-        if (!in_chain && d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && d4tiny && c->tune[SIFT3D_TUNE_TINY_OCTAVE]) {
+        if (d.X * d.Y * d.Z <= SIFT3D_TINY_VOX && d4tiny && c->tune[SIFT3D_TUNE_TINY_OCTAVE]) {
             sift3d_octave_taps ot;
             sift3d_octave_out oo;
             float sg = sigma;
@@ -1517,11 +1430,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         }
         const bool lazy_next = lazy;
         for (int j = 1; j < 6; j++) {
-            if (in_chain) { /* levels, DoG levels and the subsample are the chain's */
-                sigma *= factor;
-                sig[j] = sigma;
-                continue;
-            }
             if (tiny_done) {
                 if (j == 3 && o + 1 < oct.size()) {
                     stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N, ws);
@@ -1530,8 +1438,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                      * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
                     if (oct[o + 1].XP != oct[o + 1].X)
                         HIPCHK(c, sift3d_launch_zero_pad(ws, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
-                    rc = after_subsample(o);
-                    if (rc) return rc;
                 }
                 sigma *= factor;
                 sig[j] = sigma;
@@ -1560,8 +1466,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                  * columns zeroed here -- the blur reads them as the zero border, and the buffer may hold an earlier volume */
                 if (oct[o + 1].XP != oct[o + 1].X)
                     HIPCHK(c, sift3d_launch_zero_pad(ws, c->L[0] + oct[o + 1].off, nullptr, oct[o + 1].XP, oct[o + 1].X, oct[o + 1].Y * oct[o + 1].Z));
-                rc = after_subsample(o);
-                if (rc) return rc;
             }
             sigma *= factor;
             sig[j] = sigma;
@@ -1590,10 +1494,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 rc = enqueue_extrema(0, 0);
                 if (rc) return rc;
             }
-            if (in_chain && chain_launched && !chain_joined && c->timing != 3) { /* the extrema passes of its octaves wait for the chain */
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_chain[1], 0));
-                chain_joined = true;
-            }
             rc = enqueue_extrema(o, 1);
             if (rc) return rc;
         }
@@ -1613,8 +1513,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     int64_t ncand = 0;
     rc = cand_finalize(c, &ncand);
     if (rc) return rc;
-    if (chain_launched && (unsigned)c->h_cnt0[7] != 0u)
-        return set_err(c, SIFT3D_ERR_DEVICE, "the coarse-octave launch gave up at a grid barrier (a workgroup never arrived)");
     c->last.n_extrema = ncand;
     if (!extract) return candidates_to_host(c, levels, ncand, cands_out, n_out);
     rc = describe_sorted(c, levels, ncand, desc_mode, eig_thres, size_factor, n_out, levels_early);

@@ -65,15 +65,6 @@ static void reference_side_effects(sift3d_ctx *ctx, int64_t X, int64_t Y, int64_
         const int st = log[i].stage;
         double us = 0;
         int64_t vox = log[i].nvox;
-        if (st == SIFT3D_STAGE_BLUR_CHAIN) { /* the coarse octaves' levels in one launch: ntaps = how many octaves, one line each */
-            const int n_oct = log[i].ntaps > 0 ? log[i].ntaps : 1;
-            for (int k = 0; k < n_oct; k++) {
-                if (octaves_seen > 0) printf("done.\n");
-                printf("\n#%lld\n", (long long)(log[i].ms * 1e3 / n_oct));
-                octaves_seen++;
-            }
-            continue;
-        }
         if (st == SIFT3D_STAGE_BLUR_FUSED || st == SIFT3D_STAGE_OCTAVE_TINY) us = log[i].ms * 1e3;
         else if (st == SIFT3D_STAGE_BLUR_X && i + 2 < nlog && log[i + 1].stage == SIFT3D_STAGE_BLUR_Y && log[i + 2].stage == SIFT3D_STAGE_BLUR_Z_DOG) {
             us = (log[i].ms + log[i + 1].ms + log[i + 2].ms) * 1e3;

@@ -130,12 +130,10 @@ struct fb_ring_cfg {
  * wavefronts per SIMD, up to 256 registers) -- a zero-arithmetic march of the same tiles streams 5.4-5.8 TB/s with one
  * workgroup per CU and two z chunks against 4.4-4.9 with two per CU and four chunks (tools/stream_roof.hip), and the
  * second plane in flight covers the latency the second workgroup covered. */
-/* One workgroup's march: tile and z chunk number wi of the launch's list (tiles_x * tiles_y tiles by z chunks of zlen planes).
- * A function of its own so that a launch is a thin wrapper around it. */
 template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32>
-__device__ __forceinline__ void blur_fused_ring_body(float *__restrict__ lds, long long wi, const float *__restrict__ in, float *__restrict__ out,
-                                                     float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen, int tiles_x,
-                                                     int tiles_y, const fb_taps2 &t)
+__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
+    const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen,
+    int tiles_x, int tiles_y, long long total, fb_taps2 t)
 {
     using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
     constexpr int U = 2 * R + 1, XO = C::XO;
@@ -147,8 +145,14 @@ __device__ __forceinline__ void blur_fused_ring_body(float *__restrict__ lds, lo
     static_assert(XO == 8, "a lane filters two 16-byte vectors of a row");
     constexpr int P1PL = P1ROWS * TX, PVPL = TY * TX;
     static_assert(XW * 64 <= C::NT, "the x-pass wavefronts are wavefronts of the workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     float *const P1b = lds;
     float *const pvb = lds + 2 * P1PL;
+
+    const long long lin = blockIdx.x;
+    const long long per = (total + 7) / 8;
+    const long long wi = (lin % 8) * per + lin / 8; /* XCD-aware tile order, as in the first form */
+    if (wi >= total) return;
     const int tx = (int)(wi % tiles_x);
     const int ty = (int)((wi / tiles_x) % tiles_y);
     const int chunk = (int)(wi / ((long long)tiles_y * tiles_x));
@@ -396,26 +400,12 @@ __device__ __forceinline__ void blur_fused_ring_body(float *__restrict__ lds, lo
     }
 }
 
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32>
-__global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
-    const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen,
-    int tiles_x, int tiles_y, long long total, fb_taps2 t)
-{
-    using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
-    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-    const long long lin = blockIdx.x;
-    const long long per = (total + 7) / 8;
-    const long long wi = (lin % 8) * per + lin / 8; /* XCD-aware tile order, as in the first form */
-    if (wi >= total) return;
-    blur_fused_ring_body<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv>(lds, wi, in, out, dog, X, Y, Z, zo0, zo1, zlen, tiles_x, tiles_y, t);
-}
-
 /* chunks along z: enough workgroups to fill every CU's resident slots while the 2R lead-in planes stay cheap */
-static int fused_chunks(int R, int64_t Z, long long tiles, int resident, int forced, double slots_given = 0.0)
+static int fused_chunks(int R, int64_t Z, long long tiles, int resident, int forced)
 {
     if (forced >= 1) return forced;
     /* time ~ rounds of resident workgroups x planes marched per workgroup */
-    const double slots = slots_given > 0.0 ? slots_given : 256.0 * resident;
+    const double slots = 256.0 * resident;
     int best = 1;
     double best_cost = 0;
     for (int n = 1; n <= 256; n++) {
@@ -502,215 +492,6 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     if constexpr (R <= 4)
         if (!(out && dog)) return launch_ring_pf<R, 2, 3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
     return launch_ring_pf<R, 2, 2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
-}
-
-/* ------------------------------------------------------------------------------------------------------------------
- * The coarse octaves' levels in ONE persistent launch (round 4, second form; the first -- three passes per level through
- * L2, ninety grid barriers -- lost: profiles/r04_coarse_chain.txt).  After the first two octaves a 512^3 pyramid is sixty
- * dependent launches of 7 - 25 us that queue, one by one, behind the grids of the first octave's extrema passes.  Here
- * every level of those octaves is the march above -- x, y, z and the DoG in one step, as virtual workgroups of a resident
- * grid -- so an octave is FOUR dependent steps and a subsample instead of thirteen launches, with a grid-wide barrier
- * where a launch boundary was; the octaves of at most SIFT3D_TINY_VOX voxels are built by workgroup 0 alone in LDS, as
- * tiny_octave_kernel does.  Being resident from its first instruction the launch does not queue behind anyone.
- * Only the levels: the extrema passes of these octaves stay launches of their own (they wait for this kernel, not for
- * each other).  Same arithmetic as everywhere (it IS the same code); D_0 and L_5 are not produced (lazy levels).
- * ------------------------------------------------------------------------------------------------------------------ */
-#define FBC_THREADS 512
-#ifdef SIFT3D_DEV /* development build: workgroup 0 leaves the 100 MHz clock around every grid barrier (tools/chain_phases.py) */
-__device__ unsigned long long g_chain_clk[256];
-__device__ unsigned g_chain_nclk;
-#define FBC_CLK()                                                                                                        \
-    do {                                                                                                                 \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && g_chain_nclk < 256) g_chain_clk[g_chain_nclk++] = wall_clock64();     \
-    } while (0)
-extern "C" int sift3d_dev_chain_clocks(unsigned long long *out, int n)
-{
-    unsigned cnt = 0;
-    if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_chain_nclk), sizeof cnt) != hipSuccess) return -1;
-    if ((int)cnt > n) cnt = (unsigned)n;
-    if (cnt && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_clk), sizeof(unsigned long long) * cnt) != hipSuccess) return -1;
-    const unsigned zero = 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_nclk), &zero, sizeof zero);
-    return (int)cnt;
-}
-#else
-#define FBC_CLK() do { } while (0)
-#endif
-constexpr int fbc_max(int a, int b) { return a > b ? a : b; }
-/* the largest LDS request of the marches it runs (R = 3 .. 6, two rows per thread, two planes of prefetch, 64 x 32 tiles) */
-constexpr int FBC_LDS_FLOATS = fbc_max(fbc_max(fb_ring_cfg<3, 2, 2>::LDS_FLOATS, fb_ring_cfg<4, 2, 2>::LDS_FLOATS),
-                                       fbc_max(fb_ring_cfg<5, 2, 2>::LDS_FLOATS, fb_ring_cfg<6, 2, 2>::LDS_FLOATS));
-static_assert(FBC_LDS_FLOATS >= 3 * SIFT3D_TINY_VOX + 2 * SIFT3D_FAST_MAX_R + 1, "the single-workgroup octaves fit the same LDS");
-static_assert(fb_ring_cfg<6, 2, 2>::NT == FBC_THREADS, "the marches run with the launch's 512 threads");
-
-__device__ __forceinline__ bool fbc_grid_barrier(unsigned *sync, unsigned G, unsigned &gen)
-{
-    /* arrival counter + generation word (zeroed by the launcher); release before arriving, acquire after leaving, at agent
-     * scope: the levels one workgroup wrote are read by workgroups on other XCDs.  Every spin is bounded: a workgroup that
-     * waits longer than any healthy run could need raises the abort word, everyone who sees it leaves, the host reports it. */
-    __syncthreads();
-    if (G > 1 && threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned arrived = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == G - 1) {
-            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned spins = 0;
-            while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > SIFT3D_CHAIN_SPIN_LIMIT || __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    gen++;
-    __syncthreads();
-    return G > 1 ? __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u : true;
-}
-
-/* 2 x 2 x 2 mean with the reference's association (FeatureIO.cpp:1532-1538, as subsample_kernel); dense rows */
-__device__ __forceinline__ void fbc_subsample(unsigned wg, unsigned G, const float *__restrict__ in, int X, int Y, int Z, float *__restrict__ out)
-{
-    const unsigned ox = (unsigned)X / 2u, oy = (unsigned)Y / 2u, oz = (unsigned)Z / 2u, items = ox * oy * oz;
-    const long long XY = (long long)X * Y;
-    for (unsigned i = wg * FBC_THREADS + threadIdx.x; i < items; i += G * FBC_THREADS) {
-        const unsigned x = i % ox, yz = i / ox, y = yz % oy, z = yz / oy;
-        const float *p0 = in + (long long)(2 * z) * XY + (long long)(2 * y) * X + 2 * x;
-        const float *p1 = p0 + XY;
-        const float a00 = p0[0], a10 = p0[1], a01 = p0[X], a11 = p0[X + 1];
-        const float b00 = p1[0], b10 = p1[1], b01 = p1[X], b11 = p1[X + 1];
-        float s = 0.0f;
-        s = s + (((a00 + a01) + a10) + a11);
-        s = s + (((b00 + b01) + b10) + b11);
-        out[i] = s * 0.125f;
-    }
-}
-
-template <int AXIS>
-__device__ __forceinline__ void fbc_lds_pass(const float *src, float *dst, int X, int Y, int Z, int N, const float *f, int nt)
-{
-    const int R = nt / 2;
-    const int len = AXIS == 0 ? X : (AXIS == 1 ? Y : Z);
-    const int st = AXIS == 0 ? 1 : (AXIS == 1 ? X : X * Y);
-    for (int s = threadIdx.x; s < N; s += FBC_THREADS) {
-        const int c = AXIS == 0 ? s % X : (AXIS == 1 ? (s / X) % Y : s / (X * Y));
-        float acc = 0;
-        for (int j = 0; j < nt; j++) {
-            const int cc = c + j - R;
-            if (cc >= 0 && cc < len) acc = acc + f[j] * src[s + (cc - c) * st];
-        }
-        dst[s] = acc;
-    }
-    __syncthreads();
-}
-
-/* an octave of at most SIFT3D_TINY_VOX voxels by ONE workgroup with the octave in LDS: all five levels and all five DoG
- * levels stored (the arithmetic and the stores of tiny_octave_kernel), then level 0 of the next octave */
-__device__ __forceinline__ void fbc_tiny_octave(float *lds, const sift3d_blur_chain_octave &o, const sift3d_blur_chain_params &p)
-{
-    const int X = o.X, Y = o.Y, Z = o.Z, N = X * Y * Z;
-    float *cur = lds, *a = lds + SIFT3D_TINY_VOX, *b = lds + 2 * SIFT3D_TINY_VOX, *taps = lds + 3 * SIFT3D_TINY_VOX;
-    for (int s = threadIdx.x; s < N; s += FBC_THREADS) cur[s] = o.L[0][s];
-    __syncthreads();
-    for (int lvl = 0; lvl < 5; lvl++) {
-        const int nt = p.ntaps[lvl];
-        if ((int)threadIdx.x < nt) taps[threadIdx.x] = p.taps[lvl][threadIdx.x];
-        __syncthreads();
-        fbc_lds_pass<0>(cur, a, X, Y, Z, N, taps, nt);
-        fbc_lds_pass<1>(a, b, X, Y, Z, N, taps, nt);
-        fbc_lds_pass<2>(b, a, X, Y, Z, N, taps, nt);
-        for (int s = threadIdx.x; s < N; s += FBC_THREADS) {
-            const float v = a[s];
-            if (lvl < 4) o.L[lvl + 1][s] = v;
-            o.D[lvl][s] = cur[s] - v;
-        }
-        __syncthreads();
-        if (lvl == 2 && o.next_L0) {
-            fbc_subsample(0u, 1u, o.L[3], X, Y, Z, o.next_L0);
-            __syncthreads();
-        }
-        float *tmp = cur; cur = a; a = tmp;
-    }
-}
-
-template <int R, bool HAS_DOG>
-__device__ __forceinline__ void fbc_level(float *lds, unsigned wg, unsigned G, const sift3d_blur_chain_octave &o, int j, const fb_taps2 &t)
-{
-    const long long total = (long long)o.tiles_x * o.tiles_y * o.nch[j - 1];
-    for (long long wi = wg; wi < total; wi += G) {
-        blur_fused_ring_body<R, 2, true, HAS_DOG, 2>(lds, wi, o.L[j - 1], o.L[j], HAS_DOG ? o.D[j - 1] : nullptr, o.X, o.Y, o.Z, 0, o.Z,
-                                                     o.zlen[j - 1], o.tiles_x, o.tiles_y, t);
-        __syncthreads(); /* the next tile starts with the LDS of this one */
-    }
-}
-
-__global__ __launch_bounds__(FBC_THREADS, 2) void blur_chain_kernel(sift3d_blur_chain_params p)
-{
-    __shared__ __attribute__((aligned(16))) float lds[FBC_LDS_FLOATS];
-    const unsigned wg = blockIdx.x, G = gridDim.x;
-    unsigned gen = 0;
-    FBC_CLK();
-    for (int oi = 0; oi < p.n_grid; oi++) {
-        const sift3d_blur_chain_octave &o = p.oct[oi];
-        for (int j = 1; j <= 4; j++) {
-            fb_taps2 t;
-#pragma unroll
-            for (int q = 0; q < 2 * SIFT3D_FAST_MAX_R + 1; q++) t.f[q] = v2f(q < p.ntaps[j - 1] ? p.taps[j - 1][q] : 0.0f);
-            /* level 1's DoG (D_0) is never stored: the level below D_1 is read as L_0 - L_1 around the candidates */
-            switch (p.ntaps[j - 1] / 2) {
-            case 3: if (j == 1) fbc_level<3, false>(lds, wg, G, o, j, t); else fbc_level<3, true>(lds, wg, G, o, j, t); break;
-            case 4: if (j == 1) fbc_level<4, false>(lds, wg, G, o, j, t); else fbc_level<4, true>(lds, wg, G, o, j, t); break;
-            case 5: if (j == 1) fbc_level<5, false>(lds, wg, G, o, j, t); else fbc_level<5, true>(lds, wg, G, o, j, t); break;
-            default: if (j == 1) fbc_level<6, false>(lds, wg, G, o, j, t); else fbc_level<6, true>(lds, wg, G, o, j, t); break;
-            }
-            /* level 0 of the next octave rides with level 4: both only read L_3 */
-            if (j == 4 && o.next_L0) fbc_subsample(wg, G, o.L[3], o.X, o.Y, o.Z, o.next_L0);
-            FBC_CLK();
-            if (!fbc_grid_barrier(p.sync, G, gen)) return;
-            FBC_CLK();
-        }
-    }
-    if (wg != 0) return;
-    for (int oi = p.n_grid; oi < p.n_oct; oi++) {
-        fbc_tiny_octave(lds, p.oct[oi], p);
-        FBC_CLK();
-    }
-}
-
-hipError_t sift3d_launch_blur_chain(hipStream_t s, sift3d_blur_chain_params &p, int workgroups)
-{
-    if (p.n_oct < 1 || p.n_oct > SIFT3D_CHAIN_MAX_OCT || p.n_grid < 0 || p.n_grid > p.n_oct || workgroups < 1) return hipErrorInvalidValue;
-    for (int j = 0; j < 4; j++)
-        if (p.ntaps[j] / 2 < 3 || p.ntaps[j] / 2 > 6 || !(p.ntaps[j] & 1)) return hipErrorNotSupported;
-    if (p.ntaps[4] < 3 || p.ntaps[4] > 2 * SIFT3D_FAST_MAX_R + 1) return hipErrorNotSupported;
-    for (int j = 0; j < 5; j++)
-        for (int q = 0; q < p.ntaps[j] / 2; q++)
-            if (__builtin_bit_cast(unsigned, p.taps[j][q]) != __builtin_bit_cast(unsigned, p.taps[j][p.ntaps[j] - 1 - q])) return hipErrorNotSupported;
-    for (int i = 0; i < p.n_oct; i++) {
-        sift3d_blur_chain_octave &o = p.oct[i];
-        if (o.X % 4 != 0 || (long long)o.X * o.Y >= (1ll << 29)) return hipErrorNotSupported;
-        if (i >= p.n_grid) {
-            if ((long long)o.X * o.Y * o.Z > SIFT3D_TINY_VOX) return hipErrorNotSupported;
-            continue;
-        }
-        using C = fb_ring_cfg<6, 2, 2>;
-        o.tiles_x = (o.X + C::TX - 1) / C::TX;
-        o.tiles_y = (o.Y + C::TY - 1) / C::TY;
-        for (int j = 0; j < 4; j++) { /* z chunks: enough virtual workgroups for the resident ones, lead-in planes kept cheap */
-            const int R = p.ntaps[j] / 2;
-            const int n = fused_chunks(R, o.Z, (long long)o.tiles_x * o.tiles_y, 1, 0, (double)workgroups);
-            o.zlen[j] = (o.Z + n - 1) / n;
-            o.nch[j] = (o.Z + o.zlen[j] - 1) / o.zlen[j];
-        }
-    }
-    hipError_t e = hipMemsetAsync(p.sync, 0, sizeof(unsigned) * 4, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(blur_chain_kernel, dim3((unsigned)(p.n_grid > 0 ? workgroups : 1)), dim3(FBC_THREADS), 0, s, p);
-    return hipGetLastError();
 }
 
 /* Returns hipErrorNotSupported when the shape is outside this kernel (the caller then runs the three-pass path): rows

@@ -73,10 +73,6 @@ struct sift3d_ctx {
     float *D[5];  /* DoG levels, same layout; D[4] is only allocated when an octave has to store its last DoG level in full
                    * (ensure_level_buffer): by default that level is evaluated around the candidates only */
     float *D4tiny; /* the last DoG level of the octaves that one workgroup builds whole (at most SIFT3D_TINY_VOX voxels each) */
-    /* the coarse octaves' levels in one persistent launch (blur_chain_kernel): its barrier words, a stream, two events */
-    unsigned *chain_sync;
-    hipStream_t chain_stream;
-    hipEvent_t ev_chain[2];
     float *T[2];  /* x- and y-pass intermediates */
     float *d_taps;
     /* extrema as (key, value) pairs, unsorted (a) and sorted (b) */

@@ -118,27 +118,6 @@ hipError_t sift3d_launch_extrema(hipStream_t s, const float *dprev, const float 
 hipError_t sift3d_launch_extrema_octave_small(hipStream_t s, const float *const d[5], int64_t X, int64_t Xl, int64_t Y, int64_t Z,
                                               int lvl_id0, unsigned long long *keys, sift3d_cval *vals, unsigned long long *count,
                                               int64_t cap);
-/* ---- the coarse octaves' levels in one persistent launch (kernels_blur_fused.hip, blur_chain_kernel) ---- */
-#define SIFT3D_CHAIN_MAX_OCT 10
-#define SIFT3D_CHAIN_FIRST_VOX (1ll << 21)  /* the chain starts at the first octave (after octave 0) of at most this many voxels */
-#define SIFT3D_CHAIN_DEFAULT_WGS 32
-#define SIFT3D_CHAIN_SPIN_LIMIT (1u << 22)  /* polls of a grid barrier before the launch gives up (seconds) */
-struct sift3d_blur_chain_octave {
-    float *L[5];    /* L_0 (the input: the previous octave's subsampled L_3) .. L_4 */
-    float *D[5];    /* D_1 .. D_3 (D_0 and D_4 only for the octaves one workgroup builds in LDS: every level stored there) */
-    float *next_L0; /* level 0 of the next octave (NULL for the last) */
-    int X, Y, Z;    /* dense rows of whole 16-byte vectors */
-    int tiles_x, tiles_y, nch[4], zlen[4]; /* filled by the launcher: the march's tiles and z chunks per level */
-};
-struct sift3d_blur_chain_params {
-    sift3d_blur_chain_octave oct[SIFT3D_CHAIN_MAX_OCT];
-    int n_oct, n_grid; /* octaves [0, n_grid) are shared by the grid, [n_grid, n_oct) (at most SIFT3D_TINY_VOX voxels) built by workgroup 0 */
-    float taps[5][2 * SIFT3D_FAST_MAX_R + 1];
-    int ntaps[5];
-    unsigned *sync;    /* 4 words: arrivals, generation, abort, unused */
-};
-hipError_t sift3d_launch_blur_chain(hipStream_t s, sift3d_blur_chain_params &p, int workgroups);
-
 #define SIFT3D_SURV_SETS 96 /* one counter set per extrema pass of a pipeline run, zeroed together */
 #define SIFT3D_SURV_COUNTERS (64 * 32)
 #define SIFT3D_LIST2_COUNTERS 64

@@ -568,8 +568,7 @@ def main():
                    "ms_per_step": round(pyr_ms / nfull, 3), "alg_bytes_per_step": pyr_bytes / nfull,
                    "accounting": "fused launches (volumes >= 2^22 voxels): 12 B/voxel with DoG, 8 without; three-pass launches "
                                  "(coarse octaves): 8 B/voxel per x or y pass, 16 for the z pass with fused DoG; octaves of at "
-                                 "most 4096 voxels: one launch, 40 B/voxel (level 0 in, four levels and five DoGs out); the coarse octaves' levels as one "
-                                 "persistent launch (blur_chain): per octave 8 + 3 x 12 B/voxel for its four fused levels and 4.5 for the subsample"}
+                                 "most 4096 voxels: one launch, 40 B/voxel (level 0 in, four levels and five DoGs out)"}
         stages = {}
         for i, s in enumerate(stage_names):
             sel = full[full["stage"] == i]
@@ -586,7 +585,7 @@ def main():
             sel = excl[excl["stage"] == i]
             if len(sel) and sname in stages:
                 stages[sname]["exclusive_ms_per_step"] = round(float(sel["ms"].sum()) / len(excl_logs), 3)
-        eb = excl[np.isin(excl["stage"], [stage_names.index(q) for q in ("blur_x", "blur_y", "blur_z_dog", "blur_fused", "octave_tiny", "blur_chain") if q in stage_names])]
+        eb = excl[np.isin(excl["stage"], [stage_names.index(q) for q in ("blur_x", "blur_y", "blur_z_dog", "blur_fused", "octave_tiny")])]
         pyramid["exclusive_ms_per_step"] = round(float(eb["ms"].sum()) / len(excl_logs), 3)
         pyramid["exclusive_alg_GBs"] = round(float(eb["alg_bytes"].sum()) / (float(eb["ms"].sum()) * 1e-3) / 1e9, 1)
         pyramid["exclusive_frac_of_peak"] = round(pyramid["exclusive_alg_GBs"] / HBM_PEAK_GBS, 4)

@@ -210,8 +210,6 @@ typedef enum {
                                  * 4.2), 1..12; a run that yields more grows them (sift3d_host_buffer_grows counts) */
     SIFT3D_TUNE_FUSED_TILE,     /* (x, y) tile of the fused launch's two-rows-per-thread mapping: 0 = by measurement (default), 1 = 64 x 32,
                                  * 2 = 128 x 16 */
-    SIFT3D_TUNE_BLUR_CHAIN,     /* the levels of the octaves of at most 2^21 voxels (never the first) in one persistent launch: 1 (default), n > 1 =
-                                 * with n workgroups, 0 = launch by launch as in rounds 1 - 3 */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);
@@ -352,8 +350,6 @@ typedef enum {
     SIFT3D_STAGE_DESCRIPTOR,
     SIFT3D_STAGE_BLUR_FUSED, /* x, y, z passes and the DoG store in one kernel */
     SIFT3D_STAGE_OCTAVE_TINY, /* all five levels and DoGs of an octave of at most 4096 voxels in one workgroup */
-    SIFT3D_STAGE_BLUR_CHAIN, /* the levels of every octave of at most 2^21 voxels (never the first) in one persistent launch; the launch
-                              * record's ntaps holds the number of octaves */
     SIFT3D_STAGE_COUNT
 } sift3d_stage;
 typedef struct {

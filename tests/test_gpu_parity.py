@@ -407,68 +407,25 @@ def test_context_reuse_pitched_coarse_octaves(built, oracle, dims):
         assert (bits(gc["value"]) == bits(wc["value"])).all()
 
 
-@pytest.mark.parametrize("chain", [0, 1, 5])
 @pytest.mark.parametrize("dims", [(168, 164, 160), (166, 165, 161)])
-def test_pipeline_records_through_the_fused_blur(built, oracle, dims, chain):
+def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
     """A volume of more than 2^22 voxels: its finest octave is built by the one-launch ring kernel (two rows per thread;
     the 17-tap level is never filtered in full: test_lazy_levels_*), the 7- and 9-tap levels of the next octave (2^18
     voxels or more) too, with one row per thread; everything else by the three-pass kernels and the single-workgroup
     octave kernel.  The second shape has rows
-    that are not whole 16-byte vectors (pitched rows).  Records against the oracle.  chain = 0: that launch-by-launch form of
-    the coarse octaves (rounds 1 - 3); chain = 1 / 5 (round 4): the levels of every octave after the first in ONE persistent
-    launch (blur_chain_kernel; default number of workgroups / five) where their rows allow it -- neither shape here does
-    (84 -> 42 -> 21, 83 -> 41: pitched rows down the octaves), so all three settings take the launch-by-launch form; the
-    next test has the shapes the chain does build."""
+    that are not whole 16-byte vectors (pitched rows).  Records against the oracle."""
     vol = vol_of(built, dims, 9)
     with built.Context(*dims) as ctx:
-        ctx.set_tuning(built.TUNE_BLUR_CHAIN, chain)
         ctx.set_volume(vol)
         ctx.enable_timing(True)
         got = ctx.extract()
         log = ctx.launch_log()
-        assert ctx.extract().tobytes() == got.tobytes()
     fused = log[log["stage"] == built.STAGES.index("blur_fused")]
+    assert len(fused) == 7                    # octave 0: initial blur + four levels; octave 1: its 7- and 9-tap levels
     assert fused["ntaps"][:5].tolist() == [9, 7, 9, 11, 13]
-    if not (log["stage"] == built.STAGES.index("blur_chain")).any():
-        assert len(fused) == 7                # octave 0: initial blur + four levels; octave 1: its 7- and 9-tap levels
-        assert sorted(fused["ntaps"][5:].tolist()) == [7, 9] and (fused["nvox"][5:] < fused["nvox"][0]).all()
+    assert sorted(fused["ntaps"][5:].tolist()) == [7, 9] and (fused["nvox"][5:] < fused["nvox"][0]).all()
     want, _ = oracle.extract(vol)
     assert len(want) > 200 and _compare_records(got, want)
-
-
-@pytest.mark.parametrize("dims", [(128, 128, 128), (256, 128, 64), (256, 160, 96), (64, 64, 64), (32, 32, 32), (128, 96, 160)])
-@pytest.mark.parametrize("wgs", [1, 3, 32])
-def test_pipeline_records_through_the_persistent_coarse_launch(built, oracle, dims, wgs):
-    """Round 4: the levels of the coarse octaves -- every octave after the first of at most 2^21 voxels -- built by ONE
-    persistent launch (blur_chain_kernel: per level the fused x + y + z + DoG march as virtual workgroups of a resident grid, a
-    grid-wide barrier between levels, the octaves of at most 4 096 voxels by one workgroup in LDS), with the default number of
-    workgroups, with three (every workgroup walks several tiles) and -- SIFT3D_TUNE_BLUR_CHAIN = 0 -- launch by launch.  The
-    shapes keep rows of whole 16-byte vectors down the octaves, which is what the launch takes; candidates and records against
-    the oracle, the launch log says which form ran, and a second extraction on the same context gives the same bytes."""
-    vol = vol_of(built, dims, 23)
-    want, _ = oracle.extract(vol)
-    wc = oracle.candidates(vol)
-    with built.Context(*dims) as ctx:
-        ctx.set_tuning(built.TUNE_BLUR_CHAIN, wgs if wgs != 1 else 1)
-        ctx.set_volume(vol)
-        ctx.enable_timing(True)
-        got = ctx.extract()
-        log = ctx.launch_log()
-        ctx.enable_timing(False)
-        chain = log[log["stage"] == built.STAGES.index("blur_chain")]
-        assert len(chain) == 1 and chain["ntaps"][0] >= 2          # one launch; ntaps = the octaves it built
-        assert not (log["stage"] == built.STAGES.index("octave_tiny")).any()
-        assert (len(want) > 20 or max(dims) <= 32) and len(got) == len(want) and (len(want) == 0 or _compare_records(got, want))
-        gc = ctx.detect()
-        assert len(gc) == len(wc) and all((gc[f] == wc[f]).all() for f in ("octave", "level", "is_max", "x", "y", "z"))
-        for f in ("value", "h_value", "l_value"):
-            assert (bits(gc[f]) == bits(wc[f])).all(), f
-        assert ctx.extract().tobytes() == got.tobytes()
-        ctx.set_tuning(built.TUNE_BLUR_CHAIN, 0)
-        ctx.enable_timing(True)
-        again = ctx.extract()
-        assert not (ctx.launch_log()["stage"] == built.STAGES.index("blur_chain")).any()
-        assert again.tobytes() == got.tobytes()
 
 
 def test_pipeline_empty_volume(built, oracle, tmp_path):
