@@ -6,7 +6,10 @@
  *   host_asan_driver read <file>...      nifti_min_read every file (failures are fine, crashes are not), resample the
  *                                         readable ones to isotropic voxels (-w), print "<file> rc dims"
  *   host_asan_driver keys <dir>          write / read back text and binary .key files of synthetic records, apply a
- *                                         world transform, compare
+ *                                         world transform, compare; image.pgm of a slice, of a constant slice
+ *   host_asan_driver votes               the matcher's host side (match_votes.c, round 4): filters, descriptor bytes incl.
+ *                                         values that are not bytes, votes on well-formed neighbour lists and on lists
+ *                                         with indices / labels out of range (must be refused, not read or written through)
  */
 #include <math.h>
 #include <stdio.h>
@@ -14,6 +17,7 @@
 #include <string.h>
 
 #include "keyfile.h"
+#include "match.h"
 #include "nifti_min.h"
 #include "sift3d.h"
 #include "synth.h"
@@ -70,11 +74,61 @@ int main(int argc, char **argv)
         snprintf(p, sizeof p, "%s/missing/a.key", argv[2]);
         if (sift3d_write_key(p, f, N, 140.0f, 3, cm) == 0) return 6; /* a path that cannot be created fails cleanly */
         if (sift3d_read_key(p, &g, &n) == 0) return 7;
+        snprintf(p, sizeof p, "%s/slice.pgm", argv[2]);
+        if (sift3d_write_pgm(p, v, 16, 16) != 0) return 8;
+        float flat[12];
+        for (int i = 0; i < 12; i++) flat[i] = 2.5f;
+        if (sift3d_write_pgm(p, flat, 3, 4) != 0) return 9; /* a constant slice: 0 / 0 in the scaling, written as zeros */
+        if (sift3d_write_pgm(p, flat, 0, 4) == 0) return 10;
         printf("keys ok %d\n", N);
         free(v);
         free(f);
         return 0;
     }
-    fprintf(stderr, "usage: host_asan_driver read <file>... | keys <dir>\n");
+    if (argc == 2 && strcmp(argv[1], "votes") == 0) {
+        enum { NI = 5, PER = 40, K = 4, NF = NI * PER };
+        sift3d_feature *f = (sift3d_feature *)calloc(NF, sizeof(*f));
+        int8_t *bytes = (int8_t *)malloc((size_t)NF * SIFT3D_DESC_LEN);
+        int64_t first[NI + 1];
+        int32_t labels[NI], *idx = (int32_t *)malloc(sizeof(int32_t) * NF * K), *d2 = (int32_t *)malloc(sizeof(int32_t) * NF * K);
+        float *votes = (float *)malloc(sizeof(float) * NI * 3);
+        int32_t *counts = (int32_t *)malloc(sizeof(int32_t) * NI * 3);
+        unsigned s = 12345u;
+        for (int i = 0; i <= NI; i++) first[i] = (int64_t)i * PER;
+        for (int i = 0; i < NI; i++) labels[i] = i % 3;
+        for (int i = 0; i < NF; i++) {
+            f[i].info = (i % 3 == 0) ? 0x30u : ((i % 3 == 1) ? 0x20u : 0x00u);
+            for (int k = 0; k < SIFT3D_DESC_LEN; k++) f[i].desc[k] = (float)((k * 5 + i) % 64);
+            for (int k = 0; k < K; k++) {
+                s = s * 1664525u + 1013904223u;
+                idx[i * K + k] = (int32_t)((s >> 8) % NF);
+                d2[i * K + k] = (int32_t)(100 + 37 * k + (s & 31u));
+            }
+        }
+        if (sift3d_match_descriptors(f, NF, bytes) != 0) return 2;
+        f[7].desc[3] = 200.5f;
+        if (sift3d_match_descriptors(f, NF, bytes) == 0) return 3; /* not a byte: refused */
+        f[7].desc[3] = 1e30f;
+        if (sift3d_match_descriptors(f, NF, bytes) == 0) return 3;
+        f[7].desc[3] = 3.0f;
+        if (sift3d_match_votes(f, first, NI, labels, 3, idx, d2, K, votes, counts) != 0) return 4;
+        idx[17] = NF; /* one past the last feature */
+        if (sift3d_match_votes(f, first, NI, labels, 3, idx, d2, K, votes, counts) == 0) return 5;
+        idx[17] = -1; /* "no further neighbour": fine */
+        if (sift3d_match_votes(f, first, NI, labels, 3, idx, d2, K, votes, counts) != 0) return 6;
+        labels[2] = 3; /* a label beyond n_labels */
+        if (sift3d_match_votes(f, first, NI, labels, 3, idx, d2, K, votes, counts) == 0) return 7;
+        labels[2] = -2;
+        if (sift3d_match_votes(f, first, NI, labels, 3, idx, d2, K, votes, counts) == 0) return 7;
+        labels[2] = 2;
+        first[2] = first[3] + 1; /* offsets that do not ascend */
+        if (sift3d_match_votes(f, first, NI, labels, 3, idx, d2, K, votes, counts) == 0) return 8;
+        const int64_t kept = sift3d_match_filter(f, NF, 1, 4);
+        if (kept <= 0 || kept >= NF) return 9;
+        printf("votes ok %lld\n", (long long)kept);
+        free(f); free(bytes); free(idx); free(d2); free(votes); free(counts);
+        return 0;
+    }
+    fprintf(stderr, "usage: host_asan_driver read <file>... | keys <dir> | votes\n");
     return 1;
 }

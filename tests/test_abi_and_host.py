@@ -316,7 +316,7 @@ def test_nifti_reader_vox_offset_and_analyze(built, tmp_path):
 
 
 def test_host_code_under_sanitizers(built, tmp_path):
-    """ASan + UBSan over the plain-C host code (nifti_min.c, world.c, keyfile.c, synth.c: `make asan`) on every file shape
+    """ASan + UBSan over the plain-C host code (nifti_min.c, world.c, keyfile.c, synth.c, match_votes.c: `make asan`) on every file shape
     above plus malformed ones, and over the oracle CLI (restatement + reader) on a small volume with the -2+ / -b / -w
     options.  A sanitizer report makes the process exit non-zero."""
     csrc = os.path.join(ROOT, "3d_sift_cuda_amd", "csrc")
@@ -347,6 +347,8 @@ def test_host_code_under_sanitizers(built, tmp_path):
     assert "vox.nii rc=0" in r.stdout and "iso rc=-3" in r.stdout    # unusable voxel sizes are refused by the resampler, not crashed on
     r = subprocess.run([drv, "keys", str(tmp_path)], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "keys ok" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    r = subprocess.run([drv, "votes"], capture_output=True, text=True, env=env)   # round 4: the matcher's host side, incl. refused inputs
+    assert r.returncode == 0 and "votes ok" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr[-3000:]
     cli = os.path.join(ROOT, "oracle", "_build", "featExtract_oracle_asan")
     nii = str(tmp_path / "s.nii")
     built.write_nifti(nii, built.synth_blobs(40, 36, 32, seed=5), voxel=(1.0, 1.25, 1.5), qform=(0.1, 0.2, 0.3, -3.0, 2.0, 5.0, -1.0))
