@@ -854,7 +854,8 @@ def _tool(name):
 
 def test_randomized_parity_sweep(built, oracle):
     """40 random (shape, seed, noise, descriptor mode, initial scale, blur path) cases, records bit-identical to the
-    oracle's (tools/fuzz_parity.py, which since round 3 also draws the chunk count of the per-keypoint stage; 200 cases of the same sweep, seed 2027, and 300 with seed 2028 ran clean on the round-3 build, 600 with seed 2026 on round 2's)."""
+    oracle's (tools/fuzz_parity.py, which since round 3 also draws the chunk count of the per-keypoint stage; 200 cases of the same sweep, seed 2027, and 300 with seed 2028 ran clean on the round-3 build, 600 with seed 2026 on round 2's;
+    round 4, with the fused blur's tile and the pinned buffers' starting size drawn too: 300, 1 500 and 4 000 cases, seeds 2029 - 2031, clean)."""
     assert _tool("fuzz_parity").sweep(40, 11, 112) == 0
 
 
