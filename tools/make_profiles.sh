@@ -41,13 +41,12 @@ if tr:
 import hashlib
 import datetime, platform, subprocess
 def _gpu_name():
+    # the GPU agent as rocprofv3 itself recorded it for the profiled run (name, CUs, clock); rocminfo's marketing name is
+    # empty on some boxes of the pool
     try:
-        out = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
-        names = [l.split(":", 1)[1].strip() for l in out.splitlines() if "Marketing Name" in l]
-        gpus = [n for n in names if "MI3" in n or "Instinct" in n or "gfx" in n.lower()]
-        if not gpus:   # boxes whose GPU agent has an empty marketing name: its ISA name (gfx950) says what it is
-            gpus = [l.split(":", 1)[1].strip() for l in out.splitlines() if l.strip().startswith("Name:") and "gfx" in l]
-        return (gpus or [n for n in names if n] or ["unknown"])[-1]
+        f = glob.glob(out + "/stats/**/*agent_info.csv", recursive=True)[0]
+        g = [r for r in csv.DictReader(open(f)) if r.get("Agent_Type") == "GPU"][0]
+        return "%s, %s CUs, %s MHz" % (g.get("Name"), g.get("Cu_Count"), g.get("Max_Engine_Clk_Fcompute"))
     except Exception as e:
         return "unknown (%r)" % (e,)
 res = {"_measured": {"date_utc": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M"), "host": platform.node(), "gpu": _gpu_name(),
