@@ -37,7 +37,7 @@ INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
 STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
 # sift3d_tuning (include/sift3d.h)
-TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST, TUNE_HOST_RECORDS, TUNE_FUSED_TILE = range(10)
+TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST, TUNE_HOST_RECORDS, TUNE_FUSED_TILE, TUNE_FUSED_SUB = range(11)
 
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),
@@ -110,6 +110,7 @@ def hip_lib():
     _sig(L.sift3d_gauss_blur, I, P, P, P, I64, I64, I64, F, F)
     _sig(L.sift3d_gauss_blur_dev, I, P, P, P, I64, I64, I64, F, F)
     _sig(L.sift3d_gauss_blur_dog_dev, I, P, P, P, P, I64, I64, I64, F, F)
+    _sig(L.sift3d_gauss_blur_dog_half_dev, I, P, P, P, P, P, I64, I64, I64, F, F, C.POINTER(C.c_int))
     _sig(L.sift3d_blur_window_supported, I, I64, I64, F, F)
     _sig(L.sift3d_gauss_blur_dog_window_dev, I, P, P, P, P, I64, I64, I64, I64, I64, F, F)
     _sig(L.sift3d_dog, I, P, P, P, P, I64)
@@ -563,6 +564,14 @@ class Context:
         self._chk(self._L.sift3d_gauss_blur_dog_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)) if d_out else None,
                                                     C.c_void_p(int(d_dog)) if d_dog else None, nx, ny, nz, float(sigma),
                                                     float(min_value)), "sift3d_gauss_blur_dog_dev")
+
+    def gauss_blur_dog_half_dev(self, d_in, d_out, d_dog, d_half, nx, ny, nz, sigma, min_value=0.01):
+        """sift3d_gauss_blur_dog_half_dev: level, DoG and the half-size volume; returns True when one launch made all three."""
+        one = C.c_int(0)
+        self._chk(self._L.sift3d_gauss_blur_dog_half_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)),
+                                                         C.c_void_p(int(d_dog)) if d_dog else None, C.c_void_p(int(d_half)), nx, ny, nz,
+                                                         float(sigma), float(min_value), C.byref(one)), "sift3d_gauss_blur_dog_half_dev")
+        return bool(one.value)
 
     def gauss_blur_dev(self, d_in, d_out, nx, ny, nz, sigma, min_value=0.01):
         self._chk(self._L.sift3d_gauss_blur_dev(self._h, C.c_void_p(int(d_in)), C.c_void_p(int(d_out)), nx, ny, nz,

@@ -170,6 +170,7 @@ sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean
     c->tune[SIFT3D_TUNE_SAMPLER_CAP] = 4;
     c->tune[SIFT3D_TUNE_BANDS_FIRST] = 1;
     c->tune[SIFT3D_TUNE_HOST_RECORDS] = 5;
+    c->tune[SIFT3D_TUNE_FUSED_SUB] = 1;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -238,8 +239,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -360,6 +361,11 @@ struct stage_scope {
             hipEventRecord(e0, st);
         }
     }
+    void add_bytes(double more) /* the launch turned out to do more (the subsample riding on the level-3 blur) */
+    {
+        c->last.alg_bytes[stage] += more;
+        bytes += more;
+    }
     void cancel() /* the launch did not happen */
     {
         c->last.launches[stage] -= 1;
@@ -466,10 +472,13 @@ static int ensure_T(sift3d_ctx *c, int64_t floats)
 }
 
 /* ---- device-level building blocks -------------------------------------- */
-/* out = blur(in); if dog != NULL also dog = in - out.  out may be NULL when only the DoG is wanted.  Uses T[0], T[1]. */
+/* out = blur(in); if dog != NULL also dog = in - out.  out may be NULL when only the DoG is wanted.  Uses T[0], T[1].
+ * sub (optional): the next octave's level 0, the 2 x 2 x 2 mean of out as a dense (X / 2) x (Y / 2) x (Z / 2) volume; written
+ * only where the fused launch can carry it, *sub_done says whether -- the caller launches the subsample itself if not. */
 int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma,
-                    float min_value)
+                    float min_value, float *sub, bool *sub_done)
 {
+    if (sub_done) *sub_done = false;
     float taps[SIFT3D_MAX_TAPS];
     hipStream_t ws = c->stream;
     int n = sift3d_gauss_taps(sigma, min_value, taps);
@@ -490,8 +499,15 @@ int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, 
      * 9 taps (0.020 / 0.026 against 0.042 / 0.043 ms at 128^3), ties at 11-13 and loses at 17 */
     if (fmode == 2 || (fmode == 1 && (N >= (double)(1 << 22) || (N >= (double)(1 << 18) && n <= 9)))) {
         stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N, ws);
-        hipError_t e = sift3d_launch_blur_fused(ws, in, out, dog, X, Y, Z, taps, n, &bt);
-        if (e == hipSuccess) return SIFT3D_OK;
+        int with_sub = 0;
+        hipError_t e = sift3d_launch_blur_fused(ws, in, out, dog, X, Y, Z, taps, n, &bt, 0, -1, c->tune[SIFT3D_TUNE_FUSED_SUB] ? sub : nullptr, &with_sub);
+        if (e == hipSuccess) {
+            if (with_sub) {
+                sc.add_bytes(0.5 * N); /* one float stored per eight voxels */
+                if (sub_done) *sub_done = true;
+            }
+            return SIFT3D_OK;
+        }
         if (e != hipErrorNotSupported) HIPCHK(c, e);
         sc.cancel();
     }
@@ -609,6 +625,30 @@ extern "C" int sift3d_gauss_blur_dog_dev(sift3d_ctx *c, const float *d_in, float
     if (nz < 2) return set_err(c, SIFT3D_ERR_ARG, "2-D images are outside this path (featExtract rejects z <= 1)");
     HIPCHK(c, hipSetDevice(c->device));
     FENCED(c, blur_dev(c, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value));
+}
+
+/* level + DoG + the half-size volume the next octave starts from, as the pyramid produces them at level 3 */
+extern "C" int sift3d_gauss_blur_dog_half_dev(sift3d_ctx *c, const float *d_in, float *d_out, float *d_dog, float *d_half, int64_t nx,
+                                              int64_t ny, int64_t nz, float sigma, float min_value, int *in_one_launch)
+{
+    if (in_one_launch) *in_one_launch = 0;
+    int rc = check_shape(c, nx, ny, nz);
+    if (rc) return rc;
+    if (!d_in || !d_out || !d_half) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
+    if (nx < 2 || ny < 2 || nz < 2) return set_err(c, SIFT3D_ERR_ARG, "subsample needs every dimension >= 2");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = fence_in(c);
+    if (rc) return rc;
+    bool carried = false;
+    /* the half-size volume is dense here (rows of nx / 2): the launch can carry it when those rows are whole 16-byte vectors */
+    rc = blur_dev(c, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value, nx % 8 == 0 ? d_half : nullptr, &carried);
+    if (rc) return rc;
+    if (!carried) {
+        stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * (double)nx * ny * nz, 0, nx * ny * nz);
+        HIPCHK(c, sift3d_launch_subsample(c->stream, d_out, nx, nx, ny, nz, d_half, nx / 2));
+    }
+    if (in_one_launch) *in_one_launch = carried ? 1 : 0;
+    return fence_out(c);
 }
 
 extern "C" int sift3d_blur_window_supported(int64_t nx, int64_t ny, float sigma, float min_value)
@@ -1444,6 +1484,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                 continue;
             }
             const float ex = sigma * sqrtf(factor * factor - 1.0f);
+            bool sub_done = false;
             /* L_j = blur(L_{j-1}); D_{j-1} = L_{j-1} - L_j fused into the z pass */
             /* nothing reads L_5: only D_4 = L_4 - L_5 is needed, so the last level is not stored */
             if (!(lazy_next && j == 5)) {
@@ -1452,13 +1493,16 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
                     if (rc) return rc;
                 }
                 float *dst_dog = (lazy && j == 1) ? nullptr : c->D[j - 1] + d.off;
-                rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.Y, d.Z, ex, 0.01f);
+                /* level 3 is what the next octave starts from: the launch that makes it writes the half-size volume too where it can */
+                float *sub = nullptr;
+                if (j == 3 && o + 1 < oct.size() && d.XP % 8 == 0 && oct[o + 1].XP == d.XP / 2) sub = c->L[0] + oct[o + 1].off;
+                rc = blur_dev(c, c->L[j - 1] + d.off, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.Y, d.Z, ex, 0.01f, sub, &sub_done);
                 if (rc) return rc;
                 if (d.XP != d.X) /* the blur ran over the pitched width: its pad columns go back to zero */
                     HIPCHK(c, sift3d_launch_zero_pad(ws, j < 5 ? c->L[j] + d.off : nullptr, dst_dog, d.XP, d.X, d.Y * d.Z));
             }
             if (j == 3 && o + 1 < oct.size()) {
-                {
+                if (!sub_done) {
                     stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * N, 0, (int64_t)N, ws);
                     HIPCHK(c, sift3d_launch_subsample(ws, c->L[3] + d.off, d.XP, d.X, d.Y, d.Z, c->L[0] + oct[o + 1].off, oct[o + 1].XP));
                 }

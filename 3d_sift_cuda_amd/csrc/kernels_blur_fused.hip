@@ -130,11 +130,17 @@ struct fb_ring_cfg {
  * wavefronts per SIMD, up to 256 registers) -- a zero-arithmetic march of the same tiles streams 5.4-5.8 TB/s with one
  * workgroup per CU and two z chunks against 4.4-4.9 with two per CU and four chunks (tools/stream_roof.hip), and the
  * second plane in flight covers the latency the second workgroup covered. */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32>
+/* HAS_SUB (round 4): the launch that makes level 3 also writes level 0 of the NEXT octave -- the 2 x 2 x 2 mean of the level
+ * (fioSubSampleInterpolate, R/src_common/FeatureIO.cpp:1474-1554, its association kept: ((a00 + a01) + a10) + a11 per plane, the
+ * even plane's sum first) -- from the finished planes it holds in registers: a thread's 2 x 2 block of a plane IS one such
+ * block, and the block of the plane before waits in one register.  The subsample launch, which read the whole level again
+ * (0.10 ms at 512^3), is gone; the z chunks start on even planes so that a pair never straddles two workgroups. */
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false>
 __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
     const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen,
-    int tiles_x, int tiles_y, long long total, fb_taps2 t)
+    int tiles_x, int tiles_y, long long total, fb_taps2 t, float *__restrict__ sub = nullptr)
 {
+    static_assert(!HAS_SUB || (BR == 2 && HAS_OUT), "the subsample rides on the 2 x 2 blocks of the two-rows-per-thread mapping");
     using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
     constexpr int U = 2 * R + 1, XO = C::XO;
     constexpr int TX = C::TX, CP = C::CP;
@@ -207,6 +213,14 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES
     unsigned soff[BR];
 #pragma unroll
     for (int r = 0; r < BR; r++) soff[r] = (bx < X && y0 + brow + r < Y) ? (unsigned)((y0 + brow + r) * X + bx) * 4u : FB_OOB;
+    /* HAS_SUB: this thread's voxel of the half-size volume (X / 2 by Y / 2 by Z / 2, dense rows); an odd last row / plane has no
+     * partner and is dropped, as the reference drops it */
+    const int oX = X >> 1, oY = Y >> 1, oZ = Z >> 1;
+    unsigned suboff = FB_OOB;
+    if constexpr (HAS_SUB)
+        if (bx + 1 < X && y0 + brow + 1 < Y) suboff = (unsigned)(((y0 + brow) >> 1) * oX + (bx >> 1)) * 4u;
+    const unsigned sub_plane_bytes = (unsigned)(oX * oY) * 4u;
+    float subacc = 0.0f; /* ((a00 + a01) + a10) + a11 of the even plane of the pair */
 
     /* PF planes of window prefetch: plane z lives in buffer (z - zfirst) % PF and is loaded PF steps before its x pass */
     v4f win[PF][NV];
@@ -315,6 +329,10 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES
 #pragma unroll
         for (int r = 0; r < BR; r++) z2[r] = v2f(0.0f);
         store_plane(false, 0u, z2, z2); /* dropped; same vmcnt state as the loop's back edge */
+        if constexpr (HAS_SUB) {
+            const __amdgpu_buffer_rsrc_t rsub = __builtin_amdgcn_make_buffer_rsrc((void *)sub, 0, 0, FB_RSRC_FLAGS);
+            __builtin_amdgcn_raw_buffer_store_b32(0, rsub, (int)suboff, 0, 0);
+        }
     }
     wslot = 1;
     lds_barrier();
@@ -373,6 +391,20 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES
                 for (int r = 0; r < BR; r++) dg[r] = v2f(0.0f);
             }
             store_plane(emit, so, a, dg);
+            if constexpr (HAS_SUB) {
+                const int zo = zin - R; /* the plane just finished (meaningful when emit) */
+                const float pa = ((a[0].x + a[1].x) + a[0].y) + a[1].y;
+                float sm = 0.0f;
+                sm = sm + subacc;
+                sm = sm + pa;
+                const bool pair_done = emit && (zo & 1) && (zo >> 1) < oZ; /* wave-uniform */
+                /* issued on every step, like the other stores: through a descriptor of no records unless a pair is complete */
+                const __amdgpu_buffer_rsrc_t rsub =
+                    __builtin_amdgcn_make_buffer_rsrc((void *)sub, 0, pair_done ? (int)((unsigned)oZ * sub_plane_bytes) : 0, FB_RSRC_FLAGS);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sm * 0.125f), rsub, (int)suboff,
+                                                      pair_done ? (int)((unsigned)(zo >> 1) * sub_plane_bytes) : 0, 0);
+                subacc = pa;
+            }
         }
         cur ^= 1;
         wslot = wslot + 1 == S ? 0 : wslot + 1;
@@ -423,15 +455,15 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident, int for
 
 /* Returns false when the shape is outside the kernel (32-bit buffer offsets: a chunk with its lead-in planes must stay
  * below 4 GiB -- a volume whose planes are that large gets more z chunks, and only a plane pair beyond 4 GiB has none) */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32>
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false>
 static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
-                          const fb_taps2 &t, int forced_chunks)
+                          const fb_taps2 &t, int forced_chunks, float *sub = nullptr)
 {
     using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
     static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
     if (resident == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv>, C::NT, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv, HAS_SUB>, C::NT, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     const int64_t plane_bytes = X * Y * 4;
@@ -442,12 +474,13 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     const int64_t Zo = zo1 - zo0; /* planes to produce */
     int n = fused_chunks(R, Zo, tiles, resident, forced_chunks);
     if ((Zo + n - 1) / n > max_planes) n = (int)((Zo + max_planes - 1) / max_planes);
-    const int zlen = (int)((Zo + n - 1) / n);
+    int zlen = (int)((Zo + n - 1) / n);
+    if (HAS_SUB && (zlen & 1)) zlen++; /* a pair of planes never straddles two chunks (the window starts at plane 0) */
     const int nch = (int)((Zo + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
-    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
-                       (int)Y, (int)Z, (int)zo0, (int)zo1, zlen, tiles_x, tiles_y, total, t);
+    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv, HAS_SUB>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
+                       (int)Y, (int)Z, (int)zo0, (int)zo1, zlen, tiles_x, tiles_y, total, t, sub);
     return true;
 }
 
@@ -466,11 +499,22 @@ static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *do
  * wavefronts per workgroup help.  tune->rows_per_thread forces one of the two (tests run both on every shape). */
 template <int R>
 static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
-                        const fb_taps2 &t, const sift3d_blur_tuning *tune)
+                        const fb_taps2 &t, const sift3d_blur_tuning *tune, float *sub, int *sub_done)
 {
     const int forced = tune ? tune->rows_per_thread : 0;
     const int br = forced == 1 || forced == 2 ? forced : ((R >= 7 || X * Y * (zo1 - zo0) < (1ll << 22)) ? 1 : 2);
     const int chunks = tune ? tune->z_chunks : 0;
+    /* the half-size volume beside the level (HAS_SUB): built for the one filter the pyramid asks it of -- level 3 is 11 taps
+     * in every octave (oracle: sigma_extra[3]) -- with both arrays stored, the whole volume produced and rows that halve into
+     * whole 16-byte vectors; anything else leaves *sub_done 0 and the caller launches the subsample itself */
+    if constexpr (R == 5)
+        if (sub && br == 2 && out && dog && zo0 == 0 && zo1 == Z && X % 8 == 0 && Z >= 2 && Y >= 2) {
+            const bool wide5 = (tune ? tune->tile : 0) == 2 && X >= 128;
+            const bool ok = wide5 ? launch_ring_t<5, 2, true, true, 2, 128, 16, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub)
+                                  : launch_ring_t<5, 2, true, true, 2, FB_TX, 32, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub);
+            if (ok && sub_done) *sub_done = 1;
+            return ok;
+        }
     if (br == 1) return launch_ring_pf<R, 1, 1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
     /* tile shape of the two-rows-per-thread mapping: tune->tile 0 = by measurement (below), 1 = 64 x 32, 2 = 128 x 16 */
     /* by measurement at 512^3 (profiles/r04_tile_ab.txt, dense random data, ms per launch 64 x 32 -> 128 x 16): 7 taps level only
@@ -498,11 +542,14 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
  * must be whole 16-byte vectors, the filter at most 17 taps and symmetric bit for bit -- the z pass shares the product of
  * taps j and 2R-j (sift3d_gauss_taps' always are: (j-R)^2 and the normalising sum are the same for both).  out or dog may
  * be NULL.  [zo0, zo1): the planes to produce (zo1 < 0: all of them); planes outside the window are not written, the input
- * is read as far as the filter reaches. */
+ * is read as far as the filter reaches.  sub (optional): where the 2 x 2 x 2 mean of the produced level goes, a dense
+ * (X / 2) x (Y / 2) x (Z / 2) volume; *sub_done says whether this launch wrote it (see HAS_SUB above). */
 hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z,
-                                    const float *taps, int ntaps, const sift3d_blur_tuning *tune, int64_t zo0, int64_t zo1)
+                                    const float *taps, int ntaps, const sift3d_blur_tuning *tune, int64_t zo0, int64_t zo1, float *sub,
+                                    int *sub_done)
 {
     const int R = ntaps / 2;
+    if (sub_done) *sub_done = 0;
     if (zo1 < 0) zo1 = Z; /* the default window: the whole volume */
     if (R < 1 || R > SIFT3D_FAST_MAX_R || ntaps != 2 * R + 1 || X % 4 != 0 || X * Y >= (1ll << 29) || (!out && !dog)) return hipErrorNotSupported;
     if (zo0 < 0 || zo1 > Z || zo1 <= zo0) return hipErrorInvalidValue;
@@ -512,14 +559,14 @@ hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, 
     for (int i = 0; i < 2 * SIFT3D_FAST_MAX_R + 1; i++) t.f[i] = v2f(i < ntaps ? taps[i] : 0.0f);
     bool ok = false;
     switch (R) {
-    case 1: ok = launch_ring<1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
-    case 2: ok = launch_ring<2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
-    case 3: ok = launch_ring<3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
-    case 4: ok = launch_ring<4>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
-    case 5: ok = launch_ring<5>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
-    case 6: ok = launch_ring<6>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
-    case 7: ok = launch_ring<7>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
-    default: ok = launch_ring<8>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune); break;
+    case 1: ok = launch_ring<1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
+    case 2: ok = launch_ring<2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
+    case 3: ok = launch_ring<3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
+    case 4: ok = launch_ring<4>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
+    case 5: ok = launch_ring<5>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
+    case 6: ok = launch_ring<6>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
+    case 7: ok = launch_ring<7>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
+    default: ok = launch_ring<8>(s, in, out, dog, X, Y, Z, zo0, zo1, t, tune, sub, sub_done); break;
     }
     if (!ok) return hipErrorNotSupported;
     return hipGetLastError();

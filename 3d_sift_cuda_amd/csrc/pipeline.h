@@ -152,7 +152,8 @@ static inline int64_t pitch_of(int64_t X) { return (X + 3) / 4 * 4; }
 sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean);
 void timing_begin(sift3d_ctx *c);
 /* out = blur(in); dog = in - out when not NULL (api.hip) */
-int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma, float min_value);
+int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma, float min_value,
+             float *sub = nullptr, bool *sub_done = nullptr);
 bool blur_window_supported(int64_t X, int64_t Y, float sigma, float min_value);
 int blur_window_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1, float sigma,
                     float min_value);

@@ -72,7 +72,8 @@ struct sift3d_blur_tuning {
     int tile;            /* SIFT3D_TUNE_FUSED_TILE: 1 = 64 x 32, 2 = 128 x 16 (two-rows-per-thread mapping, up to 13 taps) */
 };
 hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z,
-                                    const float *taps, int ntaps, const sift3d_blur_tuning *tune, int64_t zo0 = 0, int64_t zo1 = -1);
+                                    const float *taps, int ntaps, const sift3d_blur_tuning *tune, int64_t zo0 = 0, int64_t zo1 = -1,
+                                    float *sub = nullptr, int *sub_done = nullptr);
 hipError_t sift3d_launch_dog(hipStream_t s, const float *a, const float *b, float *out, int64_t n);
 hipError_t sift3d_launch_subsample(hipStream_t s, const float *in, int64_t X, int64_t Xl, int64_t Y, int64_t Z, float *out,
                                    int64_t XPout);

@@ -124,6 +124,13 @@ int sift3d_gauss_blur_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, int6
  * (the pyramid does that for its sixth level); d_dog may be NULL. */
 int sift3d_gauss_blur_dog_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, float *d_dog, int64_t nx, int64_t ny,
                               int64_t nz, float sigma, float min_value);
+/* The same plus what the next octave starts from: d_half = the 2 x 2 x 2 mean of the blurred volume, a dense
+ * (nx / 2) x (ny / 2) x (nz / 2) array (fioSubSampleInterpolate, R/src_common/FeatureIO.cpp:1474-1554, called on level 3 of
+ * every octave at R/src_common/MultiScale.cpp:3113-3118).  Where the shape allows (an 11-tap filter -- the pyramid's level 3 --
+ * on at least 2^22 voxels, nx a multiple of 8) the blur launch writes it from the planes it holds in registers and
+ * *in_one_launch (optional) is 1; otherwise a subsample launch follows and it is 0.  The bytes are the same either way. */
+int sift3d_gauss_blur_dog_half_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, float *d_dog, float *d_half, int64_t nx,
+                                   int64_t ny, int64_t nz, float sigma, float min_value, int *in_one_launch);
 /* The same restricted to the output planes [z_lo, z_hi) of the volume: planes outside the window are not written, the
  * input is read as far as the filter reaches (zeros beyond the volume).  A Z-slab rank filters its two boundary bands
  * with it first, hands them to the halo exchange, and filters the interior while they travel.
@@ -210,6 +217,8 @@ typedef enum {
                                  * 4.2), 1..12; a run that yields more grows them (sift3d_host_buffer_grows counts) */
     SIFT3D_TUNE_FUSED_TILE,     /* (x, y) tile of the fused launch's two-rows-per-thread mapping: 0 = by measurement (default), 1 = 64 x 32,
                                  * 2 = 128 x 16 */
+    SIFT3D_TUNE_FUSED_SUB,      /* 1 (default): the launch that makes level 3 of an octave also writes the next octave's level 0 (the
+                                 * 2 x 2 x 2 mean) where the shape allows; 0: a subsample launch of its own, as before round 4 */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);

@@ -81,6 +81,46 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows, tile):
         assert (log["stage"] == built.STAGES.index("blur_fused")).all()   # the fused kernel is what ran
 
 
+@pytest.mark.parametrize("dims", [(64, 48, 40), (136, 37, 45), (72, 17, 3), (128, 64, 70), (264, 50, 21), (16, 2, 2), (40, 33, 12)])
+@pytest.mark.parametrize("chunks,tile", [(0, 0), (1, 1), (3, 1), (5, 2), (2, 2)])
+def test_fused_blur_carries_the_half_size_volume(built, oracle, dims, chunks, tile):
+    """Round 4: the launch that makes level 3 (11 taps, two rows per thread) also writes the next octave's level 0, the
+    2 x 2 x 2 mean of the level, from the planes it holds in registers.  Level, DoG and the half-size volume against the oracle's
+    blur -> subsample, with odd ny / nz (the last row / plane has no partner), one and several z chunks (a pair of planes must not
+    straddle two), both tiles; and the same bytes from the two-launch form (TUNE_FUSED_SUB 0) and for a filter the carry is
+    not built for."""
+    import torch
+    vol = vol_of(built, dims, 5) - np.float32(1.5)
+    nx, ny, nz = dims
+    s11 = [s for s in SIGMAS if len(oracle.taps(s)) == 11][0]
+    s_other = [s for s in SIGMAS if len(oracle.taps(s)) == 9][0]
+    with built.Context(*dims) as ctx:
+        ctx.set_tuning(built.TUNE_BLUR_FUSED, 2)
+        ctx.set_tuning(built.TUNE_FUSED_CHUNKS, chunks)
+        ctx.set_tuning(built.TUNE_FUSED_ROWS, 2)
+        ctx.set_tuning(built.TUNE_FUSED_TILE, tile)
+        d_in = torch.from_numpy(vol).cuda()
+        d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
+        d_half = torch.full((nz // 2, ny // 2, nx // 2), 7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.enable_timing(True)
+        for sigma, sub, expect_one in ((s11, 1, True), (s11, 0, False), (s_other, 1, False)):
+            want = oracle.blur(vol, sigma)
+            ctx.set_tuning(built.TUNE_FUSED_SUB, sub)
+            d_half.fill_(7.0)
+            d_out.zero_()
+            torch.cuda.synchronize()
+            one = ctx.gauss_blur_dog_half_dev(d_in.data_ptr(), d_out.data_ptr(), d_dog.data_ptr(), d_half.data_ptr(), nx, ny, nz, sigma)
+            ctx.sync()
+            assert one == expect_one, (dims, sigma, sub)
+            assert (bits(d_out.cpu().numpy()) == bits(want)).all(), (dims, sigma)
+            assert (bits(d_dog.cpu().numpy()) == bits(oracle.dog(vol, want))).all(), (dims, sigma)
+            assert (bits(d_half.cpu().numpy()) == bits(oracle.subsample(want))).all(), (dims, sigma, sub)
+        log = ctx.launch_log()
+        names = [built.STAGES[i] for i in log["stage"]]
+        assert names == ["blur_fused", "blur_fused", "subsample", "blur_fused", "subsample"]
+
+
 @pytest.mark.parametrize("dims", [(64, 48, 40), (132, 70, 33), (256, 8, 24)])
 def test_windowed_blur_writes_exactly_its_planes(built, oracle, dims):
     """sift3d_gauss_blur_dog_window_dev (what a Z-slab rank filters its boundary bands with): the planes of the window are the
@@ -426,6 +466,31 @@ def test_pipeline_records_through_the_fused_blur(built, oracle, dims):
     assert sorted(fused["ntaps"][5:].tolist()) == [7, 9] and (fused["nvox"][5:] < fused["nvox"][0]).all()
     want, _ = oracle.extract(vol)
     assert len(want) > 200 and _compare_records(got, want)
+
+
+@pytest.mark.parametrize("dims,rows", [((168, 164, 160), 0), ((166, 165, 161), 0), ((88, 61, 47), 2), ((104, 96, 81), 2)])
+def test_pipeline_level3_launch_carries_the_subsample(built, oracle, dims, rows):
+    """The pyramid with the next octave's level 0 written by the level-3 blur launch (default where the octave is built by the
+    two-rows-per-thread fused kernel and its pitched rows halve into whole vectors) against the separate subsample launch
+    (TUNE_FUSED_SUB 0): the same records, which are the oracle's, and one subsample launch less per octave that carries.
+    The small shapes force the fused kernel onto every octave it supports, so that coarse octaves with odd sizes carry too;
+    (166, ...) has pitched rows (168) whose pad columns the launch must not let into the half-size volume."""
+    vol = vol_of(built, dims, 13)
+    with built.Context(*dims) as ctx:
+        if rows:
+            ctx.set_tuning(built.TUNE_BLUR_FUSED, 2)
+            ctx.set_tuning(built.TUNE_FUSED_ROWS, rows)
+        ctx.set_volume(vol)
+        got = ctx.extract()
+        st = ctx.timings()["stages"]
+        ctx.set_tuning(built.TUNE_FUSED_SUB, 0)
+        got0 = ctx.extract()
+        st0 = ctx.timings()["stages"]
+    assert got.tobytes() == got0.tobytes()
+    assert st["subsample"]["launches"] < st0["subsample"]["launches"]
+    assert st["blur_fused"]["launches"] == st0["blur_fused"]["launches"]
+    want, _ = oracle.extract(vol)
+    assert len(want) > 20 and _compare_records(got, want)
 
 
 def test_pipeline_empty_volume(built, oracle, tmp_path):
