@@ -141,7 +141,8 @@ static void destroy_sync_objects(sift3d_ctx *c)
             hipStreamSynchronize(st);
             hipStreamDestroy(st);
         }
-    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1]};
+    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1],
+                           c->ev_split[0], c->ev_split[1], c->ev_split[2]};
     for (hipEvent_t e : events)
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_kpc)
@@ -171,15 +172,17 @@ sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean
     c->tune[SIFT3D_TUNE_BANDS_FIRST] = 1;
     c->tune[SIFT3D_TUNE_HOST_RECORDS] = 5;
     c->tune[SIFT3D_TUNE_FUSED_SUB] = 1;
+    c->tune[SIFT3D_TUNE_SPLIT_TAIL] = 1;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     hipStream_t *streams[] = {&c->ex_stream, &c->ex_stream2, &c->kp_stream};
     for (hipStream_t *st : streams) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1]};
+    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1],
+                            &c->ev_split[0], &c->ev_split[1], &c->ev_split[2]};
     for (hipEvent_t *e : events) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t &e : c->ev_kpc) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * (8 + SIFT3D_KP_MAX_CHUNKS), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * (16 + SIFT3D_KP_MAX_CHUNKS), hipHostMallocDefault) == hipSuccess;
     const size_t vb = sizeof(float) * (size_t)c->capN;
     const size_t tb = sizeof(float) * (size_t)c->capTot;
     /* nothing may depend on what hipMalloc hands back: the pad columns of pitched octaves are read as zeros.  The clears
@@ -201,7 +204,7 @@ sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean
             if (ok) c->capT = c->capN;
         }
     ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 8) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->sampler_tokens, sizeof(int) * SIFT3D_CU_SLOTS) == hipSuccess &&
          hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream) == hipSuccess;
@@ -239,8 +242,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -781,12 +784,28 @@ int cand_reset(sift3d_ctx *c, hipStream_t on)
 {
     if (!on) on = c->stream;
     c->jobs.clear();
-    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, on));
+    c->cand_split_at = 0;
+    c->cand_group = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 8, on));
     /* every extrema pass of the run gets its own counter set: one memset here instead of one per pass */
     HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, on));
     HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, on));
     c->surv_set = 0;
     return SIFT3D_OK;
+}
+
+/* where the extrema launches queued now append: the whole list, or the part of it the current group owns (split tail) */
+struct cand_target {
+    unsigned long long *keys;
+    sift3d_cval *vals;
+    unsigned long long *count;
+    int64_t cap;
+};
+static cand_target cand_target_of(const sift3d_ctx *c)
+{
+    if (c->cand_split_at <= 0) return {c->keys_a, c->vals_a, c->d_count, c->cand_cap};
+    if (c->cand_group == 0) return {c->keys_a, c->vals_a, c->d_count, c->cand_split_at};
+    return {c->keys_a + c->cand_split_at, c->vals_a + c->cand_split_at, c->d_count + 4, c->cand_cap - c->cand_split_at};
 }
 
 int cand_append(sift3d_ctx *c, const level_job &j, bool record)
@@ -839,15 +858,18 @@ int cand_append(sift3d_ctx *c, const level_job &j, bool record)
             if (!fresh) HIPCHK(c, hipMemsetAsync(lz.list2_count, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS, st));
         }
     }
-    HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Xl ? j.Xl : j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, c->keys_a,
-                                    c->vals_a, c->d_count, c->cand_cap, surv, counters, c->d_count + 2, cover, !fresh,
+    const cand_target tg = cand_target_of(c);
+    HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Xl ? j.Xl : j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, tg.keys,
+                                    tg.vals, tg.count, tg.cap, surv, counters, c->d_count + 2, cover, !fresh,
                                     lazy ? &lz : nullptr));
     return SIFT3D_OK;
 }
 
 static int cand_replay(sift3d_ctx *c)
 {
-    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 4, c->stream));
+    c->cand_split_at = 0; /* a replay fills one list, whatever the first attempt did */
+    c->cand_group = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, c->stream));
     HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, c->stream));
     c->surv_set = 0;
@@ -1088,7 +1110,7 @@ static int ensure_host_records(sift3d_ctx *c, int64_t need, int64_t keep)
  * the pinned host buffers (328 bytes a record) are sized for SIFT3D_TUNE_HOST_RECORDS records per candidate (default 5) and
  * grown by describe_launch when a run turns out to need more -- the worst case would be 12 records per candidate of
  * page-locked memory, tens of GB on an extrema-dense volume (advisor, round 3). */
-static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand)
+static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t host_for = -1) /* host_for: candidates the pinned buffers are sized for, if fewer */
 {
     if (ncand > c->kps_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1115,10 +1137,11 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand)
     int per = c->tune[SIFT3D_TUNE_HOST_RECORDS];
     if (per < 1) per = 1;
     if (per > 1 + SIFT3D_MAX_FRAMES) per = 1 + SIFT3D_MAX_FRAMES;
-    if (c->hrecs_cap < ncand * per) { /* nothing of an earlier run is in flight here: describe_finish has synchronised */
+    if (host_for < 0 || host_for > ncand) host_for = ncand;
+    if (c->hrecs_cap < host_for * per) { /* nothing of an earlier run is in flight here: describe_finish has synchronised */
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipStreamSynchronize(c->kp_stream));
-        int rc = ensure_host_records(c, ncand * per, 0);
+        int rc = ensure_host_records(c, host_for * per, 0);
         if (rc) return rc;
     }
     return SIFT3D_OK;
@@ -1199,17 +1222,48 @@ static int kp_chunks_for(const sift3d_ctx *c, int64_t ncand)
     return n;
 }
 
+/* the stage's state cleared and its two patch filters checked; taps3: the keypoint kernel's 3-tap filter */
+static int describe_begin(sift3d_ctx *c, size_t nlevels, float *taps3)
+{
+    if (sift3d_gauss_taps(0.5f, 0.01f, taps3) != 3 || sift3d_gauss_taps((float)0.95, (float)0.01, c->kp.taps5) != 5)
+        return set_err(c, SIFT3D_ERR_ARG, "unexpected patch tap counts");
+    if (nlevels > 96) return set_err(c, SIFT3D_ERR_ARG, "too many levels");
+    c->kp.ncand = 0;
+    c->kp.nchunks = 0;
+    c->kp.launched = 0;
+    c->kp.nrec = 0;
+    c->kp.split = false;
+    return SIFT3D_OK;
+}
+
+/* chunk i of the stage = candidates [a, b) of the sorted list, on stream ks: keypoint kernel, scan of the record counts, record
+ * map (which leaves the chunk's first-record index for the next chunk on the device), read-back of the chunk's end index */
+static int describe_queue_chunk(sift3d_ctx *c, int i, int64_t a, int64_t b, hipStream_t ks, const float *taps3)
+{
+    int *h_end = reinterpret_cast<int *>(c->h_cnt0 + 8); /* pinned: first record past chunk i */
+    c->kp.first[i] = a;
+    c->kp.first[i + 1] = b;
+    h_end[i] = 0;
+    {
+        sift3d_kp_params q = c->kp.p;
+        q.patch0 = c->patch0 + (size_t)a * SIFT3D_PATCH_VOX; /* the kernel indexes everything by its block number */
+        stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, b - a, ks);
+        HIPCHK(c, sift3d_launch_keypointsA(ks, q, c->keys_b + a, c->vals_b + a, b - a, c->kps + a, c->nrec + a, taps3));
+    }
+    HIPCHK(c, sift3d_scan_counts(ks, c->scan_tmp, c->scan_tmp_bytes, c->nrec + a, c->offs + a, b - a));
+    HIPCHK(c, sift3d_launch_recmap(ks, c->nrec + a, c->offs + a, b - a, (int)a, c->d_rec_base + i, c->rec_kp, c->rec_frame, c->d_count + 3));
+    HIPCHK(c, hipMemcpyAsync(&h_end[i], c->d_rec_base + i + 1, sizeof(int), hipMemcpyDeviceToHost, ks));
+    HIPCHK(c, hipEventRecord(c->ev_kpc[i], ks));
+    return SIFT3D_OK;
+}
+
 int describe_queue(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode, float eig_thres,
                           float size_factor, bool levels_on_device)
 {
     float taps3[SIFT3D_MAX_TAPS];
-    if (sift3d_gauss_taps(0.5f, 0.01f, taps3) != 3 || sift3d_gauss_taps((float)0.95, (float)0.01, c->kp.taps5) != 5)
-        return set_err(c, SIFT3D_ERR_ARG, "unexpected patch tap counts");
-    if (levels.size() > 96) return set_err(c, SIFT3D_ERR_ARG, "too many levels");
+    int rc0 = describe_begin(c, levels.size(), taps3);
+    if (rc0) return rc0;
     c->kp.ncand = ncand;
-    c->kp.nchunks = 0;
-    c->kp.launched = 0;
-    c->kp.nrec = 0;
     if (ncand <= 0) return SIFT3D_OK;
     int rc = ensure_kp_buffers(c, ncand);
     if (rc) return rc;
@@ -1220,23 +1274,9 @@ int describe_queue(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64
     c->kp.nchunks = nch;
     HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_rec_base, 0, sizeof(int), c->stream));
-    int *h_end = reinterpret_cast<int *>(c->h_cnt0 + 8); /* pinned: first record past chunk i */
     for (int i = 0; i < nch; i++) {
-        const int64_t a = ncand * i / nch, b = ncand * (i + 1) / nch;
-        c->kp.first[i] = a;
-        c->kp.first[i + 1] = b;
-        h_end[i] = 0;
-        {
-            sift3d_kp_params q = c->kp.p;
-            q.patch0 = c->patch0 + (size_t)a * SIFT3D_PATCH_VOX; /* the kernel indexes everything by its block number */
-            stage_scope sc(c, SIFT3D_STAGE_KEYPOINT, 0.0, 0, b - a);
-            HIPCHK(c, sift3d_launch_keypointsA(c->stream, q, c->keys_b + a, c->vals_b + a, b - a, c->kps + a, c->nrec + a, taps3));
-        }
-        HIPCHK(c, sift3d_scan_counts(c->stream, c->scan_tmp, c->scan_tmp_bytes, c->nrec + a, c->offs + a, b - a));
-        HIPCHK(c, sift3d_launch_recmap(c->stream, c->nrec + a, c->offs + a, b - a, (int)a, c->d_rec_base + i, c->rec_kp, c->rec_frame,
-                                       c->d_count + 3));
-        HIPCHK(c, hipMemcpyAsync(&h_end[i], c->d_rec_base + i + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipEventRecord(c->ev_kpc[i], c->stream));
+        rc = describe_queue_chunk(c, i, ncand * i / nch, ncand * (i + 1) / nch, c->stream, taps3);
+        if (rc) return rc;
     }
     return SIFT3D_OK;
 }
@@ -1249,10 +1289,14 @@ int describe_launch(sift3d_ctx *c)
     /* one chunk: the descriptor kernel follows on the main stream; several: on the second stream, beside the next chunk's
      * keypoint kernel.  With every launch bracketed by events (timing modes 1 and 3) the launches stay on the main stream,
      * so that an event pair times its kernel alone. */
-    const bool beside = nch > 1 && !(c->timing == 1 || c->timing == 3);
-    hipStream_t ds = beside ? c->kp_stream : c->stream;
+    /* split tail: the chunks were queued on kp_stream, the second one (the coarse octaves' few hundred extrema: a keypoint launch
+     * of pure latency, 0.25 ms at 512^3) behind the pyramid's last launch.  The first chunk's descriptor launch goes to the main
+     * stream, idle by then, and the second chunk's keypoint kernel and descriptors run beside it on kp_stream. */
+    const bool split = c->kp.split && nch > 1;
+    const bool beside = split || (!c->kp.split && nch > 1 && !(c->timing == 1 || c->timing == 3));
     int64_t base = 0;
     for (int i = 0; i < nch; i++) {
+        hipStream_t ds = (split ? i > 0 : beside) ? c->kp_stream : c->stream;
         HIPCHK(c, hipEventSynchronize(c->ev_kpc[i]));
         const int64_t end = h_end[i], m = end - base;
         if (end < base || end > c->recs_cap) return set_err(c, SIFT3D_ERR_DEVICE, "record map out of range (%lld of %lld)", (long long)end, (long long)c->recs_cap);
@@ -1260,6 +1304,7 @@ int describe_launch(sift3d_ctx *c)
             /* more records than the pinned buffers were sized for: wait for the descriptor launches of the earlier chunks
              * (they store into the buffers about to be replaced), grow, carry their records over */
             HIPCHK(c, hipStreamSynchronize(ds));
+            if (split) HIPCHK(c, hipStreamSynchronize(c->stream)); /* the first chunk's launch is on the main stream */
             /* chunks still to come: assume they yield records at the rate seen so far */
             const int64_t done_cand = c->kp.first[i + 1], need = done_cand > 0 && i + 1 < nch ? (int64_t)((double)end * (double)c->kp.ncand / (double)done_cand) + 1 : end;
             int rc = ensure_host_records(c, need > end ? need : end, base);
@@ -1268,7 +1313,8 @@ int describe_launch(sift3d_ctx *c)
         }
         if (m > 0) {
             stage_scope sc(c, SIFT3D_STAGE_DESCRIPTOR, 0.0, 0, m, ds);
-            if (c->kp.p.sampler_cap > 0) /* the per-CU tokens start from zero whatever became of an earlier launch */
+            if (c->kp.p.sampler_cap > 0 && !(split && i > 0)) /* the per-CU tokens start from zero whatever became of an earlier launch
+                                                                * (not under the first chunk's running kernel, which holds some) */
                 HIPCHK(c, hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, ds));
             HIPCHK(c, sift3d_launch_descriptors(ds, c->kp.p, c->kps, c->rec_kp + base, c->rec_frame + base, m, c->d_hrecs + base,
                                                 c->d_hgroup + base, c->kp.taps5));
@@ -1306,6 +1352,65 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
     return rc;
 }
 
+/* The end of run_pipeline when the candidate list is split (see there).  Called with everything queued: the first part's count is
+ * on its way to h_split[0..2] behind ev_split[2] (kp_stream), the main stream ends behind both extrema streams.  *done = false:
+ * something did not fit -- every stream has been drained and the extrema launches replayed into one list; the caller
+ * continues with the one-list schedule. */
+static int finish_split_tail(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int desc_mode, float eig_thres, float size_factor,
+                             int64_t *n_out, bool *done)
+{
+    *done = false;
+    unsigned long long *const h_split = c->h_cnt0 + 8 + SIFT3D_KP_MAX_CHUNKS;
+    const int64_t capA = c->cand_split_at, capB = c->cand_cap - capA;
+    hipStream_t ks = c->kp_stream;
+    float taps3[SIFT3D_MAX_TAPS];
+    auto fall_back = [&]() -> int {
+        HIPCHK(c, hipStreamSynchronize(ks));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return cand_replay(c); /* one list again; cand_finalize grows whatever was too small */
+    };
+    /* the second part's count (and the first part's once more, with the overflow mark as it stands at the end) */
+    h_split[3] = h_split[5] = h_split[7] = 0;
+    HIPCHK(c, hipMemcpyAsync(h_split + 3, c->d_count, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_split[2]));
+    const int64_t nA = (int64_t)h_split[0];
+    if (h_split[2] > 0 || nA > capA) return fall_back();
+    int rc = describe_begin(c, levels.size(), taps3);
+    if (rc) return rc;
+    /* room for the second part as well: it is rarely more than a fiftieth of the first */
+    rc = ensure_kp_buffers(c, nA + nA / 8 + 4096, nA);
+    if (rc) return rc;
+    kp_params_of(c, desc_mode, eig_thres, size_factor, c->kp.p);
+    c->kp.split = true;
+    HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, ks));
+    HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), ks));
+    HIPCHK(c, hipMemsetAsync(c->d_rec_base, 0, sizeof(int), ks));
+    int nch = 0;
+    if (nA > 0) {
+        HIPCHK(c, sift3d_sort_candidates(ks, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a, c->vals_b, nA));
+        rc = describe_queue_chunk(c, nch++, 0, nA, ks, taps3);
+        if (rc) return rc;
+    }
+    c->kp.nchunks = nch;
+    /* the coarse octaves: the main stream holds nothing else */
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t nB = (int64_t)h_split[7];
+    if (h_split[5] > 0 || nB > capB || nA + nB > c->kps_cap || (int64_t)h_split[3] != nA) return fall_back();
+    if (nB > 0) {
+        HIPCHK(c, sift3d_sort_candidates(ks, c->sort_tmp, c->sort_tmp_bytes, c->keys_a + capA, c->keys_b + nA, c->vals_a + capA, c->vals_b + nA, nB));
+        rc = describe_queue_chunk(c, nch++, nA, nA + nB, ks, taps3);
+        if (rc) return rc;
+    }
+    c->kp.nchunks = nch;
+    c->kp.ncand = nA + nB;
+    c->last.n_extrema = nA + nB;
+    rc = describe_launch(c);
+    if (!rc) rc = describe_finish(c, n_out);
+    if (rc) return rc;
+    *done = true;
+    return SIFT3D_OK;
+}
+
 /* The whole single-GPU path.  Host synchronisations: the extrema count, the record count, the
  * final download -- everything else is queued on the stream. */
 static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_mode, float eig_thres, float size_factor,
@@ -1336,6 +1441,20 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     rc = cand_reset(c, c->ex_stream);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev_reset, c->ex_stream));
+    /* Split tail (round 4).  Octaves 0 and 1 hold 98 - 99 % of the extrema and their detection passes are done while the chain of
+     * small launches that builds the coarser octaves is still running (0.3 ms at 512^3, the chip mostly idle under it).  The
+     * candidate list is therefore cut in two: [0, split) takes the extrema of octaves 0 and 1, the rest those of the coarser ones;
+     * as soon as the first part's count is on the host it is sorted and its keypoint kernel starts on kp_stream, beside the
+     * coarse chain; the second part follows as a second chunk of the per-keypoint stage.  The sort key leads with the level
+     * id, so the two sorted parts back to back ARE the sorted whole: records and their order are unchanged.  Any overflow
+     * (either part, the own-level lists, the per-keypoint buffers) falls back to the one-list schedule with a replay. */
+    const bool split_tail = extract && oct.size() >= 3 && c->tune[SIFT3D_TUNE_SPLIT_TAIL] && c->timing != 3 && c->tune[SIFT3D_TUNE_KP_CHUNKS] == 0;
+    if (split_tail) {
+        int64_t second = c->cand_cap / 16 + 1024 < c->cand_cap / 2 ? c->cand_cap / 16 + 1024 : c->cand_cap / 2;
+        if (c->tune[SIFT3D_TUNE_SPLIT_TAIL] == 2) second = 8; /* tests: the second part overflows, the fall-back runs with the first in flight */
+        c->cand_split_at = c->cand_cap - second;
+    }
+    unsigned long long *const h_split = c->h_cnt0 + 8 + SIFT3D_KP_MAX_CHUNKS; /* pinned: [0..2] first part, [3..7] everything */
 
     int64_t tiny_base = -1; /* float offset of the first octave of at most SIFT3D_TINY_VOX voxels */
     for (const octave_dims &d : oct)
@@ -1375,6 +1494,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             if (which == 1) used_second = true;
         }
         c->cand_stream = exs;
+        c->cand_group = o >= 2 ? 1 : 0; /* only looked at while the list is split */
         c->surv_sel = (exs != c->stream && which == 1) ? 1 : 0;
         int rc_ = SIFT3D_OK;
         /* an octave one workgroup built whole (at most 4 096 voxels, every DoG level stored): its three detection levels in one
@@ -1383,7 +1503,8 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
         if (small_octave) {
             const float *dl[5] = {c->D[0] + d.off, c->D[1] + d.off, c->D[2] + d.off, c->D[3] + d.off, pl.d4tiny};
             stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 12.0 * (double)d.XP * d.Y * d.Z, 0, d.XP * d.Y * d.Z, exs);
-            HIPCHK(c, sift3d_launch_extrema_octave_small(exs, dl, d.XP, d.X, d.Y, d.Z, (int)o * 3, c->keys_a, c->vals_a, c->d_count, c->cand_cap));
+            const cand_target tg = cand_target_of(c);
+            HIPCHK(c, sift3d_launch_extrema_octave_small(exs, dl, d.XP, d.X, d.Y, d.Z, (int)o * 3, tg.keys, tg.vals, tg.count, tg.cap));
             c->count_queued = false;
         }
         for (int l = 0; l < 3 && !rc_; l++) {
@@ -1414,6 +1535,7 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             lv.pad = 0;
         }
         c->cand_stream = nullptr;
+        c->cand_group = 0;
         c->surv_sel = 0;
         return rc_;
     };
@@ -1540,6 +1662,17 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
             }
             rc = enqueue_extrema(o, 1);
             if (rc) return rc;
+            if (o == 1 && split_tail) { /* the first part is complete behind what the two extrema streams hold now */
+                HIPCHK(c, hipEventRecord(c->ev_split[0], c->ex_stream));
+                HIPCHK(c, hipStreamWaitEvent(c->kp_stream, c->ev_split[0], 0));
+                if (used_second) {
+                    HIPCHK(c, hipEventRecord(c->ev_split[1], c->ex_stream2));
+                    HIPCHK(c, hipStreamWaitEvent(c->kp_stream, c->ev_split[1], 0));
+                }
+                h_split[0] = h_split[1] = h_split[2] = 0;
+                HIPCHK(c, hipMemcpyAsync(h_split, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->kp_stream));
+                HIPCHK(c, hipEventRecord(c->ev_split[2], c->kp_stream));
+            }
         }
         fscale *= 2.0f;
         c->last.n_octaves++;
@@ -1549,6 +1682,16 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     if (used_second) {
         HIPCHK(c, hipEventRecord(c->ev_ex2[1], c->ex_stream2));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ex2[1], 0));
+    }
+    if (split_tail) {
+        bool done = false;
+        rc = finish_split_tail(c, levels, desc_mode, eig_thres, size_factor, n_out, &done);
+        if (rc) return rc;
+        if (done) {
+            *feats_out = c->h_recs; /* pinned, owned by the context */
+            return SIFT3D_OK;
+        }
+        /* fell back: every stream is idle, the extrema launches were replayed into one list on the main stream */
     }
     /* the level table goes to the device now, behind the pyramid, not after the host has waited for the extrema count */
     const bool levels_early = extract && levels.size() <= 96;

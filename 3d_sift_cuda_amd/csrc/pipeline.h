@@ -60,9 +60,10 @@ struct sift3d_ctx {
     hipStream_t kp_stream;     /* descriptor launches of the chunked per-keypoint stage, beside the keypoint kernel of the next chunk */
     hipEvent_t ev_kpc[SIFT3D_KP_MAX_CHUNKS]; /* chunk i's keypoint kernel, scan and record map are complete */
     hipEvent_t ev_desc;        /* the descriptor launches on kp_stream are complete */
-    unsigned long long *h_cnt0; /* pinned, 8 + SIFT3D_KP_MAX_CHUNKS words: [4..7] the small read-backs the host waits for (extrema counts,
-                                 * keypoint count), [8..] the record totals of the chunks: a copy into pageable memory goes through a
-                                 * staging buffer and costs tens of microseconds more */
+    hipEvent_t ev_split[3];    /* split tail (run_pipeline): first-part extrema done on the two extrema streams; its count on the host */
+    unsigned long long *h_cnt0; /* pinned, 16 + SIFT3D_KP_MAX_CHUNKS words: [4..7] the small read-backs the host waits for (extrema counts,
+                                 * keypoint count), [8..] the record totals of the chunks, [8 + SIFT3D_KP_MAX_CHUNKS ..] the counters of the
+                                 * split tail: a copy into pageable memory goes through a staging buffer and costs tens of microseconds more */
     hipEvent_t ev_oct[2];      /* octave's DoG levels complete / extrema launches complete */
     hipEvent_t ev_fence[2];    /* ordering of the *_dev entry points with the legacy default stream (fence_in / fence_out) */
     bool own_stream;
@@ -79,7 +80,11 @@ struct sift3d_ctx {
     unsigned long long *keys_a, *keys_b;
     sift3d_cval *vals_a, *vals_b;
     int64_t cand_cap;
-    unsigned long long *d_count; /* [0] validated extrema, [1] own-level survivors of the level in flight, [2] survivor overflow high-water mark */
+    unsigned long long *d_count; /* [0] validated extrema, [1] own-level survivors of the level in flight, [2] survivor overflow high-water
+                                  * mark, [3] keypoints, [4] validated extrema of the second group (split tail) */
+    int64_t cand_split_at;       /* 0: one list in keys_a / vals_a; n > 0: entries [0, n) take the first group's extrema (counter [0]), [n, cand_cap)
+                                  * the second group's (counter [4]) -- run_pipeline's split tail */
+    int cand_group;              /* the group cand_append's launches append to */
     sift3d_survivor *surv;
     sift3d_survivor2 *list2[2];      /* extrema that passed the level below, waiting for the lazily evaluated level above: one list
                                       * per extrema stream (surv_sel) */
@@ -114,6 +119,7 @@ struct sift3d_ctx {
         int64_t ncand, nrec;
         int nchunks, launched;
         int64_t first[SIFT3D_KP_MAX_CHUNKS + 1];
+        bool split; /* the chunks were queued on kp_stream by the split tail: the first one's descriptor launch goes to the main stream */
     } kp;
     int dev_stop;           /* -DSIFT3D_DEV builds: sift3d_dev_set_stop */
     bool count_queued;      /* cand_count_queue ran and nothing was appended since */

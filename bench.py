@@ -495,7 +495,7 @@ def main():
                                          "launches": int(len(q)), "avg_launch_ms": round(float(q["ms"].mean()), 4),
                                          "GBs": round(float(q["alg_bytes"].sum()) / (float(q["ms"].sum()) * 1e-3) / 1e9, 1)})
             accounting = ("fused x+y+z+DoG launches: compulsory bytes only -- read the level once, write what is kept (level and "
-                          "DoG: 12 B/voxel; initial blur and L1, whose DoG is not stored: level only, 8 B/voxel); the three-pass "
+                          "DoG: 12 B/voxel; level 3 also writes the next octave's level 0: 12.5; initial blur and L1, whose DoG is not stored: level only, 8 B/voxel); the three-pass "
                           "form of the same work is credited 32 (24) B/voxel")
         else:   # rows that are not whole 16-byte vectors: three-pass kernels; dominant = slowest instantiation at n^3
             big = {}
@@ -531,10 +531,11 @@ def main():
                 for pi in per_inst:
                     R = pi["taps"] // 2
                     with_dog = pi["alg_bytes_per_voxel"] > 9
-                    # template arguments: <R, rows per thread, has level, has DoG, prefetch planes>
-                    exact = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and
-                             (", true, true," in k) == with_dog and (with_dog or ", true, false," in k)]
-                    twin = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and ", true, true," in k]
+                    with_sub = pi["alg_bytes_per_voxel"] > 12.2   # the level-3 launch that also writes the next octave's level 0
+                    # template arguments: <R, rows per thread, has level, has DoG, prefetch planes, tile x, tile y[, has half-size]>
+                    mine = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and k.endswith(", true>") == with_sub]
+                    exact = [k for k in mine if (", true, true," in k) == with_dog and (with_dog or ", true, false," in k)]
+                    twin = [k for k in mine if ", true, true," in k]
                     if exact:
                         w = tab[sorted(exact)[0]]["hbm_bytes_per_launch_512"]
                     elif twin:   # a level-only launch measured through its level + DoG twin: 4 B/voxel less written

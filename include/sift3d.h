@@ -209,8 +209,9 @@ typedef enum {
     SIFT3D_TUNE_TINY_OCTAVE,    /* 1 (default): an octave of at most 4096 voxels is built by one workgroup in one launch; 0: level by level */
     SIFT3D_TUNE_SAMPLER_CAP,    /* workgroups of a CU that may sample a patch at a time in the descriptor kernel: 4 (default); 0: no limit */
     SIFT3D_TUNE_KP_CHUNKS,      /* the per-keypoint stage in n chunks, the keypoint kernel of chunk i+1 on one stream beside the
-                                 * descriptor kernel of chunk i on another: 0 or 1 = one launch of each, one after the other
-                                 * (default: the overlap does not pay), up to 16 */
+                                 * descriptor kernel of chunk i on another: 0 (default) or 1 = one launch of each, one after the other
+                                 * (the overlap does not pay), up to 16; any value but 0 also switches
+                                 * SIFT3D_TUNE_SPLIT_TAIL's schedule off */
     SIFT3D_TUNE_BANDS_FIRST,    /* Z-slab drivers: 1 (default) a rank filters the two boundary bands of a level first and the interior
                                  * while they travel to its neighbours; 0: the level in one piece, then the exchange (round 2) */
     SIFT3D_TUNE_HOST_RECORDS,   /* records per candidate the pinned download buffers are first sized for: 5 (default; blob fields yield
@@ -219,6 +220,9 @@ typedef enum {
                                  * 2 = 128 x 16 */
     SIFT3D_TUNE_FUSED_SUB,      /* 1 (default): the launch that makes level 3 of an octave also writes the next octave's level 0 (the
                                  * 2 x 2 x 2 mean) where the shape allows; 0: a subsample launch of its own, as before round 4 */
+    SIFT3D_TUNE_SPLIT_TAIL,     /* 1 (default): the extrema of octaves 0 and 1 are sorted and their keypoint kernel started while the coarser
+                                 * octaves are still being built; 0: one sort and one keypoint launch behind the whole pyramid; 2 (tests): as 1 with room
+                                 * for eight extrema of the coarser octaves only, so that the fall-back to the schedule of 0 runs */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);

@@ -493,6 +493,38 @@ def test_pipeline_level3_launch_carries_the_subsample(built, oracle, dims, rows)
     assert len(want) > 20 and _compare_records(got, want)
 
 
+@pytest.mark.parametrize("dims,noise,mode", [((168, 164, 160), 0.0, 0), ((96, 80, 72), 0.0, 2), ((64, 64, 64), 30.0, 0), ((40, 36, 33), 0.0, 1),
+                                             ((16, 16, 16), 0.0, 0), ((72, 72, 72), 6.0, 3)])
+def test_split_tail_gives_the_same_records(built, oracle, dims, noise, mode):
+    """Round 4: the candidate list in two parts (octaves 0 - 1 / the coarser ones), the first sorted and its keypoint kernel
+    started while the coarse octaves are still being built (TUNE_SPLIT_TAIL 1, the default), against one sort and one launch
+    behind the whole pyramid (0): the same bytes, the oracle's records.  Value 2 leaves the second part room for eight
+    extrema: it overflows while the first part's keypoint kernel is in flight and the run falls back to the one-list
+    schedule with a replay; the dense-noise volume overflows the first part (and the own-level lists) instead.  The context is
+    used again afterwards with the default, so a fall-back leaves nothing behind."""
+    vol = vol_of(built, dims, 41)
+    if noise:
+        vol = vol + (np.random.default_rng(3).standard_normal(vol.shape) * noise).astype(np.float32)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        runs = {}
+        for v in (1, 0, 2, 1):
+            ctx.set_tuning(built.TUNE_SPLIT_TAIL, v)
+            got = ctx.extract(desc_mode=mode)
+            tm = ctx.timings()
+            runs.setdefault(v, []).append((got.tobytes(), tm["n_extrema"], tm["n_records"], tm["stages"]["keypoint"]["launches"]))
+            last = got.copy()
+    ref = runs[0][0]
+    for v, rs in runs.items():
+        for r in rs:
+            assert r[:3] == ref[:3], v
+    want, _ = oracle.extract(vol, desc_mode=mode)
+    assert len(want) == ref[2] and (len(want) == 0 or _compare_records(last, want))
+    assert runs[0][0][3] <= 1
+    if dims[0] >= 160:
+        assert runs[1][0][3] == 2    # two keypoint launches: the split schedule ran (a part without extrema has none)
+
+
 def test_pipeline_empty_volume(built, oracle, tmp_path):
     """No extremum anywhere: zero records, and the CLI still writes a well-formed .key."""
     dims = (48, 40, 36)
@@ -682,7 +714,7 @@ def test_pinned_record_buffers_grow_when_a_run_needs_more(built):
         want = ctx.extract()
         assert len(want) > 4000 and ctx.host_buffer_grows() == 0
         assert len(want) > 1.125 * ctx.timings()["n_extrema"] + 1024     # 1 per candidate (plus the allocation's slack) cannot hold them
-    for chunks in (1, 3, 8):
+    for chunks in (0, 1, 3, 8):     # 0: the default schedule (two parts, the split tail)
         with built.Context(*dims) as ctx:
             ctx.set_tuning(built.TUNE_HOST_RECORDS, 1)
             ctx.set_tuning(built.TUNE_KP_CHUNKS, chunks)

@@ -53,3 +53,14 @@ for taps, s, with_dog in cases:
         out.append("%s %.3f ms %.0f GB/s" % (name, ms, by / ms / 1e6))
     tot = sum(float(np.median(log[log["stage"] == st]["ms"])) for st in range(3))
     print("taps %2d: %s | total %.3f ms  %.0f GB/s (32N)" % (taps, " | ".join(out), tot, 32 * N / tot / 1e6))
+# the pyramid's level-3 launch: 11 taps, level + DoG + the next octave's level 0 (its own instantiation of the kernel)
+h = torch.empty(n // 2, n // 2, n // 2, device="cuda")
+for _ in range(2):
+    ctx.gauss_blur_dog_half_dev(a.data_ptr(), b.data_ptr(), d.data_ptr(), h.data_ptr(), n, n, n, sig[11])
+ctx.enable_timing(True)
+for _ in range(reps):
+    one = ctx.gauss_blur_dog_half_dev(a.data_ptr(), b.data_ptr(), d.data_ptr(), h.data_ptr(), n, n, n, sig[11])
+log = ctx.launch_log()
+ctx.enable_timing(False)
+ms = float(np.median(log[log["stage"] == 7]["ms"]))
+print("taps 11 + half-size volume (%s): fused %.3f ms  %.0f GB/s (12.5N)" % ("one launch" if one else "TWO launches", ms, 12.5 * N / ms / 1e6))

@@ -30,11 +30,12 @@ def sweep(cases=60, seed=1, max_edge=112):
         init_scale = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
         noise = float(rng.choice([0.0, 0.0, 1.0, 8.0]))
         fused = int(rng.choice([1, 1, 2, 0]))   # 2: the fused blur on every octave it supports, 0: never
-        kp_chunks = int(rng.choice([0, 1, 3, 6]))   # the per-keypoint stage in chunks on two streams
+        kp_chunks = int(rng.choice([0, 0, 0, 1, 3, 6]))   # the per-keypoint stage in chunks on two streams
         tile = int(rng.choice([0, 0, 1, 2]))        # round 4: the fused blur's tile (64 x 32 / 128 x 16)
         host_recs = int(rng.choice([5, 5, 1, 12]))  # round 4: records per candidate the pinned buffers start with (1: they grow)
         rows = int(rng.choice([0, 0, 1, 2]))        # the fused blur's thread mapping (2 on a small volume: the level-3 launch carries the subsample)
         sub = int(rng.choice([1, 1, 1, 0]))         # round 4: the subsample inside the level-3 launch / a launch of its own
+        split = int(rng.choice([1, 1, 0, 2]))       # round 4: the candidate list in two parts (2: the second part overflows -> fall-back)
         vol = pkg.synth_blobs(*dims, seed=vseed)
         if noise:
             vol = vol + (rng.standard_normal(vol.shape) * noise).astype(np.float32)
@@ -45,6 +46,7 @@ def sweep(cases=60, seed=1, max_edge=112):
             ctx.set_tuning(pkg.TUNE_HOST_RECORDS, host_recs)
             ctx.set_tuning(pkg.TUNE_FUSED_ROWS, rows)
             ctx.set_tuning(pkg.TUNE_FUSED_SUB, sub)
+            ctx.set_tuning(pkg.TUNE_SPLIT_TAIL, split)
             ctx.set_volume(vol)
             got = ctx.extract(initial_image_scale=init_scale, desc_mode=mode)
         want, _ = orc.extract(vol, init_scale=init_scale, desc_mode=mode)
@@ -53,8 +55,8 @@ def sweep(cases=60, seed=1, max_edge=112):
             bad += 1
             where = "count" if len(got) != len(want) else ",".join(
                 f for f in fields if not (got[f].view(np.uint32) == want[f].view(np.uint32)).all())
-            print("MISMATCH case %d dims %s seed %d mode %d init %.1f noise %.1f fused %s rows %d sub %d tile %d: %d / %d records, differs in %s"
-                  % (i, dims, vseed, mode, init_scale, noise, fused, rows, sub, tile, len(got), len(want), where), flush=True)
+            print("MISMATCH case %d dims %s seed %d mode %d init %.1f noise %.1f fused %s rows %d sub %d tile %d split %d: %d / %d records, differs in %s"
+                  % (i, dims, vseed, mode, init_scale, noise, fused, rows, sub, tile, split, len(got), len(want), where), flush=True)
         elif i % 10 == 0:
             print("case %d dims %s mode %d: %d records identical (%.0f s)" % (i, dims, mode, len(got), time.time() - t0), flush=True)
     print("%d cases, %d mismatches, %.0f s" % (cases, bad, time.time() - t0))
