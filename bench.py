@@ -438,6 +438,14 @@ def main():
     gpu_recs = feats.copy() if rank == 0 else None   # the timed region's last step (the pinned view is reused by the next call)
     full_logs, excl_logs = [], []
     if rank == 0:
+        # The breakdown steps run the one-list schedule (SIFT3D_TUNE_SPLIT_TAIL 0): on the production schedule the launches that
+        # build the coarse octaves queue behind the first part's keypoint kernel, and an event pair around such a launch
+        # times that wait (3 ms), not the kernel.  The timed region above ran the production schedule.
+        split_was = 1
+        for kv in args.tune:
+            if kv.split("=")[0].upper() == "SPLIT_TAIL":
+                split_was = int(kv.split("=")[1])
+        ctx.set_tuning(pkg.TUNE_SPLIT_TAIL, 0)
         ctx.enable_timing(1)
         for _ in range(2):
             ctx.extract(desc_mode=args.desc, copy=False)
@@ -447,6 +455,7 @@ def main():
             ctx.extract(desc_mode=args.desc, copy=False)
             excl_logs.append(ctx.launch_log())
         ctx.enable_timing(0)
+        ctx.set_tuning(pkg.TUNE_SPLIT_TAIL, split_was)
 
     phase("volumes: max / sum over ranks")
     red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda:%d" % local_rank   # gloo: the one-GPU rehearsal
@@ -576,7 +585,10 @@ def main():
             if len(sel):
                 stages[s] = {"ms_per_step": round(float(sel["ms"].sum()) / nfull, 3), "launches_per_step": len(sel) // nfull}
         stages["_note"] = ("kernel time per stage from two extra steps with every launch bracketed by HIP events (that costs "
-                           "about 1 ms per step, so those steps are outside the timed region); the extrema of an octave run "
+                           "about 1 ms per step, so those steps are outside the timed region) on the one-list schedule "
+                           "(SIFT3D_TUNE_SPLIT_TAIL 0: one sort, one keypoint and one descriptor launch behind the whole pyramid -- on the "
+                           "production schedule the coarse octaves' launches queue behind the first part's keypoint kernel and their "
+                           "event pairs would time that wait); the extrema of an octave run "
                            "beside the blurs of the coarser ones, so the stages add up to more than a step and a blur launch's "
                            "event pair also times the extrema kernels that share the chip with it; `exclusive_ms_per_step` is the "
                            "same from two steps in which the extrema stay on the main stream (sift3d_enable_timing mode 3): every "

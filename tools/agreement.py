@@ -27,8 +27,9 @@ for (taps, dog), p in sorted(per.items()):
     nlaunch = min(len(v), 9)
     v = v[:nlaunch]
     ms_tr = sum(v) / len(v)
-    print("| %d | %d | `%s` | %.4f | %.4f |" % (taps, 12 if dog else 8, names[0], p["avg_launch_ms"], ms_tr))
-    tot_ev += p["avg_launch_ms"]; tot_tr += ms_tr; tot_bytes += (12 if dog else 8) * float(n) ** 3
+    bpv = p["alg_bytes_per_voxel"]   # 8 level only, 12 level + DoG, 12.5 when the launch also writes the next octave's level 0
+    print("| %d | %g | `%s` | %.4f | %.4f |" % (taps, bpv, names[0], p["avg_launch_ms"], ms_tr))
+    tot_ev += p["avg_launch_ms"]; tot_tr += ms_tr; tot_bytes += bpv * float(n) ** 3
 print()
 print("Sum of the %d launches: %.3f ms by HIP events, %.3f ms by the kernel trace (%.2f GB of compulsory bytes: %.2f / %.2f TB/s, "
       "%.3f / %.3f of 8 TB/s); the profiled run takes %.2f ms per step."
