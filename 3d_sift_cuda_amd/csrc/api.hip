@@ -173,6 +173,7 @@ sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean
     c->tune[SIFT3D_TUNE_HOST_RECORDS] = 5;
     c->tune[SIFT3D_TUNE_FUSED_SUB] = 1;
     c->tune[SIFT3D_TUNE_SPLIT_TAIL] = 1;
+    c->tune[SIFT3D_TUNE_DESC_SEGMENT] = 32;
     /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
     c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -242,8 +243,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2, 1 << 20};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -1211,6 +1212,7 @@ static void kp_params_of(sift3d_ctx *c, int desc_mode, float eig_thres, float si
      * without a limit; 1: 6.6, 2: 4.5, 3: 4.09, 4: 4.03, 5: 4.12, 6-12: 4.15-4.18) */
     p.sampler_tokens = c->sampler_tokens;
     p.sampler_cap = c->tune[SIFT3D_TUNE_SAMPLER_CAP];
+    p.desc_seg = c->tune[SIFT3D_TUNE_DESC_SEGMENT] * 8;
 }
 
 static int kp_chunks_for(const sift3d_ctx *c, int64_t ncand)

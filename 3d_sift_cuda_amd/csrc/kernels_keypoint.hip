@@ -714,14 +714,25 @@ __device__ __forceinline__ void wave_splat_sequence(float *grid, int n, const sh
 
 /* Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, with its private L2), and the
  * work items arrive sorted by (level, raster index), so neighbours in the list sample neighbouring
- * image regions: give every XCD one contiguous eighth of the list instead of every eighth item, and
- * the trilinear gathers of neighbouring keypoints / of the frames of one keypoint meet in one L2.
- * Placement only changes speed, never results. */
-__device__ __forceinline__ long long xcd_contiguous_item(long long n)
+ * image regions: an XCD takes RUNS of consecutive items instead of every eighth item, and the trilinear
+ * gathers of neighbouring keypoints / of the frames of one keypoint meet in one L2.
+ * Round 4: the runs are short -- the list is cut into segments of seg items (256 by default) and each
+ * segment is dealt to the XCDs in contiguous eighths -- so that all eight XCDs are in the same part of the
+ * list at the same time.  With one eighth of the WHOLE list per XCD (rounds 2 - 3) the eighths took
+ * different times (the records of the first detection levels sample compact footprints, the later ones
+ * sparse ones) and the kernel ended with some XCDs idle for a tenth of its time: 9.60 -> 9.23 ms per 512^3
+ * extraction (profiles/r04_desc_segment.txt).  Placement only changes speed, never results. */
+__device__ __forceinline__ long long xcd_contiguous_item(long long n, int seg)
 {
     const long long b = blockIdx.x;
-    const long long per = (n + 7) / 8;
-    return (b % 8) * per + b / 8;
+    if (seg <= 0) {
+        const long long per = (n + 7) / 8;
+        return (b % 8) * per + b / 8;
+    }
+    /* the list in segments of seg items (a multiple of 8), each dealt to the XCDs in contiguous eighths: every XCD still walks
+     * neighbouring items, and all eight are in the same part of the list at the same time */
+    const long long s0 = b / seg * seg, local = b - s0;
+    return s0 + (local % 8) * (seg / 8) + local / 8;
 }
 
 /* ---------------------------------------------------------------------- */
@@ -1060,7 +1071,7 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
                                                         int *__restrict__ rec_group, sift3d_taps taps5)
 {
     __shared__ __attribute__((aligned(16))) kpB_smem<SIFT> sm;
-    const long long r = xcd_contiguous_item(nrec);
+    const long long r = xcd_contiguous_item(nrec, p.desc_seg);
     if (r >= nrec) return;
     const int lane = threadIdx.x;
     if (lane < 5) sm.taps[lane] = taps5.f[lane];
@@ -1346,7 +1357,8 @@ hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, c
     if (nrec <= 0) return hipSuccess;
     sift3d_taps t;
     for (int i = 0; i < 17; i++) t.f[i] = i < 5 ? taps5[i] : 0.0f;
-    const dim3 grid((unsigned)(((nrec + 7) / 8) * 8));
+    const int seg = p.desc_seg;
+    const dim3 grid((unsigned)(seg > 0 ? (nrec + seg - 1) / seg * seg : ((nrec + 7) / 8) * 8));
     if (p.desc_mode == SIFT3D_DESC_SIFT)
         hipLaunchKernelGGL(descriptor_kernel<true>, grid, dim3(DESC_NT), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
                            rec_group, t);

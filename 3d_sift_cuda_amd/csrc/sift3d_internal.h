@@ -134,6 +134,7 @@ struct sift3d_kp_params {
                      * phase B reads it for the un-reoriented record instead of sampling it again */
     int *sampler_tokens; /* phase B: per-CU count of workgroups in their sampling phase (SIFT3D_CU_SLOTS ints, zero between runs) */
     int sampler_cap;     /* at most this many per CU sample at a time (0: no limit) */
+    int desc_seg;        /* descriptor kernel: records per segment of the XCD-contiguous order (a multiple of 8; 0: the whole list is one) */
 };
 #define SIFT3D_CU_SLOTS 2048
 #define SIFT3D_MAX_FRAMES 11 /* determineCanonicalOrientation3D stops at FEATURE_3D_DIM frames */

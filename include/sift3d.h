@@ -223,6 +223,9 @@ typedef enum {
     SIFT3D_TUNE_SPLIT_TAIL,     /* 1 (default): the extrema of octaves 0 and 1 are sorted and their keypoint kernel started while the coarser
                                  * octaves are still being built; 0: one sort and one keypoint launch behind the whole pyramid; 2 (tests): as 1 with room
                                  * for eight extrema of the coarser octaves only, so that the fall-back to the schedule of 0 runs */
+    SIFT3D_TUNE_DESC_SEGMENT,   /* descriptor kernel: the record list is dealt to the XCDs in contiguous eighths of segments of 8 n records:
+                                 * 32 (default: 256 records a segment, all XCDs in the same part of the list at a time); 0: eighths of the
+                                 * whole list (rounds 2 - 3); 1: round-robin */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);

@@ -525,6 +525,21 @@ def test_split_tail_gives_the_same_records(built, oracle, dims, noise, mode):
         assert runs[1][0][3] == 2    # two keypoint launches: the split schedule ran (a part without extrema has none)
 
 
+@pytest.mark.parametrize("dims,mode", [((96, 80, 72), 0), ((120, 100, 90), 3), ((40, 36, 33), 1)])
+def test_descriptor_record_order_over_the_xcds_changes_nothing(built, dims, mode):
+    """Round 4: which workgroup of the descriptor kernel takes which record (TUNE_DESC_SEGMENT: contiguous eighths of segments of
+    8 n records per XCD; 0 = of the whole list, 1 = round-robin) only moves work between the XCDs: the same bytes for every
+    segment length, also one that is longer than the list and one that leaves a partial last segment."""
+    vol = vol_of(built, dims, 17)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract(desc_mode=mode)
+        assert len(want) > 3
+        for seg in (0, 1, 3, 7, 32, 1000, 1 << 20):
+            ctx.set_tuning(built.TUNE_DESC_SEGMENT, seg)
+            assert ctx.extract(desc_mode=mode).tobytes() == want.tobytes(), seg
+
+
 def test_pipeline_empty_volume(built, oracle, tmp_path):
     """No extremum anywhere: zero records, and the CLI still writes a well-formed .key."""
     dims = (48, 40, 36)

@@ -36,6 +36,7 @@ def sweep(cases=60, seed=1, max_edge=112):
         rows = int(rng.choice([0, 0, 1, 2]))        # the fused blur's thread mapping (2 on a small volume: the level-3 launch carries the subsample)
         sub = int(rng.choice([1, 1, 1, 0]))         # round 4: the subsample inside the level-3 launch / a launch of its own
         split = int(rng.choice([1, 1, 0, 2]))       # round 4: the candidate list in two parts (2: the second part overflows -> fall-back)
+        dseg = int(rng.choice([32, 32, 0, 1, 5]))   # round 4: the descriptor kernel's record order over the XCDs
         vol = pkg.synth_blobs(*dims, seed=vseed)
         if noise:
             vol = vol + (rng.standard_normal(vol.shape) * noise).astype(np.float32)
@@ -47,6 +48,7 @@ def sweep(cases=60, seed=1, max_edge=112):
             ctx.set_tuning(pkg.TUNE_FUSED_ROWS, rows)
             ctx.set_tuning(pkg.TUNE_FUSED_SUB, sub)
             ctx.set_tuning(pkg.TUNE_SPLIT_TAIL, split)
+            ctx.set_tuning(pkg.TUNE_DESC_SEGMENT, dseg)
             ctx.set_volume(vol)
             got = ctx.extract(initial_image_scale=init_scale, desc_mode=mode)
         want, _ = orc.extract(vol, init_scale=init_scale, desc_mode=mode)
