@@ -126,7 +126,7 @@ int sift3d_gauss_blur_dog_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, 
                               int64_t nz, float sigma, float min_value);
 /* The same plus what the next octave starts from: d_half = the 2 x 2 x 2 mean of the blurred volume, a dense
  * (nx / 2) x (ny / 2) x (nz / 2) array (fioSubSampleInterpolate, R/src_common/FeatureIO.cpp:1474-1554, called on level 3 of
- * every octave at R/src_common/MultiScale.cpp:3113-3118).  Where the shape allows (an 11-tap filter -- the pyramid's level 3 --
+ * every octave at R/src_common/MultiScale.cpp:409-413).  Where the shape allows (an 11-tap filter -- the pyramid's level 3 --
  * on at least 2^22 voxels, nx a multiple of 8) the blur launch writes it from the planes it holds in registers and
  * *in_one_launch (optional) is 1; otherwise a subsample launch follows and it is 0.  The bytes are the same either way. */
 int sift3d_gauss_blur_dog_half_dev(sift3d_ctx *ctx, const float *d_in, float *d_out, float *d_dog, float *d_half, int64_t nx,
