@@ -791,6 +791,8 @@ int cand_reset(sift3d_ctx *c, hipStream_t on)
     /* every extrema pass of the run gets its own counter set: one memset here instead of one per pass */
     HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, on));
     HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, on));
+    HIPCHK(c, hipMemsetAsync(c->d_rec_base, 0, sizeof(int), on)); /* first record of the per-keypoint stage's first chunk (the split tail
+                                                                    * does not clear it again when the first count arrives) */
     c->surv_set = 0;
     return SIFT3D_OK;
 }
@@ -1358,8 +1360,8 @@ static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &level
  * on its way to h_split[0..2] behind ev_split[2] (kp_stream), the main stream ends behind both extrema streams.  *done = false:
  * something did not fit -- every stream has been drained and the extrema launches replayed into one list; the caller
  * continues with the one-list schedule. */
-static int finish_split_tail(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int desc_mode, float eig_thres, float size_factor,
-                             int64_t *n_out, bool *done)
+static int finish_split_tail(sift3d_ctx *c, const std::vector<sift3d_level> &levels, bool levels_on_device, int desc_mode, float eig_thres,
+                             float size_factor, int64_t *n_out, bool *done)
 {
     *done = false;
     unsigned long long *const h_split = c->h_cnt0 + 8 + SIFT3D_KP_MAX_CHUNKS;
@@ -1384,9 +1386,10 @@ static int finish_split_tail(sift3d_ctx *c, const std::vector<sift3d_level> &lev
     if (rc) return rc;
     kp_params_of(c, desc_mode, eig_thres, size_factor, c->kp.p);
     c->kp.split = true;
-    HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, ks));
-    HIPCHK(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(unsigned long long), ks));
-    HIPCHK(c, hipMemsetAsync(c->d_rec_base, 0, sizeof(int), ks));
+    /* nothing else between the count and the sort: the level table went to the device on this stream when the run began, the
+     * keypoint counter and the first chunk's record base were cleared with the extrema counters (cand_reset) */
+    if (!levels_on_device)
+        HIPCHK(c, hipMemcpyAsync(c->d_levels, levels.data(), sizeof(sift3d_level) * levels.size(), hipMemcpyHostToDevice, ks));
     int nch = 0;
     if (nA > 0) {
         HIPCHK(c, sift3d_sort_candidates(ks, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a, c->vals_b, nA));
@@ -1474,6 +1477,37 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     };
     std::vector<ex_plan> plans(oct.size());
     bool used_second = false;
+    /* split tail: the level table does not depend on anything the loop below finds out, so it goes to the device now, on the
+     * stream the first part's keypoint kernel will run on, instead of between that part's count and its sort */
+    std::vector<sift3d_level> levels_sent;
+    bool levels_early_split = false;
+    if (split_tail && levels.size() <= 96) {
+        float sg[7] = {0, 0, 0, 0, 0, 0, 0}, s_ = 1.6f, fs = 1;
+        sg[0] = s_;
+        for (int j = 1; j < 6; j++) {
+            s_ *= factor;
+            sg[j] = s_;
+        }
+        for (size_t o = 0; o < oct.size(); o++) {
+            for (int l = 0; l < 3; l++) {
+                sift3d_level &lv = levels[o * 3 + (size_t)l];
+                memset(&lv, 0, sizeof lv);
+                lv.img = c->L[l + 1] + oct[o].off;
+                lv.dogc = c->D[l + 1] + oct[o].off;
+                lv.X = (int)oct[o].X; lv.Y = (int)oct[o].Y; lv.Z = (int)oct[o].Z;
+                lv.XP = (int)oct[o].XP;
+                lv.sigma_h = sg[l]; lv.sigma_c = sg[l + 1]; lv.sigma_l = sg[l + 2];
+                lv.octave_factor = fs;
+                lv.Zl = (int)oct[o].Z;
+                lv.z_off = 0;
+                lv.pad = 0;
+            }
+            fs *= 2.0f;
+        }
+        levels_sent = levels;
+        HIPCHK(c, hipMemcpyAsync(c->d_levels, levels_sent.data(), sizeof(sift3d_level) * levels_sent.size(), hipMemcpyHostToDevice, c->kp_stream));
+        levels_early_split = true;
+    }
     /* One chain of levels on the main stream.  (Round 3 tried two: the octaves after the first -- some sixty small launches
      * bound by launch latency, 0.5 ms of kernel time -- on a stream of their own from the moment the second octave's level 0
      * exists, beside the first octave's last level and its extrema passes.  It cannot overlap: the fused blur runs one
@@ -1687,7 +1721,10 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     }
     if (split_tail) {
         bool done = false;
-        rc = finish_split_tail(c, levels, desc_mode, eig_thres, size_factor, n_out, &done);
+        /* the table the loop above filled in is the one that was uploaded before it (same expressions); checked, not assumed */
+        const bool table_ok = levels_early_split && levels.size() == levels_sent.size() &&
+                              memcmp(levels.data(), levels_sent.data(), sizeof(sift3d_level) * levels.size()) == 0;
+        rc = finish_split_tail(c, levels, table_ok, desc_mode, eig_thres, size_factor, n_out, &done);
         if (rc) return rc;
         if (done) {
             *feats_out = c->h_recs; /* pinned, owned by the context */
