@@ -33,6 +33,21 @@ def test_library_exports_every_declared_symbol(built):
     assert not hasattr(lib, "sift3d_dev_set_stop")   # the ablation hook is not in the product library
 
 
+def test_python_tuning_constants_mirror_the_header(built):
+    """The TUNE_* constants of the Python host side are the header's sift3d_tuning enum, name by name and in its order:
+    a knob added to one side only would silently set another knob."""
+    src = open(os.path.join(ROOT, "include", "sift3d.h")).read()
+    end = src.index("} sift3d_tuning;")
+    body = src[src.rindex("typedef enum {", 0, end) + len("typedef enum {"):end]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip().split("=")[0].strip() for n in body.split(",") if n.strip()]
+    assert names[-1] == "SIFT3D_TUNE_COUNT" and len(names) >= 13
+    for value, name in enumerate(names[:-1]):
+        assert getattr(built, name.replace("SIFT3D_", "")) == value, name
+    extra = [n for n in dir(built) if n.startswith("TUNE_") and "SIFT3D_" + n not in names]
+    assert not extra, extra
+
+
 def test_product_reads_no_environment_variable(built):
     """No switch of the library hides in the caller's environment: the HIP translation units do not call getenv (the
     knobs are sift3d_set_tuning), and their objects do not import the symbol (sort_scan.o does: rocPRIM's own headers)."""
