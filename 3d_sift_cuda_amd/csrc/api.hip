@@ -1347,6 +1347,95 @@ int describe_finish(sift3d_ctx *c, int64_t *n_out)
     return SIFT3D_OK;
 }
 
+#ifdef SIFT3D_DEV
+/* Development builds only (tools/overlap_probe.py): would the keypoint kernel and the descriptor kernel gain from sharing the
+ * CUs?  After an extraction (its sorted candidates, keypoints and record map still on the device) the two kernels are run
+ * again, (a) one after the other as the pipeline does, (b) cut into slices of kslice extrema / dslice records queued
+ * alternately on two streams, so that neither grid is ever large enough to keep the other out of the CUs.  The results are
+ * the ones already there (same inputs); only the times matter.  out_ms: (a), (b). */
+extern "C" int sift3d_dev_overlap_probe(sift3d_ctx *c, int kslice, int dslice, double *out_ms)
+{
+    if (!c || !out_ms || kslice < 1 || dslice < 1 || c->kp.ncand <= 0 || c->kp.nrec <= 0) return SIFT3D_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    float taps3[SIFT3D_MAX_TAPS];
+    sift3d_gauss_taps(0.5f, 0.01f, taps3);
+    const int64_t ncand = c->kp.ncand, nrec = c->kp.nrec;
+    hipEvent_t ev[6];
+    for (hipEvent_t &e : ev) HIPCHK(c, hipEventCreate(&e));
+    hipStream_t s1 = c->stream, s2 = c->kp_stream;
+    HIPCHK(c, hipStreamSynchronize(s1));
+    HIPCHK(c, hipStreamSynchronize(s2));
+    auto launch_k = [&](hipStream_t st, int64_t a, int64_t n) -> hipError_t {
+        sift3d_kp_params q = c->kp.p;
+        q.patch0 = c->patch0 + (size_t)a * SIFT3D_PATCH_VOX;
+        return sift3d_launch_keypointsA(st, q, c->keys_b + a, c->vals_b + a, n, c->kps + a, c->nrec + a, taps3);
+    };
+    auto launch_d = [&](hipStream_t st, int64_t b, int64_t m) -> hipError_t {
+        return sift3d_launch_descriptors(st, c->kp.p, c->kps, c->rec_kp + b, c->rec_frame + b, m, c->d_hrecs + b, c->d_hgroup + b, c->kp.taps5);
+    };
+    /* (a) */
+    HIPCHK(c, hipEventRecord(ev[0], s1));
+    HIPCHK(c, launch_k(s1, 0, ncand));
+    HIPCHK(c, hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, s1));
+    HIPCHK(c, launch_d(s1, 0, nrec));
+    HIPCHK(c, hipEventRecord(ev[1], s1));
+    HIPCHK(c, hipStreamSynchronize(s1));
+    /* (b) */
+    HIPCHK(c, hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, s1));
+    HIPCHK(c, hipEventRecord(ev[2], s1));
+    HIPCHK(c, hipStreamWaitEvent(s2, ev[2], 0));
+    /* four streams for the slices of each kernel, so that the tail of one slice is covered by the next three */
+    enum { NS = 4 };
+    hipStream_t ks[NS], ds[NS];
+    hipEvent_t done[2 * NS];
+    for (int i = 0; i < NS; i++) {
+        HIPCHK(c, hipStreamCreateWithFlags(&ks[i], hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&ds[i], hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&done[NS + i], hipEventDisableTiming));
+        HIPCHK(c, hipStreamWaitEvent(ks[i], ev[2], 0));
+        HIPCHK(c, hipStreamWaitEvent(ds[i], ev[2], 0));
+    }
+    (void)s2;
+    int64_t a = 0, b = 0;
+    int ki = 0, di = 0;
+    while (a < ncand || b < nrec) { /* alternately, in proportion */
+        if (a < ncand) {
+            const int64_t n = ncand - a < kslice ? ncand - a : kslice;
+            HIPCHK(c, launch_k(ks[ki++ % NS], a, n));
+            a += n;
+        }
+        const int64_t b_to = ncand > 0 ? (int64_t)((double)nrec * (double)a / (double)ncand) : nrec;
+        while (b < nrec && (b < b_to || a >= ncand)) {
+            const int64_t m = nrec - b < dslice ? nrec - b : dslice;
+            HIPCHK(c, launch_d(ds[di++ % NS], b, m));
+            b += m;
+        }
+    }
+    for (int i = 0; i < NS; i++) {
+        HIPCHK(c, hipEventRecord(done[i], ks[i]));
+        HIPCHK(c, hipEventRecord(done[NS + i], ds[i]));
+        HIPCHK(c, hipStreamWaitEvent(s1, done[i], 0));
+        HIPCHK(c, hipStreamWaitEvent(s1, done[NS + i], 0));
+    }
+    HIPCHK(c, hipEventRecord(ev[4], s1));
+    HIPCHK(c, hipStreamSynchronize(s1));
+    for (int i = 0; i < NS; i++) {
+        hipStreamDestroy(ks[i]);
+        hipStreamDestroy(ds[i]);
+        hipEventDestroy(done[i]);
+        hipEventDestroy(done[NS + i]);
+    }
+    float m0 = 0, m1 = 0;
+    HIPCHK(c, hipEventElapsedTime(&m0, ev[0], ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&m1, ev[2], ev[4]));
+    out_ms[0] = m0;
+    out_ms[1] = m1;
+    for (hipEvent_t e : ev) hipEventDestroy(e);
+    return SIFT3D_OK;
+}
+#endif
+
 static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode,
                            float eig_thres, float size_factor, int64_t *n_out, bool levels_on_device = false)
 {
