@@ -121,6 +121,25 @@ def test_fused_blur_carries_the_half_size_volume(built, oracle, dims, chunks, ti
         assert names == ["blur_fused", "blur_fused", "subsample", "blur_fused", "subsample"]
 
 
+def test_blur_dog_half_refuses_what_it_cannot_do(built):
+    """sift3d_gauss_blur_dog_half_dev: null pointers, a dimension below 2 (nothing to halve) and a volume beyond the context are
+    errors with a message, not launches."""
+    import torch
+    with built.Context(32, 32, 32) as ctx:
+        a = torch.zeros(32, 32, 32, device="cuda")
+        o, d, h = torch.empty_like(a), torch.empty_like(a), torch.empty(16, 16, 16, device="cuda")
+        torch.cuda.synchronize()
+        for args in ((0, o.data_ptr(), d.data_ptr(), h.data_ptr(), 32, 32, 32), (a.data_ptr(), 0, d.data_ptr(), h.data_ptr(), 32, 32, 32),
+                     (a.data_ptr(), o.data_ptr(), d.data_ptr(), 0, 32, 32, 32), (a.data_ptr(), o.data_ptr(), d.data_ptr(), h.data_ptr(), 32, 32, 1),
+                     (a.data_ptr(), o.data_ptr(), d.data_ptr(), h.data_ptr(), 1, 32, 32), (a.data_ptr(), o.data_ptr(), d.data_ptr(), h.data_ptr(), 64, 64, 64)):
+            with pytest.raises(RuntimeError):
+                ctx.gauss_blur_dog_half_dev(*args, 1.9465880393981934)
+        # and the DoG output is optional
+        assert ctx.gauss_blur_dog_half_dev(a.data_ptr(), o.data_ptr(), 0, h.data_ptr(), 32, 32, 32, 1.9465880393981934) is False
+        ctx.sync()
+        assert float(h.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dims", [(64, 48, 40), (132, 70, 33), (256, 8, 24)])
 def test_windowed_blur_writes_exactly_its_planes(built, oracle, dims):
     """sift3d_gauss_blur_dog_window_dev (what a Z-slab rank filters its boundary bands with): the planes of the window are the
