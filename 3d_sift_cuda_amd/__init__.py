@@ -33,6 +33,7 @@ LIB_HOST = os.path.join(CSRC, "_build", "libsift3d_host.so")
 FEATEXTRACT = os.path.join(CSRC, "_build", "featExtract")
 
 DESC_SIFT, DESC_BRIEF, DESC_RRIEF, DESC_NRRIEF = 0, 1, 2, 3
+ABI_VERSION = 5   # SIFT3D_ABI_VERSION of include/sift3d.h: the structure layouts this file mirrors
 INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
 STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
@@ -95,6 +96,10 @@ def hip_lib():
         raise Sift3DError("%s is missing: run __graft_entry__.build() (there is no CPU fallback)" % LIB_HIP)
     L = C.CDLL(LIB_HIP)
     P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
+    _sig(L.sift3d_abi_version, I)
+    if L.sift3d_abi_version() != ABI_VERSION:   # the library writes whole structures through our pointers
+        raise Sift3DError("%s has ABI version %d, this mirror of include/sift3d.h is version %d: rebuild (__graft_entry__.build())"
+                          % (LIB_HIP, L.sift3d_abi_version(), ABI_VERSION))
     _sig(L.sift3d_device_count, I)
     _sig(L.sift3d_create, P, I, I64, I64, I64)
     _sig(L.sift3d_create_slab, P, I, I64, I64, I64)
@@ -143,6 +148,8 @@ def hip_lib():
     _sig(L.sift3d_zslab_create, P, P, I, I64, I64, I64, C.c_char_p, I64)
     _sig(L.sift3d_zslab_extract, I, P, P, F, I, F, F, P, P, P, C.c_char_p, I64)
     _sig(L.sift3d_zslab_destroy, None, P)
+    _sig(L.sift3d_zslab_set_volume, I, P, P, C.c_char_p, I64)
+    _sig(L.sift3d_zslab_extract_resident, I, P, F, I, F, F, P, P, P, C.c_char_p, I64)
     _sig(L.sift3d_knn64, I, I, P, I64, P, I64, I, P, P, I, P, C.c_char_p, I64)
     _sig(L.sift3d_get_level_slice, I, P, I, I, I64, P, P, P)
     _hip = L
@@ -159,6 +166,7 @@ def host_lib():
     L = C.CDLL(LIB_HOST)
     P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
     _sig(L.sift3d_synth_blobs, None, P, I64, I64, I64, C.c_uint32)
+    _sig(L.sift3d_synth_blobs_slices, None, P, I64, I64, I64, C.c_uint32, I64, I64)
     _sig(L.nifti_min_read, I, C.c_char_p, P)
     _sig(L.nifti_min_free, None, P)
     _sig(L.nifti_min_write_f32, I, C.c_char_p, P, I, I, I, F, F, F)
@@ -183,10 +191,12 @@ class ZSlabStats(C.Structure):
     _fields_ = [("n_ranks", C.c_int32), ("sharded_octaves", C.c_int32), ("exchanges", C.c_int64), ("halo_bytes_critical", C.c_int64),
                 ("halo_bytes_deferred", C.c_int64), ("gather_bytes", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
                 ("n_records", C.c_int64), ("wall_ms", C.c_double), ("halo_bytes_hidden", C.c_int64), ("transport", C.c_int32),
-                ("transport_fell_back", C.c_int32), ("rccl_version", C.c_int32), ("reserved", C.c_int32)]
+                ("transport_fell_back", C.c_int32), ("rccl_version", C.c_int32), ("comm_sets", C.c_int32), ("resident_volume", C.c_int32),
+                ("reserved", C.c_int32), ("merge_ms", C.c_double)]
 
 
 ZSLAB_TRANSPORT, TRANSPORT_PEER_COPY, TRANSPORT_RCCL = 1000, 0, 1   # sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, ...)
+ZSLAB_SERIAL_CHANNELS, ZSLAB_DUPLICATE_RANKS = 1001, 1002           # include/sift3d.h
 
 
 def zslab_set_transport_library(path):
@@ -240,6 +250,34 @@ class ZSlab:
             recs = np.frombuffer((C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(out.value), FEATURE_DTYPE, n.value).copy() if n.value else np.zeros(0, FEATURE_DTYPE)
         finally:
             self._L.sift3d_free(out)
+        return recs, {k: getattr(st, k) for k, _ in ZSlabStats._fields_}
+
+    def set_volume(self, vol):
+        """sift3d_zslab_set_volume: every rank's input slices uploaded once; extract_resident() then starts from HBM."""
+        vol = _f32(vol)
+        assert vol.shape == self.shape, (vol.shape, self.shape)
+        err = C.create_string_buffer(512)
+        rc = self._L.sift3d_zslab_set_volume(self._h, vol.ctypes.data, err, 512)
+        if rc != 0:
+            e = Sift3DError("sift3d_zslab_set_volume -> %d: %s" % (rc, err.value.decode(errors="replace")))
+            e.code = rc
+            raise e
+
+    def extract_resident(self, initial_image_scale=1.0, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0, copy=True):
+        """sift3d_zslab_extract_resident: (records, stats).  copy=False: a view of the handle's merge buffer, valid until
+        the handle's next call."""
+        view, n, st, err = C.c_void_p(), C.c_int64(0), ZSlabStats(), C.create_string_buffer(512)
+        rc = self._L.sift3d_zslab_extract_resident(self._h, float(initial_image_scale), int(desc_mode), float(eig_thres), float(size_factor),
+                                                   C.byref(view), C.byref(n), C.byref(st), err, 512)
+        if rc != 0:
+            e = Sift3DError("sift3d_zslab_extract_resident -> %d: %s" % (rc, err.value.decode(errors="replace")))
+            e.code = rc
+            raise e
+        if n.value:
+            recs = np.frombuffer((C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(view.value), FEATURE_DTYPE, n.value)
+            recs = recs.copy() if copy else recs
+        else:
+            recs = np.zeros(0, FEATURE_DTYPE)
         return recs, {k: getattr(st, k) for k, _ in ZSlabStats._fields_}
 
     def set_tuning(self, knob, value):
@@ -334,6 +372,15 @@ def synth_blobs(nx, ny, nz, seed=12345):
     """Deterministic blob-field volume, shape (nz, ny, nx) float32."""
     v = np.empty((nz, ny, nx), np.float32)
     host_lib().sift3d_synth_blobs(v.ctypes.data, nx, ny, nz, seed)
+    return v
+
+
+def synth_blobs_slices(nx, ny, nz, z0, z1, seed=12345):
+    """Planes [z0, z1) of synth_blobs(nx, ny, nz, seed), without making the rest: shape (z1 - z0, ny, nx)."""
+    z0, z1 = max(0, int(z0)), min(int(nz), int(z1))
+    v = np.empty((max(0, z1 - z0), ny, nx), np.float32)
+    if z1 > z0:
+        host_lib().sift3d_synth_blobs_slices(v.ctypes.data, nx, ny, nz, seed, z0, z1)
     return v
 
 

@@ -54,6 +54,8 @@ int set_err(sift3d_ctx *c, int code, const char *fmt, ...)
         if ((c) && (c)->lean) return set_err((c), SIFT3D_ERR_ARG, "%s needs a full context (sift3d_create), not a slab context", __func__); \
     } while (0)
 
+extern "C" int sift3d_abi_version(void) { return SIFT3D_ABI_VERSION; }
+
 extern "C" int sift3d_device_count(void)
 {
     int n = 0;

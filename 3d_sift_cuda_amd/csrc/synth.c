@@ -7,8 +7,8 @@
 #include <omp.h>
 #endif
 
-/* the blobs of the generator, in generation order, accumulated into planes [za, zb) only */
-static void blobs_into_planes(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t seed, int64_t za, int64_t zb)
+/* the blobs of the generator, in generation order, accumulated into planes [za, zb) only; vol holds the planes from zbase on */
+static void blobs_into_planes(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t seed, int64_t za, int64_t zb, int64_t zbase)
 {
     const int64_t N = X * Y * Z;
     uint32_t s = seed;
@@ -36,7 +36,7 @@ static void blobs_into_planes(float *vol, int64_t X, int64_t Y, int64_t Z, uint3
             float dz = (float)z - cz;
             for (int64_t y = y0; y <= y1; y++) {
                 float dy = (float)y - cy;
-                float *row = vol + (z * Y + y) * X;
+                float *row = vol + ((z - zbase) * Y + y) * X;
                 for (int64_t x = x0; x <= x1; x++) {
                     float dx = (float)x - cx;
                     float d2 = dx * dx + dy * dy + dz * dz;
@@ -50,21 +50,30 @@ static void blobs_into_planes(float *vol, int64_t X, int64_t Y, int64_t Z, uint3
 
 void sift3d_synth_blobs(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t seed)
 {
+    sift3d_synth_blobs_slices(vol, X, Y, Z, seed, 0, Z);
+}
+
+void sift3d_synth_blobs_slices(float *out, int64_t X, int64_t Y, int64_t Z, uint32_t seed, int64_t z0, int64_t z1)
+{
+    if (z0 < 0) z0 = 0;
+    if (z1 > Z) z1 = Z;
+    if (z1 <= z0) return;
+    const int64_t W = z1 - z0;
     /* A voxel's value is the float sum of its blobs in generation order.  Each thread walks the whole blob sequence (five
      * draws a blob) and adds only into its own range of planes, so every voxel still sees its blobs in that order: the
      * same bits for any thread count (a 2048 x 2048 x 1024 volume takes minutes on one core). */
 #ifdef _OPENMP
     int nt = omp_get_max_threads();
-    if (nt > Z) nt = (int)Z;
-    if (X * Y * Z < (1ll << 22) || nt < 1) nt = 1;
+    if (nt > W) nt = (int)W;
+    if (X * Y * W < (1ll << 22) || nt < 1) nt = 1;
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
     for (int t = 0; t < nt; t++) {
-        const int64_t za = Z * t / nt, zb = Z * (t + 1) / nt;
-        memset(vol + za * Y * X, 0, sizeof(float) * (size_t)((zb - za) * Y * X));
-        blobs_into_planes(vol, X, Y, Z, seed, za, zb);
+        const int64_t za = z0 + W * t / nt, zb = z0 + W * (t + 1) / nt;
+        memset(out + (za - z0) * Y * X, 0, sizeof(float) * (size_t)((zb - za) * Y * X));
+        blobs_into_planes(out, X, Y, Z, seed, za, zb, z0);
     }
 #else
-    memset(vol, 0, sizeof(float) * (size_t)(X * Y * Z));
-    blobs_into_planes(vol, X, Y, Z, seed, 0, Z);
+    memset(out, 0, sizeof(float) * (size_t)(X * Y * W));
+    blobs_into_planes(out, X, Y, Z, seed, z0, z1, z0);
 #endif
 }

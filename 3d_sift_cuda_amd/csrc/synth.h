@@ -16,6 +16,9 @@ extern "C" {
  * adds amp*expf(-d^2/(2 sigma^2)) in float over the box (int)c +- ((int)(3 sigma)+1)
  * clipped to the volume, blobs in generation order. */
 void sift3d_synth_blobs(float *vol, int64_t X, int64_t Y, int64_t Z, uint32_t seed);
+/* Planes [z0, z1) of the same volume into out ((z1 - z0) * Y * X floats): the same bits as those planes of the whole
+ * volume -- a rank of the Z-slab run generates its input slices without the 16 GB of a 2048 x 2048 x 1024 volume. */
+void sift3d_synth_blobs_slices(float *out, int64_t X, int64_t Y, int64_t Z, uint32_t seed, int64_t z0, int64_t z1);
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "pipeline.h"
@@ -89,6 +90,7 @@ struct zs_rank {
     hipEvent_t ev_patch = nullptr;     /* the patch-halo copies into this rank are done */
     std::vector<float *> allocs;       /* what this run had to allocate beside the arena */
     float *arena = nullptr;            /* one block reused from run to run (sized after the first run of a handle) */
+    float *vol_dev = nullptr;          /* sift3d_zslab_set_volume: this rank's input slices [i0, i1), resident between extractions */
     int64_t arena_cap = 0, arena_used = 0, need = 0; /* floats */
     float *L[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *D[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t z0 = 0, z1 = 0, e0 = 0, e1 = 0; /* current octave: own slices [z0, z1), buffer extent [e0, e1) */
@@ -167,7 +169,11 @@ struct sift3d_zslab {
     int lazy_levels = 1;    /* SIFT3D_TUNE_LAZY_LEVELS */
     int bands_first = 1;    /* SIFT3D_TUNE_BANDS_FIRST */
     int transport_want = ZS_TRANSPORT_PEER; /* SIFT3D_ZSLAB_TRANSPORT */
+    int transport_flags = 0;                /* ZS_FLAG_*: SIFT3D_ZSLAB_SERIAL_CHANNELS, SIFT3D_ZSLAB_DUPLICATE_RANKS */
     zs_transport *tr = nullptr;             /* created by the first extraction after the choice (zslab_transport.hip) */
+    bool has_volume = false;                /* sift3d_zslab_set_volume has put every rank's input slices on its device */
+    sift3d_feature *merged = nullptr;       /* the merged records of the last resident extraction (host; what its view points at) */
+    int64_t merged_cap = 0;
     sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
 };
 
@@ -192,11 +198,13 @@ extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
         if (q.ev_halo) hipEventDestroy(q.ev_halo);
         for (float *p : q.allocs) hipFree(p);
         hipFree(q.arena);
+        hipFree(q.vol_dev);
         if (q.ev_level) hipEventDestroy(q.ev_level);
         if (q.ev_l3) hipEventDestroy(q.ev_l3);
         if (q.ev_patch) hipEventDestroy(q.ev_patch);
         sift3d_destroy(q.c);
     }
+    free(h->merged);
     delete h;
 }
 
@@ -210,6 +218,16 @@ extern "C" int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value)
             h->tr = nullptr;
         }
         h->transport_want = value;
+        return SIFT3D_OK;
+    }
+    if (knob == SIFT3D_ZSLAB_SERIAL_CHANNELS || knob == SIFT3D_ZSLAB_DUPLICATE_RANKS) {
+        const int bit = knob == SIFT3D_ZSLAB_SERIAL_CHANNELS ? ZS_FLAG_SERIAL_CHANNELS : ZS_FLAG_DUPLICATE_RANKS;
+        const int flags = value ? (h->transport_flags | bit) : (h->transport_flags & ~bit);
+        if (h->tr && flags != h->transport_flags) { /* the next extraction builds its transport anew */
+            zs_transport_destroy(h->tr);
+            h->tr = nullptr;
+        }
+        h->transport_flags = flags;
         return SIFT3D_OK;
     }
     for (zs_rank &q : h->R) {
@@ -289,19 +307,27 @@ extern "C" sift3d_zslab *sift3d_zslab_create(const int *devices, int n_devices, 
     return zslab_create_impl(devices, n_devices, nx, ny, nz, err, err_len, nullptr);
 }
 
-extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_scale, int desc_mode, float eig_thres,
-                                    float size_factor, sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
-                                    int64_t err_len)
+/* vol: the whole volume in host memory, uploaded slab by slab inside the call -- or NULL: every rank's input slices are on
+ * its device already (sift3d_zslab_set_volume).  out: the merged records malloc'ed for the caller -- or, with out == NULL,
+ * *view: the handle's own merge buffer, valid until the handle's next call. */
+static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                              sift3d_feature **out, const sift3d_feature **view, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
+                              int64_t err_len)
 {
     char errbuf[512] = "";
     int rc = SIFT3D_OK;
     int r = 0;
     if (err && err_len > 0) err[0] = 0;
-    if (!h || !vol || !out || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) {
+    if (!h || (!out && !view) || !n_out || desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) {
         if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
         return SIFT3D_ERR_ARG;
     }
-    *out = nullptr;
+    if (!vol && !h->has_volume) {
+        if (err && err_len > 0) snprintf(err, (size_t)err_len, "no volume: call sift3d_zslab_set_volume first");
+        return SIFT3D_ERR_ARG;
+    }
+    if (out) *out = nullptr;
+    if (view) *view = nullptr;
     *n_out = 0;
     const zs_plan &plan = h->plan;
     const int64_t nx = plan.nx, ny = plan.ny, nz = plan.nz;
@@ -316,7 +342,8 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
         std::vector<int> devs((size_t)S);
         for (int i = 0; i < S; i++) devs[(size_t)i] = R[(size_t)i].dev;
         char terr[400];
-        h->tr = zs_transport_create(h->transport_want == SIFT3D_TRANSPORT_RCCL ? ZS_TRANSPORT_RCCL : ZS_TRANSPORT_PEER, devs.data(), S, terr, sizeof terr);
+        h->tr = zs_transport_create(h->transport_want == SIFT3D_TRANSPORT_RCCL ? ZS_TRANSPORT_RCCL : ZS_TRANSPORT_PEER, h->transport_flags, devs.data(), S,
+                                    terr, sizeof terr);
         if (!h->tr) {
             if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", terr);
             return SIFT3D_ERR_COMM;
@@ -325,8 +352,9 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
     st.transport = zs_transport_kind(h->tr) == ZS_TRANSPORT_RCCL ? SIFT3D_TRANSPORT_RCCL : SIFT3D_TRANSPORT_PEER_COPY;
     st.transport_fell_back = zs_transport_fell_back(h->tr);
     st.rccl_version = zs_transport_version(h->tr);
-    std::vector<std::vector<sift3d_feature>> recs((size_t)S);
-    std::vector<std::vector<int>> grps((size_t)S);
+    st.comm_sets = zs_transport_comm_sets(h->tr);
+    st.resident_volume = vol ? 0 : 1;
+    std::vector<int64_t> nrecs((size_t)S, 0);
     const auto wall0 = std::chrono::steady_clock::now();
 
     /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
@@ -359,9 +387,9 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
         timing_begin(q.c);
         /* level 0 = initial blur of the input, on slab +- 8 from input slab +- 16 */
         const int64_t XY = nx * ny;
-        float *din = q.alloc((i1 - i0) * XY), *tmp = q.alloc((i1 - i0) * XY);
+        float *din = vol ? q.alloc((i1 - i0) * XY) : q.vol_dev, *tmp = q.alloc((i1 - i0) * XY);
         if (!din || !tmp) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-        ZS_HIP(hipMemcpyAsync(din, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream));
+        if (vol) ZS_HIP(hipMemcpyAsync(din, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream));
         ZS_RC(blur_dev(q.c, din, tmp, nullptr, nx, ny, i1 - i0, extra0, 0.01f));
         int64_t z0 = 0, z1 = nz;
         if (S > 1) plan.slab(r, 0, z0, z1);
@@ -629,32 +657,76 @@ extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float ini
             int64_t nrec = 0;
             ZS_HIP(hipSetDevice(q.dev));
             ZS_RC(describe_finish(q.c, &nrec));
-            recs[(size_t)r].assign(q.c->h_recs, q.c->h_recs + nrec);
-            grps[(size_t)r].assign(q.c->h_group, q.c->h_group + nrec);
+            nrecs[(size_t)r] = nrec;
             st.n_keypoints += q.c->last.n_keypoints;
         }
     }
     {
-        /* merge: within a group (level, is_max) slabs are in z order, so rank order is the serial raster order */
+        /* merge: within a group (level, is_max) slabs are in z order, so rank order is the serial raster order.  A rank's
+         * records are sorted by group already (the sort key leads with it), so the merged list is, group by group, a run of
+         * every rank in rank order: the runs are copied straight out of the ranks' pinned download buffers (still valid:
+         * nothing has run on the contexts since), one host thread per rank. */
+        const auto merge0 = std::chrono::steady_clock::now();
+        const int NG = 2 * 96 + 1; /* level id * 2 + is_max; the last slot takes anything out of range */
         int64_t total = 0;
-        for (r = 0; r < S; r++) total += (int64_t)recs[(size_t)r].size();
-        sift3d_feature *res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));
-        if (!res) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "out of host memory"); goto done; }
-        std::vector<int64_t> count(2 * 96 + 2, 0);
-        for (r = 0; r < S; r++)
-            for (int g : grps[(size_t)r]) count[(size_t)(g < 0 || g >= 192 ? 192 : g) + 1]++;
-        for (size_t g = 1; g < count.size(); g++) count[g] += count[g - 1];
-        for (r = 0; r < S; r++)
-            for (size_t i = 0; i < recs[(size_t)r].size(); i++) {
-                const int g = grps[(size_t)r][i];
-                res[count[(size_t)(g < 0 || g >= 192 ? 192 : g)]++] = recs[(size_t)r][i];
+        for (r = 0; r < S; r++) total += nrecs[(size_t)r];
+        sift3d_feature *res;
+        if (out) {
+            res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));
+        } else {
+            if (total > h->merged_cap) {
+                free(h->merged);
+                h->merged_cap = total + total / 8 + 1024;
+                h->merged = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)h->merged_cap);
+                if (!h->merged) h->merged_cap = 0;
             }
-        *out = res;
+            res = h->merged;
+        }
+        if (!res) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "out of host memory"); goto done; }
+        std::vector<int64_t> cnt((size_t)S * NG, 0), at((size_t)S * NG, 0);
+        bool sorted = true;
+        for (r = 0; r < S; r++) {
+            const int *g = R[(size_t)r].c->h_group;
+            int prev = -1;
+            for (int64_t i = 0; i < nrecs[(size_t)r]; i++) {
+                const int gi = g[i] < 0 || g[i] >= NG - 1 ? NG - 1 : g[i];
+                cnt[(size_t)r * NG + gi]++;
+                sorted = sorted && gi >= prev;
+                prev = gi;
+            }
+        }
+        if (!sorted) { rc = SIFT3D_ERR_ARG; snprintf(errbuf, sizeof errbuf, "a rank's records are not in group order"); if (out) free(res); goto done; }
+        int64_t pos = 0;
+        for (int gi = 0; gi < NG; gi++)
+            for (r = 0; r < S; r++) {
+                at[(size_t)r * NG + gi] = pos;
+                pos += cnt[(size_t)r * NG + gi];
+            }
+        auto copy_rank = [&](int rr) {
+            const sift3d_feature *src = R[(size_t)rr].c->h_recs;
+            int64_t i = 0;
+            for (int gi = 0; gi < NG; gi++) {
+                const int64_t m = cnt[(size_t)rr * NG + gi];
+                if (m) memcpy(res + at[(size_t)rr * NG + gi], src + i, sizeof(sift3d_feature) * (size_t)m);
+                i += m;
+            }
+        };
+        if (S > 1 && total > 4096) {
+            std::vector<std::thread> th;
+            for (r = 1; r < S; r++) th.emplace_back(copy_rank, r);
+            copy_rank(0);
+            for (std::thread &t : th) t.join();
+        } else {
+            for (r = 0; r < S; r++) copy_rank(r);
+        }
+        if (out) *out = res; else *view = res;
         *n_out = total;
         st.n_records = total;
+        st.merge_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge0).count();
     }
 
 done:
+    if (rc != SIFT3D_OK) zs_xfer_abort(h->tr); /* a step that failed between its begin and its end leaves no group open */
     for (size_t i = 0; i < R.size(); i++) { /* everything queued has to be done before the buffers go back */
         zs_rank &q = R[i];
         hipSetDevice(q.dev);
@@ -666,10 +738,71 @@ done:
         hipSetDevice(R[i].dev);
         R[i].recycle();
     }
+    if (rc == SIFT3D_ERR_COMM) { /* the next extraction starts with fresh communicators (the streams are drained: nothing is in flight) */
+        zs_transport_destroy(h->tr);
+        h->tr = nullptr;
+    }
     st.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = st;
     if (rc != SIFT3D_OK && err && err_len > 0) snprintf(err, (size_t)err_len, "%s", errbuf);
     return rc;
+}
+
+extern "C" int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_scale, int desc_mode, float eig_thres,
+                                    float size_factor, sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
+                                    int64_t err_len)
+{
+    if (!vol || !out) {
+        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
+        return SIFT3D_ERR_ARG;
+    }
+    return zslab_extract_impl(h, vol, initial_image_scale, desc_mode, eig_thres, size_factor, out, nullptr, n_out, stats, err, err_len);
+}
+
+/* The whole volume (host memory) cut into the ranks' input slices and uploaded, once; the extractions that follow
+ * (sift3d_zslab_extract_resident) start from HBM, as sift3d_extract does after sift3d_set_volume. */
+extern "C" int sift3d_zslab_set_volume(sift3d_zslab *h, const float *vol, char *err, int64_t err_len)
+{
+    if (err && err_len > 0) err[0] = 0;
+    if (!h || !vol) {
+        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
+        return SIFT3D_ERR_ARG;
+    }
+    const zs_plan &plan = h->plan;
+    const int S = (int)h->R.size();
+    const int64_t XY = plan.nx * plan.ny;
+    h->has_volume = false;
+    for (int r = 0; r < S; r++) {
+        zs_rank &q = h->R[(size_t)r];
+        int64_t i0 = 0, i1 = plan.nz;
+        if (S > 1) plan.input_range(r, i0, i1);
+        hipError_t e = hipSetDevice(q.dev);
+        if (e == hipSuccess && !q.vol_dev) e = hipMalloc((void **)&q.vol_dev, sizeof(float) * (size_t)((i1 - i0) * XY));
+        if (e == hipSuccess) e = hipMemcpyAsync(q.vol_dev, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream);
+        if (e != hipSuccess) {
+            if (err && err_len > 0) snprintf(err, (size_t)err_len, "rank %d: input slices [%lld, %lld): %s", r, (long long)i0, (long long)i1, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? SIFT3D_ERR_MEMORY : SIFT3D_ERR_DEVICE;
+        }
+    }
+    for (int r = 0; r < S; r++) { /* the caller's buffer is free again when this returns */
+        hipSetDevice(h->R[(size_t)r].dev);
+        if (hipStreamSynchronize(h->R[(size_t)r].c->stream) != hipSuccess) {
+            if (err && err_len > 0) snprintf(err, (size_t)err_len, "rank %d: upload failed", r);
+            return SIFT3D_ERR_DEVICE;
+        }
+    }
+    h->has_volume = true;
+    return SIFT3D_OK;
+}
+
+extern "C" int sift3d_zslab_extract_resident(sift3d_zslab *h, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                                             const sift3d_feature **view, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len)
+{
+    if (!view) {
+        if (err && err_len > 0) snprintf(err, (size_t)err_len, "bad arguments");
+        return SIFT3D_ERR_ARG;
+    }
+    return zslab_extract_impl(h, nullptr, initial_image_scale, desc_mode, eig_thres, size_factor, nullptr, view, n_out, stats, err, err_len);
 }
 
 extern "C" int sift3d_extract_zslab_over(int transport, const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,

@@ -77,14 +77,15 @@ struct zs_transport {
     int version = 0;
     std::vector<int> devices;
     rccl_api api;
-    std::vector<ncclComm_t> comm[ZS_CHANNELS];
+    std::vector<ncclComm_t> comm[ZS_CHANNELS]; /* with ZS_FLAG_SERIAL_CHANNELS comm[1] is a copy of comm[0]'s handles */
+    int comm_sets = 0;
     bool in_group = false;
     char err[384] = "";
 };
 
 extern "C" void zs_transport_set_library(const char *path) { g_library = path ? path : ""; }
 
-extern "C" zs_transport *zs_transport_create(int kind, const int *devices, int n, char *err, size_t err_len)
+extern "C" zs_transport *zs_transport_create(int kind, int flags, const int *devices, int n, char *err, size_t err_len)
 {
     if (err && err_len) err[0] = 0;
     if (!devices || n < 1 || (kind != ZS_TRANSPORT_PEER && kind != ZS_TRANSPORT_RCCL)) {
@@ -94,7 +95,7 @@ extern "C" zs_transport *zs_transport_create(int kind, const int *devices, int n
     zs_transport *t = new zs_transport();
     t->devices.assign(devices, devices + n);
     if (kind == ZS_TRANSPORT_PEER) return t;
-    for (int i = 0; i < n && !t->fell_back; i++)
+    for (int i = 0; i < n && !t->fell_back && !(flags & ZS_FLAG_DUPLICATE_RANKS); i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) t->fell_back = 1; /* one device, several ranks: not something RCCL does */
     if (t->fell_back) return t;
@@ -106,6 +107,11 @@ extern "C" zs_transport *zs_transport_create(int kind, const int *devices, int n
     }
     t->api.GetVersion(&t->version);
     for (int ch = 0; ch < ZS_CHANNELS; ch++) {
+        if (ch > 0 && (flags & ZS_FLAG_SERIAL_CHANNELS)) { /* one set: RCCL orders a communicator's operations, so channel 1 queues behind channel 0 */
+            t->comm[ch] = t->comm[0];
+            continue;
+        }
+        t->comm_sets++;
         t->comm[ch].assign((size_t)n, nullptr);
         const ncclResult_t r = t->api.CommInitAll(t->comm[ch].data(), n, devices);
         if (r != ncclSuccess) {
@@ -122,9 +128,12 @@ extern "C" zs_transport *zs_transport_create(int kind, const int *devices, int n
 extern "C" void zs_transport_destroy(zs_transport *t)
 {
     if (!t) return;
-    for (int ch = 0; ch < ZS_CHANNELS; ch++)
+    if (t->in_group) zs_xfer_abort(t); /* a communicator is not destroyed inside an open group */
+    for (int ch = 0; ch < ZS_CHANNELS; ch++) {
+        if (ch > 0 && !t->comm[ch].empty() && !t->comm[0].empty() && t->comm[ch][0] == t->comm[0][0]) continue; /* the serial form's alias */
         for (ncclComm_t c : t->comm[ch])
             if (c) t->api.CommDestroy(c);
+    }
     if (t->api.lib) dlclose(t->api.lib);
     delete t;
 }
@@ -132,6 +141,7 @@ extern "C" void zs_transport_destroy(zs_transport *t)
 extern "C" int zs_transport_kind(const zs_transport *t) { return t ? t->kind : ZS_TRANSPORT_PEER; }
 extern "C" int zs_transport_fell_back(const zs_transport *t) { return t ? t->fell_back : 0; }
 extern "C" int zs_transport_version(const zs_transport *t) { return t ? t->version : 0; }
+extern "C" int zs_transport_comm_sets(const zs_transport *t) { return t ? t->comm_sets : 0; }
 extern "C" const char *zs_transport_error(const zs_transport *t) { return t ? t->err : ""; }
 
 extern "C" int zs_xfer_begin(zs_transport *t)
@@ -196,4 +206,11 @@ extern "C" int zs_xfer_end(zs_transport *t)
         return -1;
     }
     return 0;
+}
+
+extern "C" void zs_xfer_abort(zs_transport *t)
+{
+    if (!t || t->kind != ZS_TRANSPORT_RCCL || !t->in_group) return;
+    t->in_group = false;
+    (void)t->api.GroupEnd(); /* whatever the group had collected is launched or refused; the caller drops the transport afterwards */
 }

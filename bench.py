@@ -5,20 +5,31 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one full sift3d_extract (Gaussian pyramid + DoG + extrema + keypoints +
-SIFT-rank descriptors, all octaves, records copied back to the host) of one
-512^3 float32 blob-field volume that is already resident in HBM.  With N > 1
-every rank extracts its own 512^3 volume on its own GPU (independent volumes,
-no data-path collective: weak scaling) -- that is `value`.  The Z-slab split of
-ONE 512^3 volume across the same ranks (halo exchange over RCCL, DESIGN.md
-section 6) then runs under a watchdog and is attached to the line as `zslab`
-(strong scaling: its own ms_per_step and records/s, and whether the merged
-records are the bytes of the single-GPU run).
+A step = one full extraction (Gaussian pyramid + DoG + extrema + keypoints +
+SIFT-rank descriptors, all octaves, records back on the host) of ONE 512^3
+float32 blob-field volume that is already resident in HBM.
 
-With N > 1 the line also carries, at top level, the strong-scaling result of the
-Z-slab run: `zslab_value` (keypoints/s of ONE 512^3 volume over all N GPUs),
-`zslab_ms_per_step`, `zslab_same_bytes_as_single_gpu` (null if that child job
-failed; details in `zslab`).  `value` itself stays the weak-scaling workload.
+N = 1: the volume on one GPU (sift3d_extract).  `value` = .key records per second.
+
+N > 1 (round 5): `value`, `ms_per_step` and `scaling` ("strong") are the Z-SLAB
+SPLIT OF THAT ONE VOLUME over the N GPUs -- one process per GPU, halo exchange
+over RCCL (torch.distributed), DESIGN.md section 6 -- with
+`same_bytes_as_single_gpu` beside it: what BASELINE.json's "1/2/4/8-GPU Z-slab
+scaling" asks for.  It runs as a child job under a time limit after the ranks'
+own measurement; if it fails, the line is still printed (`value` null, the child's
+exit code and stderr tail under `zslab`) and bench.py exits with code 5 -- a
+replica figure is never printed under the north-star label.  Beside it:
+  volumes_value / volumes_ms_per_step   every rank extracting its OWN 512^3 volume
+                (independent volumes, no collective: weak scaling; rounds 1-4's
+                headline), measured first, by all ranks, barrier to barrier;
+  zslab_c       the same Z-slab split driven from C in ONE process over all N
+                devices (sift3d_zslab_set_volume + sift3d_zslab_extract_resident:
+                what `featExtract -d0,1,..` ships), once with peer copies and once
+                with RCCL as the transport.
+`--config c4` / `--config c5` run BASELINE's configs C4 (1024 x 1024 x 512,
+N = 4) and C5 (2048 x 2048 x 1024, NRRIEF, N = 8) through the same code; for
+those only rank 0 extracts the whole volume (the single-GPU records the merged
+ones are compared with), there is no replica leg.
 
 Rank 0 prints ONE JSON line: metric = keypoints/s (.key records per second,
 whole job), plus
@@ -26,7 +37,9 @@ whole job), plus
                level): algorithmic = compulsory bytes (12 B/voxel,
                8 where only the level or only the DoG is kept) / launch time over its
                512^3 launches, measured here with HIP events on the stream the kernels
-               run on; per tap count in `per_instantiation`
+               run on; per tap count in `per_instantiation`; `ceiling_*` = what a
+               zero-arithmetic march of the same tiles and write streams sustains in
+               this process on this box (tools/roof_lib.hip)
   pyramid      Gauss-pyramid + DoG GB/s over all blur launches of a step
   cpu_baseline the CPU restatement (oracle/, single thread like the reference's
                extractor) timed on this box on the 512^3 metric volume, N = 1 only;
@@ -46,6 +59,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 PMC_TABLE = "r04_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
 BLUR_SOURCE = os.path.join("3d_sift_cuda_amd", "csrc", "kernels_blur_fused.hip")   # what the PMC table was measured on
+
+
+# BASELINE.json configs that bench.py can run at N > 1 besides the metric volume: (nx, ny, nz, descriptor mode)
+CONFIGS = {"c4": (1024, 1024, 512, 0), "c5": (2048, 2048, 1024, 3)}
+
+
+def resolve_volume(args):
+    """(nx, ny, nz, desc, label) of the run: --config, else --dims, else the cube of edge --size."""
+    if args.config:
+        nx, ny, nz, desc = CONFIGS[args.config]
+    elif args.dims:
+        nx, ny, nz = (int(v) for v in args.dims.split(","))
+        desc = None
+    else:
+        nx = ny = nz = args.size
+        desc = None
+    if args.desc is not None:
+        desc = args.desc
+    if desc is None:
+        desc = 0
+    label = "%d^3" % nx if nx == ny == nz else "%d x %d x %d" % (nx, ny, nz)
+    return nx, ny, nz, desc, label
 
 
 def blur_source_hash():
@@ -152,17 +187,17 @@ def self_launch(args, argv):
 
 
 def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, phase=lambda *a: None):
-    """ONE n^3 volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records on rank 0.
+    """ONE volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records on rank 0.
     Returns the result object on rank 0 (None elsewhere).  expect: the single-GPU records of the same volume, if the
     caller has them (rank 0), to state whether the merged records are the same bytes."""
     phase("zslab: plan, slab context, upload")
     zs = importlib.import_module("3d_sift_cuda_amd.zslab")
-    n = args.size
+    nx, ny, nz, desc, label = resolve_volume(args)
     ndev = torch.cuda.device_count()
     dev = local_rank % max(1, ndev)
-    plan = zs.SlabPlan(n, n, n, world)
+    plan = zs.SlabPlan(nx, ny, nz, world)
     i0, i1 = plan.input_range(rank)
-    ctx = pkg.Context(n, n, zs.slab_context_slices(plan, rank), device=dev, slab=True)   # no level buffers of its own
+    ctx = pkg.Context(nx, ny, zs.slab_context_slices(plan, rank), device=dev, slab=True)   # no level buffers of its own
     be = zs.HipBackend(pkg, ctx, torch)
     # the deferred patch-halo batch on a communicator of its own, so that it cannot queue in front of a level's halo
     dgroup = dist.new_group(ranks=list(range(world)), backend=dist.get_backend())
@@ -174,7 +209,8 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     dist.all_reduce(warm)
     dist.all_reduce(warm, group=dgroup)
     # the rank's input slices live in HBM before timing starts, as the volume of the per-GPU run does
-    slab = torch.from_numpy(pkg.synth_blobs(n, n, n, seed=12345)[i0:i1].copy()).to("cuda:%d" % dev)
+    # (only its own slices are generated: the same bits as those planes of the whole volume, without the 16 GB of config C5)
+    slab = torch.from_numpy(pkg.synth_blobs_slices(nx, ny, nz, i0, i1, seed=12345)).to("cuda:%d" % dev)
     torch.cuda.synchronize(dev)
 
     def barrier():
@@ -186,7 +222,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
         with be.stream_scope():
             ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup)
             ex.run(slab, i0)
-            recs, grp = ex.describe(desc_mode=args.desc, copy=False)   # views of the pinned download buffers
+            recs, grp = ex.describe(desc_mode=desc, copy=False)   # views of the pinned download buffers
             merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev, dtype=pkg.FEATURE_DTYPE)
         return ex, merged
 
@@ -211,7 +247,8 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
         nrec = 0 if merged is None else len(merged)
         res = {"value": round(nrec / (ms_per_step * 1e-3), 1), "unit": "keypoints/s", "ms_per_step": round(ms_per_step, 3),
                "scaling": "strong", "records": nrec,
-               "workload": "ONE %d^3 float32 blob-field volume cut into %d Z-slabs, full featExtract path, all octaves" % (n, world),
+               "workload": "ONE %s float32 blob-field volume cut into %d Z-slabs, full featExtract path (%s descriptor), all octaves"
+                           % (label, world, ["SIFT-rank", "BRIEF", "RRIEF", "NRRIEF"][desc]),
                "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
                "parallelism": "zslab%d: halo exchange with torch.distributed (%s), coarse octaves on rank 0" % (world, dist.get_backend()),
                "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"],
@@ -260,31 +297,97 @@ def zslab_child(args, world, expect, limit_s):
     the headline measurement with it: the child is killed as a process group at the limit, the parent job always ends
     normally."""
     import hashlib
-    import signal
     import socket
-    import subprocess
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
-            "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
-    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--size", str(args.size), "--desc", str(args.desc), "--mode", "zslab",
+           str(args.warmup), "--dims", "%d,%d,%d" % resolve_volume(args)[:3], "--desc", str(resolve_volume(args)[3]), "--mode", "zslab",
            "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)]
+    # End exactly the job started here (run_child): torch.distributed.run puts every rank in a session of its own, so the
+    # launcher's process group does not contain them -- their PIDs are noted first, the launcher is asked to stop (it
+    # terminates its ranks on SIGTERM), then whatever of it is still there is killed.
+    rc, so, se = run_child(cmd, child_env(), limit_s)
+    if rc is None:
+        return {"status": "no result within %d s (a rank failed or the exchange stalled); the child job was killed" % limit_s,
+                "exit_code": None, "stderr_tail": se[-600:]}
+    line = None
+    for l in so.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+    if rc != 0 or line is None:
+        return {"status": "the child job failed", "exit_code": rc, "stderr_tail": se[-600:]}
+    d = json.loads(line)
+    res = {"status": "ok", "exit_code": 0, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "scaling": "strong"}
+    res.update(d["config"])
+    if expect is not None:
+        res["same_bytes_as_single_gpu"] = bool(res.get("records_sha256") == hashlib.sha256(expect.tobytes()).hexdigest())
+    return res
+
+
+def zslab_c_main(args, pkg):
+    """`--mode zslab_c` (ONE process, no launcher): the Z-slab split of the volume driven from C over `--gpus` devices --
+    sift3d_zslab_create, sift3d_zslab_set_volume once, then sift3d_zslab_extract_resident per step: the driver
+    `featExtract -d0,1,..` ships, in its resident form (round-4 review item 1b).  Once with peer copies, once with RCCL
+    (ncclSend / ncclRecv in groups, two communicator sets).  One JSON line per transport as soon as it is measured, so that a
+    stall in the second leaves the first on record; the parent embeds them as `zslab_c`.  A step is bracketed by the call
+    itself: it returns when every device's streams have drained and the records are merged on the host."""
+    import hashlib
+    nx, ny, nz, desc, label = resolve_volume(args)
+    ndev = pkg.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py --mode zslab_c: no HIP device")
+    N = args.gpus
+    devices = list(range(N)) if ndev >= N else [i % ndev for i in range(N)]   # fewer devices than ranks: the one-GPU rehearsal
+    rehearsal_lib = os.environ.get("SIFT3D_BENCH_RCCL_LIBRARY")               # tests/rccl_shim on a one-GPU box
+    vol = pkg.synth_blobs(nx, ny, nz, seed=12345)
+    with pkg.ZSlab(nx, ny, nz, devices) as h:
+        h.set_volume(vol)
+        del vol
+        for name, tr in (("peer_copy", pkg.TRANSPORT_PEER_COPY), ("rccl", pkg.TRANSPORT_RCCL)):
+            res = {"transport_asked": name, "devices": devices}
+            try:
+                if tr == pkg.TRANSPORT_RCCL and rehearsal_lib:
+                    pkg.zslab_set_transport_library(rehearsal_lib)
+                    h.set_tuning(pkg.ZSLAB_DUPLICATE_RANKS, 1)
+                    res["rccl_library"] = rehearsal_lib
+                h.set_tuning(pkg.ZSLAB_TRANSPORT, tr)
+                for _ in range(max(1, args.warmup)):
+                    recs, st = h.extract_resident(desc_mode=desc, copy=False)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    recs, st = h.extract_resident(desc_mode=desc, copy=False)
+                ms = 1e3 * (time.perf_counter() - t0) / args.steps
+                res.update({"status": "ok", "value": round(len(recs) / (ms * 1e-3), 1), "unit": "keypoints/s", "ms_per_step": round(ms, 3),
+                            "scaling": "strong", "records": int(len(recs)), "records_sha256": hashlib.sha256(recs.tobytes()).hexdigest(),
+                            "n_ranks": st["n_ranks"], "sharded_octaves": st["sharded_octaves"],
+                            "transport": "rccl" if st["transport"] == pkg.TRANSPORT_RCCL else "peer_copy",
+                            "transport_fell_back": bool(st["transport_fell_back"]), "rccl_version": st["rccl_version"], "comm_sets": st["comm_sets"],
+                            "halo_bytes_critical": st["halo_bytes_critical"], "halo_bytes_hidden": st["halo_bytes_hidden"],
+                            "halo_bytes_deferred": st["halo_bytes_deferred"], "gather_bytes": st["gather_bytes"],
+                            "merge_ms": round(st["merge_ms"], 3), "resident_volume": bool(st["resident_volume"]),
+                            "workload": "ONE %s volume, %d Z-slabs, one process over devices %s (sift3d_zslab_extract_resident)" % (label, N, devices)})
+            except pkg.Sift3DError as e:
+                res.update({"status": "failed", "error": str(e)[-400:]})
+            print(json.dumps({"zslab_c": res}), flush=True)
+
+
+def run_child(cmd, env, limit_s):
+    """Start cmd in a session of its own, wait at most limit_s, end exactly what was started.  Returns (returncode or None,
+    stdout, stderr)."""
+    import signal
+    import subprocess
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
         so, se = p.communicate(timeout=limit_s)
+        return p.returncode, so, se
     except subprocess.TimeoutExpired:
-        # End exactly the job started here.  torch.distributed.run puts every rank in a session of its own, so the
-        # launcher's process group does not contain them: note their PIDs first, ask the launcher to stop (it terminates
-        # its ranks on SIGTERM), then kill whatever of it is still there.
         try:
             import psutil
             try:
                 kids = psutil.Process(p.pid).children(recursive=True)
             except psutil.NoSuchProcess:
                 kids = []
-        except ImportError:   # without psutil: the launcher's own termination of its ranks has to do
+        except ImportError:
             psutil, kids = None, []
         p.send_signal(signal.SIGTERM)
         try:
@@ -296,22 +399,36 @@ def zslab_child(args, world, expect, limit_s):
             try:
                 if k.is_running():
                     k.kill()
-            except psutil.NoSuchProcess:
+            except Exception:
                 pass
-        return {"status": "no result within %d s (a rank failed or the exchange stalled); the child job was killed" % limit_s,
-                "exit_code": None, "stderr_tail": se[-600:]}
-    line = None
+        return None, so, se
+
+
+def child_env():
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+            "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+    return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
+
+
+def zslab_c_child(args, world, expect, limit_s):
+    """rank 0, after the process group is gone: `bench.py --mode zslab_c --gpus N` as ONE child process (no launcher)."""
+    import hashlib
+    nx, ny, nz, desc, _ = resolve_volume(args)
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "zslab_c", "--gpus", str(world), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--dims", "%d,%d,%d" % (nx, ny, nz), "--desc", str(desc)]
+    rc, so, se = run_child(cmd, child_env(), limit_s)
+    out = {}
     for l in so.splitlines():
-        if l.startswith("{") and '"metric"' in l:
-            line = l
-    if p.returncode != 0 or line is None:
-        return {"status": "the child job failed", "exit_code": p.returncode, "stderr_tail": se[-600:]}
-    d = json.loads(line)
-    res = {"status": "ok", "exit_code": 0, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "scaling": "strong"}
-    res.update(d["config"])
-    if expect is not None:
-        res["same_bytes_as_single_gpu"] = bool(res.get("records_sha256") == hashlib.sha256(expect.tobytes()).hexdigest())
-    return res
+        if l.startswith("{") and '"zslab_c"' in l:
+            r = json.loads(l)["zslab_c"]
+            if expect is not None and r.get("records_sha256"):
+                r["same_bytes_as_single_gpu"] = bool(r["records_sha256"] == hashlib.sha256(expect.tobytes()).hexdigest())
+            out[r.pop("transport_asked")] = r
+    out["status"] = "ok" if rc == 0 else ("no result within %d s; the child was killed" % limit_s if rc is None else "the child failed")
+    out["exit_code"] = rc
+    if rc != 0:
+        out["stderr_tail"] = se[-600:]
+    return out
 
 
 def main():
@@ -320,14 +437,20 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume (512 = the BASELINE metric)")
+    ap.add_argument("--dims", default=None, metavar="NX,NY,NZ", help="a volume that is not a cube (overrides --size)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="a BASELINE.json configuration instead of the metric volume: c4 = 1024 x 1024 x 512 (start it with --gpus 4), "
+                         "c5 = 2048 x 2048 x 1024 with the NRRIEF descriptor (--gpus 8); N > 1 only")
     ap.add_argument("--cpu-sample", type=int, default=512,
                     help="edge of the CPU-baseline volume (0 = skip); 512 = the metric volume itself, about 25 s on one core")
-    ap.add_argument("--desc", type=int, default=0, help="0 SIFT-rank, 1 BRIEF, 2 RRIEF, 3 NRRIEF")
-    ap.add_argument("--mode", default="volumes", choices=["volumes", "zslab"],
-                    help="N > 1: 'volumes' = one volume per GPU (default, weak scaling; the Z-slab run of ONE volume is "
-                         "attached as `zslab`); 'zslab' = only the Z-slab run (strong scaling)")
-    ap.add_argument("--zslab-limit", type=int, default=120,
-                    help="N > 1, mode volumes: seconds the attached Z-slab child job may take (0 = do not attach it)")
+    ap.add_argument("--desc", type=int, default=None, help="0 SIFT-rank (default), 1 BRIEF, 2 RRIEF, 3 NRRIEF")
+    ap.add_argument("--mode", default="auto", choices=["auto", "volumes", "zslab", "zslab_c"],
+                    help="N > 1: 'auto' (default) = the ranks' own volumes first (weak scaling, `volumes_value`), then the Z-slab "
+                         "split of ONE volume as a child job = the line's `value` (strong scaling), then the C driver's resident "
+                         "form (`zslab_c`); 'volumes' = only the first; 'zslab' = only the Z-slab run (under a launcher); "
+                         "'zslab_c' = only the one-process C driver (no launcher)")
+    ap.add_argument("--zslab-limit", type=int, default=180,
+                    help="N > 1: seconds each of the two Z-slab child jobs may take")
     ap.add_argument("--phase-limit", type=int, default=300,
                     help="N > 1: seconds any one phase of a rank (set-up, warm-up, the timed steps, a reduction) may take before "
                          "the rank ends the job with exit code 3 and the phase name (0 = no limit)")
@@ -339,6 +462,11 @@ def main():
                          "seen and leave -- 'fail': rank 1 exits with code 7 instead (tests of the self-launch path)")
     args = ap.parse_args()
 
+    if args.mode == "zslab_c":   # one process over all devices: no launcher, no torch
+        pkg = importlib.import_module("3d_sift_cuda_amd")
+        return zslab_c_main(args, pkg)
+    if args.config and args.gpus == 1:
+        raise SystemExit("bench.py: --config %s is a multi-GPU configuration (use --gpus N); on one GPU use --dims" % args.config)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))   # before torch is imported: this process never touches the GPU
 
@@ -392,18 +520,36 @@ def main():
     pkg = importlib.import_module("3d_sift_cuda_amd")
     if not os.path.exists(pkg.LIB_HIP):
         raise SystemExit("libsift3d_hip.so missing: run python __graft_entry__.py (no CPU fallback)")
-    n = args.size
+    nx, ny, nz, desc, vol_label = resolve_volume(args)
+    args.desc = desc
+    n = nx   # (the roofline bookkeeping below is written for the cubic metric volume; other shapes only fill the generic fields)
+    nvox = nx * ny * nz
     if args.mode == "zslab" and world > 1:
         return zslab_main(args, pkg, torch, dist, rank, world, local_rank, phase)
+    # The ranks' own volumes (weak scaling).  For the large configurations (--config c4 / c5) only rank 0 extracts the whole
+    # volume -- the single-GPU records the Z-slab run's merged records are compared with -- and the others wait at the barrier.
+    replicas = args.config is None
+    if not replicas and rank != 0:
+        phase("volumes: waiting for rank 0's single-GPU run")
+        dist.barrier(); dist.barrier()   # rank 0's barriers around its timed steps
+        z = torch.zeros(1, dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda:%d" % local_rank)
+        dist.all_reduce(z, op=dist.ReduceOp.MAX)   # elapsed
+        dist.all_reduce(z, op=dist.ReduceOp.SUM)   # records
+        phase("volumes: leaving the process group")
+        dist.barrier()
+        dist.destroy_process_group()
+        if wd is not None:
+            wd.done()
+        return
     phase("volumes: synthetic volume, context, upload")
-    vol = pkg.synth_blobs(n, n, n, seed=12345 + rank)
-    ctx = pkg.Context(n, n, n, device=local_rank)
+    vol = pkg.synth_blobs(nx, ny, nz, seed=12345 + (rank if replicas else 0))
+    ctx = pkg.Context(nx, ny, nz, device=local_rank)
     for kv in args.tune:
         k, v = kv.split("=")
         ctx.set_tuning(getattr(pkg, "TUNE_" + k.upper()), int(v))
     dvol = torch.from_numpy(vol).to("cuda:%d" % local_rank)   # the input lives in HBM before timing starts
     torch.cuda.synchronize(local_rank)
-    ctx.set_volume_dev(dvol.data_ptr(), n, n, n)
+    ctx.set_volume_dev(dvol.data_ptr(), nx, ny, nz)
     ctx.sync()
 
     def barrier():
@@ -470,7 +616,7 @@ def main():
     phase("volumes: result line (rank 0: breakdown, CPU baseline)", 0)
 
     if rank == 0:
-        nfullvox = ((n + 3) // 4 * 4) * n * n   # rows are padded to whole 16-byte vectors inside the pipeline
+        nfullvox = ((nx + 3) // 4 * 4) * ny * nz   # rows are padded to whole 16-byte vectors inside the pipeline
         log = np.concatenate(logs)            # timed region: the blur launches on the n^3 volume
         full = np.concatenate(full_logs)      # two extra steps with every launch bracketed (per-stage breakdown)
         nfull = len(full_logs)
@@ -494,13 +640,15 @@ def main():
                         "(the %d launches per volume at %d^3: initial blur + the levels stored in full -- L1..L4 by default, the "
                         "17-tap level L5 only exists around the candidates of D3 (extrema_validate_lazy_kernel); two rows per "
                         "thread, two planes of prefetch, one workgroup per CU)" % (len(sel) // args.steps, n))
+            if not (nx == ny == nz):
+                dom_name = dom_name.replace("%d^3" % n, vol_label)
             dom_all = full[full["stage"] == fused_id]
             per_inst = []
             for taps in sorted(set(int(t) for t in sel["ntaps"])):
                 for dogflag in (False, True):
                     q = sel[(sel["ntaps"] == taps) & ((sel["alg_bytes"] > 8.5 * sel["nvox"]) == dogflag)]
                     if len(q):
-                        per_inst.append({"taps": taps, "alg_bytes_per_voxel": round(float(q["alg_bytes"][0]) / n ** 3, 1),
+                        per_inst.append({"taps": taps, "alg_bytes_per_voxel": round(float(q["alg_bytes"][0]) / nvox, 1),
                                          "launches": int(len(q)), "avg_launch_ms": round(float(q["ms"].mean()), 4),
                                          "GBs": round(float(q["alg_bytes"].sum()) / (float(q["ms"].sum()) * 1e-3) / 1e9, 1)})
             accounting = ("fused x+y+z+DoG launches: compulsory bytes only -- read the level once, write what is kept (level and "
@@ -527,7 +675,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", PMC_TABLE)
         if not os.path.exists(pmc):
             traffic_note = "no PMC table profiles/%s" % PMC_TABLE
-        elif n != 512 or not per_inst:
+        elif (nx, ny, nz) != (512, 512, 512) or not per_inst:
             traffic_note = "the PMC table holds 512^3 launches of the fused kernels only"
         else:
             try:   # PMC bytes of every instantiation (keys "blur_fused_ring_kernel<R, ...>"), averaged over the launches
@@ -548,7 +696,7 @@ def main():
                     if exact:
                         w = tab[sorted(exact)[0]]["hbm_bytes_per_launch_512"]
                     elif twin:   # a level-only launch measured through its level + DoG twin: 4 B/voxel less written
-                        w = tab[sorted(twin)[0]]["hbm_bytes_per_launch_512"] - 4.0 * n ** 3
+                        w = tab[sorted(twin)[0]]["hbm_bytes_per_launch_512"] - 4.0 * nvox
                     else:
                         raise LookupError("no PMC entry for %d taps" % pi["taps"])
                     tot += w * pi["launches"]; cnt += pi["launches"]
@@ -560,10 +708,10 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": dom_name,
-                    "launch": "%d^3 volume (octave 0)" % n, "launches": int(len(sel)),
+                    "launch": "%s volume (octave 0)" % vol_label, "launches": int(len(sel)),
                     "avg_launch_ms": round(big_ms / max(1, len(sel)), 4),
                     "alg_bytes_per_launch": big_bytes / max(1, len(sel)),
-                    "alg_bytes_per_voxel": round(big_bytes / max(1, len(sel)) / n ** 3, 2),
+                    "alg_bytes_per_voxel": round(big_bytes / max(1, len(sel)) / nvox, 2),
                     "accounting": accounting,
                     "per_instantiation": per_inst,
                     "all_launches": {"launches": int(len(dom_all)), "avg_launch_ms": round(float(dom_all["ms"].mean()), 4),
@@ -608,7 +756,7 @@ def main():
         # the north star names: 24N per blur + 8N per fused DoG = 176N for octave 0, 152N for every later octave (N / 8 each):
         # 197.7N = 26.5 GB at 512^3, "70 % target => <= 4.7 ms for Gaussian + DoG".  The same time priced that way, for
         # comparison with that target only (roofline.* and pyramid.frac_of_peak stay on the compulsory bytes of what is launched):
-        n_vox = float(n) ** 3
+        n_vox = float(nvox)
         b8d = n_vox * (176.0 + 152.0 / 7.0)
         pyramid["survey_8d_accounting"] = {
             "alg_bytes_per_step": b8d, "target_ms_at_70_percent_of_peak": round(b8d / (0.7 * HBM_PEAK_GBS * 1e9) * 1e3, 3),
@@ -625,8 +773,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d^3 float32 blob-field volume per GPU, full featExtract path (pyramid + DoG + extrema + keypoints + %s descriptor), all octaves"
-                                   % (n, ["SIFT-rank", "BRIEF", "RRIEF", "NRRIEF"][args.desc]),
+            "config": {"workload": "%s float32 blob-field volume per GPU, full featExtract path (pyramid + DoG + extrema + keypoints + %s descriptor), all octaves"
+                                   % (vol_label, ["SIFT-rank", "BRIEF", "RRIEF", "NRRIEF"][args.desc]),
                        "records_per_volume": int(nrec), "octaves": int(tim["n_octaves"]), "extrema": int(tim["n_extrema"]),
                        "keypoints": int(tim["n_keypoints"]),
                        "parallelism": "1 volume per GPU (independent volumes, no collective)" if world > 1 else "single GPU",
@@ -683,17 +831,39 @@ def main():
         dist.destroy_process_group()   # the measurement is complete; ranks other than 0 are done and leave the GPUs
     if wd is not None:
         wd.done()
-    if rank == 0:
-        if world > 1 and args.zslab_limit > 0:
-            torch.cuda.empty_cache()
-            out["zslab"] = zslab_child(args, world, expect, args.zslab_limit)
-            # the strong-scaling figures of the same line, as top-level keys (documented in the module docstring): ONE volume
-            # over all N GPUs -- what BASELINE.json's "1/2/4/8-GPU Z-slab scaling" asks for; null when the child job failed
-            z = out["zslab"]
-            out["zslab_value"] = z.get("value")
-            out["zslab_ms_per_step"] = z.get("ms_per_step")
-            out["zslab_same_bytes_as_single_gpu"] = z.get("same_bytes_as_single_gpu")
+    if rank != 0:
+        return
+    if world == 1 or args.mode == "volumes":
         print(json.dumps(out), flush=True)
+        return
+    # ---- N > 1: the line's value is the Z-slab split of ONE volume over the N GPUs (strong scaling) ----
+    torch.cuda.empty_cache()
+    vol_out = {k: out[k] for k in ("value", "ms_per_step", "scaling")}
+    z = zslab_child(args, world, expect, args.zslab_limit)
+    zc = zslab_c_child(args, world, expect, args.zslab_limit)
+    ok = z.get("status") == "ok" and z.get("value") is not None
+    out["volumes_value"] = vol_out["value"] if replicas else None
+    out["volumes_ms_per_step"] = vol_out["ms_per_step"]
+    out["volumes_scaling"] = "weak" if replicas else None
+    out["volumes_note"] = ("every rank extracting its own %s volume, barrier to barrier, max over ranks (rounds 1-4's headline)" % vol_label
+                           if replicas else "rank 0 alone extracting the whole %s volume: the single-GPU time and records the Z-slab run is "
+                                            "compared with (no replica leg for --config runs)" % vol_label)
+    out["value"] = z.get("value") if ok else None
+    out["ms_per_step"] = z.get("ms_per_step") if ok else None
+    out["scaling"] = "strong"
+    out["same_bytes_as_single_gpu"] = z.get("same_bytes_as_single_gpu")
+    out["speedup_vs_single_gpu"] = round(vol_out["ms_per_step"] / z["ms_per_step"], 3) if ok and z.get("ms_per_step") else None
+    out["config"]["workload"] = z.get("workload") or ("ONE %s float32 blob-field volume cut into %d Z-slabs (the child job failed: see `zslab`)" % (vol_label, world))
+    out["config"]["parallelism"] = z.get("parallelism") or "zslab%d" % world
+    out["config"]["single_gpu_workload"] = "%s volume on one GPU (`volumes_*`; `roofline`, `pyramid`, `stages` are rank 0's single-GPU kernels)" % vol_label
+    out["zslab"] = z
+    out["zslab_c"] = zc
+    # (kept for readers of the rounds 3-4 line)
+    out["zslab_value"], out["zslab_ms_per_step"], out["zslab_same_bytes_as_single_gpu"] = z.get("value"), z.get("ms_per_step"), z.get("same_bytes_as_single_gpu")
+    print(json.dumps(out), flush=True)
+    if not ok:
+        sys.stderr.write("bench.py: the Z-slab job did not produce a result (%s): value is null, exit code 5\n" % z.get("status"))
+        sys.exit(5)
 
 
 if __name__ == "__main__":

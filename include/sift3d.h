@@ -28,6 +28,14 @@
 extern "C" {
 #endif
 
+/* Layout version of the structures this header passes by pointer (sift3d_zslab_stats, sift3d_timings, sift3d_feature, ...).
+ * The library writes WHOLE structures through the caller's pointers, so a binding compiled against another layout would be
+ * overrun: a binding checks sift3d_abi_version() == SIFT3D_ABI_VERSION once, when it loads the library (the in-tree ctypes
+ * mirror and featExtract do).  5: sift3d_zslab_stats gained comm_sets, resident_volume, merge_ms (round 5); 4: transport,
+ * transport_fell_back, rccl_version (round 4). */
+#define SIFT3D_ABI_VERSION 5
+int sift3d_abi_version(void);
+
 #define SIFT3D_DESC_LEN 64
 #define SIFT3D_INFO_MIN0MAX1 0x00000010u /* R/src_common/MultiScale.h:28 */
 #define SIFT3D_INFO_REORIENT 0x00000020u /* R/src_common/MultiScale.h:30 */
@@ -307,7 +315,10 @@ typedef struct {
     int32_t transport_fell_back;  /* 1: RCCL was asked for, but a device is listed more than once (not something RCCL ranks can
                                    * be): peer copies were used */
     int32_t rccl_version;         /* ncclGetVersion() of the library that was loaded (0 with peer copies) */
+    int32_t comm_sets;            /* RCCL communicator sets in use: 2, or 1 with SIFT3D_ZSLAB_SERIAL_CHANNELS (0 with peer copies) */
+    int32_t resident_volume;      /* 1: the input slices were on the devices already (sift3d_zslab_extract_resident): no upload in wall_ms */
     int32_t reserved;
+    double merge_ms;              /* host time of the merge of the ranks' records into the single-GPU order (part of wall_ms) */
 } sift3d_zslab_stats;
 /* How a block of slices travels from one rank's device to another's (sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, v),
  * sift3d_extract_zslab_over): peer copies -- hipMemcpyPeerAsync on the receiver's stream behind the sender's event, the
@@ -319,6 +330,16 @@ typedef struct {
 #define SIFT3D_ZSLAB_TRANSPORT 1000
 #define SIFT3D_TRANSPORT_PEER_COPY 0
 #define SIFT3D_TRANSPORT_RCCL 1
+/* sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_SERIAL_CHANNELS, 1): RCCL with ONE communicator set -- the deferred patch halos go
+ * through the communicators of the per-level halos and queue behind them (RCCL orders a communicator's operations).  Slower
+ * by design (3 x 24 deferred slices in front of the next level's 8); it exists as the fallback to try in the same lease if two
+ * communicators per device ever stall each other on real links.  Results are the same bytes. */
+#define SIFT3D_ZSLAB_SERIAL_CHANNELS 1001
+/* sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_DUPLICATE_RANKS, 1): a device listed more than once is handed to ncclCommInitAll as
+ * it is instead of falling back to peer copies.  Real RCCL refuses such a list (SIFT3D_ERR_COMM); the rehearsal library of
+ * tests/rccl_shim (given to sift3d_zslab_set_transport_library) accepts it, which is how the RCCL half of the exchange --
+ * group pairing, stream order, the two communicator sets -- runs with 2 .. 8 ranks on a one-GPU box. */
+#define SIFT3D_ZSLAB_DUPLICATE_RANKS 1002
 void sift3d_zslab_set_transport_library(const char *path);
 int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
                          float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,
@@ -336,6 +357,13 @@ int sift3d_zslab_extract(sift3d_zslab *h, const float *vol, float initial_image_
                          float size_factor, sift3d_feature **out, int64_t *n_out, sift3d_zslab_stats *stats, char *err,
                          int64_t err_len);
 void sift3d_zslab_destroy(sift3d_zslab *h);
+/* The resident form (round 5) -- what sift3d_set_volume + sift3d_extract_view are to one device: sift3d_zslab_set_volume
+ * cuts the host volume into the ranks' input slices (slab +- 16) and uploads them once; sift3d_zslab_extract_resident then
+ * runs any number of extractions from HBM.  *view is the handle's own host buffer with the merged records (single-GPU order,
+ * single-GPU bytes), valid until the handle's next call; do not free it.  stats->wall_ms then holds no upload. */
+int sift3d_zslab_set_volume(sift3d_zslab *h, const float *vol, char *err, int64_t err_len);
+int sift3d_zslab_extract_resident(sift3d_zslab *h, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
+                                  const sift3d_feature **view, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len);
 /* sift3d_set_tuning on every slab's context (and the driver's own use of SIFT3D_TUNE_LAZY_LEVELS) */
 int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value);
 
