@@ -129,6 +129,9 @@ def hip_lib():
     _sig(L.sift3d_set_volume, I, P, P, I64, I64, I64)
     _sig(L.sift3d_set_volume_dev, I, P, P, I64, I64, I64)
     _sig(L.sift3d_set_volume_resized, I, P, P, I64, I64, I64, I)
+    _sig(L.sift3d_set_volume_begin, I, P, I64, I64, I64, I)
+    _sig(L.sift3d_set_volume_planes, I, P, P, I64, I64)
+    _sig(L.sift3d_set_volume_end, I, P)
     _sig(L.sift3d_detect, I, P, F, P, P)
     _sig(L.sift3d_extract, I, P, F, I, F, F, P, P)
     _sig(L.sift3d_extract_view, I, P, F, I, F, F, P, P)
@@ -581,6 +584,16 @@ class Context:
         vol = _f32(vol)
         nz, ny, nx = vol.shape
         self._chk(self._L.sift3d_set_volume_resized(self._h, vol.ctypes.data, nx, ny, nz, int(resize)), "sift3d_set_volume_resized")
+
+    def set_volume_in_runs(self, vol, runs, resize=0):
+        """sift3d_set_volume_begin / _planes / _end: the volume handed over in the given runs of planes [(z0, n), ...]."""
+        vol = _f32(vol)
+        nz, ny, nx = vol.shape
+        self._chk(self._L.sift3d_set_volume_begin(self._h, nx, ny, nz, int(resize)), "sift3d_set_volume_begin")
+        for z0, n in runs:
+            part = vol[z0:z0 + n]
+            self._chk(self._L.sift3d_set_volume_planes(self._h, part.ctypes.data, int(z0), int(n)), "sift3d_set_volume_planes")
+        self._chk(self._L.sift3d_set_volume_end(self._h), "sift3d_set_volume_end")
 
     def set_volume_dev(self, dev_ptr, nx, ny, nz):
         self._chk(self._L.sift3d_set_volume_dev(self._h, C.c_void_p(int(dev_ptr)), nx, ny, nz), "sift3d_set_volume_dev")

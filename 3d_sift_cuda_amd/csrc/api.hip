@@ -885,6 +885,20 @@ static int cand_replay(sift3d_ctx *c)
     return SIFT3D_OK;
 }
 
+/* An own-level list was cut short (high_water = the length it would have needed): from now on the lists of this context are
+ * sized for the worst case of a level, and the first one is grown to the mark.  Nothing may be running on the context. */
+static int surv_make_room(sift3d_ctx *c, unsigned long long high_water)
+{
+    c->surv_div = 1;
+    if ((int64_t)high_water > c->surv_cap) {
+        hipFree(c->surv);
+        c->surv = nullptr;
+        c->surv_cap = (int64_t)high_water + (int64_t)high_water / 4 + 4096;
+        HIPCHK(c, hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap));
+    }
+    return SIFT3D_OK;
+}
+
 /* The count of validated extrema comes back in two steps so that a driver with several contexts can queue the read-back
  * on all of them before it waits for the first: cand_count_queue (asynchronous), cand_finalize (waits, replays the extrema
  * launches into bigger lists if one overflowed, sorts). */
@@ -908,14 +922,9 @@ int cand_finalize(sift3d_ctx *c, int64_t *count_out)
         c->count_queued = false;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (cnt[2] > 0) { /* an own-level list was cut short: make room and redo the extrema launches */
-            c->surv_div = 1;
-            if ((int64_t)cnt[2] > c->surv_cap) {
-                hipFree(c->surv);
-                c->surv = nullptr;
-                c->surv_cap = (int64_t)cnt[2] + (int64_t)cnt[2] / 4 + 4096;
-                HIPCHK(c, hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap));
-            }
-            int rc = cand_replay(c);
+            int rc = surv_make_room(c, cnt[2]);
+            if (rc) return rc;
+            rc = cand_replay(c);
             if (rc) return rc;
             continue;
         }
@@ -1000,6 +1009,23 @@ static int ensure_level_buffer(sift3d_ctx *c, float **buf)
 
 /* The pipeline's copy of the volume has its rows padded to whole 16-byte vectors (octave_list).  When the padded
  * geometry changes, every level buffer is cleared once: the pad columns are never written afterwards. */
+/* before a volume of this shape is copied into c->vol: the pad columns of pitched rows cleared (once per geometry) */
+static int load_volume_prepare(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz)
+{
+    const int64_t xp = pitch_of(nx);
+    if (xp != nx && (c->pad_nx != nx || c->pad_ny != ny || c->pad_nz != nz)) {
+        for (int i = 0; i < 6; i++)
+            if (c->L[i]) HIPCHK(c, hipMemsetAsync(c->L[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
+        for (int i = 0; i < 5; i++)
+            if (c->D[i]) HIPCHK(c, hipMemsetAsync(c->D[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->vol, 0, sizeof(float) * (size_t)c->capN, c->stream));
+        c->pad_nx = nx; c->pad_ny = ny; c->pad_nz = nz;
+    }
+    if (xp == nx) c->pad_nx = 0; /* dense rows overwrite what would be pad columns of another geometry */
+    return SIFT3D_OK;
+}
+
 static int load_volume(sift3d_ctx *c, const float *src, bool from_host, int64_t nx, int64_t ny, int64_t nz)
 {
     const int64_t xp = pitch_of(nx);
@@ -1078,6 +1104,76 @@ extern "C" int sift3d_set_volume_resized(sift3d_ctx *c, const float *vol, int64_
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller may free vol */
     c->nx = ox; c->ny = oy; c->nz = oz;
+    c->has_volume = true;
+    return SIFT3D_OK;
+}
+
+/* The volume in runs of whole z planes (round 5: featExtract uploads what it has read while the rest of the file is still
+ * being read or inflated).  begin: the shape that will arrive (and resize as in sift3d_set_volume_resized); planes: planes
+ * [z0, z0 + n) from host memory, queued on the context's stream -- any order, every plane exactly once; end: the resize
+ * launch if one was asked for, then waits until the volume is resident.  Equivalent to sift3d_set_volume[_resized] of the
+ * assembled volume. */
+extern "C" int sift3d_set_volume_begin(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz, int resize)
+{
+    NEED_LEVELS(c);
+    if (!c || nx < 1 || ny < 1 || nz < 1 || nx * ny * nz > c->capN) return set_err(c, SIFT3D_ERR_ARG, "set_volume_begin: bad shape");
+    if (resize != 0 && (nx < 2 || ny < 2 || nz < 2)) return set_err(c, SIFT3D_ERR_ARG, "set_volume_begin: bad shape for a resize");
+    const int64_t ox = resize > 0 ? 2 * nx : (resize < 0 ? nx / 2 : nx), oy = resize > 0 ? 2 * ny : (resize < 0 ? ny / 2 : ny),
+                  oz = resize > 0 ? 2 * nz : (resize < 0 ? nz / 2 : nz);
+    int rc = check_shape(c, ox, oy, oz);
+    if (rc) return rc;
+    if (oz <= 1) return set_err(c, SIFT3D_ERR_ARG, "Could not read volume (z <= 1)");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->has_volume = false;
+    if (resize != 0) {
+        rc = ensure_T(c, ox * oy * oz > nx * ny * nz ? ox * oy * oz : nx * ny * nz);
+        if (rc) return rc;
+    } else {
+        rc = load_volume_prepare(c, nx, ny, nz);
+        if (rc) return rc;
+    }
+    c->up.open = true;
+    c->up.nx = nx; c->up.ny = ny; c->up.nz = nz;
+    c->up.got = 0;
+    c->up.resize = resize;
+    return SIFT3D_OK;
+}
+
+extern "C" int sift3d_set_volume_planes(sift3d_ctx *c, const float *planes, int64_t z0, int64_t n)
+{
+    if (!c || !c->up.open) return set_err(c, SIFT3D_ERR_ARG, "set_volume_planes without set_volume_begin");
+    if (!planes || z0 < 0 || n < 1 || z0 + n > c->up.nz) return set_err(c, SIFT3D_ERR_ARG, "set_volume_planes: planes [%lld, %lld) of %lld", (long long)z0, (long long)(z0 + n), (long long)c->up.nz);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t nx = c->up.nx, ny = c->up.ny, xp = pitch_of(nx);
+    if (c->up.resize != 0) {
+        HIPCHK(c, hipMemcpyAsync(c->T[0] + z0 * nx * ny, planes, sizeof(float) * (size_t)(n * nx * ny), hipMemcpyHostToDevice, c->stream));
+    } else if (xp == nx) {
+        HIPCHK(c, hipMemcpyAsync(c->vol + z0 * nx * ny, planes, sizeof(float) * (size_t)(n * nx * ny), hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpy2DAsync(c->vol + z0 * xp * ny, sizeof(float) * (size_t)xp, planes, sizeof(float) * (size_t)nx, sizeof(float) * (size_t)nx,
+                                   (size_t)(ny * n), hipMemcpyHostToDevice, c->stream));
+    }
+    c->up.got += n;
+    return SIFT3D_OK;
+}
+
+extern "C" int sift3d_set_volume_end(sift3d_ctx *c)
+{
+    if (!c || !c->up.open) return set_err(c, SIFT3D_ERR_ARG, "set_volume_end without set_volume_begin");
+    c->up.open = false;
+    if (c->up.got != c->up.nz) return set_err(c, SIFT3D_ERR_ARG, "set_volume_end: %lld of %lld planes arrived", (long long)c->up.got, (long long)c->up.nz);
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t nx = c->up.nx, ny = c->up.ny, nz = c->up.nz;
+    if (c->up.resize != 0) {
+        const int64_t ox = c->up.resize > 0 ? 2 * nx : nx / 2, oy = c->up.resize > 0 ? 2 * ny : ny / 2, oz = c->up.resize > 0 ? 2 * nz : nz / 2;
+        if (c->up.resize > 0) HIPCHK(c, sift3d_launch_double_size(c->stream, c->T[0], nx, ny, nz, c->T[1]));
+        else HIPCHK(c, sift3d_launch_halve_size(c->stream, c->T[0], nx, ny, nz, c->T[1]));
+        const int rc = load_volume(c, c->T[1], false, ox, oy, oz);
+        if (rc) return rc;
+        nx = ox; ny = oy; nz = oz;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller may free its planes */
+    c->nx = nx; c->ny = ny; c->nz = nz;
     c->has_volume = true;
     return SIFT3D_OK;
 }
@@ -1459,17 +1555,24 @@ static int finish_split_tail(sift3d_ctx *c, const std::vector<sift3d_level> &lev
     const int64_t capA = c->cand_split_at, capB = c->cand_cap - capA;
     hipStream_t ks = c->kp_stream;
     float taps3[SIFT3D_MAX_TAPS];
-    auto fall_back = [&]() -> int {
+    /* overflow_mark: the own-level overflow word that triggered the fall-back (0: it was a validated-extrema list or a
+     * per-keypoint buffer).  The remedy cand_finalize would apply after ANOTHER overflowing pass is applied here, before the
+     * replay (advisor finding, round 4: three extrema passes instead of two on dense volumes). */
+    auto fall_back = [&](unsigned long long overflow_mark) -> int {
         HIPCHK(c, hipStreamSynchronize(ks));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        return cand_replay(c); /* one list again; cand_finalize grows whatever was too small */
+        if (overflow_mark > 0) {
+            const int rc = surv_make_room(c, overflow_mark);
+            if (rc) return rc;
+        }
+        return cand_replay(c); /* one list again; cand_finalize grows whatever else was too small */
     };
     /* the second part's count (and the first part's once more, with the overflow mark as it stands at the end) */
     h_split[3] = h_split[5] = h_split[7] = 0;
     HIPCHK(c, hipMemcpyAsync(h_split + 3, c->d_count, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev_split[2]));
     const int64_t nA = (int64_t)h_split[0];
-    if (h_split[2] > 0 || nA > capA) return fall_back();
+    if (h_split[2] > 0 || nA > capA) return fall_back(h_split[2]);
     int rc = describe_begin(c, levels.size(), taps3);
     if (rc) return rc;
     /* room for the second part as well: it is rarely more than a fiftieth of the first */
@@ -1491,7 +1594,7 @@ static int finish_split_tail(sift3d_ctx *c, const std::vector<sift3d_level> &lev
     /* the coarse octaves: the main stream holds nothing else */
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int64_t nB = (int64_t)h_split[7];
-    if (h_split[5] > 0 || nB > capB || nA + nB > c->kps_cap || (int64_t)h_split[3] != nA) return fall_back();
+    if (h_split[5] > 0 || nB > capB || nA + nB > c->kps_cap || (int64_t)h_split[3] != nA) return fall_back(h_split[5]);
     if (nB > 0) {
         HIPCHK(c, sift3d_sort_candidates(ks, c->sort_tmp, c->sort_tmp_bytes, c->keys_a + capA, c->keys_b + nA, c->vals_a + capA, c->vals_b + nA, nB));
         rc = describe_queue_chunk(c, nch++, nA, nA + nB, ks, taps3);

@@ -89,12 +89,30 @@ static size_t dtype_size(int dt)
     }
 }
 
-int nifti_min_read(const char *path, nifti_min_image *img)
+struct nifti_min_stream {
+    gzFile df;
+    int datatype, sw;
+    size_t es, left; /* bytes per stored voxel; voxels not yet read */
+    unsigned char *raw;
+    size_t raw_cap;
+};
+
+void nifti_min_close(nifti_min_stream *s)
+{
+    if (!s) return;
+    if (s->df) gzclose(s->df);
+    free(s->raw);
+    free(s);
+}
+
+int nifti_min_open(const char *path, nifti_min_image *img, nifti_min_stream **out)
 {
     unsigned char h[348];
     memset(img, 0, sizeof(*img));
+    *out = 0;
     gzFile f = gzopen(path, "rb"); /* gzopen reads plain files transparently */
     if (!f) return -1;
+    gzbuffer(f, 1u << 20);
     if (gzread(f, h, 348) != 348) {
         gzclose(f);
         return -1;
@@ -191,36 +209,51 @@ int nifti_min_read(const char *path, nifti_min_image *img)
         }
         free(ip);
         if (!df) return -2;
+        gzbuffer(df, 1u << 20);
         if (vox_offset > 0) gzseek(df, (long)vox_offset, SEEK_SET);
     }
-    /* float32 voxels are read straight into the result; every other type goes through a raw buffer and a cast */
-    const int direct = img->datatype == 16;
-    img->data = (float *)malloc(nvox * sizeof(float));
-    unsigned char *raw = direct ? (unsigned char *)img->data : (unsigned char *)malloc(nvox * es);
-    if (!raw || !img->data) {
-        if (!direct) free(raw);
-        free(img->data);
-        img->data = 0;
+    nifti_min_stream *s = (nifti_min_stream *)calloc(1, sizeof *s);
+    if (!s) {
         gzclose(df);
         return -4;
     }
-    size_t got = 0, want = nvox * es;
+    s->df = df;
+    s->datatype = img->datatype;
+    s->sw = sw;
+    s->es = es;
+    s->left = nvox;
+    *out = s;
+    return 0;
+}
+
+/* the next nvox voxels of the file, cast to float with a plain C cast (featExtract.cpp:18-77) */
+int nifti_min_read_voxels(nifti_min_stream *s, float *dst, size_t nvox)
+{
+    if (!s || !dst || nvox > s->left) return -2;
+    /* float32 voxels are read straight into the result; every other type goes through a raw buffer and a cast */
+    const int direct = s->datatype == 16;
+    unsigned char *raw = (unsigned char *)dst;
+    if (!direct) {
+        if (s->raw_cap < nvox * s->es) {
+            free(s->raw);
+            s->raw = (unsigned char *)malloc(nvox * s->es);
+            s->raw_cap = s->raw ? nvox * s->es : 0;
+            if (!s->raw) return -4;
+        }
+        raw = s->raw;
+    }
+    size_t got = 0, want = nvox * s->es;
     while (got < want) {
         unsigned chunk = (want - got) > (1u << 30) ? (1u << 30) : (unsigned)(want - got);
-        int r = gzread(df, raw + got, chunk);
+        int r = gzread(s->df, raw + got, chunk);
         if (r <= 0) break;
         got += (size_t)r;
     }
-    gzclose(df);
-    if (got != want) {
-        if (!direct) free(raw);
-        free(img->data);
-        img->data = 0;
-        return -2;
-    }
-    if (sw && es > 1) swap_bytes(raw, es, nvox);
-    float *o = img->data;
-    switch (img->datatype) {
+    if (got != want) return -2;
+    s->left -= nvox;
+    if (s->sw && s->es > 1) swap_bytes(raw, s->es, nvox);
+    float *o = dst;
+    switch (s->datatype) {
     case 2: for (size_t i = 0; i < nvox; i++) o[i] = (float)((unsigned char *)raw)[i]; break;
     case 256: for (size_t i = 0; i < nvox; i++) o[i] = (float)((signed char *)raw)[i]; break; /* DT_INT8: plain char may be unsigned */
     case 512: for (size_t i = 0; i < nvox; i++) o[i] = (float)((unsigned short *)raw)[i]; break;
@@ -230,7 +263,28 @@ int nifti_min_read(const char *path, nifti_min_image *img)
     case 16: break; /* already in place */
     case 64: for (size_t i = 0; i < nvox; i++) o[i] = (float)((double *)raw)[i]; break;
     }
-    if (!direct) free(raw);
+    return 0;
+}
+
+int nifti_min_read(const char *path, nifti_min_image *img)
+{
+    nifti_min_stream *s = 0;
+    int rc = nifti_min_open(path, img, &s);
+    if (rc < 0) return rc;
+    const size_t nvox = (size_t)img->nx * (size_t)img->ny * (size_t)img->nz * (size_t)img->nt;
+    img->data = (float *)malloc(nvox * sizeof(float));
+    if (!img->data) {
+        nifti_min_close(s);
+        return -4;
+    }
+    const size_t step = (size_t)1 << 24; /* 16 M voxels a time: the raw buffer of a cast stays small */
+    for (size_t at = 0; at < nvox && rc == 0; at += step) rc = nifti_min_read_voxels(s, img->data + at, nvox - at < step ? nvox - at : step);
+    nifti_min_close(s);
+    if (rc < 0) {
+        free(img->data);
+        img->data = 0;
+        return rc;
+    }
     return 0;
 }
 

@@ -11,6 +11,7 @@
  */
 #ifndef NIFTI_MIN_H
 #define NIFTI_MIN_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -29,6 +30,14 @@ typedef struct {
 /* Returns 0 on success; -1 cannot open/parse header, -2 no voxel data,
  * -3 unsupported datatype, -4 out of memory. */
 int nifti_min_read(const char *path, nifti_min_image *img);
+/* The same in two steps, for a caller that wants the voxels as they arrive (featExtract uploads the planes it has while the
+ * rest of a .nii.gz is still being inflated): nifti_min_open parses the header into *img (data stays NULL) and leaves the
+ * stream at the first voxel; nifti_min_read_voxels casts the next nvox voxels into dst (0, -2 short file, -4 memory);
+ * nifti_min_close releases the stream.  nifti_min_read is open + read everything + close. */
+typedef struct nifti_min_stream nifti_min_stream;
+int nifti_min_open(const char *path, nifti_min_image *img, nifti_min_stream **s);
+int nifti_min_read_voxels(nifti_min_stream *s, float *dst, size_t nvox);
+void nifti_min_close(nifti_min_stream *s);
 /* Writes a float32 single-file .nii (or .nii.gz by extension), voxel size (dx,dy,dz). */
 int nifti_min_write_f32(const char *path, const float *data, int nx, int ny, int nz, float dx, float dy, float dz);
 /* As above with a qform (quaternion b,c,d, offsets, qfac = pixdim[0]) and/or an sform (3 rows of 4):

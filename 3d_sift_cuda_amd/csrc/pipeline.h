@@ -127,6 +127,11 @@ struct sift3d_ctx {
     int64_t nx, ny, nz;
     int64_t pad_nx, pad_ny, pad_nz; /* geometry the pad columns of the level buffers were last cleared for */
     bool has_volume;
+    struct {                /* sift3d_set_volume_begin / _planes / _end: a volume arriving in runs of planes */
+        bool open;
+        int64_t nx, ny, nz, got; /* dims of what arrives; planes received so far */
+        int resize;
+    } up;
     int max_octaves; /* 0: the reference's only stop rule (a dimension <= 2); n > 0: at most n octaves */
     int tune[SIFT3D_TUNE_COUNT]; /* sift3d_set_tuning */
     int64_t host_grows;          /* times describe_launch had to grow the pinned record buffers (tests) */

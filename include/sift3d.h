@@ -187,6 +187,15 @@ int sift3d_set_volume_dev(sift3d_ctx *ctx, const float *d_vol, int64_t nx, int64
  * (resize = +1: doubled to 2nx*2ny*2nz, -1: halved to (nx/2)*(ny/2)*(nz/2), 0: as it is) and make the result the
  * context's volume.  The context must have been created for the larger of the two sizes. */
 int sift3d_set_volume_resized(sift3d_ctx *ctx, const float *vol, int64_t nx, int64_t ny, int64_t nz, int resize);
+/* The same volume arriving in runs of whole z planes (round 5; the reference reads the whole file and then copies the whole
+ * volume, blocking, once per octave: fioCopy, R/src_common/FeatureIO.cpp:1841-1863): sift3d_set_volume_begin names the shape
+ * that will arrive and the resize; sift3d_set_volume_planes queues planes [z0, z0 + n) (host memory, nx*ny*n floats) on the
+ * context's stream and returns -- every plane exactly once, in any order; the caller keeps a run of planes unchanged until
+ * sift3d_set_volume_end, which runs the resize if one was asked for and returns when the volume is resident.  featExtract
+ * uploads what it has read while the rest of a .nii.gz is still being inflated. */
+int sift3d_set_volume_begin(sift3d_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int resize);
+int sift3d_set_volume_planes(sift3d_ctx *ctx, const float *planes, int64_t z0, int64_t n);
+int sift3d_set_volume_end(sift3d_ctx *ctx);
 /* Scale-space + detection only: validated extrema of every octave/level in the
  * reference's order.  *out is malloc'ed (sift3d_free). */
 int sift3d_detect(sift3d_ctx *ctx, float initial_image_scale, sift3d_candidate **out, int64_t *n_out);

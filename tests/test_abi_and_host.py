@@ -161,6 +161,55 @@ def test_key_writer_number_formatting(built, oracle, tmp_path):
     assert a == b
 
 
+def test_key_writer_in_parallel_blocks_writes_the_serial_bytes(built, oracle, tmp_path):
+    """Round 5: the writer formats blocks of 2 048 records in parallel and writes them at their offsets.  30 000 records (15
+    blocks, the last one short) with the eigenvalue filter dropping a third of them, written with 1, 3 and 8 threads
+    (OMP_NUM_THREADS is read when the process starts): the same bytes, and the oracle writer's (plain fprintf)."""
+    import sys
+    rng = np.random.default_rng(11)
+    n = 30000
+    recs = np.zeros(n, built.FEATURE_DTYPE)
+    for f in ("x", "y", "z", "scale"):
+        recs[f] = (rng.random(n) * 500).astype(np.float32)
+    recs["ori"] = (rng.random((n, 9)) * 2 - 1).astype(np.float32)
+    recs["eigs"] = (rng.random((n, 3)) * np.array([1.0, 0.3, 0.05])).astype(np.float32)   # a third fails (e1+e2+e3)^3 < 140 e1 e2 e3
+    recs["info"] = rng.integers(0, 64, n).astype(np.uint32)
+    recs["desc"] = np.argsort(rng.random((n, 64)), axis=1).astype(np.float32)
+    ref = str(tmp_path / "ref.key")
+    oracle.write_key(ref, recs, comments=["a", "b", "c"])
+    want = open(ref, "rb").read()
+    kept = int(want.split(b"Features: ")[1].split(b"\n")[0])
+    assert 0.2 * n < kept < 0.95 * n and want.count(b"\n") == kept + 6
+    np.save(str(tmp_path / "recs.npy"), recs)
+    code = ("import importlib, sys, numpy as np; sys.path.insert(0, %r); p = importlib.import_module('3d_sift_cuda_amd'); "
+            "p.write_key(sys.argv[2], np.load(sys.argv[1]), comments=['a', 'b', 'c'])" % ROOT)
+    for threads in (1, 3, 8):
+        out = str(tmp_path / ("t%d.key" % threads))
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "recs.npy"), out], capture_output=True, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        assert r.returncode == 0, r.stderr
+        assert open(out, "rb").read() == want, threads
+    # nothing to write, and fewer records than a block
+    for m in (0, 1, 2047, 2048, 2049):
+        a, b = str(tmp_path / "a.key"), str(tmp_path / "b.key")
+        oracle.write_key(a, recs[:m], eig_thres=-1.0, comments=[])
+        built.write_key(b, recs[:m], eig_thres=-1.0, comments=[])
+        assert open(a, "rb").read() == open(b, "rb").read(), m
+
+
+def test_synth_slices_are_the_planes_of_the_whole_volume(built):
+    """sift3d_synth_blobs_slices (bench.py's Z-slab ranks generate only their input slices): the same bits as those planes of
+    the whole volume, for ranges at the faces, inside, empty and clipped; above and below the size where the generator
+    goes parallel."""
+    for dims in ((40, 36, 50), (200, 180, 170)):
+        v = built.synth_blobs(*dims, seed=9)
+        nz = dims[2]
+        for a, b in ((0, nz), (13, 37), (nz - 9, nz), (0, 1), (20, 20), (-5, 8), (nz - 3, nz + 10)):
+            s = built.synth_blobs_slices(dims[0], dims[1], nz, a, b, seed=9)
+            lo, hi = max(0, a), min(nz, b)
+            assert s.shape == (max(0, hi - lo), dims[1], dims[0]) and s.tobytes() == v[lo:hi].tobytes(), (dims, a, b)
+
+
 def test_key_reader_and_binary_writer(built, oracle, tmp_path):
     """msFeature3DVectorInputText / msFeature3DVectorOutputBin (MultiScale.h:228-384) on the host side."""
     import struct

@@ -632,6 +632,67 @@ def test_cli_key_file_is_byte_identical(built, oracle, tmp_path):
     assert open(k1, "rb").read() == open(k2, "rb").read() and len(open(k1).readlines()) > 8
 
 
+def test_volume_in_runs_of_planes_is_the_volume(built):
+    """sift3d_set_volume_begin / _planes / _end (round 5: the CLI uploads what it has read while the rest of the file is still
+    being inflated): dense and pitched rows, -2+ and -2-, runs in and out of order -- the records of sift3d_set_volume; a plane
+    missing, a plane beyond the volume, planes without a begin: refused."""
+    for dims, resize in (((64, 48, 40), 0), ((50, 44, 37), 0), ((40, 36, 32), 1), ((64, 64, 64), -1), ((33, 30, 41), 1)):
+        vol = vol_of(built, dims, 17)
+        nz = dims[2]
+        cd = tuple(2 * d for d in dims) if resize > 0 else dims
+        with built.Context(*cd) as ctx:
+            ctx.set_volume(vol, resize=resize)
+            want = ctx.extract()
+            for runs in ([(0, nz)], [(0, 7), (7, 1), (8, nz - 8)], [(nz - 5, 5), (0, 11), (11, nz - 16)]):
+                ctx.set_volume_in_runs(vol, runs, resize=resize)
+                got = ctx.extract()
+                assert got.tobytes() == want.tobytes() and len(got) > 10, (dims, resize, runs)
+            with pytest.raises(built.Sift3DError):
+                ctx.set_volume_in_runs(vol, [(0, nz - 1)], resize=resize)          # a plane never arrived
+            with pytest.raises(built.Sift3DError):
+                ctx.set_volume_in_runs(vol, [(0, nz), (nz - 1, 2)], resize=resize)   # beyond the volume
+            with pytest.raises(built.Sift3DError):
+                ctx._chk(ctx._L.sift3d_set_volume_planes(ctx._h, vol.ctypes.data, 0, 1), "planes without begin")
+            ctx.set_volume(vol, resize=resize)                                        # the context is still usable
+            assert ctx.extract().tobytes() == want.tobytes()
+
+
+def test_cli_reads_and_uploads_side_by_side(built, tmp_path):
+    """The command line brings up the device and uploads the planes it has while the file is still being read (round 5): the
+    same .key for .nii, .nii.gz and an int16 file of several runs of planes, with and without -2+; a truncated file is the
+    reference's 'could not read input file', not a hang of the uploading thread."""
+    import gzip
+    import _oracle
+    vol = np.round(vol_of(built, (96, 80, 300), 5))          # 2.3 M voxels a ... 9 MB: more than one 32 MB run only as int16? no: force several runs below
+    vol = np.tile(vol, (4, 1, 1))[:1100]                     # 96 x 80 x 1100 = 8.4 M voxels = 34 MB: two runs
+    nii, gz, i16 = str(tmp_path / "v.nii"), str(tmp_path / "v.nii.gz"), str(tmp_path / "i16.nii")
+    built.write_nifti(nii, vol)
+    with open(nii, "rb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
+        g.write(f.read())
+    raw = bytearray(open(nii, "rb").read()[:352])
+    raw[70:72] = (4).to_bytes(2, "little"); raw[72:74] = (16).to_bytes(2, "little")   # datatype DT_INT16, bitpix 16
+    with open(i16, "wb") as f:
+        f.write(bytes(raw) + vol.astype("<i2").tobytes())
+    keys = {}
+    for src in (nii, gz, i16):
+        for flags in ([], ["-2-"]):
+            k = str(tmp_path / "out.key")
+            r = subprocess.run([built.FEATEXTRACT, "-d0"] + flags + [src, k], capture_output=True, text=True, env=dict(os.environ, SIFT3D_CLI_TIMES="1"))
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert "the planes were uploaded while the file was read" in r.stderr
+            keys.setdefault(tuple(flags), []).append(open(k, "rb").read())
+    for flags, ks in keys.items():
+        assert ks[0] == ks[1] == ks[2] and ks[0].count(b"\n") > 50, flags
+    k2 = str(tmp_path / "cpu.key")
+    assert subprocess.run([_oracle.CLI, nii, k2], capture_output=True).returncode == 0
+    assert open(k2, "rb").read() == keys[()][0]
+    cut = str(tmp_path / "cut.nii")
+    with open(cut, "wb") as f:
+        f.write(open(nii, "rb").read()[:352 + 4 * 96 * 80 * 700])
+    r = subprocess.run([built.FEATEXTRACT, "-d0", cut, str(tmp_path / "x.key")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 255 and "Error: could not read input file" in r.stdout
+
+
 def test_cli_side_effects_of_the_reference(built, oracle, tmp_path):
     """What the reference's pyramid leaves behind besides its result (MultiScale.cpp:296-302,373-388,558): a '#<microseconds>'
     line after the initial blur and after the first blur of every octave, 'done.' per octave, and ./image.pgm -- the middle

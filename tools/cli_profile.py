@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""GPU box: what `featExtract in.nii out.key` costs end to end (round-4 review item 2).
+
+    python tools/cli_profile.py [sizes=256,512] [reps=3] [oracle_sizes=256,512]
+
+For every size: a blob-field volume written as .nii and .nii.gz (float32), then `SIFT3D_CLI_TIMES=1 featExtract -d0`
+on each, `reps` times (the first run of a process pays the page-in of the HIP runtime), the per-phase wall times the CLI
+prints (read image, device context, upload, extraction, write features) and the process's whole wall time; beside them
+the oracle's CLI (`oracle/_build/featExtract_oracle`, the CPU restatement behind the same command line: TEST infrastructure,
+timed here as the CPU side of the same box).  The .key files of the two are compared byte for byte.
+"""
+import hashlib
+import importlib
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3d_sift_cuda_amd")
+sizes = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "256,512").split(",")]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+osizes = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "256,512").split(",") if v]
+ORACLE = os.path.join(ROOT, "oracle", "_build", "featExtract_oracle")
+PHASES = ["read image", "device context", "upload", "extraction", "write features"]
+
+
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for b in iter(lambda: f.read(1 << 22), b""):
+            h.update(b)
+    return h.hexdigest()[:16]
+
+
+def run_cli(args, env=None):
+    t0 = time.perf_counter()
+    r = subprocess.run(args, capture_output=True, text=True, env=env)
+    wall = time.perf_counter() - t0
+    ph = {}
+    for m in re.finditer(r"^# ([a-z ]+): ([0-9.]+) s", r.stderr, re.M):
+        ph[m.group(1)] = float(m.group(2))
+    return r.returncode, wall, ph, r
+
+
+d = tempfile.mkdtemp()
+print("featExtract end to end on this box (%d host cores visible); times in seconds" % (os.cpu_count() or 0))
+for n in sizes:
+    vol = pkg.synth_blobs(n, n, n, seed=12345)
+    nii, gz = os.path.join(d, "v%d.nii" % n), os.path.join(d, "v%d.nii.gz" % n)
+    pkg.write_nifti(nii, vol)
+    subprocess.run("gzip -1 -c %s > %s" % (nii, gz), shell=True, check=True)
+    print("\n== %d^3 float32: .nii %.0f MB, .nii.gz %.0f MB ==" % (n, os.path.getsize(nii) / 1e6, os.path.getsize(gz) / 1e6))
+    print("%-28s %8s | %s" % ("run", "wall", " ".join("%14s" % p for p in PHASES)))
+    keys = {}
+    for src, tag in ((nii, ".nii"), (gz, ".nii.gz")):
+        key = os.path.join(d, "out%d%s.key" % (n, tag.replace(".", "_")))
+        for rep in range(reps):
+            rc, wall, ph, r = run_cli([pkg.FEATEXTRACT, "-d0", src, key], env=dict(os.environ, SIFT3D_CLI_TIMES="1"))
+            if rc != 0:
+                print("featExtract failed:", r.stdout[-300:], r.stderr[-300:])
+                sys.exit(1)
+            print("%-28s %8.3f | %s" % ("featExtract -d0 %s #%d" % (tag, rep), wall, " ".join("%14.3f" % ph.get(p, float("nan")) for p in PHASES)))
+        keys[tag] = sha(key)
+        print("%-28s .key %.1f MB sha %s" % ("", os.path.getsize(key) / 1e6, keys[tag]))
+    if n in osizes and os.path.exists(ORACLE):
+        key = os.path.join(d, "oracle%d.key" % n)
+        rc, wall, ph, r = run_cli([ORACLE, nii, key])
+        print("%-28s %8.3f | (CPU restatement, one thread; rc %d) .key sha %s%s" % ("featExtract_oracle .nii", wall, rc, sha(key) if rc == 0 else "-",
+                                                                                  "  == GPU CLI bytes" if rc == 0 and sha(key) == keys[".nii"] else "  DIFFERENT"))
+    assert keys[".nii"] == keys[".nii.gz"]
