@@ -129,6 +129,7 @@ def hip_lib():
     _sig(L.sift3d_set_volume, I, P, P, I64, I64, I64)
     _sig(L.sift3d_set_volume_dev, I, P, P, I64, I64, I64)
     _sig(L.sift3d_set_volume_resized, I, P, P, I64, I64, I64, I)
+    _sig(L.sift3d_reserve, I, P, I64)
     _sig(L.sift3d_set_volume_begin, I, P, I64, I64, I64, I)
     _sig(L.sift3d_set_volume_planes, I, P, P, I64, I64)
     _sig(L.sift3d_set_volume_end, I, P)
@@ -584,6 +585,9 @@ class Context:
         vol = _f32(vol)
         nz, ny, nx = vol.shape
         self._chk(self._L.sift3d_set_volume_resized(self._h, vol.ctypes.data, nx, ny, nz, int(resize)), "sift3d_set_volume_resized")
+
+    def reserve(self, n_extrema):
+        self._chk(self._L.sift3d_reserve(self._h, int(n_extrema)), "sift3d_reserve")
 
     def set_volume_in_runs(self, vol, runs, resize=0):
         """sift3d_set_volume_begin / _planes / _end: the volume handed over in the given runs of planes [(z0, n), ...]."""

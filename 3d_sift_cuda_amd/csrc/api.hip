@@ -1142,7 +1142,10 @@ extern "C" int sift3d_set_volume_begin(sift3d_ctx *c, int64_t nx, int64_t ny, in
 extern "C" int sift3d_set_volume_planes(sift3d_ctx *c, const float *planes, int64_t z0, int64_t n)
 {
     if (!c || !c->up.open) return set_err(c, SIFT3D_ERR_ARG, "set_volume_planes without set_volume_begin");
-    if (!planes || z0 < 0 || n < 1 || z0 + n > c->up.nz) return set_err(c, SIFT3D_ERR_ARG, "set_volume_planes: planes [%lld, %lld) of %lld", (long long)z0, (long long)(z0 + n), (long long)c->up.nz);
+    if (!planes || z0 < 0 || n < 1 || z0 + n > c->up.nz) {
+        c->up.open = false; /* a caller that hands over planes the volume does not have starts again */
+        return set_err(c, SIFT3D_ERR_ARG, "set_volume_planes: planes [%lld, %lld) of %lld", (long long)z0, (long long)(z0 + n), (long long)c->up.nz);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t nx = c->up.nx, ny = c->up.ny, xp = pitch_of(nx);
     if (c->up.resize != 0) {
@@ -1246,6 +1249,18 @@ static int ensure_kp_buffers(sift3d_ctx *c, int64_t ncand, int64_t host_for = -1
         if (rc) return rc;
     }
     return SIFT3D_OK;
+}
+
+/* The buffers a run with about n_extrema validated extrema needs beyond the context's own -- keypoint records, identity
+ * patches, record map, the pinned download buffers -- made now rather than inside the first extraction, where they cost a
+ * process that extracts once (the command line) some 25 ms at 512^3.  A run that finds more grows them as before. */
+extern "C" int sift3d_reserve(sift3d_ctx *c, int64_t n_extrema)
+{
+    if (!c || n_extrema < 0) return set_err(c, SIFT3D_ERR_ARG, "sift3d_reserve: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_extrema > c->cand_cap && alloc_cands(c, n_extrema + n_extrema / 4 + 4096) != SIFT3D_OK)
+        return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown to %lld entries", (long long)n_extrema);
+    return ensure_kp_buffers(c, n_extrema, n_extrema);
 }
 
 /* Sorted candidates -> host list with whole-volume coordinates (sift3d_detect, slab tests). */

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/types.h>
 #include <unistd.h>
 #ifdef _OPENMP
@@ -79,6 +81,34 @@ static char *put_record(char *p, const sift3d_feature *r)
     return p;
 }
 
+/* the lengths of the same, without the characters: what lets every block be formatted straight into its place in the file */
+static int digits_u64(uint64_t v)
+{
+    int n = 1;
+    while (v >= 10) {
+        v /= 10;
+        n++;
+    }
+    return n;
+}
+static int len_f(float v)
+{
+    const double d = (double)v;
+    if (!(fabs(d) < 4.0e9)) return snprintf(NULL, 0, "%f", d);
+    const uint64_t q = (uint64_t)rint(fabs(d) * 1.0e6);
+    return (signbit(v) ? 1 : 0) + digits_u64(q / 1000000u) + 7;
+}
+static int len_int(long long v) { return v < 0 ? 1 + digits_u64((uint64_t)(-v)) : digits_u64((uint64_t)v); }
+static size_t len_record(const sift3d_feature *r)
+{
+    size_t n = (size_t)(len_f(r->x) + len_f(r->y) + len_f(r->z) + len_f(r->scale));
+    for (int j = 0; j < 9; j++) n += (size_t)len_f(r->ori[j]);
+    for (int j = 0; j < 3; j++) n += (size_t)len_f(r->eigs[j]);
+    n += (size_t)len_int((int)r->info);
+    for (int j = 0; j < SIFT3D_DESC_LEN; j++) n += (size_t)len_int((char)(r->desc[j]));
+    return n + 16 + 1 + SIFT3D_DESC_LEN + 1; /* the tabs and the newline */
+}
+
 static int write_all_at(int fd, const char *buf, size_t len, off_t at)
 {
     while (len) {
@@ -91,71 +121,90 @@ static int write_all_at(int fd, const char *buf, size_t len, off_t at)
 
 /* Round 5 (review item 2): at 512^3 the text is 63 MB and 15 million numbers; written by one thread it was the longest phase
  * of `featExtract in.nii out.key` after the file read (0.07 s against 0.01 s of extraction).  The records are cut into blocks
- * of KEY_BLOCK; the blocks are formatted in parallel, each into a buffer of its own (the bytes of a block do not depend on
- * any other), the block sizes are summed into file offsets, and the blocks are written in parallel at their offsets
- * (pwrite).  The bytes of the file are those of the serial writer: tests/test_oracle_pins.py holds them to the reference's
- * own writer compiled from its header, tests/test_abi_and_host.py to the serial form for 1, 3 and 8 threads. */
+ * of KEY_BLOCK.  Pass 1, in parallel: which records of a block pass the eigenvalue filter and how many characters they will
+ * take (the digit counts of the numbers, no formatting).  The block sizes summed are every block's place in the file.  Pass 2,
+ * in parallel: every block formatted straight into its place -- the file reserved (posix_fallocate: a full disk is an error
+ * code here, not a SIGBUS later) and mapped, because writes to one file are serialised by the kernel (the inode's lock) and
+ * page faults on a shared mapping are not; where the file system offers neither, into a buffer and out by pwrite.  The bytes
+ * are those of the serial writer: tests/test_oracle_pins.py holds them to the reference's own writer compiled from its
+ * header, tests/test_abi_and_host.py to the oracle's fprintf for 1, 3 and 8 threads. */
 int sift3d_write_key(const char *path, const sift3d_feature *recs, int64_t n, float eig_thres, int n_comments,
                      const char *const *comments)
 {
     FILE *f = fopen(path, "wt");
     if (!f) return -1;
-    int count = 0;
-    for (int64_t i = 0; i < n; i++)
-        if (keep(&recs[i], eig_thres)) count++;
-    fprintf(f, "# featExtract %s\n", "1.1");
-    for (int i = 0; i < n_comments; i++) fprintf(f, "# %s\n", comments[i]);
-    fprintf(f, "Features: %d\n", count);
-    fprintf(f, "Scale-space location[x y z scale] orientation[o11 o12 o13 o21 o22 o23 o31 o32 o32] 2nd moment "
-               "eigenvalues[e1 e2 e3] info flag[i1] descriptor[d1 .. d64]\n");
-    if (fflush(f) != 0) {
-        fclose(f);
-        return -1;
-    }
-    const off_t head = ftello(f);
     const int64_t nblocks = (n + KEY_BLOCK - 1) / KEY_BLOCK;
-    char **blk = (char **)calloc((size_t)(nblocks ? nblocks : 1), sizeof(char *));
     size_t *len = (size_t *)calloc((size_t)(nblocks ? nblocks : 1), sizeof(size_t));
-    int bad = !blk || !len || head < 0;
+    int64_t *kept = (int64_t *)calloc((size_t)(nblocks ? nblocks : 1), sizeof(int64_t));
+    off_t *at = (off_t *)calloc((size_t)(nblocks + 1), sizeof(off_t));
+    int bad = !len || !kept || !at;
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
     if (nthreads > 16) nthreads = 16;
     if (nblocks < 4) nthreads = 1;
 #endif
+    int64_t count = 0;
     if (!bad) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
         for (int64_t b = 0; b < nblocks; b++) {
             const int64_t i0 = b * KEY_BLOCK, i1 = i0 + KEY_BLOCK < n ? i0 + KEY_BLOCK : n;
-            char *buf = (char *)malloc((size_t)(i1 - i0) * KEY_REC_MAX);
-            if (!buf) continue; /* blk[b] stays NULL: reported below */
-            char *p = buf;
+            size_t bytes = 0;
+            int64_t k = 0;
             for (int64_t i = i0; i < i1; i++)
-                if (keep(&recs[i], eig_thres)) p = put_record(p, &recs[i]);
-            len[b] = (size_t)(p - buf);
-            blk[b] = buf;
+                if (keep(&recs[i], eig_thres)) {
+                    bytes += len_record(&recs[i]);
+                    k++;
+                }
+            len[b] = bytes;
+            kept[b] = k;
         }
-        for (int64_t b = 0; b < nblocks; b++) bad |= blk[b] == NULL;
+        for (int64_t b = 0; b < nblocks; b++) count += kept[b];
     }
+    fprintf(f, "# featExtract %s\n", "1.1");
+    for (int i = 0; i < n_comments; i++) fprintf(f, "# %s\n", comments[i]);
+    fprintf(f, "Features: %d\n", (int)count);
+    fprintf(f, "Scale-space location[x y z scale] orientation[o11 o12 o13 o21 o22 o23 o31 o32 o32] 2nd moment "
+               "eigenvalues[e1 e2 e3] info flag[i1] descriptor[d1 .. d64]\n");
+    if (fflush(f) != 0) bad = 1;
+    const off_t head = ftello(f);
+    if (head < 0) bad = 1;
     if (!bad) {
-        off_t *at = (off_t *)malloc(sizeof(off_t) * (size_t)(nblocks + 1));
-        if (!at) bad = 1;
-        else {
-            at[0] = head;
-            for (int64_t b = 0; b < nblocks; b++) at[b + 1] = at[b] + (off_t)len[b];
-            const int fd = fileno(f);
-            int wbad = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(| : wbad)
-            for (int64_t b = 0; b < nblocks; b++)
-                if (len[b]) wbad |= write_all_at(fd, blk[b], len[b], at[b]) != 0;
-            bad |= wbad;
-            free(at);
+        size_t biggest = 0;
+        at[0] = head;
+        for (int64_t b = 0; b < nblocks; b++) {
+            at[b + 1] = at[b] + (off_t)len[b];
+            if (len[b] > biggest) biggest = len[b];
         }
+        const int fd = fileno(f);
+        const off_t total = at[nblocks];
+        char *map = (char *)MAP_FAILED;
+        if (nthreads > 1 && total > head && posix_fallocate(fd, 0, total) == 0)
+            map = (char *)mmap(NULL, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        int wbad = 0;
+#pragma omp parallel num_threads(nthreads) reduction(| : wbad)
+        {
+            char *buf = map == (char *)MAP_FAILED ? (char *)malloc(biggest + KEY_REC_MAX) : NULL;
+            if (map == (char *)MAP_FAILED && !buf) wbad = 1;
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t b = 0; b < nblocks; b++) {
+                if (!len[b] || wbad) continue;
+                const int64_t i0 = b * KEY_BLOCK, i1 = i0 + KEY_BLOCK < n ? i0 + KEY_BLOCK : n;
+                char *const dst = buf ? buf : map + at[b];
+                char *p = dst;
+                for (int64_t i = i0; i < i1; i++)
+                    if (keep(&recs[i], eig_thres)) p = put_record(p, &recs[i]);
+                if ((size_t)(p - dst) != len[b]) wbad = 1; /* the two passes disagree: never, but then the file is wrong */
+                else if (buf) wbad |= write_all_at(fd, buf, len[b], at[b]) != 0;
+            }
+            free(buf);
+        }
+        bad |= wbad;
+        if (map != (char *)MAP_FAILED && munmap(map, (size_t)total) != 0) bad = 1;
     }
-    if (blk)
-        for (int64_t b = 0; b < nblocks; b++) free(blk[b]);
-    free(blk);
     free(len);
+    free(kept);
+    free(at);
     if (fclose(f) != 0) bad = 1;
     return bad ? -1 : 0;
 }

@@ -720,6 +720,42 @@ def main():
                     "traffic_source": ("profiles/" + PMC_TABLE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per "
                                        "MI355X_MICROARCH.md), averaged over the launches; a table committed with the source it was measured on "
                                        "(hash-checked), NOT counters of this run: " + traffic_when) if traffic else traffic_note}
+        # ---- the ceiling of the kernel's ACCESS SHAPE, measured now, in this process, on this box (round-4 review item 4):
+        # the zero-arithmetic march of the same tiles (tools/roof_lib.hip: 64 x 32 and 128 x 16 tiles, two z chunks, one
+        # workgroup per CU, one plane read and one or two planes stored per step).  Per instantiation the better of the two
+        # tiles for its store streams; the sum of those march times over the step's launches is what a kernel that does
+        # nothing but move these tiles would take.  frac_of_ceiling = frac / ceiling_frac.
+        roofline["ceiling"] = None
+        if per_inst and (nx, ny, nz) == (512, 512, 512):
+            try:
+                import ctypes
+                lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_build", "libroof.so"))
+                lib.roof_march.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+                torch.cuda.synchronize(local_rank)
+                ms4 = (ctypes.c_float * 4)()
+                rc_roof = lib.roof_march(512, 10, ms4)
+                if rc_roof != 0:
+                    raise RuntimeError("roof_march -> %d" % rc_roof)
+                m1, m2 = min(ms4[0], ms4[1]), min(ms4[2], ms4[3])   # one / two store streams, the better tile
+                c_ms, c_bytes, rows = 0.0, 0.0, []
+                for pi in per_inst:
+                    bpv = pi["alg_bytes_per_voxel"]
+                    march = m1 if bpv < 9 else m2 * (bpv / 12.0)     # 12.5 B/voxel (the half-size volume rides along): the 12-byte march, scaled
+                    c_ms += march * pi["launches"]; c_bytes += bpv * nvox * pi["launches"]
+                    rows.append({"taps": pi["taps"], "alg_bytes_per_voxel": bpv, "march_ms": round(march, 4), "kernel_ms": pi["avg_launch_ms"],
+                                 "kernel_over_march": round(pi["avg_launch_ms"] / march, 3)})
+                c_gbs = c_bytes / (c_ms * 1e-3) / 1e9
+                roofline["ceiling"] = {
+                    "what": "zero-arithmetic march of the same tiles (tools/roof_lib.hip), measured in this process after the timed region: "
+                            "what a kernel that only moves the fused blur's tiles sustains on this box",
+                    "achieved": round(c_gbs, 1), "unit": "GB/s", "frac": round(c_gbs / HBM_PEAK_GBS, 4),
+                    "march_ms": {"64x32_1_store": round(ms4[0], 4), "128x16_1_store": round(ms4[1], 4),
+                                 "64x32_2_stores": round(ms4[2], 4), "128x16_2_stores": round(ms4[3], 4)},
+                    "per_instantiation": rows}
+                roofline["ceiling_frac"] = roofline["ceiling"]["frac"]
+                roofline["frac_of_ceiling"] = round(roofline["frac"] / roofline["ceiling"]["frac"], 4)
+            except Exception as e:   # a measurement aid: its absence must not cost the line
+                roofline["ceiling"] = {"note": "not measured: %r (tools/_build/libroof.so is built by __graft_entry__.build())" % (e,)}
         pyr_ms = sum(v["ms"] for v in blur_groups.values())
         pyr_bytes = sum(v["bytes"] for v in blur_groups.values())
         pyramid = {"alg_GBs": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9, 1), "frac_of_peak": round(pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -762,9 +798,11 @@ def main():
             "alg_bytes_per_step": b8d, "target_ms_at_70_percent_of_peak": round(b8d / (0.7 * HBM_PEAK_GBS * 1e9) * 1e3, 3),
             "ms_per_step": pyramid["ms_per_step"], "exclusive_ms_per_step": pyramid["exclusive_ms_per_step"],
             "equivalent_GBs": round(b8d / (pyramid["ms_per_step"] * 1e-3) / 1e9, 1),
-            "met": bool(pyramid["ms_per_step"] <= b8d / (0.7 * HBM_PEAK_GBS * 1e9) * 1e3),
-            "note": "three-pass bytes of SURVEY.md 8d (24N per blur, +8N per DoG, all octaves) over the time the pyramid's blur launches take here; "
-                    "the fused launches move a third of those bytes, which is why this figure may exceed the HBM peak"}
+            "within_three_pass_time_budget": bool(pyramid["ms_per_step"] <= b8d / (0.7 * HBM_PEAK_GBS * 1e9) * 1e3),
+            "note": "a TIME budget, not the roofline target: the three-pass bytes of SURVEY.md 8d (24N per blur, +8N per DoG, all octaves) over the "
+                    "time the pyramid's blur launches take here; the fused launches move a third of those bytes, which is why `equivalent_GBs` "
+                    "may exceed the HBM peak.  The north star's 0.70 of the HBM roofline is judged on roofline.frac (compulsory bytes of what is "
+                    "launched) and is NOT met at 0.61 - 0.62; see roofline.ceiling for what the access shape allows"}
         out = {
             "metric": "keypoints/s (.key records per second; Gauss-pyramid GB/s vs HBM roofline in `pyramid`/`roofline`)",
             "value": round(total_records / (ms_per_step * 1e-3), 1),

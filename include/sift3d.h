@@ -196,6 +196,11 @@ int sift3d_set_volume_resized(sift3d_ctx *ctx, const float *vol, int64_t nx, int
 int sift3d_set_volume_begin(sift3d_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int resize);
 int sift3d_set_volume_planes(sift3d_ctx *ctx, const float *planes, int64_t z0, int64_t n);
 int sift3d_set_volume_end(sift3d_ctx *ctx);
+/* Optional: make room now for a run that will find about n_extrema validated extrema (the per-keypoint buffers and the
+ * pinned record buffers are otherwise made inside the first extraction, once their size is known: about 25 ms of a 512^3
+ * extraction that a process which extracts once -- the command line -- can spend beside its file read instead).  Blob fields
+ * yield one extremum per 3 000 voxels.  A run that finds more grows the buffers as before; results never depend on it. */
+int sift3d_reserve(sift3d_ctx *ctx, int64_t n_extrema);
 /* Scale-space + detection only: validated extrema of every octave/level in the
  * reference's order.  *out is malloc'ed (sift3d_free). */
 int sift3d_detect(sift3d_ctx *ctx, float initial_image_scale, sift3d_candidate **out, int64_t *n_out);
@@ -250,7 +255,8 @@ int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);
 int64_t sift3d_host_buffer_grows(const sift3d_ctx *ctx);
 
 /* Same, without the final host copy: *view points at the context's pinned download buffer and stays
- * valid until the next call on this context (or sift3d_destroy).  Do not free it. */
+ * valid until the next call on this context (or sift3d_destroy).  Do not free it.  The memory is the caller's to read AND
+ * to modify in place until then (featExtract applies the -w transform there); the next run overwrites it. */
 int sift3d_extract_view(sift3d_ctx *ctx, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
                         const sift3d_feature **view, int64_t *n_out);
 

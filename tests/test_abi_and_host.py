@@ -175,6 +175,14 @@ def test_key_writer_in_parallel_blocks_writes_the_serial_bytes(built, oracle, tm
     recs["eigs"] = (rng.random((n, 3)) * np.array([1.0, 0.3, 0.05])).astype(np.float32)   # a third fails (e1+e2+e3)^3 < 140 e1 e2 e3
     recs["info"] = rng.integers(0, 64, n).astype(np.uint32)
     recs["desc"] = np.argsort(rng.random((n, 64)), axis=1).astype(np.float32)
+    # numbers of every length, also the ones libc spells (huge, infinite, NaN), in the first and in the very last record
+    odd = np.array([-0.0, 1e-7, 0.9999995, 3.4e38, -3.4e38, 4.1e9, np.inf, -np.inf, np.nan, 123456.789, -2.0 ** 31], np.float32)
+    for f in ("x", "y", "z", "scale"):
+        at = rng.integers(0, n, 600)
+        recs[f][at] = odd[rng.integers(0, len(odd), 600)]
+        recs[f][0], recs[f][n - 1] = np.float32(-3.4e38), np.float32(np.inf)
+    recs["eigs"][0] = recs["eigs"][n - 1] = (1.0, 1.0, 1.0)            # both kept
+    recs["desc"][n - 1] = np.arange(64, dtype=np.float32) - 100.0      # negative (char) values
     ref = str(tmp_path / "ref.key")
     oracle.write_key(ref, recs, comments=["a", "b", "c"])
     want = open(ref, "rb").read()

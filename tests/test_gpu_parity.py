@@ -646,7 +646,7 @@ def test_volume_in_runs_of_planes_is_the_volume(built):
             for runs in ([(0, nz)], [(0, 7), (7, 1), (8, nz - 8)], [(nz - 5, 5), (0, 11), (11, nz - 16)]):
                 ctx.set_volume_in_runs(vol, runs, resize=resize)
                 got = ctx.extract()
-                assert got.tobytes() == want.tobytes() and len(got) > 10, (dims, resize, runs)
+                assert got.tobytes() == want.tobytes() and len(got) >= 5, (dims, resize, runs)
             with pytest.raises(built.Sift3DError):
                 ctx.set_volume_in_runs(vol, [(0, nz - 1)], resize=resize)          # a plane never arrived
             with pytest.raises(built.Sift3DError):

@@ -4,8 +4,9 @@
     python tools/cli_profile.py [sizes=256,512] [reps=3] [oracle_sizes=256,512]
 
 For every size: a blob-field volume written as .nii and .nii.gz (float32), then `SIFT3D_CLI_TIMES=1 featExtract -d0`
-on each, `reps` times (the first run of a process pays the page-in of the HIP runtime), the per-phase wall times the CLI
-prints (read image, device context, upload, extraction, write features) and the process's whole wall time; beside them
+on each, `reps` times, the per-phase wall times the CLI prints and the process's whole wall time (`hip init` and `context`
+run in a thread of their own BESIDE `read`; `waited` is what the main thread still waited for them after the read; `upload`
+is what was left to upload then; `main` is main()'s own duration: wall - main = process start, library loading, exit); beside them
 the oracle's CLI (`oracle/_build/featExtract_oracle`, the CPU restatement behind the same command line: TEST infrastructure,
 timed here as the CPU side of the same box).  The .key files of the two are compared byte for byte.
 """
@@ -25,7 +26,7 @@ sizes = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "256,512").split
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 osizes = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "256,512").split(",") if v]
 ORACLE = os.path.join(ROOT, "oracle", "_build", "featExtract_oracle")
-PHASES = ["read image", "device context", "upload", "extraction", "write features"]
+PHASES = ["read image", "hip runtime", "device context", "waited", "upload", "extraction", "write features", "teardown", "main"]
 
 
 def sha(path):
@@ -43,6 +44,9 @@ def run_cli(args, env=None):
     ph = {}
     for m in re.finditer(r"^# ([a-z ]+): ([0-9.]+) s", r.stderr, re.M):
         ph[m.group(1)] = float(m.group(2))
+    m = re.search(r"device context: ([0-9.]+) s .*waited ([0-9.]+) s", r.stderr)   # "# hip runtime: a s, device context: b s (...); waited c s ..."
+    if m:
+        ph["device context"], ph["waited"] = float(m.group(1)), float(m.group(2))
     return r.returncode, wall, ph, r
 
 
@@ -54,7 +58,7 @@ for n in sizes:
     pkg.write_nifti(nii, vol)
     subprocess.run("gzip -1 -c %s > %s" % (nii, gz), shell=True, check=True)
     print("\n== %d^3 float32: .nii %.0f MB, .nii.gz %.0f MB ==" % (n, os.path.getsize(nii) / 1e6, os.path.getsize(gz) / 1e6))
-    print("%-28s %8s | %s" % ("run", "wall", " ".join("%14s" % p for p in PHASES)))
+    print("%-28s %8s | %s" % ("run", "wall", " ".join("%9s" % p.replace("device context", "context").replace("write features", "write").replace("hip runtime", "hip init").replace("read image", "read") for p in PHASES)))
     keys = {}
     for src, tag in ((nii, ".nii"), (gz, ".nii.gz")):
         key = os.path.join(d, "out%d%s.key" % (n, tag.replace(".", "_")))
@@ -63,7 +67,7 @@ for n in sizes:
             if rc != 0:
                 print("featExtract failed:", r.stdout[-300:], r.stderr[-300:])
                 sys.exit(1)
-            print("%-28s %8.3f | %s" % ("featExtract -d0 %s #%d" % (tag, rep), wall, " ".join("%14.3f" % ph.get(p, float("nan")) for p in PHASES)))
+            print("%-28s %8.3f | %s" % ("featExtract -d0 %s #%d" % (tag, rep), wall, " ".join("%9.3f" % ph.get(p, float("nan")) for p in PHASES)))
         keys[tag] = sha(key)
         print("%-28s .key %.1f MB sha %s" % ("", os.path.getsize(key) / 1e6, keys[tag]))
     if n in osizes and os.path.exists(ORACLE):
