@@ -138,7 +138,7 @@ struct fb_ring_cfg {
 template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false>
 __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
     const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen,
-    int tiles_x, int tiles_y, long long total, fb_taps2 t, float *__restrict__ sub = nullptr)
+    int tiles_x, int tiles_y, long long total, int order, fb_taps2 t, float *__restrict__ sub = nullptr)
 {
     static_assert(!HAS_SUB || (BR == 2 && HAS_OUT), "the subsample rides on the 2 x 2 blocks of the two-rows-per-thread mapping");
     using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
@@ -155,9 +155,32 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES
     float *const P1b = lds;
     float *const pvb = lds + 2 * P1PL;
 
+    /* Which tile this workgroup takes.  Workgroup b of a launch runs on XCD b mod 8 (each with an L2 of its own), so the order
+     * decides which tiles share an L2 and which addresses an XCD asks the fabric for.  wi = x + tiles_x * (y + tiles_y * chunk).
+     *   order 1  XCD x walks the x-th eighth of the tiles in (x, y, chunk) order: whole rows of tiles per XCD (rounds 1 - 4);
+     *   order 2  workgroup b takes tile b;
+     *   order 3  column strips: XCD x owns column x mod tiles_x of the tiles (all of it, or -- fewer columns than XCDs -- a
+     *            contiguous part of its (y, chunk) list), walking down y: a tile's y neighbours, with which it shares 2R of
+     *            its TY + 2R input rows, are on its own XCD, and an XCD always asks for the same byte columns of every row.
+     *            The launcher only passes 3 where the counts divide. */
     const long long lin = blockIdx.x;
     const long long per = (total + 7) / 8;
-    const long long wi = (lin % 8) * per + lin / 8; /* XCD-aware tile order, as in the first form */
+    long long wi;
+    if (order == 3) {
+        const int xcd = (int)(lin % 8);
+        const long long j = lin / 8, M = total / tiles_x; /* (y, chunk) pairs of a column */
+        if (tiles_x >= 8) {
+            const int cols = tiles_x / 8;
+            wi = (xcd + 8 * (j % cols)) + (long long)tiles_x * (j / cols);
+        } else {
+            const int g = 8 / tiles_x;
+            wi = (xcd % tiles_x) + (long long)tiles_x * ((xcd / tiles_x) * (M / g) + j);
+        }
+    } else if (order == 2) {
+        wi = lin;
+    } else {
+        wi = (lin % 8) * per + lin / 8;
+    }
     if (wi >= total) return;
     const int tx = (int)(wi % tiles_x);
     const int ty = (int)((wi / tiles_x) % tiles_y);
@@ -457,7 +480,7 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident, int for
  * below 4 GiB -- a volume whose planes are that large gets more z chunks, and only a plane pair beyond 4 GiB has none) */
 template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false>
 static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
-                          const fb_taps2 &t, int forced_chunks, float *sub = nullptr)
+                          const fb_taps2 &t, int forced_chunks, float *sub = nullptr, int order = 0)
 {
     using C = fb_ring_cfg<R, BR, PF, TXv, TYv>;
     static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
@@ -479,18 +502,26 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     const int nch = (int)((Zo + zlen - 1) / zlen);
     const long long total = tiles * nch;
     const long long per = (total + 7) / 8;
+    /* the column-strip order needs counts that divide: 8 | tiles_x, or tiles_x | 8 with the (y, chunk) list of a column cut
+     * evenly over the 8 / tiles_x XCDs that share it; everything else keeps the order of rounds 1 - 4 */
+    if (order == 0) order = 1; /* by measurement: see DESIGN.md section 4 (round 5) */
+    if (order == 3) {
+        const long long M = (long long)tiles_y * nch;
+        const bool ok = tiles_x >= 8 ? tiles_x % 8 == 0 : (8 % tiles_x == 0 && M % (8 / tiles_x) == 0);
+        if (!ok) order = 1;
+    }
     hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv, HAS_SUB>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
-                       (int)Y, (int)Z, (int)zo0, (int)zo1, zlen, tiles_x, tiles_y, total, t, sub);
+                       (int)Y, (int)Z, (int)zo0, (int)zo1, zlen, tiles_x, tiles_y, total, order, t, sub);
     return true;
 }
 
 template <int R, int BR, int PF, int TXv = FB_TX, int TYv = 32>
 static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
-                           const fb_taps2 &t, int chunks)
+                           const fb_taps2 &t, int chunks, int order)
 {
-    if (out && dog) return launch_ring_t<R, BR, true, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
-    if (out) return launch_ring_t<R, BR, true, false, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
-    return launch_ring_t<R, BR, false, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    if (out && dog) return launch_ring_t<R, BR, true, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
+    if (out) return launch_ring_t<R, BR, true, false, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
+    return launch_ring_t<R, BR, false, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
 }
 
 /* The two mappings, by measurement at 512^3 and 256^3: two rows per thread, two planes of window
@@ -504,18 +535,19 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     const int forced = tune ? tune->rows_per_thread : 0;
     const int br = forced == 1 || forced == 2 ? forced : ((R >= 7 || X * Y * (zo1 - zo0) < (1ll << 22)) ? 1 : 2);
     const int chunks = tune ? tune->z_chunks : 0;
+    const int order = tune ? tune->order : 0;
     /* the half-size volume beside the level (HAS_SUB): built for the one filter the pyramid asks it of -- level 3 is 11 taps
      * in every octave (oracle: sigma_extra[3]) -- with both arrays stored, the whole volume produced and rows that halve into
      * whole 16-byte vectors; anything else leaves *sub_done 0 and the caller launches the subsample itself */
     if constexpr (R == 5)
         if (sub && br == 2 && out && dog && zo0 == 0 && zo1 == Z && X % 8 == 0 && Z >= 2 && Y >= 2) {
             const bool wide5 = (tune ? tune->tile : 0) == 2 && X >= 128;
-            const bool ok = wide5 ? launch_ring_t<5, 2, true, true, 2, 128, 16, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub)
-                                  : launch_ring_t<5, 2, true, true, 2, FB_TX, 32, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub);
+            const bool ok = wide5 ? launch_ring_t<5, 2, true, true, 2, 128, 16, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order)
+                                  : launch_ring_t<5, 2, true, true, 2, FB_TX, 32, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order);
             if (ok && sub_done) *sub_done = 1;
             return ok;
         }
-    if (br == 1) return launch_ring_pf<R, 1, 1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+    if (br == 1) return launch_ring_pf<R, 1, 1>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
     /* tile shape of the two-rows-per-thread mapping: tune->tile 0 = by measurement (below), 1 = 64 x 32, 2 = 128 x 16 */
     /* by measurement at 512^3 (profiles/r04_tile_ab.txt, dense random data, ms per launch 64 x 32 -> 128 x 16): 7 taps level only
      * 0.217 -> 0.201 - 0.207, 9 taps level + DoG 0.333 - 0.337 -> 0.318 - 0.323, 7 taps level + DoG 0.329 - 0.331 -> 0.321 - 0.326; no
@@ -527,15 +559,15 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     if constexpr (R <= 6)
         if (wide && X >= 128) {
             if constexpr (R <= 4)
-                if (!(out && dog)) return launch_ring_pf<R, 2, 3, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
-            return launch_ring_pf<R, 2, 2, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+                if (!(out && dog)) return launch_ring_pf<R, 2, 3, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
+            return launch_ring_pf<R, 2, 2, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
         }
     /* three planes of window prefetch where the registers are there and only one array is stored (7 and 9 taps, level
      * only: 0.213 / 0.224 ms at 512^3 against 0.225 - 0.232 / 0.233 - 0.237 with two; with the DoG store beside it three planes
      * change nothing: 0.324 / 0.338 against 0.328 / 0.334 - 0.342; four planes, level only: 0.225 / 0.220, no better than three) */
     if constexpr (R <= 4)
-        if (!(out && dog)) return launch_ring_pf<R, 2, 3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
-    return launch_ring_pf<R, 2, 2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks);
+        if (!(out && dog)) return launch_ring_pf<R, 2, 3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
+    return launch_ring_pf<R, 2, 2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
 }
 
 /* Returns hipErrorNotSupported when the shape is outside this kernel (the caller then runs the three-pass path): rows

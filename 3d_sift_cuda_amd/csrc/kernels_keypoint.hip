@@ -862,6 +862,46 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
     /* The SVD + eigen test (one lane, double-precision internals) and the first orientation-histogram splat (one
      * wavefront, a chain of LDS atomics) do not depend on each other: the splat runs on wavefront 0 while lane 0 of
      * the last wavefront does the SVD.  For the ~15 % of the extrema the eigen test rejects the splat was wasted. */
+    auto svd_and_eigen_test = [&]() {
+        float mat[3][3], w[3], v[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                mat[i][j] = sm.sc[i * 3 + j];
+                v[i][j] = 0;
+            }
+        w[0] = w[1] = w[2] = 0;
+        svd3(mat, w, v);
+        sort_eig(w, v);
+        /* eigen test, MultiScale.cpp:1748-1769 */
+        float es = w[0] + w[1] + w[2];
+        float ep = w[0] * w[1] * w[2];
+        float esp = es * es * es;
+        int keep = (esp < p.eig_thres * ep || p.eig_thres < 0) ? 1 : 0;
+        sm.sc[15] = keep ? 1.0f : 0.0f;
+        if (keep) {
+            kp->x = fx; kp->y = fy; kp->z = fz; kp->scale = scale;
+            kp->eigs[0] = w[0]; kp->eigs[1] = w[1]; kp->eigs[2] = w[2];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) kp->ori0[i * 3 + j] = v[i][j];
+            kp->info = is_max ? SIFT3D_INFO_MIN0MAX1 : 0u;
+            kp->lvl = lvl;
+        } else {
+            nrec_out[k] = 0;
+        }
+    };
+#ifdef SIFT3D_DEV
+    /* development build, stop code 40 (round-4 review item 5b): the SVD and the eigen test BEFORE the first splat instead of
+     * beside it -- the 16 % of the extrema the test rejects then skip the patch hand-over, the splat pre-pass and the splat;
+     * the others lose the overlap of the SVD (one lane, ~0.7 us of double-precision chain) with the splat */
+    const bool svd_first = p.debug_stop == 40;
+    if (svd_first) {
+        if (lane == KP_NT - 64) svd_and_eigen_test();
+        __syncthreads();
+        if (sm.sc[15] == 0.0f) return;
+    }
+#else
+    constexpr bool svd_first = false;
+#endif
     /* the un-reoriented record is described from exactly this patch (identity frame, normalised once): hand it to
      * phase B instead of having it gathered from the image a second time (unused if the eigen test rejects) */
     for (int s = lane; s < PV; s += KP_NT) p.patch0[(long long)k * PV + s] = patch[s];
@@ -890,33 +930,7 @@ __global__ __launch_bounds__(KP_NT, 7) void keypoint_kernel(sift3d_kp_params p, 
         sp4[i] = q;
     }
     __syncthreads();
-    if (lane == KP_NT - 64) {
-        float mat[3][3], w[3], v[3][3];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                mat[i][j] = sm.sc[i * 3 + j];
-                v[i][j] = 0;
-            }
-        w[0] = w[1] = w[2] = 0;
-        svd3(mat, w, v);
-        sort_eig(w, v);
-        /* eigen test, MultiScale.cpp:1748-1769 */
-        float es = w[0] + w[1] + w[2];
-        float ep = w[0] * w[1] * w[2];
-        float esp = es * es * es;
-        int keep = (esp < p.eig_thres * ep || p.eig_thres < 0) ? 1 : 0;
-        sm.sc[15] = keep ? 1.0f : 0.0f;
-        if (keep) {
-            kp->x = fx; kp->y = fy; kp->z = fz; kp->scale = scale;
-            kp->eigs[0] = w[0]; kp->eigs[1] = w[1]; kp->eigs[2] = w[2];
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) kp->ori0[i * 3 + j] = v[i][j];
-            kp->info = is_max ? SIFT3D_INFO_MIN0MAX1 : 0u;
-            kp->lvl = lvl;
-        } else {
-            nrec_out[k] = 0;
-        }
-    }
+    if (!svd_first && lane == KP_NT - 64) svd_and_eigen_test();
     wave_splat_sequence(t0, nrad, sm.r.sp_base, sp4); /* wavefront 0; ends with a barrier */
     if (sm.sc[15] == 0.0f) return;
 #ifdef SIFT3D_DEV

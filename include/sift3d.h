@@ -248,6 +248,10 @@ typedef enum {
     SIFT3D_TUNE_DESC_SEGMENT,   /* descriptor kernel: the record list is dealt to the XCDs in contiguous eighths of segments of 8 n records:
                                  * 32 (default: 256 records a segment, all XCDs in the same part of the list at a time); 0: eighths of the
                                  * whole list (rounds 2 - 3); 1: round-robin */
+    SIFT3D_TUNE_FUSED_ORDER,    /* fused blur: which workgroup takes which tile.  Workgroup b of a launch goes to XCD b mod 8.  0: by measurement;
+                                 * 1: XCD x walks the x-th eighth of the tiles in (x, y, chunk) order -- whole rows of tiles per XCD (rounds 1 - 4);
+                                 * 2: workgroup b takes tile b; 3: column strips -- XCD x owns the tiles of column x mod tiles_x, so that a
+                                 * tile's y neighbours share its L2 and an XCD always reads the same byte columns of every row */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);

@@ -81,6 +81,36 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows, tile):
         assert (log["stage"] == built.STAGES.index("blur_fused")).all()   # the fused kernel is what ran
 
 
+@pytest.mark.parametrize("dims", [(64, 40, 30), (128, 64, 33), (256, 48, 20), (512, 64, 16), (1024, 32, 12), (192, 40, 17), (320, 33, 9)])
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_fused_blur_tile_orders_cover_every_tile_once(built, oracle, dims, order):
+    """Round 5: which workgroup takes which tile of the fused launch is a knob (SIFT3D_TUNE_FUSED_ORDER: rows of tiles per XCD,
+    workgroup b = tile b, column strips per XCD).  Every order must hand out every (tile, chunk) exactly once: level and DoG
+    bit-identical to the oracle for 1, 2, 4, 8 and 16 tile columns (where the strip order applies: the counts divide), 3 and 5
+    columns (where the launcher falls back), both tiles, one and several z chunks (also counts the strips cannot split evenly)."""
+    import torch
+    vol = vol_of(built, dims, 23) + np.float32(0.5)
+    nx, ny, nz = dims
+    want = {s: oracle.blur(vol, s) for s in (SIGMAS[2], SIGMAS[5])}
+    with built.Context(*dims) as ctx:
+        ctx.set_tuning(built.TUNE_BLUR_FUSED, 2)
+        ctx.set_tuning(built.TUNE_FUSED_ORDER, order)
+        d_in = torch.from_numpy(vol).cuda()
+        d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
+        torch.cuda.synchronize()
+        for tile, rows, chunks in ((1, 2, 0), (2, 2, 0), (1, 2, 3), (2, 2, 2), (1, 1, 0), (2, 2, 5)):
+            ctx.set_tuning(built.TUNE_FUSED_TILE, tile)
+            ctx.set_tuning(built.TUNE_FUSED_ROWS, rows)
+            ctx.set_tuning(built.TUNE_FUSED_CHUNKS, chunks)
+            for s, w in want.items():
+                d_out.fill_(-7.0); d_dog.fill_(-7.0)
+                torch.cuda.synchronize()
+                ctx.gauss_blur_dog_dev(d_in.data_ptr(), d_out.data_ptr(), d_dog.data_ptr(), nx, ny, nz, s)
+                ctx.sync()
+                assert (bits(d_out.cpu().numpy()) == bits(w)).all(), (dims, order, tile, rows, chunks, s)
+                assert (bits(d_dog.cpu().numpy()) == bits(oracle.dog(vol, w))).all(), (dims, order, tile, rows, chunks, s)
+
+
 @pytest.mark.parametrize("dims", [(64, 48, 40), (136, 37, 45), (72, 17, 3), (128, 64, 70), (264, 50, 21), (16, 2, 2), (40, 33, 12)])
 @pytest.mark.parametrize("chunks,tile", [(0, 0), (1, 1), (3, 1), (5, 2), (2, 2)])
 def test_fused_blur_carries_the_half_size_volume(built, oracle, dims, chunks, tile):
