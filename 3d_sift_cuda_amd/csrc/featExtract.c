@@ -186,7 +186,12 @@ int main(int argc, char **argv)
             for (const char *p = argv[arg] + 2; *p && n_devices < 64; p++) {
                 if (*p == ',') continue;
                 if (*p == ':') { /* -d0,1,2,3:rccl -- the slabs' halos over RCCL instead of peer copies */
-                    if (strcmp(p, ":rccl") == 0) transport = SIFT3D_TRANSPORT_RCCL;
+                    if (strcmp(p, ":rccl") == 0) {
+                        transport = SIFT3D_TRANSPORT_RCCL;
+                        /* (stderr: the usage text and stdout stay the reference's) */
+                        fprintf(stderr, "featExtract: the RCCL slab transport is EXPERIMENTAL -- rehearsed on one GPU against a stand-in library only, never "
+                                        "run between two GPUs; \":peer\" (the default) moves the halos with peer copies over the same links\n");
+                    }
                     else if (strcmp(p, ":peer") != 0) {
                         printf("Error: unknown slab transport: %s\n", p + 1);
                         print_options();

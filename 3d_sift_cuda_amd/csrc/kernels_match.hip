@@ -124,7 +124,10 @@ __device__ __forceinline__ void knn_dispatch_rank(int k, F &&f)
  * CN: every database vector has the same squared norm (rank descriptors: always 85 344) -- then the distance is a decreasing
  * function of q.b alone and the common case needs no arithmetic on the candidates at all: the largest of a lane's sixteen
  * dot products (a tree of eight three-operand maxima) against one per-lane threshold. */
-template <int KK, bool CN, int G>
+/* AHEAD: subtiles the matrix cores run in front of the vector unit.  1 (the product): the products of subtile s + 1 are issued,
+ * then the results of s are looked at.  2 (development builds, round-4 review item 7): three accumulator sets, the products
+ * of s + 2 issued before s is looked at -- measured, DESIGN.md section 7a. */
+template <int KK, bool CN, int G, int AHEAD = 1>
 __global__ __launch_bounds__(256, KNN_WAVES(KK, CN, G)) void knn_search_kernel(const signed char *__restrict__ db, const int *__restrict__ db_norm, long long n_db,
                                                          const signed char *__restrict__ q, const int *__restrict__ q_norm, long long n_q,
                                                          int const_norm, int k, long long tiles_per_segment, int *__restrict__ part_d,
@@ -290,6 +293,26 @@ __global__ __launch_bounds__(256, KNN_WAVES(KK, CN, G)) void knn_search_kernel(c
          * subtile earlier costs 14 - 60 registers and gains nothing: four wavefronts per SIMD cover the LDS latency.) */
         /* the two operand addresses march with the loop (one add each per trip); the subtile inside a trip is an immediate */
         const signed char *p0 = tb + a_off0, *p1 = tb + a_off1;
+        if constexpr (AHEAD == 2) {
+            constexpr int NS = KNN_TILE / 32;
+            m_v16i acc3[3][G];
+            auto issue = [&](int sub, int slot) __attribute__((always_inline)) {
+                const m_v4i x0 = *reinterpret_cast<const m_v4i *>(p0 + sub * 32 * KNN_DIM), x1 = *reinterpret_cast<const m_v4i *>(p1 + sub * 32 * KNN_DIM);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc3[slot][g] = gram(x0, x1, g);
+            };
+            issue(0, 0);
+            issue(1, 1);
+#pragma unroll
+            for (int sub = 0; sub < NS; sub++) {
+                if (sub + 2 < NS) issue(sub + 2, (sub + 2) % 3);
+#pragma unroll
+                for (int g = 0; g < G; g++) take(acc3[sub % 3][g], g, buf, sub, t);
+            }
+            if (t + 1 < t_end) stash(buf ^ 1);
+            __syncthreads();
+            continue;
+        }
         m_v16i acc_a[G], acc_b[G];
         {
             const m_v4i x0 = *reinterpret_cast<const m_v4i *>(p0), x1 = *reinterpret_cast<const m_v4i *>(p1);
@@ -375,11 +398,13 @@ int sift3d_knn_list_length(int k) { return k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32
 
 static int g_knn_dev_groups = 0, g_knn_dev_segments = 0; /* -DSIFT3D_DEV builds: sift3d_dev_knn_plan */
 #ifdef SIFT3D_DEV
+static int g_knn_dev_ahead = 1;
 extern "C" void sift3d_dev_knn_plan(int groups, int segments)
 {
     g_knn_dev_groups = groups;
     g_knn_dev_segments = segments;
 }
+extern "C" void sift3d_dev_knn_ahead(int ahead) { g_knn_dev_ahead = ahead == 2 ? 2 : 1; }
 #endif
 
 /* How a search is cut.  One group of 32 queries per wavefront (two were slower at every size tried: the insertion path, not
@@ -420,6 +445,9 @@ hipError_t sift3d_launch_knn(hipStream_t s, const signed char *db, const int *db
     if (const_norm >= 0) {
 #ifdef SIFT3D_DEV /* two groups per wavefront: measured slower at every size; development builds keep it */
         if (KK == 8 && groups == 2) KNN_LAUNCH(8, true, 2);
+        else if (KK == 8 && g_knn_dev_ahead == 2) /* the matrix cores two subtiles ahead (round-4 review item 7) */
+            hipLaunchKernelGGL((knn_search_kernel<8, true, 1, 2>), grid, dim3(256), 0, s, db, db_norm, (long long)n_db, q, q_norm, (long long)n_q, const_norm, k,
+                               tps, part_d, part_i);
         else
 #endif
         if (KK == 8) KNN_LAUNCH(8, true, 1);

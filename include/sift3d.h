@@ -448,6 +448,9 @@ int sift3d_dev_set_stop(sift3d_ctx *ctx, int n);
 /* Development builds only (tools/bench_match.py with KNN_PLAN=groups,segments): overrides how sift3d_knn64 cuts a search
  * (0 = the library's own choice). */
 void sift3d_dev_knn_plan(int groups, int segments);
+/* Development builds only (KNN_AHEAD=2 tools/bench_match.py): the search kernel with the matrix cores two subtiles ahead of the
+ * vector unit (three accumulator sets) instead of one. */
+void sift3d_dev_knn_ahead(int ahead);
 /* Development builds only (tools/overlap_probe.py): the keypoint and the descriptor kernel of the last extraction run again,
  * one after the other (out_ms[0]) and in alternating slices on two streams (out_ms[1]). */
 int sift3d_dev_overlap_probe(sift3d_ctx *ctx, int kslice, int dslice, double *out_ms);

@@ -16,10 +16,15 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("3d_sift_cuda_amd")
 import _oracle
 plan = os.environ.get("KNN_PLAN")
+ahead = os.environ.get("KNN_AHEAD")   # 2: the development build's two-subtiles-ahead form of the search kernel
+if ahead and not plan:
+    plan = "0,0"
 if plan:
     import ctypes
     pkg.LIB_HIP = os.path.join(pkg.CSRC, os.environ.get("KNN_BUILD", "_build_dev"), "libsift3d_hip.so")   # KNN_BUILD: another development build
     pkg.hip_lib().sift3d_dev_knn_plan(*[ctypes.c_int(int(v)) for v in plan.split(",")])
+    if ahead:
+        pkg.hip_lib().sift3d_dev_knn_ahead(ctypes.c_int(int(ahead)))
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 5
