@@ -200,14 +200,17 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     ctx = pkg.Context(nx, ny, zs.slab_context_slices(plan, rank), device=dev, slab=True)   # no level buffers of its own
     be = zs.HipBackend(pkg, ctx, torch)
     # the deferred patch-halo batch on a communicator of its own, so that it cannot queue in front of a level's halo
-    dgroup = dist.new_group(ranks=list(range(world)), backend=dist.get_backend())
+    # (--zslab-one-group: no second communicator; the deferred batch then queues behind the per-level halos on the first -- the
+    # fallback to try in the same lease if a first run on real links stalls with two communicators per device)
+    dgroup = None if args.zslab_one_group else dist.new_group(ranks=list(range(world)), backend=dist.get_backend())
     # one collective on each group before the first halo: with RCCL that creates both communicators here, on every rank at
     # the same point, instead of inside the first point-to-point batch (where a rank talks to one or two neighbours only
     # and the ranks would be setting up connections in different orders)
     phase("zslab: first collective on both process groups")
     warm = torch.zeros(1, device="cpu" if dist.get_backend() == "gloo" else "cuda:%d" % dev)
     dist.all_reduce(warm)
-    dist.all_reduce(warm, group=dgroup)
+    if dgroup is not None:
+        dist.all_reduce(warm, group=dgroup)
     # the rank's input slices live in HBM before timing starts, as the volume of the per-GPU run does
     # (only its own slices are generated: the same bits as those planes of the whole volume, without the 16 GB of config C5)
     slab = torch.from_numpy(pkg.synth_blobs_slices(nx, ny, nz, i0, i1, seed=12345)).to("cuda:%d" % dev)
@@ -250,7 +253,8 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
                "workload": "ONE %s float32 blob-field volume cut into %d Z-slabs, full featExtract path (%s descriptor), all octaves"
                            % (label, world, ["SIFT-rank", "BRIEF", "RRIEF", "NRRIEF"][desc]),
                "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
-               "parallelism": "zslab%d: halo exchange with torch.distributed (%s), coarse octaves on rank 0" % (world, dist.get_backend()),
+               "parallelism": "zslab%d: halo exchange with torch.distributed (%s, %s), coarse octaves on rank 0"
+                              % (world, dist.get_backend(), "one communicator" if dgroup is None else "two communicators: per-level halos / deferred patch halos"),
                "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"],
                "halo_bytes_critical_per_rank_per_step": ex.stats["exchange_bytes"] - ex.stats["deferred_bytes"],
                "halo_bytes_deferred_per_rank_per_step": ex.stats["deferred_bytes"],
@@ -302,7 +306,7 @@ def zslab_child(args, world, expect, limit_s):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
            str(args.warmup), "--dims", "%d,%d,%d" % resolve_volume(args)[:3], "--desc", str(resolve_volume(args)[3]), "--mode", "zslab",
-           "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)]
+           "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)] + (["--zslab-one-group"] if args.zslab_one_group else [])
     # End exactly the job started here (run_child): torch.distributed.run puts every rank in a session of its own, so the
     # launcher's process group does not contain them -- their PIDs are noted first, the launcher is asked to stop (it
     # terminates its ranks on SIGTERM), then whatever of it is still there is killed.
@@ -351,6 +355,7 @@ def zslab_c_main(args, pkg):
                     h.set_tuning(pkg.ZSLAB_DUPLICATE_RANKS, 1)
                     res["rccl_library"] = rehearsal_lib
                 h.set_tuning(pkg.ZSLAB_TRANSPORT, tr)
+                h.set_tuning(pkg.ZSLAB_SERIAL_CHANNELS, 1 if args.zslab_one_group else 0)
                 for _ in range(max(1, args.warmup)):
                     recs, st = h.extract_resident(desc_mode=desc, copy=False)
                 t0 = time.perf_counter()
@@ -415,7 +420,7 @@ def zslab_c_child(args, world, expect, limit_s):
     import hashlib
     nx, ny, nz, desc, _ = resolve_volume(args)
     cmd = [sys.executable, os.path.abspath(__file__), "--mode", "zslab_c", "--gpus", str(world), "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--dims", "%d,%d,%d" % (nx, ny, nz), "--desc", str(desc)]
+           str(args.warmup), "--dims", "%d,%d,%d" % (nx, ny, nz), "--desc", str(desc)] + (["--zslab-one-group"] if args.zslab_one_group else [])
     rc, so, se = run_child(cmd, child_env(), limit_s)
     out = {}
     for l in so.splitlines():
@@ -451,6 +456,9 @@ def main():
                          "'zslab_c' = only the one-process C driver (no launcher)")
     ap.add_argument("--zslab-limit", type=int, default=180,
                     help="N > 1: seconds each of the two Z-slab child jobs may take")
+    ap.add_argument("--zslab-one-group", action="store_true",
+                    help="N > 1: the Z-slab run's deferred patch-halo batch on the SAME communicator as the per-level halos (default: a "
+                         "second one); for the C driver the same switch is SIFT3D_ZSLAB_SERIAL_CHANNELS")
     ap.add_argument("--phase-limit", type=int, default=300,
                     help="N > 1: seconds any one phase of a rank (set-up, warm-up, the timed steps, a reduction) may take before "
                          "the rank ends the job with exit code 3 and the phase name (0 = no limit)")
