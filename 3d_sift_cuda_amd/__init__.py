@@ -196,7 +196,7 @@ class ZSlabStats(C.Structure):
                 ("halo_bytes_deferred", C.c_int64), ("gather_bytes", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
                 ("n_records", C.c_int64), ("wall_ms", C.c_double), ("halo_bytes_hidden", C.c_int64), ("transport", C.c_int32),
                 ("transport_fell_back", C.c_int32), ("rccl_version", C.c_int32), ("comm_sets", C.c_int32), ("resident_volume", C.c_int32),
-                ("reserved", C.c_int32), ("merge_ms", C.c_double)]
+                ("reserved", C.c_int32), ("merge_ms", C.c_double), ("enqueue_ms", C.c_double)]
 
 
 ZSLAB_TRANSPORT, TRANSPORT_PEER_COPY, TRANSPORT_RCCL = 1000, 0, 1   # sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, ...)

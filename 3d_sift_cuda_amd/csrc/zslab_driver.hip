@@ -641,6 +641,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             /* (the main stream already waits for the deferred patch halos of every sharded octave: ev_patch above) */
             ZS_RC(cand_count_queue(q.c));
         }
+        st.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         for (r = 0; r < S; r++) {
             zs_rank &q = R[(size_t)r];
             ZS_HIP(hipSetDevice(q.dev));

@@ -338,6 +338,8 @@ typedef struct {
     int32_t resident_volume;      /* 1: the input slices were on the devices already (sift3d_zslab_extract_resident): no upload in wall_ms */
     int32_t reserved;
     double merge_ms;              /* host time of the merge of the ranks' records into the single-GPU order (part of wall_ms) */
+    double enqueue_ms;            /* host time from the start of the call until every rank's pyramid and extrema passes are queued (before the
+                                   * first host wait): what ONE host thread spends enqueueing for all devices */
 } sift3d_zslab_stats;
 /* How a block of slices travels from one rank's device to another's (sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, v),
  * sift3d_extract_zslab_over): peer copies -- hipMemcpyPeerAsync on the receiver's stream behind the sender's event, the
