@@ -37,6 +37,8 @@ def sweep(cases=60, seed=1, max_edge=112):
         sub = int(rng.choice([1, 1, 1, 0]))         # round 4: the subsample inside the level-3 launch / a launch of its own
         split = int(rng.choice([1, 1, 0, 2]))       # round 4: the candidate list in two parts (2: the second part overflows -> fall-back)
         dseg = int(rng.choice([32, 32, 0, 1, 5]))   # round 4: the descriptor kernel's record order over the XCDs
+        order = int(rng.choice([0, 0, 1, 2, 3]))    # round 5: which workgroup takes which tile of the fused blur
+        runs = int(rng.choice([0, 0, 1, 3]))        # round 5: the volume handed over in runs of planes (sift3d_set_volume_begin / _planes / _end)
         vol = pkg.synth_blobs(*dims, seed=vseed)
         if noise:
             vol = vol + (rng.standard_normal(vol.shape) * noise).astype(np.float32)
@@ -49,7 +51,17 @@ def sweep(cases=60, seed=1, max_edge=112):
             ctx.set_tuning(pkg.TUNE_FUSED_SUB, sub)
             ctx.set_tuning(pkg.TUNE_SPLIT_TAIL, split)
             ctx.set_tuning(pkg.TUNE_DESC_SEGMENT, dseg)
-            ctx.set_volume(vol)
+            ctx.set_tuning(pkg.TUNE_FUSED_ORDER, order)
+            if i % 5 == 4:
+                ctx.reserve(int(rng.integers(0, 4000)))   # round 5: buffers made ahead of the run (more or fewer than it needs)
+            if runs == 0:
+                ctx.set_volume(vol)
+            else:
+                nzv = vol.shape[0]
+                cuts = sorted(set([0, nzv] + [int(v) for v in rng.integers(1, nzv, runs)]))
+                pieces = [(cuts[k], cuts[k + 1] - cuts[k]) for k in range(len(cuts) - 1)]
+                rng.shuffle(pieces)
+                ctx.set_volume_in_runs(vol, pieces)
             got = ctx.extract(initial_image_scale=init_scale, desc_mode=mode)
         want, _ = orc.extract(vol, init_scale=init_scale, desc_mode=mode)
         ok = len(got) == len(want) and all((got[f].view(np.uint32) == want[f].view(np.uint32)).all() for f in fields)
