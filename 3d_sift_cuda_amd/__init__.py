@@ -38,7 +38,7 @@ INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
 STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
 # sift3d_tuning (include/sift3d.h)
-TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST, TUNE_HOST_RECORDS, TUNE_FUSED_TILE, TUNE_FUSED_SUB, TUNE_SPLIT_TAIL, TUNE_DESC_SEGMENT, TUNE_FUSED_ORDER, TUNE_DESC_THREADS = range(15)
+TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST, TUNE_HOST_RECORDS, TUNE_FUSED_TILE, TUNE_FUSED_SUB, TUNE_SPLIT_TAIL, TUNE_DESC_SEGMENT, TUNE_FUSED_ORDER = range(14)
 
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),

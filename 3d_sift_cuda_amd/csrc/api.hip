@@ -245,10 +245,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2, 1 << 20, 3, 128};
-    if (knob == SIFT3D_TUNE_DESC_THREADS && value != 0 && value != 64 && value != 128)
-        return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: SIFT3D_TUNE_DESC_THREADS takes 0, 64 or 128");
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2, 1 << 20, 3};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -1330,7 +1328,6 @@ static void kp_params_of(sift3d_ctx *c, int desc_mode, float eig_thres, float si
     p.sampler_tokens = c->sampler_tokens;
     p.sampler_cap = c->tune[SIFT3D_TUNE_SAMPLER_CAP];
     p.desc_seg = c->tune[SIFT3D_TUNE_DESC_SEGMENT] * 8;
-    p.desc_threads = c->tune[SIFT3D_TUNE_DESC_THREADS] == 64 ? 64 : 128; /* 0: by measurement */
 }
 
 static int kp_chunks_for(const sift3d_ctx *c, int64_t ncand)

@@ -364,7 +364,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
  * the order-independent phases (gathers, gradients, pre-passes, patch blurs, peak tests), while the
  * sequential chains run on wavefront 0 and the others wait at the barrier. */
 #define KP_NT 256   /* phase A: four wavefronts per keypoint */
-/* phase B: DESC_NT threads per record -- 128 (two wavefronts: rounds 2 - 4) or 64 (round 5, SIFT-rank only); a template argument of descriptor_kernel */
+#define DESC_NT 128  /* phase B: one wavefront per record (15 independent records per CU beat 8 four-wave workgroups) */
 #define NRAD 515 /* voxels of the 11^3 patch with dx^2+dy^2+dz^2 < 25 (all of them interior) */
 #define NRAD_PAD 516
 #define NINT 729 /* interior voxels 1..9 in each axis */
@@ -1066,7 +1066,7 @@ struct kpB_sift { /* SIFT-rank: per interior voxel gradient magnitude + orientat
 struct kpB_brief { /* BRIEF family: blur output (the middle pass goes back into the patch) */
     float t1[PV + 1];
 };
-/* LDS of one record: 10.6 KB for both instantiations of the two-wavefront form */
+/* LDS of one record: 10.6 KB for both instantiations */
 template <bool SIFT>
 struct kpB_smem {
     float patch[PV + 1];
@@ -1076,38 +1076,15 @@ struct kpB_smem {
     float sc[16];
     float taps[8];
     float wtab[2][PD + 1];
-    __device__ __forceinline__ float *patch_ptr() { return patch; }
-    __device__ __forceinline__ typename std::conditional<SIFT, kpB_sift, kpB_brief>::type &work() { return u.v; }
 };
-/* Round 5: the SIFT-rank record in ONE wavefront and 5.5 KB.  From the gradient pre-pass on only wavefront 0 of the record has
- * work, and everything after the pre-pass lives in the 5.1 KB of (magnitude, octant, order) that the patch no longer needs to
- * coexist with: the pre-pass keeps its results in registers until every lane has read its last patch value, then the work
- * arrays take the patch's place.  Half the LDS and half the wavefronts per record: 28 records per CU instead of 14 hide each
- * other's sequential chains (the kernel is latency-bound there: one useful lane per instruction, VALU 25 % busy). */
-struct kpB_smem_small {
-    union {
-        float patch[PV + 1];
-        kpB_sift v;
-    } u;
-    float sc[16];
-    float taps[8];
-    float wtab[2][PD + 1];
-    __device__ __forceinline__ float *patch_ptr() { return u.patch; }
-    __device__ __forceinline__ kpB_sift &work() { return u.v; }
-};
-static_assert(sizeof(kpB_sift) <= sizeof(float) * (PV + 1), "the work arrays of the SIFT-rank record fit where its patch was");
 
-template <bool SIFT, int DESC_NT = 128>
-__global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
+template <bool SIFT>
+__global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p, const sift3d_dkp *__restrict__ kps,
                                                         const int *__restrict__ rec_kp, const int *__restrict__ rec_frame,
                                                         long long nrec, sift3d_feature *__restrict__ recs,
                                                         int *__restrict__ rec_group, sift3d_taps taps5)
 {
-    constexpr bool SMALL = SIFT && DESC_NT == 64; /* one wavefront per record, the work arrays where the patch was */
-    static_assert(DESC_NT == 128 || SMALL, "64 threads: the SIFT-rank record only");
-    __shared__ __attribute__((aligned(16))) typename std::conditional<SMALL, kpB_smem_small, kpB_smem<SIFT>>::type sm;
-    float *const sm_patch = sm.patch_ptr();
-    auto &sm_v = sm.work();
+    __shared__ __attribute__((aligned(16))) kpB_smem<SIFT> sm;
     const long long r = xcd_contiguous_item(nrec, p.desc_seg);
     if (r >= nrec) return;
     const int lane = threadIdx.x;
@@ -1123,7 +1100,7 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
     const sift3d_level lv = p.levels[kp->lvl];
 #ifdef SIFT3D_DEV /* timing ablation (tools/desc_ablate.py): every record samples one cache-resident region */
     if (p.debug_stop >= 21 && p.debug_stop <= 26) { /* development aid: every record samples one cache-resident region (22: and runs to the end, 23/24/25: stops where 12/13/14 do, 26: after the bin chains) */
-        wave_sample_patch<DESC_NT>(sm_patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
+        wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, 20.0f, 20.0f, 20.0f, 3.0f, ori);
         if (p.debug_stop == 21) return;
     } else
 #endif
@@ -1131,7 +1108,7 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
         /* record 0 is sampled with the identity frame and normalised once inside generateFeature3D
          * (MultiScale.cpp:1742): phase A did exactly that and left the result in patch0 */
         const float *src = p.patch0 + (long long)rec_kp[r] * PV;
-        for (int s = lane; s < PV; s += DESC_NT) sm_patch[s] = src[s];
+        for (int s = lane; s < PV; s += DESC_NT) sm.patch[s] = src[s];
         __syncthreads();
     } else {
         /* The gathers of this phase are paced by the L1's miss handling, and the fewer footprints (a patch's is the size of
@@ -1157,14 +1134,14 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
             }
             __syncthreads();
         }
-        wave_sample_patch<DESC_NT>(sm_patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
+        wave_sample_patch<DESC_NT>(sm.patch, lv.img, lv.X, lv.XP, lv.Y, lv.Z, lv.Zl, lv.z_off, kp->x, kp->y, kp->z, kp->scale, ori);
         if (tok && lane == 0) atomicSub(tok, 1);
     }
     /* ... and every record is normalised once more in main (featExtract.cpp:480) */
 #ifdef SIFT3D_DEV
     if (p.debug_stop == 11) return;
 #endif
-    wave_normalize_patch<DESC_NT>(sm_patch, sm.sc);
+    wave_normalize_patch<DESC_NT>(sm.patch, sm.sc);
 #ifdef SIFT3D_DEV
     if (p.debug_stop == 12 || p.debug_stop == 23) return;
 #endif
@@ -1175,14 +1152,13 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
         /* msResampleFeaturesGradientOrientationHistogram, MultiScale.cpp:583-710.  Border voxels
          * have zero gradient (FeatureIO.cpp:2307-2312) and are skipped there, so only the 9^3
          * interior takes part. */
-        /* gradient magnitude and orientation octant of interior voxel q, from the patch */
-        auto grad_of = [&](int q, float &mg, int &best) __attribute__((always_inline)) {
+        for (int q = lane; q < NINT; q += DESC_NT) {
             const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
             const int s = (z * PD + y) * PD + x;
-            float e[3] = {sm_patch[s + 1] - sm_patch[s - 1], sm_patch[s + PD] - sm_patch[s - PD],
-                          sm_patch[s + PD * PD] - sm_patch[s - PD * PD]};
-            mg = v3_mag(e);
-            best = 8; /* 8 = no contribution */
+            float e[3] = {sm.patch[s + 1] - sm.patch[s - 1], sm.patch[s + PD] - sm.patch[s - PD],
+                          sm.patch[s + PD * PD] - sm.patch[s - PD * PD]};
+            float mg = v3_mag(e);
+            int best = 8; /* 8 = no contribution */
             if (mg > 0) {
                 v3_norm(e);
                 const float oa[8][3] = {{1, 1, 1},  {1, 1, -1},  {1, -1, 1},  {1, -1, -1},
@@ -1198,37 +1174,8 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
                     }
                 }
             }
-        };
-        if constexpr (SMALL) {
-            /* the work arrays take the patch's place: every lane keeps its twelve results in registers until all have read
-             * their last patch value */
-            constexpr int PER = (NINT + DESC_NT - 1) / DESC_NT;
-            float mgr[PER];
-            int bnr[PER];
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int q = lane + u * DESC_NT;
-                mgr[u] = 0;
-                bnr[u] = 8;
-                if (q < NINT) grad_of(q, mgr[u], bnr[u]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int q = lane + u * DESC_NT;
-                if (q < NINT) {
-                    sm_v.mag[q] = mgr[u];
-                    sm_v.bin[q] = (unsigned char)bnr[u];
-                }
-            }
-        } else {
-            for (int q = lane; q < NINT; q += DESC_NT) {
-                float mg;
-                int best;
-                grad_of(q, mg, best);
-                sm_v.mag[q] = mg;
-                sm_v.bin[q] = (unsigned char)best;
-            }
+            sm.u.v.mag[q] = mg;
+            sm.u.v.bin[q] = (unsigned char)best;
         }
         if (lane < PD) {
             /* spatial coordinate of patch index c in the 2-bin grid (MultiScale.cpp:641-671), then the
@@ -1258,7 +1205,7 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
             for (int o = 0; o < 8; o++) cnt[o] = 0;
             for (int base = 0; base < NINT; base += 64) {
                 const int q = base + lane;
-                const int b = q < NINT ? sm_v.bin[q] : 8;
+                const int b = q < NINT ? sm.u.v.bin[q] : 8;
 #pragma unroll
                 for (int o = 0; o < 8; o++) cnt[o] += __popcll(__ballot(b == o));
             }
@@ -1267,19 +1214,19 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
 #pragma unroll
             for (int o = 0; o < 8; o++) {
                 run[o] = acc0;
-                if (lane == 0) sm_v.start[o] = acc0;
+                if (lane == 0) sm.u.v.start[o] = acc0;
                 acc0 += cnt[o];
             }
-            if (lane == 0) sm_v.start[8] = acc0;
+            if (lane == 0) sm.u.v.start[8] = acc0;
             for (int base = 0; base < NINT; base += 64) {
                 const int q = base + lane;
-                const int b = q < NINT ? sm_v.bin[q] : 8;
+                const int b = q < NINT ? sm.u.v.bin[q] : 8;
 #pragma unroll
                 for (int o = 0; o < 8; o++) {
                     const unsigned long long m = __ballot(b == o);
                     if (b == o) {
                         const int x = q % 9 + 1, y = (q / 9) % 9 + 1, z = q / 81 + 1;
-                        sm_v.order[run[o] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 4) | (z << 8));
+                        sm.u.v.order[run[o] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 4) | (z << 8));
                     }
                     run[o] += __popcll(m);
                 }
@@ -1293,12 +1240,12 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
             /* lane = ((z*2+y)*2+x)*8 + orientation: one sequential chain per bin over its octant's voxels */
             const int o = lane & 7, bx = (lane >> 3) & 1, by = (lane >> 4) & 1, bz = (lane >> 5) & 1;
             const float *wxs = sm.wtab[bx], *wys = sm.wtab[by], *wzs = sm.wtab[bz];
-            const int k0 = sm_v.start[o], k1 = sm_v.start[o + 1];
+            const int k0 = sm.u.v.start[o], k1 = sm.u.v.start[o + 1];
             float acc = 0;
             for (int kk = k0; kk < k1; kk++) {
-                const unsigned v = sm_v.order[kk];
+                const unsigned v = sm.u.v.order[kk];
                 const int x = v & 15, y = (v >> 4) & 15, z = v >> 8;
-                const float mg = sm_v.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
+                const float mg = sm.u.v.mag[((z - 1) * 9 + (y - 1)) * 9 + (x - 1)];
                 acc += mg * wxs[x] * wys[y] * wzs[z];
             }
 #ifdef SIFT3D_DEV
@@ -1324,9 +1271,9 @@ __global__ __launch_bounds__(DESC_NT, (DESC_NT == 64 ? 7 : 1)) void descriptor_k
         }
     } else {
         /* msResampleFeaturesBRIEF, MultiScale.cpp:989-1049 */
-        wave_blur_patch<DESC_NT>(sm_patch, sm_v.t1, sm_patch, sm.taps, 5);
+        wave_blur_patch<DESC_NT>(sm.patch, sm.u.v.t1, sm.patch, sm.taps, 5);
         if (w0) {
-            const float *bl = sm_v.t1;
+            const float *bl = sm.u.v.t1;
             const int x1 = c_brief_x[3 * lane], y1 = c_brief_x[3 * lane + 1], z1 = c_brief_x[3 * lane + 2];
             const int x2 = c_brief_y[3 * lane], y2 = c_brief_y[3 * lane + 1], z2 = c_brief_y[3 * lane + 2];
             float d = bl[x1 + y1 * PD + z1 * PD * PD] - bl[x2 + y2 * PD + z2 * PD * PD];
@@ -1426,11 +1373,11 @@ hipError_t sift3d_launch_descriptors(hipStream_t s, const sift3d_kp_params &p, c
     for (int i = 0; i < 17; i++) t.f[i] = i < 5 ? taps5[i] : 0.0f;
     const int seg = p.desc_seg;
     const dim3 grid((unsigned)(seg > 0 ? (nrec + seg - 1) / seg * seg : ((nrec + 7) / 8) * 8));
-    if (p.desc_mode == SIFT3D_DESC_SIFT && p.desc_threads == 64)
-        hipLaunchKernelGGL((descriptor_kernel<true, 64>), grid, dim3(64), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs, rec_group, t);
-    else if (p.desc_mode == SIFT3D_DESC_SIFT)
-        hipLaunchKernelGGL((descriptor_kernel<true, 128>), grid, dim3(128), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs, rec_group, t);
+    if (p.desc_mode == SIFT3D_DESC_SIFT)
+        hipLaunchKernelGGL(descriptor_kernel<true>, grid, dim3(DESC_NT), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
+                           rec_group, t);
     else
-        hipLaunchKernelGGL((descriptor_kernel<false, 128>), grid, dim3(128), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs, rec_group, t);
+        hipLaunchKernelGGL(descriptor_kernel<false>, grid, dim3(DESC_NT), 0, s, p, kps, rec_kp, rec_frame, (long long)nrec, recs,
+                           rec_group, t);
     return hipGetLastError();
 }

@@ -136,7 +136,6 @@ struct sift3d_kp_params {
     int *sampler_tokens; /* phase B: per-CU count of workgroups in their sampling phase (SIFT3D_CU_SLOTS ints, zero between runs) */
     int sampler_cap;     /* at most this many per CU sample at a time (0: no limit) */
     int desc_seg;        /* descriptor kernel: records per segment of the XCD-contiguous order (a multiple of 8; 0: the whole list is one) */
-    int desc_threads;    /* descriptor kernel, SIFT-rank: 64 (one wavefront and 5.5 KB of LDS per record) or 128 (two and 10.6 KB) */
 };
 #define SIFT3D_CU_SLOTS 2048
 #define SIFT3D_MAX_FRAMES 11 /* determineCanonicalOrientation3D stops at FEATURE_3D_DIM frames */

@@ -252,9 +252,6 @@ typedef enum {
                                  * 1: XCD x walks the x-th eighth of the tiles in (x, y, chunk) order -- whole rows of tiles per XCD (rounds 1 - 4);
                                  * 2: workgroup b takes tile b; 3: column strips -- XCD x owns the tiles of column x mod tiles_x, so that a
                                  * tile's y neighbours share its L2 and an XCD always reads the same byte columns of every row */
-    SIFT3D_TUNE_DESC_THREADS,   /* descriptor kernel, SIFT-rank: threads per record.  0: by measurement; 64: one wavefront and 5.5 KB of LDS per record
-                                 * (28 records in flight per CU; round 5); 128: two wavefronts and 10.6 KB (14 in flight; rounds 2 - 4).  The BRIEF
-                                 * family always runs 128 (its patch blur needs two buffers) */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);
