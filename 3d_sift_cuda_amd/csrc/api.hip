@@ -100,6 +100,9 @@ static void free_dev(sift3d_ctx *c)
     hipFree(c->rec_frame);
     if (c->h_recs) hipHostFree(c->h_recs);
     if (c->h_group) hipHostFree(c->h_group);
+    hipFree(c->place.d_counts);
+    hipFree(c->place.d_shift);
+    if (c->place.h_counts) hipHostFree(c->place.h_counts);
 }
 
 /* octave list of a volume: halve while every dimension stays above 2 (MultiScale.cpp:359-360,546-556) */
@@ -1328,6 +1331,7 @@ static void kp_params_of(sift3d_ctx *c, int desc_mode, float eig_thres, float si
     p.sampler_tokens = c->sampler_tokens;
     p.sampler_cap = c->tune[SIFT3D_TUNE_SAMPLER_CAP];
     p.desc_seg = c->tune[SIFT3D_TUNE_DESC_SEGMENT] * 8;
+    p.rec_shift = nullptr;
 }
 
 static int kp_chunks_for(const sift3d_ctx *c, int64_t ncand)
@@ -1350,6 +1354,46 @@ static int describe_begin(sift3d_ctx *c, size_t nlevels, float *taps3)
     c->kp.launched = 0;
     c->kp.nrec = 0;
     c->kp.split = false;
+    c->place.dst = nullptr; /* a shared destination holds for one run */
+    return SIFT3D_OK;
+}
+
+void describe_want_group_counts(sift3d_ctx *c, bool on) { c->place.counts = on; }
+
+static int ensure_place_buffers(sift3d_ctx *c)
+{
+    if (c->place.d_counts) return SIFT3D_OK;
+    HIPCHK(c, hipMalloc((void **)&c->place.d_counts, sizeof(int) * SIFT3D_GROUPS));
+    HIPCHK(c, hipMalloc((void **)&c->place.d_shift, sizeof(int) * SIFT3D_GROUPS));
+    HIPCHK(c, hipHostMalloc((void **)&c->place.h_counts, sizeof(int) * SIFT3D_GROUPS, hipHostMallocDefault));
+    return SIFT3D_OK;
+}
+
+int describe_group_counts(sift3d_ctx *c, const int **counts, int64_t *total)
+{
+    if (!c->place.counts) return set_err(c, SIFT3D_ERR_ARG, "describe_group_counts: not asked for before describe_queue");
+    {
+        const int rc = ensure_place_buffers(c); /* (a run without candidates has not made them) */
+        if (rc) return rc;
+    }
+    *total = 0;
+    if (c->kp.ncand <= 0 || c->kp.nchunks != 1) { /* nothing queued (no candidates): every count is zero */
+        memset(c->place.h_counts, 0, sizeof(int) * SIFT3D_GROUPS);
+        *counts = c->place.h_counts;
+        return c->kp.nchunks > 1 ? set_err(c, SIFT3D_ERR_ARG, "describe_group_counts: the stage runs in chunks") : SIFT3D_OK;
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_kpc[0]));
+    for (int g = 0; g < SIFT3D_GROUPS; g++) *total += c->place.h_counts[g];
+    *counts = c->place.h_counts;
+    return SIFT3D_OK;
+}
+
+int describe_placement(sift3d_ctx *c, sift3d_feature *shared_list, const int *shift)
+{
+    if (!shared_list || !shift || !c->place.d_shift) return set_err(c, SIFT3D_ERR_ARG, "describe_placement: bad arguments");
+    /* (pageable source: the copy has been staged when the call returns, the caller's table may go) */
+    HIPCHK(c, hipMemcpyAsync(c->place.d_shift, shift, sizeof(int) * SIFT3D_GROUPS, hipMemcpyHostToDevice, c->stream));
+    c->place.dst = shared_list;
     return SIFT3D_OK;
 }
 
@@ -1370,6 +1414,13 @@ static int describe_queue_chunk(sift3d_ctx *c, int i, int64_t a, int64_t b, hipS
     HIPCHK(c, sift3d_scan_counts(ks, c->scan_tmp, c->scan_tmp_bytes, c->nrec + a, c->offs + a, b - a));
     HIPCHK(c, sift3d_launch_recmap(ks, c->nrec + a, c->offs + a, b - a, (int)a, c->d_rec_base + i, c->rec_kp, c->rec_frame, c->d_count + 3));
     HIPCHK(c, hipMemcpyAsync(&h_end[i], c->d_rec_base + i + 1, sizeof(int), hipMemcpyDeviceToHost, ks));
+    if (c->place.counts && i == 0) { /* records per group, for a driver that places several contexts' records in one list */
+        int rc = ensure_place_buffers(c);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->place.d_counts, 0, sizeof(int) * SIFT3D_GROUPS, ks));
+        HIPCHK(c, sift3d_launch_group_counts(ks, c->keys_b + a, c->nrec + a, b - a, c->place.d_counts));
+        HIPCHK(c, hipMemcpyAsync(c->place.h_counts, c->place.d_counts, sizeof(int) * SIFT3D_GROUPS, hipMemcpyDeviceToHost, ks));
+    }
     HIPCHK(c, hipEventRecord(c->ev_kpc[i], ks));
     return SIFT3D_OK;
 }
@@ -1417,7 +1468,7 @@ int describe_launch(sift3d_ctx *c)
         HIPCHK(c, hipEventSynchronize(c->ev_kpc[i]));
         const int64_t end = h_end[i], m = end - base;
         if (end < base || end > c->recs_cap) return set_err(c, SIFT3D_ERR_DEVICE, "record map out of range (%lld of %lld)", (long long)end, (long long)c->recs_cap);
-        if (end > c->hrecs_cap) {
+        if (end > c->hrecs_cap && !c->place.dst) {
             /* more records than the pinned buffers were sized for: wait for the descriptor launches of the earlier chunks
              * (they store into the buffers about to be replaced), grow, carry their records over */
             HIPCHK(c, hipStreamSynchronize(ds));
@@ -1433,8 +1484,18 @@ int describe_launch(sift3d_ctx *c)
             if (c->kp.p.sampler_cap > 0 && !(split && i > 0)) /* the per-CU tokens start from zero whatever became of an earlier launch
                                                                 * (not under the first chunk's running kernel, which holds some) */
                 HIPCHK(c, hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, ds));
-            HIPCHK(c, sift3d_launch_descriptors(ds, c->kp.p, c->kps, c->rec_kp + base, c->rec_frame + base, m, c->d_hrecs + base,
-                                                c->d_hgroup + base, c->kp.taps5));
+            sift3d_kp_params q = c->kp.p;
+            q.rec_shift = c->place.dst ? c->place.d_shift : nullptr;
+            /* (with a shared destination the per-record group words still go to this context's own buffer, which then has to
+             * hold them: ensure_kp_buffers sized it for the candidates, and a run that outgrows it falls back to growing it) */
+            if (c->place.dst && end > c->hrecs_cap) {
+                HIPCHK(c, hipStreamSynchronize(ds));
+                int rc = ensure_host_records(c, end, 0);
+                if (rc) return rc;
+                c->host_grows++;
+            }
+            HIPCHK(c, sift3d_launch_descriptors(ds, q, c->kps, c->rec_kp + base, c->rec_frame + base, m,
+                                                (c->place.dst ? c->place.dst : c->d_hrecs) + base, c->d_hgroup + base, c->kp.taps5));
         }
         base = end;
     }

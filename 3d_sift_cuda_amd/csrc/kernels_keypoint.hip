@@ -1296,7 +1296,11 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
         float vj = lane_value(myval, j);
         rank += (vj < myval || (vj == myval && j < lane)) ? 1 : 0;
     }
-    sift3d_feature *out = recs + r;
+    /* where the record goes: slot r of this launch's records -- or, when several contexts write ONE merged list (the slab
+     * driver), shifted by a per-group offset: a rank's records are sorted by group already, so the merged position of its
+     * record r is r + rec_shift[group] (group = level id * 2 + is_max) */
+    const int grp = kp->lvl * 2 + ((kp->info & SIFT3D_INFO_MIN0MAX1) ? 1 : 0);
+    sift3d_feature *out = recs + r + (p.rec_shift ? (long long)p.rec_shift[grp] : 0ll);
     out->desc[lane] = (float)rank;
     /* The seventeen words in front of the descriptor, one lane each: one 68-byte store instead of seventeen 4-byte ones by
      * lane 0 (the records may lie in host memory, where every store is a transaction on the bus). */
@@ -1320,8 +1324,28 @@ __global__ __launch_bounds__(DESC_NT) void descriptor_kernel(sift3d_kp_params p,
             word = kp->info | (fr < 0 ? 0u : SIFT3D_INFO_REORIENT);
         }
         reinterpret_cast<unsigned *>(out)[lane] = word;
-        if (lane == 0) rec_group[r] = kp->lvl * 2 + ((kp->info & SIFT3D_INFO_MIN0MAX1) ? 1 : 0);
+        if (lane == 0) rec_group[r] = grp;
     }
+}
+
+/* Records per group (level id * 2 + is_max; SIFT3D_GROUPS - 1 takes anything beyond) of a sorted candidate list: what a driver
+ * with several contexts needs to place every context's records in one merged list before the descriptor launches run. */
+__global__ void group_count_kernel(const unsigned long long *__restrict__ keys, const int *__restrict__ nrec, long long ncand, int *__restrict__ counts)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncand) return;
+    const int n = nrec[k];
+    if (n <= 0) return;
+    int g = (int)(keys[k] >> SIFT3D_KEY_LVL_SHIFT) * 2 + (int)((keys[k] >> SIFT3D_KEY_MAX_SHIFT) & 1ull);
+    if (g < 0 || g >= SIFT3D_GROUPS - 1) g = SIFT3D_GROUPS - 1;
+    atomicAdd(counts + g, n);
+}
+
+hipError_t sift3d_launch_group_counts(hipStream_t s, const unsigned long long *keys, const int *nrec, int64_t ncand, int *counts)
+{
+    if (ncand <= 0) return hipSuccess;
+    hipLaunchKernelGGL(group_count_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s, keys, nrec, (long long)ncand, counts);
+    return hipGetLastError();
 }
 
 /* Record r of candidate k: rec_kp = k (counted over the whole sorted list), rec_frame = -1 (un-reoriented) or the frame

@@ -121,6 +121,11 @@ struct sift3d_ctx {
         int64_t first[SIFT3D_KP_MAX_CHUNKS + 1];
         bool split; /* the chunks were queued on kp_stream by the split tail: the first one's descriptor launch goes to the main stream */
     } kp;
+    struct {                /* records placed straight into a list several contexts share (the slab driver; describe_placement) */
+        bool counts;            /* describe_queue also counts the records per group (d_counts -> h_counts, behind ev_kpc[0]) */
+        int *d_counts, *h_counts, *d_shift; /* SIFT3D_GROUPS ints each: device, pinned host, device */
+        sift3d_feature *dst;    /* device-visible address of the shared list (NULL: the context's own pinned buffer) */
+    } place;
     int dev_stop;           /* -DSIFT3D_DEV builds: sift3d_dev_set_stop */
     bool count_queued;      /* cand_count_queue ran and nothing was appended since */
     std::vector<struct level_job> jobs; /* extrema launches since the last reset (replayed if the buffer must grow) */
@@ -177,6 +182,13 @@ int cand_finalize(sift3d_ctx *c, int64_t *count_out);
  * waits for any */
 int describe_queue(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode, float eig_thres, float size_factor,
                    bool levels_on_device);
+/* between describe_queue and describe_launch, for a context whose records go into a list shared with other contexts:
+ * describe_group_counts waits for the keypoint side of the stage and returns the records per group (SIFT3D_GROUPS ints, valid
+ * until the next run; needs describe_want_group_counts(c, true) before describe_queue); describe_placement names the shared
+ * list (its address as this context's device sees it) and the per-group shift of this context's records in it */
+void describe_want_group_counts(sift3d_ctx *c, bool on);
+int describe_group_counts(sift3d_ctx *c, const int **counts, int64_t *total);
+int describe_placement(sift3d_ctx *c, sift3d_feature *shared_list, const int *shift);
 int describe_launch(sift3d_ctx *c);
 int describe_finish(sift3d_ctx *c, int64_t *n_out);
 #pragma GCC visibility pop

@@ -9,7 +9,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
 #include <vector>
 
 #include "pipeline.h"
@@ -172,7 +171,11 @@ struct sift3d_zslab {
     int transport_flags = 0;                /* ZS_FLAG_*: SIFT3D_ZSLAB_SERIAL_CHANNELS, SIFT3D_ZSLAB_DUPLICATE_RANKS */
     zs_transport *tr = nullptr;             /* created by the first extraction after the choice (zslab_transport.hip) */
     bool has_volume = false;                /* sift3d_zslab_set_volume has put every rank's input slices on its device */
-    sift3d_feature *merged = nullptr;       /* the merged records of the last resident extraction (host; what its view points at) */
+    /* The merged records (round 5): ONE pinned host buffer every rank's device can store into (hipHostMallocPortable).  A rank's
+     * records are sorted by group already, so their merged positions are the rank's own positions shifted group by group: once
+     * every rank's records per group are known (a 193-word read-back beside the record total each rank waits for anyway) the
+     * descriptor kernels store straight into their merged places and there is no merge left to do. */
+    sift3d_feature *merged = nullptr;
     int64_t merged_cap = 0;
     sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
 };
@@ -204,7 +207,7 @@ extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
         if (q.ev_patch) hipEventDestroy(q.ev_patch);
         sift3d_destroy(q.c);
     }
-    free(h->merged);
+    if (h->merged) hipHostFree(h->merged);
     delete h;
 }
 
@@ -647,8 +650,56 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             ZS_HIP(hipSetDevice(q.dev));
             ZS_RC(cand_finalize(q.c, &ncands[(size_t)r]));
             st.n_extrema += ncands[(size_t)r];
+            describe_want_group_counts(q.c, true);
+            q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the placement below needs the whole list's counts before the one descriptor launch */
             ZS_RC(describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false));
         }
+        /* every rank's records per group (level, is_max): the merged list is, group by group, a run of every rank in rank order --
+         * within a group slabs are in z order, so rank order is the serial raster order */
+        std::vector<std::vector<int>> cnt((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0));
+        int64_t total = 0;
+        for (r = 0; r < S; r++) {
+            const int *hc = nullptr;
+            int64_t tr = 0;
+            ZS_HIP(hipSetDevice(R[(size_t)r].dev));
+            ZS_RC(describe_group_counts(R[(size_t)r].c, &hc, &tr));
+            cnt[(size_t)r].assign(hc, hc + SIFT3D_GROUPS);
+            nrecs[(size_t)r] = tr;
+            total += tr;
+        }
+        const auto merge0 = std::chrono::steady_clock::now(); /* (the waits for the keypoint kernels are behind us) */
+        if (total > h->merged_cap) { /* nothing stores into the list yet: the descriptor launches follow */
+            if (h->merged) hipHostFree(h->merged);
+            h->merged = nullptr;
+            h->merged_cap = total + total / 8 + 1024;
+            if (hipHostMalloc((void **)&h->merged, sizeof(sift3d_feature) * (size_t)h->merged_cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+                h->merged = nullptr;
+                h->merged_cap = 0;
+                rc = SIFT3D_ERR_MEMORY;
+                snprintf(errbuf, sizeof errbuf, "out of pinned host memory for %lld merged records", (long long)total);
+                goto done;
+            }
+        }
+        {
+            int64_t pos = 0;
+            std::vector<std::vector<int>> shift((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0));
+            std::vector<int64_t> local((size_t)S, 0); /* a rank's own position: its records before this group */
+            for (int g = 0; g < SIFT3D_GROUPS; g++)
+                for (r = 0; r < S; r++) {
+                    shift[(size_t)r][(size_t)g] = (int)(pos - local[(size_t)r]);
+                    pos += cnt[(size_t)r][(size_t)g];
+                    local[(size_t)r] += cnt[(size_t)r][(size_t)g];
+                }
+            for (r = 0; r < S; r++) {
+                zs_rank &q = R[(size_t)r];
+                if (nrecs[(size_t)r] <= 0) continue;
+                ZS_HIP(hipSetDevice(q.dev));
+                sift3d_feature *dview = nullptr; /* the list as this rank's device sees it */
+                ZS_HIP(hipHostGetDevicePointer((void **)&dview, h->merged, 0));
+                ZS_RC(describe_placement(q.c, dview, shift[(size_t)r].data()));
+            }
+        }
+        st.merge_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge0).count();
         for (r = 0; r < S; r++) {
             ZS_HIP(hipSetDevice(R[(size_t)r].dev));
             ZS_RC(describe_launch(R[(size_t)r].c));
@@ -658,72 +709,20 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             int64_t nrec = 0;
             ZS_HIP(hipSetDevice(q.dev));
             ZS_RC(describe_finish(q.c, &nrec));
-            nrecs[(size_t)r] = nrec;
+            if (nrec != nrecs[(size_t)r]) { rc = SIFT3D_ERR_DEVICE; snprintf(errbuf, sizeof errbuf, "rank %d: %lld records where its groups add up to %lld", r, (long long)nrec, (long long)nrecs[(size_t)r]); goto done; }
             st.n_keypoints += q.c->last.n_keypoints;
         }
-    }
-    {
-        /* merge: within a group (level, is_max) slabs are in z order, so rank order is the serial raster order.  A rank's
-         * records are sorted by group already (the sort key leads with it), so the merged list is, group by group, a run of
-         * every rank in rank order: the runs are copied straight out of the ranks' pinned download buffers (still valid:
-         * nothing has run on the contexts since), one host thread per rank. */
-        const auto merge0 = std::chrono::steady_clock::now();
-        const int NG = 2 * 96 + 1; /* level id * 2 + is_max; the last slot takes anything out of range */
-        int64_t total = 0;
-        for (r = 0; r < S; r++) total += nrecs[(size_t)r];
-        sift3d_feature *res;
+        /* the list is complete where every rank's kernel put it */
         if (out) {
-            res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));
+            sift3d_feature *res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));
+            if (!res) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "out of host memory"); goto done; }
+            if (total) memcpy(res, h->merged, sizeof(sift3d_feature) * (size_t)total);
+            *out = res;
         } else {
-            if (total > h->merged_cap) {
-                free(h->merged);
-                h->merged_cap = total + total / 8 + 1024;
-                h->merged = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)h->merged_cap);
-                if (!h->merged) h->merged_cap = 0;
-            }
-            res = h->merged;
+            *view = h->merged;
         }
-        if (!res) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "out of host memory"); goto done; }
-        std::vector<int64_t> cnt((size_t)S * NG, 0), at((size_t)S * NG, 0);
-        bool sorted = true;
-        for (r = 0; r < S; r++) {
-            const int *g = R[(size_t)r].c->h_group;
-            int prev = -1;
-            for (int64_t i = 0; i < nrecs[(size_t)r]; i++) {
-                const int gi = g[i] < 0 || g[i] >= NG - 1 ? NG - 1 : g[i];
-                cnt[(size_t)r * NG + gi]++;
-                sorted = sorted && gi >= prev;
-                prev = gi;
-            }
-        }
-        if (!sorted) { rc = SIFT3D_ERR_ARG; snprintf(errbuf, sizeof errbuf, "a rank's records are not in group order"); if (out) free(res); goto done; }
-        int64_t pos = 0;
-        for (int gi = 0; gi < NG; gi++)
-            for (r = 0; r < S; r++) {
-                at[(size_t)r * NG + gi] = pos;
-                pos += cnt[(size_t)r * NG + gi];
-            }
-        auto copy_rank = [&](int rr) {
-            const sift3d_feature *src = R[(size_t)rr].c->h_recs;
-            int64_t i = 0;
-            for (int gi = 0; gi < NG; gi++) {
-                const int64_t m = cnt[(size_t)rr * NG + gi];
-                if (m) memcpy(res + at[(size_t)rr * NG + gi], src + i, sizeof(sift3d_feature) * (size_t)m);
-                i += m;
-            }
-        };
-        if (S > 1 && total > 4096) {
-            std::vector<std::thread> th;
-            for (r = 1; r < S; r++) th.emplace_back(copy_rank, r);
-            copy_rank(0);
-            for (std::thread &t : th) t.join();
-        } else {
-            for (r = 0; r < S; r++) copy_rank(r);
-        }
-        if (out) *out = res; else *view = res;
         *n_out = total;
         st.n_records = total;
-        st.merge_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge0).count();
     }
 
 done:

@@ -337,7 +337,9 @@ typedef struct {
     int32_t comm_sets;            /* RCCL communicator sets in use: 2, or 1 with SIFT3D_ZSLAB_SERIAL_CHANNELS (0 with peer copies) */
     int32_t resident_volume;      /* 1: the input slices were on the devices already (sift3d_zslab_extract_resident): no upload in wall_ms */
     int32_t reserved;
-    double merge_ms;              /* host time of the merge of the ranks' records into the single-GPU order (part of wall_ms) */
+    double merge_ms;              /* host time spent on the merged order (part of wall_ms).  Round 5: the ranks' descriptor kernels store their
+                                   * records straight into their places in ONE pinned list, so this is the per-group offset table and its
+                                   * upload (microseconds) plus, when the list has to grow, its allocation -- there is no merge left */
     double enqueue_ms;            /* host time from the start of the call until every rank's pyramid and extrema passes are queued (before the
                                    * first host wait): what ONE host thread spends enqueueing for all devices */
 } sift3d_zslab_stats;
@@ -382,6 +384,9 @@ void sift3d_zslab_destroy(sift3d_zslab *h);
  * cuts the host volume into the ranks' input slices (slab +- 16) and uploads them once; sift3d_zslab_extract_resident then
  * runs any number of extractions from HBM.  *view is the handle's own host buffer with the merged records (single-GPU order,
  * single-GPU bytes), valid until the handle's next call; do not free it.  stats->wall_ms then holds no upload. */
+/* (Both extraction forms: the ranks' records are placed in the merged order by the descriptor kernels themselves -- a rank's
+ * records are sorted by (level, is_max) group already, so once every rank's records per group are known, a 193-word read-back
+ * beside the record total each rank waits for anyway, a record's merged position is its own position plus a per-group shift.) */
 int sift3d_zslab_set_volume(sift3d_zslab *h, const float *vol, char *err, int64_t err_len);
 int sift3d_zslab_extract_resident(sift3d_zslab *h, float initial_image_scale, int desc_mode, float eig_thres, float size_factor,
                                   const sift3d_feature **view, int64_t *n_out, sift3d_zslab_stats *stats, char *err, int64_t err_len);
