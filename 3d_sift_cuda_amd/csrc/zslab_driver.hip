@@ -390,10 +390,9 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         timing_begin(q.c);
         /* level 0 = initial blur of the input, on slab +- 8 from input slab +- 16 */
         const int64_t XY = nx * ny;
-        float *din = vol ? q.alloc((i1 - i0) * XY) : q.vol_dev, *tmp = q.alloc((i1 - i0) * XY);
-        if (!din || !tmp) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
+        float *din = vol ? q.alloc((i1 - i0) * XY) : q.vol_dev;
+        if (!din) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
         if (vol) ZS_HIP(hipMemcpyAsync(din, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream));
-        ZS_RC(blur_dev(q.c, din, tmp, nullptr, nx, ny, i1 - i0, extra0, 0.01f));
         int64_t z0 = 0, z1 = nz;
         if (S > 1) plan.slab(r, 0, z0, z1);
         const bool lo = S > 1 && r > 0, hi = S > 1 && r < S - 1;
@@ -401,7 +400,19 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         const int64_t c0 = lo ? std::max(e0, z0 - ZS_BLUR) : e0, c1 = hi ? std::min(e1, z1 + ZS_BLUR) : e1;
         float *l0 = q.alloc((e1 - e0) * XY);
         if (!l0) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-        ZS_HIP(hipMemcpyAsync(l0 + (c0 - e0) * XY, tmp + (c0 - i0) * XY, sizeof(float) * (size_t)((c1 - c0) * XY), hipMemcpyDeviceToDevice, q.c->stream));
+        /* Level 0 = the initial blur of the input, wanted on slab +- 8 (planes [c0, c1)) from input slab +- 16 (planes [i0, i1)).
+         * Where the blur has its windowed form it writes exactly those planes straight into the level buffer: seen from the
+         * input's plane numbering the buffer starts i0 - e0 planes before its own first plane (i0 >= e0: the input reaches 16
+         * slices beyond the slab, the buffer 32), and only the window is written.  Otherwise: the whole input slab into a
+         * scratch volume, then a copy of the planes that are exact (rounds 2 - 4). */
+        if (i0 >= e0 && blur_window_supported(nx, ny, extra0, 0.01f)) {
+            ZS_RC(blur_window_dev(q.c, din, l0 + (i0 - e0) * XY, nullptr, nx, ny, i1 - i0, c0 - i0, c1 - i0, extra0, 0.01f));
+        } else {
+            float *tmp = q.alloc((i1 - i0) * XY);
+            if (!tmp) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
+            ZS_RC(blur_dev(q.c, din, tmp, nullptr, nx, ny, i1 - i0, extra0, 0.01f));
+            ZS_HIP(hipMemcpyAsync(l0 + (c0 - e0) * XY, tmp + (c0 - i0) * XY, sizeof(float) * (size_t)((c1 - c0) * XY), hipMemcpyDeviceToDevice, q.c->stream));
+        }
         next0[r] = l0;
     }
 
@@ -547,10 +558,16 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 }
             }
         }
-        /* extrema of the rank's own slices; the level table in whole-volume terms */
+        /* extrema of the rank's own slices; the level table in whole-volume terms.  Round 5: on the context's extrema stream,
+         * behind everything the main stream holds so far (this octave's levels, their halos, the DoG slices redone on them), so
+         * that the passes of octave o run beside the levels of octave o + 1 as they do on one device (run_pipeline); the main
+         * stream waits for them once, before the counts are read. */
         for (r = 0; r < nr; r++) {
             zs_rank &q = R[(size_t)r];
             ZS_HIP(hipSetDevice(q.dev));
+            ZS_HIP(hipEventRecord(q.c->ev_oct[0], q.c->stream));
+            ZS_HIP(hipStreamWaitEvent(q.c->ex_stream, q.c->ev_oct[0], 0));
+            q.c->cand_stream = q.c->ex_stream;
             for (int l = 0; l < 3; l++) {
                 const int id = o * 3 + l;
                 level_job jb = {q.D[l], q.D[l + 1], q.D[l + 2], X, Y, q.e1 - q.e0, (int)(q.z0 - q.e0), (int)(q.z1 - q.e0), id, 0};
@@ -564,7 +581,12 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                     jb.next_ntaps = ntaps5;
                     for (int t = 0; t < ntaps5; t++) jb.next_taps[t] = taps5[t];
                 }
-                ZS_RC(cand_append(q.c, jb, true));
+                rc = cand_append(q.c, jb, true);
+                if (rc != SIFT3D_OK) {
+                    q.c->cand_stream = nullptr;
+                    snprintf(errbuf, sizeof errbuf, "rank %d: %s", r, sift3d_last_error(q.c));
+                    goto done;
+                }
                 sift3d_level &lv = q.levels[(size_t)id];
                 lv.img = q.L[l + 1]; lv.dogc = q.D[l + 1];
                 lv.X = (int)X; lv.Y = (int)Y; lv.Z = (int)zo; lv.XP = (int)X;
@@ -572,6 +594,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 lv.octave_factor = fscale;
                 lv.Zl = (int)(q.e1 - q.e0); lv.z_off = (int)q.e0; lv.pad = 0;
             }
+            q.c->cand_stream = nullptr;
             if (q.lo || q.hi) ZS_HIP(hipStreamWaitEvent(q.c->stream, q.ev_patch, 0)); /* before the subsample reads L3 beyond +- 8 */
         }
         fscale *= 2.0f;
@@ -642,6 +665,8 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             zs_rank &q = R[(size_t)r];
             ZS_HIP(hipSetDevice(q.dev));
             /* (the main stream already waits for the deferred patch halos of every sharded octave: ev_patch above) */
+            ZS_HIP(hipEventRecord(q.c->ev_oct[1], q.c->ex_stream)); /* every extrema pass of the run is behind this */
+            ZS_HIP(hipStreamWaitEvent(q.c->stream, q.c->ev_oct[1], 0));
             ZS_RC(cand_count_queue(q.c));
         }
         st.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -731,6 +756,8 @@ done:
         zs_rank &q = R[i];
         hipSetDevice(q.dev);
         hipStreamSynchronize(q.c->stream);
+        hipStreamSynchronize(q.c->ex_stream);
+        q.c->cand_stream = nullptr;
         hipStreamSynchronize(q.copy_stream);
         hipStreamSynchronize(q.halo_stream);
     }
