@@ -176,6 +176,7 @@ def host_lib():
     _sig(L.nifti_min_write_f32, I, C.c_char_p, P, I, I, I, F, F, F)
     _sig(L.nifti_min_write_f32_ex, I, C.c_char_p, P, I, I, I, F, F, F, P, P)
     _sig(L.sift3d_write_key, I, C.c_char_p, P, I64, F, I, P)
+    _sig(L.sift3d_write_key_mode, None, I)
     _sig(L.sift3d_write_key_bin, I, C.c_char_p, P, I64, F)
     _sig(L.sift3d_read_key, I, C.c_char_p, P, P)
     _sig(L.sift3d_write_pgm, I, C.c_char_p, P, I, I)

@@ -109,6 +109,11 @@ static size_t len_record(const sift3d_feature *r)
     return n + 16 + 1 + SIFT3D_DESC_LEN + 1; /* the tabs and the newline */
 }
 
+/* 0: positional writes (the default); 1: a shared mapping of the reserved file where the file system offers one (tests and
+ * tools/key_writer_bench.c run both) */
+static int g_key_writer_mode = 0;
+void sift3d_write_key_mode(int mode) { g_key_writer_mode = mode == 1 ? 1 : 0; }
+
 static int write_all_at(int fd, const char *buf, size_t len, off_t at)
 {
     while (len) {
@@ -123,15 +128,17 @@ static int write_all_at(int fd, const char *buf, size_t len, off_t at)
  * of `featExtract in.nii out.key` after the file read (0.07 s against 0.01 s of extraction).  The records are cut into blocks
  * of KEY_BLOCK.  Pass 1, in parallel: which records of a block pass the eigenvalue filter and how many characters they will
  * take (the digit counts of the numbers, no formatting).  The block sizes summed are every block's place in the file.  Pass 2,
- * in parallel: every block formatted straight into its place -- the file reserved (posix_fallocate: a full disk is an error
- * code here, not a SIGBUS later) and mapped, because writes to one file are serialised by the kernel (the inode's lock) and
- * page faults on a shared mapping are not; where the file system offers neither, into a buffer and out by pwrite.  The bytes
- * are those of the serial writer: tests/test_oracle_pins.py holds them to the reference's own writer compiled from its
- * header, tests/test_abi_and_host.py to the oracle's fprintf for 1, 3 and 8 threads. */
+ * in parallel: every block formatted into a buffer of its thread and written at its place (pwrite).  The other way to get the
+ * blocks in -- the file reserved (posix_fallocate) and mapped, every block formatted straight into the mapping -- is kept as
+ * mode 1: on the development container (ext4) it is the faster one (0.036 - 0.047 against 0.042 - 0.08 s with 8 threads), on the GPU
+ * boxes (overlayfs) page faults on a shared mapping cost twice what the writes do (0.034 against 0.018 s with 16 threads; one
+ * thread: 0.096 s; profiles/r05_cli.txt).  The bytes are those of the serial writer: tests/test_oracle_pins.py holds them to the
+ * reference's own writer compiled from its header, tests/test_abi_and_host.py to the oracle's fprintf for 1, 3 and 8 threads and
+ * both modes. */
 int sift3d_write_key(const char *path, const sift3d_feature *recs, int64_t n, float eig_thres, int n_comments,
                      const char *const *comments)
 {
-    FILE *f = fopen(path, "wt");
+    FILE *f = fopen(path, "w+"); /* read-write: a shared mapping that is written needs a descriptor opened for both */
     if (!f) return -1;
     const int64_t nblocks = (n + KEY_BLOCK - 1) / KEY_BLOCK;
     size_t *len = (size_t *)calloc((size_t)(nblocks ? nblocks : 1), sizeof(size_t));
@@ -179,7 +186,7 @@ int sift3d_write_key(const char *path, const sift3d_feature *recs, int64_t n, fl
         const int fd = fileno(f);
         const off_t total = at[nblocks];
         char *map = (char *)MAP_FAILED;
-        if (nthreads > 1 && total > head && posix_fallocate(fd, 0, total) == 0)
+        if (nthreads > 1 && total > head && g_key_writer_mode == 1 && posix_fallocate(fd, 0, total) == 0)
             map = (char *)mmap(NULL, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         int wbad = 0;
 #pragma omp parallel num_threads(nthreads) reduction(| : wbad)

@@ -13,6 +13,10 @@ extern "C" {
 /* Returns 0, or -1 if the file cannot be opened.  eig_thres < 0 keeps every record. */
 int sift3d_write_key(const char *path, const sift3d_feature *recs, int64_t n, float eig_thres, int n_comments,
                      const char *const *comments);
+/* How the parallel text writer puts its blocks into the file: 0 (default) positional writes, 1 a shared mapping of the
+ * reserved file where the file system offers one (faster on some file systems, slower on the GPU boxes' overlayfs).  The bytes are
+ * the same; tests and tools/key_writer_bench.c run both. */
+void sift3d_write_key_mode(int mode);
 /* The binary flavour, msFeature3DVectorOutputBin (MultiScale.h:228-303): the same two header lines as text
  * ("# featExtract 1.1", "Features: N"), then per kept record 4+9+3 floats, the info word and the 64 descriptor
  * values as unsigned char. */

@@ -190,13 +190,16 @@ def test_key_writer_in_parallel_blocks_writes_the_serial_bytes(built, oracle, tm
     assert 0.2 * n < kept < 0.95 * n and want.count(b"\n") == kept + 6
     np.save(str(tmp_path / "recs.npy"), recs)
     code = ("import importlib, sys, numpy as np; sys.path.insert(0, %r); p = importlib.import_module('3d_sift_cuda_amd'); "
+            "p.host_lib().sift3d_write_key_mode(int(sys.argv[3])); "
             "p.write_key(sys.argv[2], np.load(sys.argv[1]), comments=['a', 'b', 'c'])" % ROOT)
-    for threads in (1, 3, 8):
-        out = str(tmp_path / ("t%d.key" % threads))
-        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "recs.npy"), out], capture_output=True, text=True,
+    for threads, mode in ((1, 0), (3, 0), (8, 0), (8, 1), (3, 1)):   # mode 0: positional writes; 1: into the mapped file
+        out = str(tmp_path / ("t%d_%d.key" % (threads, mode)))
+        with open(out, "wb") as f:
+            f.write(b"x" * (len(want) + 12345))   # an older, longer file of that name: the writer must leave none of it
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "recs.npy"), out, str(mode)], capture_output=True, text=True,
                            env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
         assert r.returncode == 0, r.stderr
-        assert open(out, "rb").read() == want, threads
+        assert open(out, "rb").read() == want, (threads, mode)
     # nothing to write, and fewer records than a block
     for m in (0, 1, 2047, 2048, 2049):
         a, b = str(tmp_path / "a.key"), str(tmp_path / "b.key")
