@@ -358,6 +358,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
     st.comm_sets = zs_transport_comm_sets(h->tr);
     st.resident_volume = vol ? 0 : 1;
     std::vector<int64_t> nrecs((size_t)S, 0);
+    std::vector<std::vector<int>> shift; /* per rank: where its records of a group go in the merged list (alive until the streams are drained) */
     const auto wall0 = std::chrono::steady_clock::now();
 
     /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
@@ -707,7 +708,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         }
         {
             int64_t pos = 0;
-            std::vector<std::vector<int>> shift((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0));
+            shift.assign((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0)); /* (declared with the function's vectors: the uploads below read it) */
             std::vector<int64_t> local((size_t)S, 0); /* a rank's own position: its records before this group */
             for (int g = 0; g < SIFT3D_GROUPS; g++)
                 for (r = 0; r < S; r++) {
