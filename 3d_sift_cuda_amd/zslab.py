@@ -385,11 +385,17 @@ class ZSlabExtractor:
                 # level 0 = initial blur of the input, computed on slab +- BLUR_HALO from input slab +- 2*BLUR_HALO
                 L0 = be.empty((e1 - e0, Y, X))
                 i0 = input_z0
-                tmp = be.empty(vol.shape)
-                be.blur(vol, tmp, extra0)
                 c0 = max(e0, z0 - BLUR_HALO) if has_lo else e0
                 c1 = min(e1, z1 + BLUR_HALO) if has_hi else e1
-                L0[c0 - e0:c1 - e0].copy_(tmp[c0 - i0:c1 - i0])
+                if i0 >= e0 and hasattr(be, "window_ok") and be.window_ok(tuple(vol.shape), extra0):
+                    # round 5: the windowed blur writes planes [c0, c1) straight into the level buffer -- seen from the input's
+                    # plane numbering the buffer starts i0 - e0 planes before its own first plane (the input reaches 16 slices
+                    # beyond the slab, the buffer 32), and only the window is written: no scratch volume, no copy
+                    be.blur_dog_window(vol, L0[i0 - e0:], None, c0 - i0, c1 - i0, extra0)
+                else:
+                    tmp = be.empty(vol.shape)
+                    be.blur(vol, tmp, extra0)
+                    L0[c0 - e0:c1 - e0].copy_(tmp[c0 - i0:c1 - i0])
             else:
                 L0 = nxt
             want_next = o + 1 < len(plan.octaves)
