@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "pipeline.h"
@@ -265,38 +267,61 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
     const int S = h->plan.K > 0 ? n_devices : 1; /* too thin to shard: the whole volume on the first device */
     h->devices.assign(devices, devices + n_devices);
     h->R.resize((size_t)S);
-    for (int r = 0; r < S; r++) {
-        zs_rank &q = h->R[(size_t)r];
-        q.dev = devices[r];
-        int64_t i0 = 0, i1 = nz;
-        if (S > 1) h->plan.input_range(r, i0, i1);
-        ZS_HIP(hipSetDevice(q.dev));
-        /* a slab context owns no level buffers (they come from the rank's arena); its pass intermediates must hold the
-         * largest volume the rank ever blurs: its slab with halos, and on rank 0 the first unsharded octave, which is
-         * gathered there (nz / 2^K slices of a plane a 4^K-th the size: smaller than the slab unless the slabs are many) */
-        int64_t ctx_nz = (i1 - i0) + 2 * ZS_HALO;
-        if (r == 0 && S > 1 && (size_t)h->plan.K < h->plan.oct.size()) {
-            const std::vector<int64_t> &g = h->plan.oct[(size_t)h->plan.K];
-            const int64_t need = (pitch_of(g[0]) * g[1] * g[2] + pitch_of(nx) * ny - 1) / (pitch_of(nx) * ny);
-            ctx_nz = std::max(ctx_nz, need);
-        }
-        q.c = ctx_create(q.dev, nx, ny, ctx_nz, S > 1);
-        if (!q.c) {
-            snprintf(errbuf, sizeof errbuf, "rank %d: no context on device %d (memory?)", r, q.dev);
-            rc = SIFT3D_ERR_MEMORY;
-            goto done;
-        }
-        ZS_HIP(hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking));
-        ZS_HIP(hipStreamCreateWithFlags(&q.halo_stream, hipStreamNonBlocking));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_halo, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_level, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_l3, hipEventDisableTiming));
-        ZS_HIP(hipEventCreateWithFlags(&q.ev_patch, hipEventDisableTiming));
-        for (int p = 0; p < S; p++) /* direct copies between the devices where the fabric allows (errors: already on, or same device) */
-            if (devices[p] != q.dev) (void)hipDeviceEnablePeerAccess(devices[p], 0);
-        (void)hipGetLastError();
+    {
+        /* One rank's context, streams and events.  Round 5: the ranks are set up by one host thread each -- a context is 30 - 45 ms of
+         * allocations, and on eight devices the one-shot call (featExtract -d0,..,7) spent a third of a second creating them one
+         * after the other.  */
+        std::vector<int> rcs((size_t)S, SIFT3D_OK);
+        std::vector<std::string> errs((size_t)S);
+        auto setup = [&](int r) {
+            zs_rank &q = h->R[(size_t)r];
+            char eb[256];
+            auto hipfail = [&](hipError_t e, const char *what) {
+                snprintf(eb, sizeof eb, "rank %d: %s failed: %s", r, what, hipGetErrorString(e));
+                errs[(size_t)r] = eb;
+                rcs[(size_t)r] = SIFT3D_ERR_DEVICE;
+            };
+            q.dev = devices[r];
+            int64_t i0 = 0, i1 = nz;
+            if (S > 1) h->plan.input_range(r, i0, i1);
+            hipError_t e = hipSetDevice(q.dev);
+            if (e != hipSuccess) return hipfail(e, "hipSetDevice");
+            /* a slab context owns no level buffers (they come from the rank's arena); its pass intermediates must hold the
+             * largest volume the rank ever blurs: its slab with halos, and on rank 0 the first unsharded octave, which is
+             * gathered there (nz / 2^K slices of a plane a 4^K-th the size: smaller than the slab unless the slabs are many) */
+            int64_t ctx_nz = (i1 - i0) + 2 * ZS_HALO;
+            if (r == 0 && S > 1 && (size_t)h->plan.K < h->plan.oct.size()) {
+                const std::vector<int64_t> &g = h->plan.oct[(size_t)h->plan.K];
+                const int64_t need = (pitch_of(g[0]) * g[1] * g[2] + pitch_of(nx) * ny - 1) / (pitch_of(nx) * ny);
+                ctx_nz = std::max(ctx_nz, need);
+            }
+            q.c = ctx_create(q.dev, nx, ny, ctx_nz, S > 1);
+            if (!q.c) {
+                snprintf(eb, sizeof eb, "rank %d: no context on device %d (memory?)", r, q.dev);
+                errs[(size_t)r] = eb;
+                rcs[(size_t)r] = SIFT3D_ERR_MEMORY;
+                return;
+            }
+            if ((e = hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreateWithFlags");
+            if ((e = hipStreamCreateWithFlags(&q.halo_stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreateWithFlags");
+            hipEvent_t *evs[] = {&q.ev_halo, &q.ev_level, &q.ev_l3, &q.ev_patch};
+            for (hipEvent_t *ev : evs)
+                if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreateWithFlags");
+            for (int p = 0; p < S; p++) /* direct copies between the devices where the fabric allows (errors: already on, or same device) */
+                if (devices[p] != q.dev) (void)hipDeviceEnablePeerAccess(devices[p], 0);
+            (void)hipGetLastError();
+        };
+        /* (also when ranks share a device -- the rehearsal on one GPU -- so that the tests run the path a node runs) */
+        std::vector<std::thread> th;
+        for (int r = 1; r < S; r++) th.emplace_back(setup, r);
+        setup(0);
+        for (std::thread &t : th) t.join();
+        for (int r = 0; r < S && rc == SIFT3D_OK; r++)
+            if (rcs[(size_t)r] != SIFT3D_OK) {
+                rc = rcs[(size_t)r];
+                snprintf(errbuf, sizeof errbuf, "%s", errs[(size_t)r].c_str());
+            }
     }
-done:
     if (status_out) *status_out = rc;
     if (rc != SIFT3D_OK) {
         sift3d_zslab_destroy(h);
