@@ -179,6 +179,7 @@ def host_lib():
     _sig(L.sift3d_write_key_mode, None, I)
     _sig(L.sift3d_write_key_bin, I, C.c_char_p, P, I64, F)
     _sig(L.sift3d_read_key, I, C.c_char_p, P, P)
+    _sig(L.sift3d_read_key_mode, None, I)
     _sig(L.sift3d_write_pgm, I, C.c_char_p, P, I, I)
     _sig(L.sift3d_world_transform, None, P, I64, P)
     _sig(L.sift3d_match_filter, I64, P, I64, I, I)

@@ -25,6 +25,9 @@ int sift3d_write_key_bin(const char *path, const sift3d_feature *recs, int64_t n
  * "Features: N" and the column line, reads N records.  *recs is malloc'ed (release with free()).  Returns 0, -1 if
  * the file cannot be opened or has no valid header, -2 if a record is incomplete. */
 int sift3d_read_key(const char *path, sift3d_feature **recs, int64_t *n);
+/* 0 (default): a file in the writers' own layout (one record a line, plain decimal numbers) is parsed from memory by all threads,
+ * anything else by the fscanf loop; 1: the fscanf loop always.  The records are the same bits either way (tests run both). */
+void sift3d_read_key_mode(int mode);
 /* ./image.pgm, the reference's debug picture: an x-y slice of floats (rows = y, cols = x) scaled to 0..255 as
  * output_float does (R/src_common/PpImageFloatOutput.cpp:131-180) and written as binary PGM the way
  * GenericImage::WriteToFile does (R/src_common/GenericImage.cpp:135-180).  Returns 0 or -1. */

@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 int64_t sift3d_match_filter(sift3d_feature *f, int64_t n, int reoriented, int peaks)
 {
@@ -163,8 +166,12 @@ int sift3d_match_votes(const sift3d_feature *feats, const int64_t *first, int n_
     /* Query images are independent -- each writes its own row of votes / counts and keeps its own map -- and the reference
      * runs this loop over images with OpenMP (featMatchMultiple.cpp:108).  Within an image the order is the serial one, so
      * the rows are the same bytes for any thread count. */
+    int vote_threads = 1;
 #ifdef _OPENMP
-#pragma omp parallel
+    vote_threads = omp_get_max_threads(); /* (capped: a box of the pool shows 256 cores to a 16-CPU share) */
+    if (vote_threads > 32) vote_threads = 32;
+    if (vote_threads > n_images) vote_threads = n_images > 0 ? n_images : 1;
+#pragma omp parallel num_threads(vote_threads)
 #endif
     {
         int32_t *iscratch = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)k);

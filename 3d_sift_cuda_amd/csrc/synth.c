@@ -64,6 +64,7 @@ void sift3d_synth_blobs_slices(float *out, int64_t X, int64_t Y, int64_t Z, uint
      * same bits for any thread count (a 2048 x 2048 x 1024 volume takes minutes on one core). */
 #ifdef _OPENMP
     int nt = omp_get_max_threads();
+    if (nt > 32) nt = 32; /* (a box of the pool shows 256 cores to a 16-CPU share; every thread walks the whole blob sequence) */
     if (nt > W) nt = (int)W;
     if (X * Y * W < (1ll << 22) || nt < 1) nt = 1;
 #pragma omp parallel for schedule(static, 1) num_threads(nt)

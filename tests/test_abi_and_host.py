@@ -208,6 +208,85 @@ def test_key_writer_in_parallel_blocks_writes_the_serial_bytes(built, oracle, tm
         assert open(a, "rb").read() == open(b, "rb").read(), m
 
 
+def test_key_reader_fast_path_returns_the_fscanf_bits(built, tmp_path):
+    """Round 5: sift3d_read_key parses a file in the writers' own layout from memory, in parallel, and gives everything else to
+    the fscanf loop (mode 1 forces the loop: the reference's reader restated, pinned in test_oracle_pins.py).  Same bits both ways
+    for: 20 000 records of random bit patterns (NaN, infinities and 47-character numbers among them: whole-file fall-back),
+    ordinary records (fast path), 30 000 hand-written decimals of up to 15 digits that sit on and beside midpoints of two floats
+    (the tokens the fast conversion hands to strtof), layouts the fast path must not take (spaces for tabs, two records a line,
+    a record over two lines, an exponent), more lines than the header counts; and the same refusals (a short file, a bad field)."""
+    host = built.host_lib()
+    rng = np.random.default_rng(21)
+
+    def both(path):
+        out = []
+        for mode in (0, 1):
+            host.sift3d_read_key_mode(mode)
+            try:
+                out.append(built.read_key(path).tobytes())
+            except built.Sift3DError as e:
+                out.append(str(e).split("(")[-1])
+            finally:
+                host.sift3d_read_key_mode(0)
+        assert out[0] == out[1], path
+        return out[0]
+
+    n = 20000
+    recs = np.zeros(n, built.FEATURE_DTYPE)
+    for f, k in (("x", 1), ("y", 1), ("z", 1), ("scale", 1), ("ori", 9), ("eigs", 3)):
+        recs[f] = rng.integers(0, 1 << 32, n * k, dtype=np.uint64).astype(np.uint32).view(np.float32).reshape(recs[f].shape)
+    recs["info"] = rng.integers(0, 1 << 31, n).astype(np.uint32)
+    recs["desc"] = rng.integers(-128, 128, (n, 64)).astype(np.float32)
+    p1 = str(tmp_path / "bits.key")
+    built.write_key(p1, recs, eig_thres=-1.0, comments=["a", "b", "c"])
+    assert b"nan" in open(p1, "rb").read() and len(both(p1)) == n * built.FEATURE_DTYPE.itemsize
+    fin = recs.copy()
+    for f in ("x", "y", "z", "scale", "ori", "eigs"):
+        fin[f] = (rng.random(fin[f].shape) * 10.0 ** rng.integers(-6, 9, fin[f].shape) * rng.choice([-1.0, 1.0], fin[f].shape)).astype(np.float32)
+    p2 = str(tmp_path / "fin.key")
+    built.write_key(p2, fin, eig_thres=-1.0, comments=[])
+    got = np.frombuffer(both(p2), built.FEATURE_DTYPE)
+    assert (got["desc"] == fin["desc"]).all() and (got["info"] == fin["info"]).all()
+    # decimals on and beside the midpoints of neighbouring floats, with few enough digits for the fast conversion
+    head = "# featExtract 1.1\nFeatures: %d\nScale-space location[x y z scale] orientation[o11 o12 o13 o21 o22 o23 o31 o32 o32] 2nd moment eigenvalues[e1 e2 e3] info flag[i1] descriptor[d1 .. d64]\n"
+    tail = "\t".join(["1.000000"] * 12 + ["16"] + ["%d" % (i % 64) for i in range(64)]) + "\t\n"
+    lines = []
+    for i in range(7500):
+        e = int(rng.integers(-20, 21))
+        f0 = np.float32(rng.integers(1 << 23, 1 << 24) * 2.0 ** e)
+        mid = (float(f0) + float(np.nextafter(f0, np.float32(np.inf)))) / 2.0     # exact in double
+        toks = []
+        for digits in (15, 12, 9, 7):
+            t = np.format_float_positional(mid, precision=digits, unique=False, fractional=False, trim="-")
+            toks.append(t if "e" not in t and len(t.replace(".", "").lstrip("0")) <= 15 else "0.5")
+        lines.append("\t".join(toks) + "\t" + tail)
+    p3 = str(tmp_path / "mid.key")
+    open(p3, "w").write(head % len(lines) + "".join(lines))
+    mids = np.frombuffer(both(p3), built.FEATURE_DTYPE)
+    assert len(mids) == 7500 and (mids["info"] == 16).all()
+    # layouts the fast path must leave to fscanf, and refusals
+    text = open(p2).read().split("\n")
+    body = text[3:203]
+    variants = {"spaces.key": "\n".join(text[:1] + ["Features: 200", text[2]] + [l.replace("\t", " ") for l in body]) + "\n",
+                "twoperline.key": "\n".join(text[:1] + ["Features: 200", text[2]] + [body[i] + body[i + 1] for i in range(0, 200, 2)]) + "\n",
+                "split.key": "\n".join(text[:1] + ["Features: 200", text[2]] + [l[:40] + "\n" + l[40:] if l[39] == "\t" else l for l in body]) + "\n",
+                "exponent.key": "\n".join(text[:1] + ["Features: 200", text[2]] + ["1e2\t" + l.split("\t", 1)[1] for l in body]) + "\n",
+                "more.key": "\n".join(text[:1] + ["Features: 150", text[2]] + body) + "\n",
+                "short.key": "\n".join(text[:1] + ["Features: 300", text[2]] + body) + "\n",
+                "badfield.key": "\n".join(text[:1] + ["Features: 200", text[2]] + body[:100] + ["x" + body[100]] + body[101:]) + "\n"}
+    res = {}
+    for name, content in variants.items():
+        q = str(tmp_path / name)
+        open(q, "w").write(content)
+        res[name] = both(q)
+    want200 = np.frombuffer(both(p2), built.FEATURE_DTYPE)[:200].tobytes()
+    for name in ("spaces.key", "twoperline.key", "split.key"):
+        assert res[name] == want200, name
+    assert res["more.key"] == want200[:150 * built.FEATURE_DTYPE.itemsize]
+    assert np.frombuffer(res["exponent.key"], built.FEATURE_DTYPE)["x"].tolist() == [100.0] * 200
+    assert res["short.key"] == "-2)" and res["badfield.key"] == "-2)"
+
+
 def test_synth_slices_are_the_planes_of_the_whole_volume(built):
     """sift3d_synth_blobs_slices (bench.py's Z-slab ranks generate only their input slices): the same bits as those planes of
     the whole volume, for ranges at the faces, inside, empty and clipped; above and below the size where the generator

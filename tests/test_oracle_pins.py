@@ -321,12 +321,17 @@ def test_key_reader_against_reference_source(built, tmp_path):
     files.append(p)
     assert len(files) >= 8
     for f in files:
-        mine = built.read_key(f)
-        buf = np.zeros(len(mine) + 8, mine.dtype)
-        n = C.c_int(0)
-        assert ref.ref_read_key_text(f.encode(), buf.ctypes.data, len(buf), C.byref(n)) == 0
-        assert n.value == len(mine) > 0
-        assert buf[:n.value].tobytes() == mine.tobytes(), f
+        for mode in (0, 1):   # round 5: 0 = the parallel in-memory reader (with its fall-backs), 1 = the fscanf loop
+            built.host_lib().sift3d_read_key_mode(mode)
+            try:
+                mine = built.read_key(f)
+            finally:
+                built.host_lib().sift3d_read_key_mode(0)
+            buf = np.zeros(len(mine) + 8, mine.dtype)
+            n = C.c_int(0)
+            assert ref.ref_read_key_text(f.encode(), buf.ctypes.data, len(buf), C.byref(n)) == 0
+            assert n.value == len(mine) > 0
+            assert buf[:n.value].tobytes() == mine.tobytes(), (f, mode)
     bad = {"nofeat.key": "# featExtract 1.1\nScale-space location[x y z scale]\n",
            "zero.key": "# featExtract 1.1\nFeatures: 0\nScale-space location[x y z scale]\n",
            "cols.key": "# featExtract 1.1\nFeatures: 1\nsomething else\n1 2 3\n"}
