@@ -127,9 +127,10 @@ static void *device_thread(void *arg)
     j->ctx = sift3d_create(j->device, j->cx, j->cy, j->cz);
     j->t_ctx = now_s() - t0;
     if (!j->ctx) return NULL;
-    /* room for the extrema a volume of this size usually has (one per 2 500 voxels is a fifth above blob fields), made here,
+    /* room for the extrema a volume of this size usually has (one per 2 500 voxels of the image AS THE FILE HAS IT is a fifth
+     * above blob fields; a volume doubled by -2+ has about the extrema of the original, not eight times as many), made here,
      * beside the read, instead of inside the one extraction this process runs */
-    (void)sift3d_reserve(j->ctx, j->cx * j->cy * j->cz / 2500 + 256);
+    (void)sift3d_reserve(j->ctx, j->X * j->Y * j->Z / 2500 + 256);
     if (!j->want_upload) return NULL;
     j->rc = sift3d_set_volume_begin(j->ctx, j->X, j->Y, j->Z, j->resize);
     int64_t sent = 0;
