@@ -154,6 +154,10 @@ static void *device_thread(void *arg)
 int main(int argc, char **argv)
 {
     const double t_main = now_s();
+    if (sift3d_abi_version() != SIFT3D_ABI_VERSION) { /* the library writes whole structures through this program's pointers */
+        fprintf(stderr, "featExtract: libsift3d_hip.so has ABI version %d, this program was built against %d\n", sift3d_abi_version(), SIFT3D_ABI_VERSION);
+        return -1;
+    }
     if (argc < 3) {
         print_options();
         return -1;

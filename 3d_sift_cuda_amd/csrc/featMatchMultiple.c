@@ -84,6 +84,10 @@ done:
 
 int main(int argc, char **argv)
 {
+    if (sift3d_abi_version() != SIFT3D_ABI_VERSION) { /* the library writes whole structures through this program's pointers */
+        fprintf(stderr, "featMatchMultiple: libsift3d_hip.so has ABI version %d, this program was built against %d\n", sift3d_abi_version(), SIFT3D_ABI_VERSION);
+        return -1;
+    }
     if (argc < 3) {
         usage();
         return -1;
