@@ -65,3 +65,20 @@ def test_watchdog_names_the_phase_and_ends_the_process():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3
     assert "rank 5: phase 'stuck exchange' exceeded its limit" in r.stderr and "first" in r.stderr
+
+
+def test_volume_presets_and_the_one_gpu_refusal():
+    """--config c4 / c5 are BASELINE's multi-GPU configurations (their own shape and descriptor); --dims and --size name other
+    volumes; a preset on one GPU is refused before anything touches the device."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    ns = lambda **kw: argparse.Namespace(**dict(dict(config=None, dims=None, size=512, desc=None), **kw))
+    assert bench.resolve_volume(ns()) == (512, 512, 512, 0, "512^3")
+    assert bench.resolve_volume(ns(config="c4")) == (1024, 1024, 512, 0, "1024 x 1024 x 512")
+    assert bench.resolve_volume(ns(config="c5")) == (2048, 2048, 1024, 3, "2048 x 2048 x 1024")
+    assert bench.resolve_volume(ns(config="c5", desc=0))[3] == 0          # an explicit --desc wins
+    assert bench.resolve_volume(ns(dims="96,80,160", desc=2)) == (96, 80, 160, 2, "96 x 80 x 160")
+    assert bench.resolve_volume(ns(size=256)) == (256, 256, 256, 0, "256^3")
+    r = subprocess.run([sys.executable, BENCH, "--config", "c4"], capture_output=True, text=True, env=_env(), timeout=120)
+    assert r.returncode != 0 and "multi-GPU configuration" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
