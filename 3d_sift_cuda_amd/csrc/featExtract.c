@@ -103,6 +103,9 @@ static void reference_side_effects(sift3d_ctx *ctx, int64_t X, int64_t Y, int64_
  * whole volume from the host. */
 typedef struct {
     int device, want_ctx, want_upload, resize;
+    int want_slabs, n_devices, transport; /* several devices, the volume as the file has it: the slab handle (one context per device) */
+    const int *devices;
+    sift3d_zslab *zs;
     int64_t cx, cy, cz, X, Y, Z;
     const float *data;
     pthread_mutex_t mu;
@@ -122,6 +125,13 @@ static void *device_thread(void *arg)
     double t0 = now_s();
     j->ndev = sift3d_device_count();
     j->t_init = now_s() - t0;
+    if (j->ndev > 0 && j->want_slabs) { /* the contexts of all listed devices, made side by side while the file is read */
+        t0 = now_s();
+        j->zs = sift3d_zslab_create(j->devices, j->n_devices, j->X, j->Y, j->Z, j->err, sizeof j->err);
+        if (j->zs) sift3d_zslab_set_tuning(j->zs, SIFT3D_ZSLAB_TRANSPORT, j->transport);
+        j->t_ctx = now_s() - t0;
+        return NULL;
+    }
     if (j->ndev <= 0 || j->device >= j->ndev || !j->want_ctx) return NULL;
     t0 = now_s();
     j->ctx = sift3d_create(j->device, j->cx, j->cy, j->cz);
@@ -265,6 +275,10 @@ int main(int argc, char **argv)
     job.cx = PX > X ? PX : X; job.cy = PY > Y ? PY : Y; job.cz = PZ > Z ? PZ : Z;
     job.want_ctx = !world_mode && (!multi || resize != 0) && PZ > 1 && PX > 0 && PY > 0;
     job.want_upload = job.want_ctx && !multi && img.nt == 1;
+    job.want_slabs = multi && !world_mode && resize == 0 && Z > 1;
+    job.devices = devices;
+    job.n_devices = n_devices;
+    job.transport = transport;
     pthread_mutex_init(&job.mu, NULL);
     pthread_cond_init(&job.cv, NULL);
     const size_t nvox = (size_t)X * (size_t)Y * (size_t)Z * (size_t)img.nt;
@@ -371,7 +385,9 @@ int main(int argc, char **argv)
         t1 = now_s();
         if (times) fprintf(stderr, "# resize: %.3f s\n", t1 - t0);
         t0 = t1;
-        if (rc == SIFT3D_OK)
+        if (rc == SIFT3D_OK && job.zs) /* the handle the device thread made beside the read (left to the process's end, like the context) */
+            rc = sift3d_zslab_extract(job.zs, pv, initial_scale, desc_mode, eig_thres, size_factor, &feats, &n, &zst, zerr, sizeof zerr);
+        else if (rc == SIFT3D_OK)
             rc = sift3d_extract_zslab_over(transport, devices, n_devices, pv, PX, PY, PZ, initial_scale, desc_mode, eig_thres, size_factor,
                                            &feats, &n, &zst, zerr, sizeof zerr);
         if (pv != img.data) free(pv);
@@ -460,6 +476,7 @@ int main(int argc, char **argv)
     if (feats_owned) sift3d_free(feats);
     free(img.data);
     sift3d_destroy(ctx);
+    sift3d_zslab_destroy(job.zs);
     t1 = now_s();
     if (times) fprintf(stderr, "# teardown: %.3f s\n# main: %.3f s\n", t1 - t0, t1 - t_main);
     return 0;
