@@ -1431,3 +1431,20 @@ def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
         want = ctx.extract(desc_mode=mode)
     assert len(want) > 50 and len(merged) == len(want)
     assert (merged.view(np.uint8) == want.view(np.uint8)).all()   # bit-identical records, same order
+
+
+def test_roofline_ceiling_probe_runs(built):
+    """tools/_build/libroof.so (bench.py's roofline.ceiling: the zero-arithmetic march of the fused blur's tiles): four march times
+    that are positive, ordered as their byte counts, and faster than any blur of the same volume could be."""
+    import ctypes
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_build", "libroof.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(lib))], check=True, capture_output=True)
+    L = ctypes.CDLL(lib)
+    L.roof_march.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    ms = (ctypes.c_float * 4)()
+    assert L.roof_march(256, 5, ms) == 0
+    one, two = min(ms[0], ms[1]), min(ms[2], ms[3])
+    assert 0.0 < one < two < 1.0, list(ms)                      # 256^3: 16.8 M voxels, 8 and 12 B each: tens of microseconds
+    assert 8.0 * 256 ** 3 / (one * 1e-3) / 1e9 < 8000.0          # below the HBM peak
+    assert L.roof_march(100, 5, ms) != 0                         # a volume its tiles do not divide is refused, not marched out of bounds
