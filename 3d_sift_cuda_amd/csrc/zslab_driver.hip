@@ -21,13 +21,23 @@
  * the GPUs of a node).  The reference has no multi-GPU code; the partitioning is the one of
  * 3d_sift_cuda_amd/zslab.py (which runs one process per GPU over RCCL for bench.py): slabs along z with boundaries that are
  * multiples of 2^K, every level recomputed on slab +- 8 slices and its 8-slice halo refreshed from the two neighbours, the
- * other 24 slices of the L1..L3 patch halos copied once per octave on a second stream while L4, L5 and the extrema passes
- * run, the first unsharded octave assembled on rank 0.  A halo copy is queued on the RECEIVER's stream behind an event the
+ * rest of the L1..L3 halos copied on a second stream while L4, L5 and the extrema passes run (the eight slices of L3 the
+ * subsample reads, then what the patches of each level can reach: ZS_PATCH_REACH), the first unsharded octave assembled on rank 0.  A halo copy is queued on the RECEIVER's stream behind an event the
  * sender records when the level is complete, so no host thread ever waits inside the pyramid; the host enqueues the work
  * of all devices round-robin.  The same device may be listed several times (a rehearsal of the slab logic on one GPU).
  * ====================================================================================================================== */
 namespace {
-const int64_t ZS_HALO = 32; /* slices of L1..L3 kept around a slab: an 11^3 patch reaches < 29 slices from its keypoint */
+const int64_t ZS_HALO = 32; /* slices of L1..L3 a slab's buffers keep around it (and the least a slab must be thick) */
+/* Slices of L_l (l = 1..3) beyond a slab that the patches of its own keypoints can reach (round 5; rounds 1 - 4 fetched ZS_HALO of
+ * every level).  A keypoint of detection level l samples L_l at most 5 sqrt(3) patch steps of 2 s / 5 from its centre, s its
+ * scale; s = 2 x the vertex of the parabola through (sigma_h, sigma_c, sigma_l) and the three DoG values, and because the centre
+ * value is a strict extremum of the three (it passed the tests against both neighbour levels) the vertex lies between the
+ * midpoints of the two intervals: s <= sigma_c + sigma_l = 1.6 (2^(l/3) + 2^((l+1)/3)) = 4.556, 5.740, 7.232.  With the
+ * centre's own refinement (within [iz, iz + 1]) and the two voxels a trilinear sample reads: ceil(2 sqrt(3) s + 1.5) = 18, 22,
+ * 27 slices; one more each for frames that are orthonormal only to rounding.  tests: SIFT3D_ZSLAB_POISON_HALO fills every slice
+ * that is NOT fetched with NaN, so a patch that reached further would show in the records. */
+const int64_t ZS_PATCH_REACH[4] = {0, 19, 23, 28};
+const int64_t ZS_SUB = 16; /* the subsample that seeds the next octave's slab +- 8 reads L3 on slab +- 16 */
 const int64_t ZS_BLUR = 8;  /* slices recomputed / exchanged for the next blur (largest filter half-width) */
 
 struct zs_plan {
@@ -88,7 +98,7 @@ struct zs_rank {
     hipEvent_t ev_halo = nullptr;      /* those copies are done */
     hipEvent_t ev_level = nullptr;     /* this rank's current level is complete (its own slices are final) */
     hipEvent_t ev_l3 = nullptr;        /* L1..L3 of the current octave are complete */
-    hipEvent_t ev_patch = nullptr;     /* the patch-halo copies into this rank are done */
+    hipEvent_t ev_patch = nullptr;     /* the slices of L3 the subsample reads beyond +- 8 have arrived (first deferred step) */
     std::vector<float *> allocs;       /* what this run had to allocate beside the arena */
     float *arena = nullptr;            /* one block reused from run to run (sized after the first run of a handle) */
     float *vol_dev = nullptr;          /* sift3d_zslab_set_volume: this rank's input slices [i0, i1), resident between extractions */
@@ -171,6 +181,8 @@ struct sift3d_zslab {
     int bands_first = 1;    /* SIFT3D_TUNE_BANDS_FIRST */
     int transport_want = ZS_TRANSPORT_PEER; /* SIFT3D_ZSLAB_TRANSPORT */
     int transport_flags = 0;                /* ZS_FLAG_*: SIFT3D_ZSLAB_SERIAL_CHANNELS, SIFT3D_ZSLAB_DUPLICATE_RANKS */
+    int patch_wait = 0;                     /* SIFT3D_ZSLAB_PATCH_WAIT: 0 the patch-only halos are waited for before the per-keypoint stage, 1 at their octave's end */
+    int poison_halo = 0;                    /* SIFT3D_ZSLAB_POISON_HALO (tests): the halo slices of L1..L3 that are not fetched hold NaN */
     zs_transport *tr = nullptr;             /* created by the first extraction after the choice (zslab_transport.hip) */
     bool has_volume = false;                /* sift3d_zslab_set_volume has put every rank's input slices on its device */
     /* The merged records (round 5): ONE pinned host buffer every rank's device can store into (hipHostMallocPortable).  A rank's
@@ -223,6 +235,15 @@ extern "C" int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value)
             h->tr = nullptr;
         }
         h->transport_want = value;
+        return SIFT3D_OK;
+    }
+    if (knob == SIFT3D_ZSLAB_PATCH_WAIT) {
+        if (value != 0 && value != 1) return SIFT3D_ERR_ARG;
+        h->patch_wait = value;
+        return SIFT3D_OK;
+    }
+    if (knob == SIFT3D_ZSLAB_POISON_HALO) {
+        h->poison_halo = value < 0 ? 0 : value; /* 1 + k: the poison starts k slices INSIDE what was fetched (how much margin the bound has) */
         return SIFT3D_OK;
     }
     if (knob == SIFT3D_ZSLAB_SERIAL_CHANNELS || knob == SIFT3D_ZSLAB_DUPLICATE_RANKS) {
@@ -547,41 +568,65 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                     ZS_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + (q.z1 - q.e0) * XY, q.L[j] + (q.z1 - q.e0) * XY, q.D[j - 1] + (q.z1 - q.e0) * XY, (b - (q.z1 - q.e0)) * XY));
             }
             if (j == 3) {
-                /* L1..L3 are final: the other 24 slices of their patch halos, on the copy stream, while L4, L5 and the
-                 * extrema passes run on the main one */
-                ZS_X(zs_xfer_begin(h->tr));
-                for (r = 0; r < nr; r++) {
-                    zs_rank &q = R[(size_t)r];
-                    if (!q.lo && !q.hi) continue;
-                    for (int l = 1; l <= 3; l++) {
-                        if (q.lo) {
-                            zs_rank &p = R[(size_t)r - 1];
-                            const int64_t s0 = std::max(q.e0, q.z0 - ZS_HALO), s1 = q.z0 - ZS_BLUR;
-                            if (s1 > s0) {
-                                ZS_X(zs_xfer(h->tr, 1, r - 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
-                                             (size_t)((s1 - s0) * XY)));
-                                st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                /* L1..L3 are final: what is left of their halos, on the copy stream, while L4 and the extrema passes run.  Two steps
+                 * (round 5; rounds 1 - 4: one batch of 3 x 24 slices, and the NEXT OCTAVE waited for all of it):
+                 *   step 0  the eight slices of L3 beyond +- 8 that the subsample reads (slab +- 16): all the next octave waits for;
+                 *   step 1  what only patches reach: L1 and L2 from 8, L3 from 16, as deep as a patch of that level can reach
+                 *           (ZS_PATCH_REACH: 19 / 23 / 28 slices, not 32) -- waited for before the per-keypoint stage, i.e. with the
+                 *           whole rest of the pyramid to arrive in.
+                 * Both steps travel on channel 1 in this order; a transport orders a channel's steps. */
+                for (int step = 0; step < 2; step++) {
+                    ZS_X(zs_xfer_begin(h->tr));
+                    for (r = 0; r < nr; r++) {
+                        zs_rank &q = R[(size_t)r];
+                        if (!q.lo && !q.hi) continue;
+                        for (int l = step == 0 ? 3 : 1; l <= 3; l++) {
+                            const int64_t from = (step == 0 || l < 3) ? ZS_BLUR : ZS_SUB, to = step == 0 ? ZS_SUB : ZS_PATCH_REACH[l];
+                            if (q.lo) {
+                                zs_rank &p = R[(size_t)r - 1];
+                                const int64_t s0 = std::max(q.e0, q.z0 - to), s1 = q.z0 - from;
+                                if (s1 > s0) {
+                                    ZS_X(zs_xfer(h->tr, 1, r - 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
+                                                 (size_t)((s1 - s0) * XY)));
+                                    st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                                    if (step == 0) st.halo_bytes_subsample += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                                }
+                            }
+                            if (q.hi) {
+                                zs_rank &p = R[(size_t)r + 1];
+                                const int64_t s0 = q.z1 + from, s1 = std::min(q.e1, q.z1 + to);
+                                if (s1 > s0) {
+                                    ZS_X(zs_xfer(h->tr, 1, r + 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
+                                                 (size_t)((s1 - s0) * XY)));
+                                    st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                                    if (step == 0) st.halo_bytes_subsample += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                                }
                             }
                         }
-                        if (q.hi) {
-                            zs_rank &p = R[(size_t)r + 1];
-                            const int64_t s0 = q.z1 + ZS_BLUR, s1 = std::min(q.e1, q.z1 + ZS_HALO);
-                            if (s1 > s0) {
-                                ZS_X(zs_xfer(h->tr, 1, r + 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
-                                             (size_t)((s1 - s0) * XY)));
-                                st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
-                            }
+                        st.exchanges++;
+                    }
+                    ZS_X(zs_xfer_end(h->tr));
+                    if (step == h->patch_wait)
+                        for (r = 0; r < nr; r++) {
+                            zs_rank &q = R[(size_t)r];
+                            if (!q.lo && !q.hi) continue;
+                            ZS_HIP(hipSetDevice(q.dev));
+                            ZS_HIP(hipEventRecord(q.ev_patch, q.copy_stream)); /* the subsample's slices are in */
+                        }
+                }
+                if (h->poison_halo) /* tests: a patch that reaches beyond what was fetched reads NaN and shows in the records */
+                    for (r = 0; r < nr; r++) {
+                        zs_rank &q = R[(size_t)r];
+                        if (!q.lo && !q.hi) continue;
+                        ZS_HIP(hipSetDevice(q.dev));
+                        for (int l = 1; l <= 3; l++) {
+                            const int64_t reach = std::max(ZS_PATCH_REACH[l] - (h->poison_halo - 1), l == 3 ? ZS_SUB : ZS_BLUR);
+                            if (q.lo && q.z0 - reach > q.e0)
+                                ZS_HIP(hipMemsetD32Async((hipDeviceptr_t)q.L[l], 0x7FC00000, (size_t)((q.z0 - reach - q.e0) * XY), q.copy_stream));
+                            if (q.hi && q.e1 > q.z1 + reach)
+                                ZS_HIP(hipMemsetD32Async((hipDeviceptr_t)(q.L[l] + (q.z1 + reach - q.e0) * XY), 0x7FC00000, (size_t)((q.e1 - q.z1 - reach) * XY), q.copy_stream));
                         }
                     }
-                    st.exchanges++;
-                }
-                ZS_X(zs_xfer_end(h->tr));
-                for (r = 0; r < nr; r++) {
-                    zs_rank &q = R[(size_t)r];
-                    if (!q.lo && !q.hi) continue;
-                    ZS_HIP(hipSetDevice(q.dev));
-                    ZS_HIP(hipEventRecord(q.ev_patch, q.copy_stream));
-                }
             }
         }
         /* extrema of the rank's own slices; the level table in whole-volume terms.  Round 5: on the context's extrema stream,
@@ -621,7 +666,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 lv.Zl = (int)(q.e1 - q.e0); lv.z_off = (int)q.e0; lv.pad = 0;
             }
             q.c->cand_stream = nullptr;
-            if (q.lo || q.hi) ZS_HIP(hipStreamWaitEvent(q.c->stream, q.ev_patch, 0)); /* before the subsample reads L3 beyond +- 8 */
+            if (q.lo || q.hi) ZS_HIP(hipStreamWaitEvent(q.c->stream, q.ev_patch, 0)); /* before the subsample reads L3 beyond +- 8: the first deferred step only */
         }
         fscale *= 2.0f;
         if (o + 1 >= (int)plan.oct.size()) break;
@@ -690,7 +735,10 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         for (r = 0; r < S; r++) {
             zs_rank &q = R[(size_t)r];
             ZS_HIP(hipSetDevice(q.dev));
-            /* (the main stream already waits for the deferred patch halos of every sharded octave: ev_patch above) */
+            /* the patch halos of every sharded octave (the second deferred step: the copy stream, in order) must be in before
+             * the keypoint kernel samples them: everything the copy stream holds is behind this event */
+            ZS_HIP(hipEventRecord(q.ev_l3, q.copy_stream)); /* (ev_l3 is free here: its last use was the last octave's sends) */
+            ZS_HIP(hipStreamWaitEvent(q.c->stream, q.ev_l3, 0));
             ZS_HIP(hipEventRecord(q.c->ev_oct[1], q.c->ex_stream)); /* every extrema pass of the run is behind this */
             ZS_HIP(hipStreamWaitEvent(q.c->stream, q.c->ev_oct[1], 0));
             ZS_RC(cand_count_queue(q.c));

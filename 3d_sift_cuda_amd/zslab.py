@@ -17,16 +17,19 @@ Why the result equals the single-GPU result bit for bit:
     (level, is_max, index) and slabs are in z order, so concatenating ranks per group is the serial raster order;
   * per-keypoint geometry is computed in whole-volume coordinates (sift3d_level_desc.z_offset).
 
-Halo widths: 8 slices feed the next blur (R <= 8); L1..L3 carry 32 slices because an 11^3 patch reaches
-< 29 slices from its keypoint (|offset| <= 5*sqrt(3) samples * 2*scale/5, scale <= 2*4.04); DoG levels need 1.
+Halo widths: 8 slices feed the next blur (R <= 8); the buffers of L1..L3 keep 32 slices around a slab, of which the patches
+of the slab's own keypoints can reach 19 / 23 / 28 (PATCH_REACH below: |offset| <= 5*sqrt(3) samples * 2*scale/5, scale <=
+sigma_c + sigma_l of the detection level); DoG levels need 1.
 
-Exchange schedule (round 2).  What the next blur waits for is only the 8-slice halo, so that is all a level exchanges
-on the critical path: five exchanges of 8 slices per octave and direction.  The other 24 slices of the patch halos of
-L1..L3 are needed by nothing before the per-keypoint stage (and by the subsample that seeds the next octave, which
-reads L3 on slab +- 16): they are fetched once per octave in ONE batched exchange issued as soon as L3 is complete and
-waited for at the end of the octave, so that on RCCL (which runs its transfers on a stream of its own) they move while
-L4, L5 and the extrema passes compute.  Round 1 exchanged 32 slices after each of L1..L3 and waited each time: the same
-112 slices per octave and direction, 96 of them on the critical path; now 40 are.
+Exchange schedule.  What the next blur waits for is only the 8-slice halo, so that is all a level exchanges on the critical
+path: four or five exchanges of 8 slices per octave and direction (round 2).  The rest of the halos of L1..L3 is needed by
+nothing before the per-keypoint stage, except the eight slices of L3 beyond +- 8 that the subsample seeding the next octave
+reads (slab +- 16).  Round 5 fetches them in TWO batches issued as soon as L3 is complete: those eight slices of L3, waited for
+at the end of the octave; and the patch-only slices (11 + 15 + 12 per direction), waited for when the whole pyramid has been
+queued -- so on RCCL (which runs its transfers on a stream of its own) they have every later octave to arrive in.  Rounds 2 - 4
+moved 3 x 24 slices in one batch and made the next octave wait for all of it; round 1 exchanged 32 slices after each of L1..L3
+and waited each time.  Per octave and direction: 33 (40 with every level stored) slices on the critical path, 8 at the octave's
+end, 38 at the run's end.
 
 The compute backend is pluggable: ``HipBackend`` drives the C-ABI ``*_dev`` operators on torch CUDA tensors;
 the CPU test-suite plugs the oracle in (tests/test_zslab_cpu.py) to check the slab logic with gloo, world size 2.
@@ -35,7 +38,14 @@ import math
 
 import numpy as np
 
-HALO = 32        # slices of L1..L3 kept around a slab (patch sampling)
+HALO = 32        # slices of L1..L3 a slab's buffers keep around it (and the least a slab must be thick)
+# Slices of L1, L2, L3 beyond a slab that the patches of its own keypoints can reach (round 5; before: HALO of each).  A keypoint of
+# detection level l samples L_l within 5 sqrt(3) steps of 2 s / 5 of its centre; its scale s is twice the vertex of the parabola
+# through the three sigmas, and the centre DoG value being a strict extremum of the three puts that vertex between the midpoints
+# of the two intervals: s <= sigma_c + sigma_l = 4.556, 5.740, 7.232.  With the centre's refinement and the trilinear footprint:
+# 18, 22, 27 slices; one more each for rounding.  (csrc/zslab_driver.hip: ZS_PATCH_REACH, and its NaN-poison test knob.)
+PATCH_REACH = (None, 19, 23, 28)
+SUB_HALO = 16    # the subsample that seeds the next octave's slab +- 8 reads L3 on slab +- 16
 BLUR_HALO = 8    # slices recomputed / exchanged for the next blur (largest half-width in the schedule)
 
 
@@ -212,7 +222,7 @@ class HipBackend:
 class ZSlabExtractor:
     """Runs the pyramid of ONE volume across the ranks of a torch.distributed group."""
 
-    def __init__(self, backend, plan, rank, dist=None, group=None, deferred_group=None):
+    def __init__(self, backend, plan, rank, dist=None, group=None, deferred_group=None, poison_halo=False):
         """deferred_group: a second process group over the same ranks (dist.new_group()) for the once-per-octave batch of
         deferred patch halos.  RCCL serialises the operations of one communicator on one internal stream, so on the main
         group that batch (3 x 24 slices) would sit in front of the next level's 8-slice exchange; a group of its own has its
@@ -220,6 +230,7 @@ class ZSlabExtractor:
         critical ones)."""
         self.be, self.plan, self.rank, self.dist, self.group = backend, plan, rank, dist, group
         self.deferred_group = deferred_group
+        self.poison_halo = poison_halo   # tests: the halo slices of L1..L3 that no exchange fetches hold NaN
         self.levels = []       # level table entries, index = level id
         self.level_ids = []
         # exchange_bytes: everything this rank received and sent; of that, deferred_bytes moved in the once-per-octave
@@ -232,15 +243,18 @@ class ZSlabExtractor:
         self._keepalive = []
 
     # ---- halo exchange of one level buffer -------------------------------------------------
-    def _exchange(self, bufs, z0, z1, e0, width, has_lo, has_hi, inner=0, defer=False, patch=True):
+    def _exchange(self, bufs, z0, z1, e0, width, has_lo, has_hi, inner=0, defer=False, patch=True, spans=None):
         """Refresh, in every buffer of `bufs`, the slices [z0-width, z0-inner) from the lower neighbour and
         [z1+inner, z1+width) from the upper one (and send it the mirror bands of this slab), as ONE batch of
-        point-to-point operations.  defer=True returns a closure that completes the batch (for the caller to run later:
-        the transfers of an RCCL batch proceed on the communicator's stream meanwhile); otherwise it is completed here."""
-        if self.dist is None or (not has_lo and not has_hi) or width <= inner:
-            return (lambda: None) if defer else None
+        point-to-point operations.  spans: (inner, width) per buffer instead of one pair for all.  defer=True returns a
+        closure that completes the batch (for the caller to run later: the transfers of an RCCL batch proceed on the
+        communicator's stream meanwhile); otherwise it is completed here."""
         if not isinstance(bufs, (list, tuple)):
             bufs = [bufs]
+        if spans is None:
+            spans = [(inner, width)] * len(bufs)
+        if self.dist is None or (not has_lo and not has_hi) or all(w <= i for i, w in spans):
+            return (lambda: None) if defer else None
         d, ops, back = self.dist, [], []
         grp = self.deferred_group if (defer and patch and self.deferred_group is not None) else self.group
         self.be.before_exchange()
@@ -257,8 +271,11 @@ class ZSlabExtractor:
             h = t.cpu()
             back.append((t, h))
             return h
-        n = width - inner
-        for buf in bufs:
+        n = 0
+        for buf, (inner, width) in zip(bufs, spans):
+            if width <= inner:
+                continue
+            n += width - inner
             if has_lo:   # my slices [z0+inner, z0+width) are the lower neighbour's upper band; its [z0-width, z0-inner) are mine
                 ops.append(d.P2POp(d.isend, snd(buf[z0 + inner - e0:z0 + width - e0]), self.rank - 1, grp))
                 ops.append(d.P2POp(d.irecv, rcv(buf[z0 - width - e0:z0 - inner - e0]), self.rank - 1, grp))
@@ -266,7 +283,7 @@ class ZSlabExtractor:
                 ops.append(d.P2POp(d.isend, snd(buf[z1 - width - e0:z1 - inner - e0]), self.rank + 1, grp))
                 ops.append(d.P2POp(d.irecv, rcv(buf[z1 + inner - e0:z1 + width - e0]), self.rank + 1, grp))
         works = d.batch_isend_irecv(ops)
-        nbytes = 2 * n * bufs[0].shape[1] * bufs[0].shape[2] * 4 * (int(has_lo) + int(has_hi)) * len(bufs)
+        nbytes = 2 * n * bufs[0].shape[1] * bufs[0].shape[2] * 4 * (int(has_lo) + int(has_hi))
         self.stats["exchanges"] += 1
         self.stats["exchange_bytes"] += nbytes
         if defer and patch:
@@ -301,6 +318,13 @@ class ZSlabExtractor:
         nlev = 4 if lazy else 5
         L = [L0] + [be.empty(shape) if j <= nlev else None for j in range(1, 6)]
         D = [None if (lazy and j in (0, 4)) else be.empty(shape) for j in range(5)]
+        if self.poison_halo:   # nothing writes these slices: a patch that reached them would show in the records
+            for l in (1, 2, 3):
+                reach = max(PATCH_REACH[l], SUB_HALO if l == 3 else BLUR_HALO)
+                if has_lo and z0 - reach > e0:
+                    L[l][:z0 - reach - e0] = float("nan")
+                if has_hi and e1 > z1 + reach:
+                    L[l][z1 + reach - e0:] = float("nan")
         # region recomputed per level: slab +- BLUR_HALO, clipped to what the buffer holds (at a face of the
         # whole volume the buffer ends at the face, which is what makes the zero border exact)
         c0 = max(e0, z0 - BLUR_HALO) if has_lo else e0
@@ -337,9 +361,14 @@ class ZSlabExtractor:
             if has_hi and D[j - 1] is not None:
                 be.dog(L[j - 1][z1 - e0:b], L[j][z1 - e0:b], D[j - 1][z1 - e0:b])
             if j == 3:
-                # L1..L3 are final: fetch the rest of their patch halos (slices BLUR_HALO..HALO beyond the faces) in one
-                # batch that completes while L4, L5 and the extrema passes run
-                patch_halos = self._exchange(L[1:4], z0, z1, e0, HALO, has_lo, has_hi, inner=BLUR_HALO, defer=True)
+                # L1..L3 are final: what is left of their halos, in two batches that move while L4, L5 and the extrema passes
+                # run (round 5; before: one batch of 3 x 24 slices, all of it waited for before the next octave):
+                #   the eight slices of L3 beyond +- 8 that the subsample reads -- all the NEXT OCTAVE waits for;
+                #   what only patches reach (L1, L2 from 8, L3 from 16, as deep as PATCH_REACH says) -- completed at the end
+                #   of run(), i.e. with the whole rest of the pyramid to arrive in.
+                patch_halos = self._exchange(L[3], z0, z1, e0, SUB_HALO, has_lo, has_hi, inner=BLUR_HALO, defer=True)
+                self._pending.append(self._exchange(L[1:4], z0, z1, e0, HALO, has_lo, has_hi, defer=True,
+                                                    spans=[(BLUR_HALO, PATCH_REACH[1]), (BLUR_HALO, PATCH_REACH[2]), (SUB_HALO, PATCH_REACH[3])]))
         for l in range(3):
             lid = o * 3 + l
             if lazy and l == 0:
@@ -350,7 +379,7 @@ class ZSlabExtractor:
                 be.extrema_append(D[l], D[l + 1], D[l + 2], lid, z0 - e0, z1 - e0)
             self.levels.append(be.level_entry(L[l + 1], D[l + 1], zo, e0, sig[l], sig[l + 1], sig[l + 2], factor))
             self.level_ids.append(lid)
-        patch_halos()   # before the subsample below reads L3 beyond +- BLUR_HALO, and long before the per-keypoint stage
+        patch_halos()   # before the subsample below reads L3 beyond +- BLUR_HALO (the patch-only slices: end of run())
         self._keepalive.append((D, L))   # a replay of the extrema passes reads D1..D3 and, in the unstored form, L0, L1 and L4
         return L[3] if want_next else None
 
@@ -364,6 +393,15 @@ class ZSlabExtractor:
         be.reset()
         self.levels, self.level_ids = [], []
         self._keepalive = []
+        self._pending = []   # the patch-only halo batches of the sharded octaves, completed before run() returns
+        try:
+            return self._run(input_slab, input_z0, plan, be, rank, S, extra0, extras, sig, K)
+        finally:
+            for fin in self._pending:   # before anything samples a patch -- and so that no receive outlives its buffer
+                fin()
+            self._pending = []
+
+    def _run(self, input_slab, input_z0, plan, be, rank, S, extra0, extras, sig, K):
         factor = 1.0
         vol = be.from_host(input_slab)
         nxt = None

@@ -262,9 +262,10 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
                "exchange_schedule": "per stored level (L1..L4: the 17-tap L5 is only evaluated around candidates, from L4): the 8-slice blur halo "
                                     "(what the next blur needs; 9 slices of L4), issued BANDS FIRST -- a rank filters its two boundary "
                                     "bands, hands them to the exchange and filters its interior while they travel (`hidden` bytes); per "
-                                    "octave: one deferred batch with the other 24 slices of the L1..L3 patch halos on a communicator of "
-                                    "its own, issued when L3 is complete and waited for after the extrema passes (rank 0's counts; "
-                                    "interior ranks exchange on both sides)"}
+                                    "octave: two deferred batches on a communicator of their own, issued when L3 is complete -- the 8 slices of "
+                                    "L3 the subsample reads (waited for at the octave's end) and the 11 + 15 + 12 slices of L1..L3 only "
+                                    "patches reach (waited for at the end of the pyramid) (rank 0's counts; interior ranks exchange on "
+                                    "both sides)"}
         import hashlib
         res["records_sha256"] = hashlib.sha256(merged.tobytes()).hexdigest() if merged is not None else None
         if expect is not None:

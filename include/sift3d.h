@@ -31,7 +31,7 @@ extern "C" {
 /* Layout version of the structures this header passes by pointer (sift3d_zslab_stats, sift3d_timings, sift3d_feature, ...).
  * The library writes WHOLE structures through the caller's pointers, so a binding compiled against another layout would be
  * overrun: a binding checks sift3d_abi_version() == SIFT3D_ABI_VERSION once, when it loads the library (the in-tree ctypes
- * mirror and featExtract do).  5: sift3d_zslab_stats gained comm_sets, resident_volume, merge_ms (round 5); 4: transport,
+ * mirror and featExtract do).  5: sift3d_zslab_stats gained comm_sets, resident_volume, merge_ms, halo_bytes_subsample, enqueue_ms (round 5); 4: transport,
  * transport_fell_back, rccl_version (round 4). */
 #define SIFT3D_ABI_VERSION 5
 int sift3d_abi_version(void);
@@ -340,6 +340,8 @@ typedef struct {
     double merge_ms;              /* host time spent on the merged order (part of wall_ms).  Round 5: the ranks' descriptor kernels store their
                                    * records straight into their places in ONE pinned list, so this is the per-group offset table and its
                                    * upload (microseconds) plus, when the list has to grow, its allocation -- there is no merge left */
+    int64_t halo_bytes_subsample; /* the part of halo_bytes_deferred the next octave waits for: the eight slices of L3 beyond +- 8 that the
+                                   * subsample reads (first deferred step); the rest is waited for before the per-keypoint stage only */
     double enqueue_ms;            /* host time from the start of the call until every rank's pyramid and extrema passes are queued (before the
                                    * first host wait): what ONE host thread spends enqueueing for all devices */
 } sift3d_zslab_stats;
@@ -355,7 +357,7 @@ typedef struct {
 #define SIFT3D_TRANSPORT_RCCL 1
 /* sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_SERIAL_CHANNELS, 1): RCCL with ONE communicator set -- the deferred patch halos go
  * through the communicators of the per-level halos and queue behind them (RCCL orders a communicator's operations).  Slower
- * by design (3 x 24 deferred slices in front of the next level's 8); it exists as the fallback to try in the same lease if two
+ * by design (the deferred slices in front of the next level's 8); it exists as the fallback to try in the same lease if two
  * communicators per device ever stall each other on real links.  Results are the same bytes. */
 #define SIFT3D_ZSLAB_SERIAL_CHANNELS 1001
 /* sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_DUPLICATE_RANKS, 1): a device listed more than once is handed to ncclCommInitAll as
@@ -363,6 +365,15 @@ typedef struct {
  * tests/rccl_shim (given to sift3d_zslab_set_transport_library) accepts it, which is how the RCCL half of the exchange --
  * group pairing, stream order, the two communicator sets -- runs with 2 .. 8 ranks on a one-GPU box. */
 #define SIFT3D_ZSLAB_DUPLICATE_RANKS 1002
+/* sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_POISON_HALO, 1) (tests): every halo slice of L1..L3 that the exchange does NOT fetch is
+ * filled with NaN before the per-keypoint stage -- a patch that reached further than the driver's bound would show in the records.
+ * 1 + k: the NaN start k slices earlier, inside what was fetched (never inside what the pyramid itself reads): the smallest k that
+ * changes a record is the margin the bound has on that volume. */
+#define SIFT3D_ZSLAB_POISON_HALO 1003
+/* sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_PATCH_WAIT, v): when a rank waits for the halo slices of L1..L3 that only patches read.
+ * 0 (default): before its per-keypoint stage -- they have every later octave to arrive in; 1: at the end of their own octave, with
+ * the subsample's slices (rounds 2 - 4).  Same bytes either way. */
+#define SIFT3D_ZSLAB_PATCH_WAIT 1004
 void sift3d_zslab_set_transport_library(const char *path);
 int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
                          float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,

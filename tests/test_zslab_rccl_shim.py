@@ -75,6 +75,7 @@ def test_rccl_branch_gives_the_single_gpu_bytes(built, shim, dims, ranks, mode):
     with built.ZSlab(dims[0], dims[1], dims[2], [0] * ranks) as h:
         h.set_tuning(built.ZSLAB_TRANSPORT, built.TRANSPORT_RCCL)
         h.set_tuning(built.ZSLAB_DUPLICATE_RANKS, 1)
+        h.set_tuning(built.ZSLAB_POISON_HALO, 1)   # what the exchange does not fetch of L1..L3 holds NaN
         got, st = h.extract(vol, desc_mode=mode)
         s = shim.stats()
         assert st["n_ranks"] == ranks and st["sharded_octaves"] >= 1
