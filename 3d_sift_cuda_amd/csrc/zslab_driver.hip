@@ -4,16 +4,20 @@
  * zslab_transport.hip (peer copies or RCCL).  Split from api.hip in round 4 (round-3 review, weak 9).
  */
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "pipeline.h"
+#include "zs_crew.h"
 #include "zslab_transport.h"
 
 /* ======================================================================================================================
@@ -146,15 +150,6 @@ struct zs_rank {
             goto done;                                                                                                 \
         }                                                                                                              \
     } while (0)
-#define ZS_COMM(call)                                                                                                  \
-    do {                                                                                                               \
-        hipError_t e_ = (call);                                                                                        \
-        if (e_ != hipSuccess) {                                                                                        \
-            snprintf(errbuf, sizeof errbuf, "slab exchange: %s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            rc = SIFT3D_ERR_COMM;                                                                                      \
-            goto done;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
 #define ZS_X(call) /* a step of the exchange through the handle's transport (peer copies or RCCL) */                 \
     do {                                                                                                               \
         if ((call) != 0) {                                                                                             \
@@ -163,14 +158,36 @@ struct zs_rank {
             goto done;                                                                                                 \
         }                                                                                                              \
     } while (0)
-#define ZS_RC(call)                                                                                  \
-    do {                                                                                             \
-        rc = (call);                                                                                 \
-        if (rc != SIFT3D_OK) {                                                                       \
-            snprintf(errbuf, sizeof errbuf, "rank %d: %s", r, sift3d_last_error(R[(size_t)r].c));    \
-            goto done;                                                                               \
-        }                                                                                            \
+/* The same inside a rank's step (a lambda run by the rank's host thread, `r` its rank): the failure goes to the rank's own slot and the
+ * step returns; the calling thread looks at the slots when every rank is back (crew_failed). */
+#define ZR_FAIL(code, ...)                                             \
+    do {                                                               \
+        rrc[(size_t)r] = (code);                                       \
+        snprintf(rerr[(size_t)r].b, sizeof rerr[0].b, __VA_ARGS__);    \
+        return;                                                        \
     } while (0)
+#define ZR_HIP(call)                                                                                                                      \
+    do {                                                                                                                                  \
+        hipError_t e_ = (call);                                                                                                           \
+        if (e_ != hipSuccess) ZR_FAIL(SIFT3D_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);      \
+    } while (0)
+#define ZR_COMM(call)                                                                                                                            \
+    do {                                                                                                                                         \
+        hipError_t e_ = (call);                                                                                                                  \
+        if (e_ != hipSuccess) ZR_FAIL(SIFT3D_ERR_COMM, "slab exchange: %s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define ZR_X(call)                                                                     \
+    do {                                                                               \
+        if ((call) != 0) ZR_FAIL(SIFT3D_ERR_COMM, "%s", zs_transport_error(h->tr));    \
+    } while (0)
+#define ZR_RC(call)                                                                                         \
+    do {                                                                                                    \
+        const int rc_ = (call);                                                                             \
+        if (rc_ != SIFT3D_OK) ZR_FAIL(rc_, "rank %d: %s", r, sift3d_last_error(R[(size_t)r].c));            \
+    } while (0)
+
+struct zs_errline { char b[400]; };
+struct zs_tally { int64_t critical = 0, hidden = 0, deferred = 0, subsample = 0, exchanges = 0; char pad[24]; }; /* per rank: a cache line each */
 } // namespace
 
 struct sift3d_zslab {
@@ -191,12 +208,14 @@ struct sift3d_zslab {
      * descriptor kernels store straight into their merged places and there is no merge left to do. */
     sift3d_feature *merged = nullptr;
     int64_t merged_cap = 0;
+    zs_crew crew; /* one host thread per rank beyond the first (started with the handle) */
     sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
 };
 
 extern "C" void sift3d_zslab_destroy(sift3d_zslab *h)
 {
     if (!h) return;
+    h->crew.stop();
     for (zs_rank &q : h->R) /* nothing of an exchange may be in flight when its communicators go */
         if (q.c) {
             hipSetDevice(q.dev);
@@ -348,6 +367,11 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
         sift3d_zslab_destroy(h);
         return fail(errbuf);
     }
+    {
+        std::vector<int> devs((size_t)S);
+        for (int r = 0; r < S; r++) devs[(size_t)r] = h->R[(size_t)r].dev;
+        h->crew.start(S - 1, [devs](int r) { (void)hipSetDevice(devs[(size_t)r]); });
+    }
     return h;
 }
 
@@ -405,6 +429,18 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
     st.resident_volume = vol ? 0 : 1;
     std::vector<int64_t> nrecs((size_t)S, 0);
     std::vector<std::vector<int>> shift; /* per rank: where its records of a group go in the merged list (alive until the streams are drained) */
+    std::vector<int> rrc((size_t)S, SIFT3D_OK); /* what a rank's step reports (ZR_*), looked at when the step's ranks are back */
+    std::vector<zs_errline> rerr((size_t)S);
+    std::vector<zs_tally> tally((size_t)S);
+    auto crew_failed = [&]() -> bool {
+        for (int i = 0; i < S; i++)
+            if (rrc[(size_t)i] != SIFT3D_OK) {
+                rc = rrc[(size_t)i];
+                snprintf(errbuf, sizeof errbuf, "%s", rerr[(size_t)i].b);
+                return true;
+            }
+        return false;
+    };
     const auto wall0 = std::chrono::steady_clock::now();
 
     /* sigma schedule, MultiScale.cpp:288-294,369,526-527 (float arithmetic as there) */
@@ -426,48 +462,50 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
     for (int i = 0; i < 64; i++) next0[i] = nullptr;
     float fscale = 1.0f;
 
-    /* ---- input slabs, level 0 of octave 0 ---- */
-    for (r = 0; r < S; r++) {
+    /* ---- input slabs, level 0 of octave 0: every rank by its own host thread (an upload from pageable memory is a chain of
+     * staged copies the calling thread takes part in: S of them side by side) ---- */
+    h->crew.run(S, [&](int r) {
         zs_rank &q = R[(size_t)r];
         int64_t i0 = 0, i1 = nz;
         if (S > 1) plan.input_range(r, i0, i1);
-        ZS_HIP(hipSetDevice(q.dev));
+        ZR_HIP(hipSetDevice(q.dev));
         q.levels.assign(plan.oct.size() * 3, sift3d_level());
-        ZS_RC(cand_reset(q.c));
+        ZR_RC(cand_reset(q.c));
         timing_begin(q.c);
         /* level 0 = initial blur of the input, on slab +- 8 from input slab +- 16 */
         const int64_t XY = nx * ny;
         float *din = vol ? q.alloc((i1 - i0) * XY) : q.vol_dev;
-        if (!din) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-        if (vol) ZS_HIP(hipMemcpyAsync(din, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream));
+        if (!din) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
+        if (vol) ZR_HIP(hipMemcpyAsync(din, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream));
         int64_t z0 = 0, z1 = nz;
         if (S > 1) plan.slab(r, 0, z0, z1);
         const bool lo = S > 1 && r > 0, hi = S > 1 && r < S - 1;
         const int64_t e0 = lo ? std::max<int64_t>(0, z0 - ZS_HALO) : z0, e1 = hi ? std::min<int64_t>(nz, z1 + ZS_HALO) : z1;
         const int64_t c0 = lo ? std::max(e0, z0 - ZS_BLUR) : e0, c1 = hi ? std::min(e1, z1 + ZS_BLUR) : e1;
         float *l0 = q.alloc((e1 - e0) * XY);
-        if (!l0) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
+        if (!l0) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
         /* Level 0 = the initial blur of the input, wanted on slab +- 8 (planes [c0, c1)) from input slab +- 16 (planes [i0, i1)).
          * Where the blur has its windowed form it writes exactly those planes straight into the level buffer: seen from the
          * input's plane numbering the buffer starts i0 - e0 planes before its own first plane (i0 >= e0: the input reaches 16
          * slices beyond the slab, the buffer 32), and only the window is written.  Otherwise: the whole input slab into a
          * scratch volume, then a copy of the planes that are exact (rounds 2 - 4). */
         if (i0 >= e0 && blur_window_supported(nx, ny, extra0, 0.01f)) {
-            ZS_RC(blur_window_dev(q.c, din, l0 + (i0 - e0) * XY, nullptr, nx, ny, i1 - i0, c0 - i0, c1 - i0, extra0, 0.01f));
+            ZR_RC(blur_window_dev(q.c, din, l0 + (i0 - e0) * XY, nullptr, nx, ny, i1 - i0, c0 - i0, c1 - i0, extra0, 0.01f));
         } else {
             float *tmp = q.alloc((i1 - i0) * XY);
-            if (!tmp) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-            ZS_RC(blur_dev(q.c, din, tmp, nullptr, nx, ny, i1 - i0, extra0, 0.01f));
-            ZS_HIP(hipMemcpyAsync(l0 + (c0 - e0) * XY, tmp + (c0 - i0) * XY, sizeof(float) * (size_t)((c1 - c0) * XY), hipMemcpyDeviceToDevice, q.c->stream));
+            if (!tmp) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
+            ZR_RC(blur_dev(q.c, din, tmp, nullptr, nx, ny, i1 - i0, extra0, 0.01f));
+            ZR_HIP(hipMemcpyAsync(l0 + (c0 - e0) * XY, tmp + (c0 - i0) * XY, sizeof(float) * (size_t)((c1 - c0) * XY), hipMemcpyDeviceToDevice, q.c->stream));
         }
         next0[r] = l0;
-    }
+    });
+    if (crew_failed()) goto done;
 
     /* ---- octaves ---- */
     for (int o = 0; o < (int)plan.oct.size(); o++) {
         const int64_t X = plan.oct[(size_t)o][0], Y = plan.oct[(size_t)o][1], zo = plan.oct[(size_t)o][2], XY = X * Y;
         const bool sharded = S > 1 && o < K;
-        const int nr = sharded ? S : 1; /* the gathered octaves live on rank 0 */
+        const int nr = sharded ? S : 1; /* the gathered octaves live on rank 0 (one rank: crew.run runs it on the calling thread) */
         /* As on one device (run_pipeline): D_0 is read as L_0 - L_1 around the extrema of D_1, and L_5 -- hence D_4 -- is
          * filtered only around the candidates of D_3, from L_4.  A slab then blurs four levels instead of five and exchanges
          * four halos per octave instead of five; the third extrema phase reads L_4 nine slices beyond a candidate, so L_4's
@@ -477,7 +515,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         const int ntaps5 = sift3d_gauss_taps(extras[4], 0.01f, taps5);
         const bool lazy = ntaps5 == 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X >= 8 && XY < (1ll << 29) && Y >= 3 && zo >= 3 && h->lazy_levels;
         const int nlev = lazy ? 4 : 5;
-        for (r = 0; r < nr; r++) {
+        for (r = 0; r < nr; r++) { /* (bump allocations from the rank's arena: nothing to share out) */
             zs_rank &q = R[(size_t)r];
             if (sharded) plan.slab(r, o, q.z0, q.z1); else { q.z0 = 0; q.z1 = zo; }
             q.lo = sharded && r > 0;
@@ -502,142 +540,162 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
              * interior.  Without the windowed form (other row lengths): the level on slab +- 8 in one piece, then the
              * exchange, as in round 2. */
             const bool banded = sharded && blur_window_supported(X, Y, extras[j - 1], 0.01f) && h->bands_first;
-            for (r = 0; r < nr; r++) {
+            /* -- the level's launches: every rank by its own thread (bands, event, interior).  The transfers of the bands are
+             *    queued in the step after this one -- in host time behind the interior launch, on the device behind the event only -- */
+            h->crew.run(nr, [&](int r) {
                 zs_rank &q = R[(size_t)r];
                 const int64_t c0 = q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0, c1 = q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1;
                 const int64_t a = c0 - q.e0, b = c1 - q.e0, nzl = q.e1 - q.e0;
-                ZS_HIP(hipSetDevice(q.dev));
+                ZR_HIP(hipSetDevice(q.dev));
                 if (banded && (q.lo || q.hi)) {
-                    if (q.lo) ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z0 - q.e0, q.z0 - q.e0 + hb, extras[j - 1], 0.01f));
-                    if (q.hi) ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z1 - q.e0 - hb, q.z1 - q.e0, extras[j - 1], 0.01f));
-                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream)); /* the bands are final: the neighbours may fetch them */
+                    if (q.lo) ZR_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z0 - q.e0, q.z0 - q.e0 + hb, extras[j - 1], 0.01f));
+                    if (q.hi) ZR_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, q.z1 - q.e0 - hb, q.z1 - q.e0, extras[j - 1], 0.01f));
+                    ZR_HIP(hipEventRecord(q.ev_level, q.c->stream)); /* the bands are final: the neighbours may fetch them */
+                    const int64_t w0 = q.lo ? q.z0 - q.e0 + hb : 0, w1 = q.hi ? q.z1 - q.e0 - hb : q.e1 - q.e0;
+                    ZR_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, nzl, w0, w1, extras[j - 1], 0.01f)); /* the interior, while the bands travel */
+                    if (j == 3) ZR_HIP(hipEventRecord(q.ev_l3, q.c->stream));
                 } else {
                     /* level j on slab +- 8 (clipped to the buffer: at a face of the whole volume the buffer ends at the face,
                      * which is what makes the zero border exact), D_{j-1} fused */
-                    ZS_RC(blur_dev(q.c, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] ? q.D[j - 1] + a * XY : nullptr, X, Y, b - a, extras[j - 1], 0.01f));
-                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
-                    if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
+                    ZR_RC(blur_dev(q.c, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] ? q.D[j - 1] + a * XY : nullptr, X, Y, b - a, extras[j - 1], 0.01f));
+                    ZR_HIP(hipEventRecord(q.ev_level, q.c->stream));
+                    if (j == 3) ZR_HIP(hipEventRecord(q.ev_l3, q.c->stream));
                 }
-            }
-            if (banded)
-                for (r = 0; r < nr; r++) { /* the interior, while the bands travel */
-                    zs_rank &q = R[(size_t)r];
-                    if (!q.lo && !q.hi) continue;
-                    const int64_t w0 = q.lo ? q.z0 - q.e0 + hb : 0, w1 = q.hi ? q.z1 - q.e0 - hb : q.e1 - q.e0;
-                    ZS_HIP(hipSetDevice(q.dev));
-                    ZS_RC(blur_window_dev(q.c, q.L[j - 1], q.L[j], q.D[j - 1], X, Y, q.e1 - q.e0, w0, w1, extras[j - 1], 0.01f));
-                    if (j == 3) ZS_HIP(hipEventRecord(q.ev_l3, q.c->stream));
-                }
-            /* the hb-slice halo of the new level from the two neighbours (their own slices, exact), queued behind the
-             * sender's event -- on the receiver's halo stream beside its interior launch (bands first), or on its main
-             * stream; then the fused DoG redone on the halo slices */
-            ZS_X(zs_xfer_begin(h->tr));
-            for (r = 0; r < nr; r++) {
+            });
+            if (crew_failed()) goto done;
+            if (!sharded) continue; /* one rank holds the whole octave: no halo, nothing to redo */
+            /* -- the hb-slice halo of the new level from the two neighbours (their own slices, exact), queued behind the sender's
+             *    event -- on the receiver's halo stream beside its interior launch (bands first), or on its main stream; then the
+             *    fused DoG redone on the halo slices; after level 3, what is left of the halos of L1..L3 (below).
+             *    Peer copies are queued by the RECEIVER's thread (a copy into rank r is an operation of r's streams); RCCL's sends and
+             *    receives of one step belong in one group of one thread, so the calling thread queues them for all ranks. -- */
+            auto incoming = [&](int r) -> int { /* the transfers into rank r of this level; 0 or -1 (the transport holds the message) */
                 zs_rank &q = R[(size_t)r];
                 const size_t bytes = sizeof(float) * (size_t)(hb * XY);
                 hipStream_t hs = banded ? q.halo_stream : q.c->stream;
                 if (q.lo) { /* global slices [z0 - hb, z0): the lower neighbour's last own slices */
                     zs_rank &p = R[(size_t)r - 1];
-                    ZS_X(zs_xfer(h->tr, 0, r - 1, p.L[j] + (q.z0 - hb - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
-                                 q.L[j] + (q.z0 - hb - q.e0) * XY, hs, (size_t)(hb * XY)));
-                    st.halo_bytes_critical += (int64_t)bytes;
-                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
-                    st.exchanges++;
+                    if (zs_xfer(h->tr, 0, r - 1, p.L[j] + (q.z0 - hb - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
+                                q.L[j] + (q.z0 - hb - q.e0) * XY, hs, (size_t)(hb * XY)) != 0) return -1;
+                    tally[(size_t)r].critical += (int64_t)bytes;
+                    if (banded) tally[(size_t)r].hidden += (int64_t)bytes;
+                    tally[(size_t)r].exchanges++;
                 }
                 if (q.hi) { /* global slices [z1, z1 + hb): the upper neighbour's first own slices */
                     zs_rank &p = R[(size_t)r + 1];
-                    ZS_X(zs_xfer(h->tr, 0, r + 1, p.L[j] + (q.z1 - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
-                                 q.L[j] + (q.z1 - q.e0) * XY, hs, (size_t)(hb * XY)));
-                    st.halo_bytes_critical += (int64_t)bytes;
-                    if (banded) st.halo_bytes_hidden += (int64_t)bytes;
-                    st.exchanges++;
+                    if (zs_xfer(h->tr, 0, r + 1, p.L[j] + (q.z1 - p.e0) * XY, banded ? p.halo_stream : p.c->stream, p.ev_level, r,
+                                q.L[j] + (q.z1 - q.e0) * XY, hs, (size_t)(hb * XY)) != 0) return -1;
+                    tally[(size_t)r].critical += (int64_t)bytes;
+                    if (banded) tally[(size_t)r].hidden += (int64_t)bytes;
+                    tally[(size_t)r].exchanges++;
                 }
-            }
-            ZS_X(zs_xfer_end(h->tr)); /* RCCL queues the step's sends and receives here: what follows is behind them */
-            for (r = 0; r < nr; r++) {
+                return 0;
+            };
+            /* L1..L3 are final after level 3: what is left of their halos, on the copy stream, while L4 and the extrema passes run.
+             * Two steps (round 5; rounds 1 - 4: one batch of 3 x 24 slices, and the NEXT OCTAVE waited for all of it):
+             *   step 0  the eight slices of L3 beyond +- 8 that the subsample reads (slab +- 16): all the next octave waits for;
+             *   step 1  what only patches reach: L1 and L2 from 8, L3 from 16, as deep as a patch of that level can reach
+             *           (ZS_PATCH_REACH: 19 / 23 / 28 slices, not 32) -- waited for before the per-keypoint stage, i.e. with the
+             *           whole rest of the pyramid to arrive in.
+             * Both steps travel on channel 1 in this order; a transport orders a channel's steps. */
+            auto incoming_deferred = [&](int r, int step) -> int {
                 zs_rank &q = R[(size_t)r];
-                ZS_HIP(hipSetDevice(q.dev));
+                if (!q.lo && !q.hi) return 0;
+                for (int l = step == 0 ? 3 : 1; l <= 3; l++) {
+                    const int64_t from = (step == 0 || l < 3) ? ZS_BLUR : ZS_SUB, to = step == 0 ? ZS_SUB : ZS_PATCH_REACH[l];
+                    if (q.lo) {
+                        zs_rank &p = R[(size_t)r - 1];
+                        const int64_t s0 = std::max(q.e0, q.z0 - to), s1 = q.z0 - from;
+                        if (s1 > s0) {
+                            if (zs_xfer(h->tr, 1, r - 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
+                                        (size_t)((s1 - s0) * XY)) != 0) return -1;
+                            tally[(size_t)r].deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                            if (step == 0) tally[(size_t)r].subsample += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                        }
+                    }
+                    if (q.hi) {
+                        zs_rank &p = R[(size_t)r + 1];
+                        const int64_t s0 = q.z1 + from, s1 = std::min(q.e1, q.z1 + to);
+                        if (s1 > s0) {
+                            if (zs_xfer(h->tr, 1, r + 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
+                                        (size_t)((s1 - s0) * XY)) != 0) return -1;
+                            tally[(size_t)r].deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                            if (step == 0) tally[(size_t)r].subsample += (int64_t)sizeof(float) * (s1 - s0) * XY;
+                        }
+                    }
+                }
+                tally[(size_t)r].exchanges++;
+                return 0;
+            };
+            auto after_arrival = [&](int r) { /* rank r's side of the step once its transfers are queued */
+                zs_rank &q = R[(size_t)r];
+                ZR_HIP(hipSetDevice(q.dev));
                 if (banded && (q.lo || q.hi)) { /* the main stream goes on behind the arrivals */
-                    ZS_COMM(hipEventRecord(q.ev_halo, q.halo_stream));
-                    ZS_COMM(hipStreamWaitEvent(q.c->stream, q.ev_halo, 0));
+                    ZR_COMM(hipEventRecord(q.ev_halo, q.halo_stream));
+                    ZR_COMM(hipStreamWaitEvent(q.c->stream, q.ev_halo, 0));
                 }
                 const int64_t a = (q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0) - q.e0, b = (q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1) - q.e0;
                 if (q.D[j - 1] && q.lo && q.z0 - q.e0 > a)
-                    ZS_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] + a * XY, (q.z0 - q.e0 - a) * XY));
+                    ZR_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + a * XY, q.L[j] + a * XY, q.D[j - 1] + a * XY, (q.z0 - q.e0 - a) * XY));
                 if (q.D[j - 1] && q.hi && b > q.z1 - q.e0)
-                    ZS_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + (q.z1 - q.e0) * XY, q.L[j] + (q.z1 - q.e0) * XY, q.D[j - 1] + (q.z1 - q.e0) * XY, (b - (q.z1 - q.e0)) * XY));
-            }
-            if (j == 3) {
-                /* L1..L3 are final: what is left of their halos, on the copy stream, while L4 and the extrema passes run.  Two steps
-                 * (round 5; rounds 1 - 4: one batch of 3 x 24 slices, and the NEXT OCTAVE waited for all of it):
-                 *   step 0  the eight slices of L3 beyond +- 8 that the subsample reads (slab +- 16): all the next octave waits for;
-                 *   step 1  what only patches reach: L1 and L2 from 8, L3 from 16, as deep as a patch of that level can reach
-                 *           (ZS_PATCH_REACH: 19 / 23 / 28 slices, not 32) -- waited for before the per-keypoint stage, i.e. with the
-                 *           whole rest of the pyramid to arrive in.
-                 * Both steps travel on channel 1 in this order; a transport orders a channel's steps. */
-                for (int step = 0; step < 2; step++) {
-                    ZS_X(zs_xfer_begin(h->tr));
-                    for (r = 0; r < nr; r++) {
-                        zs_rank &q = R[(size_t)r];
-                        if (!q.lo && !q.hi) continue;
-                        for (int l = step == 0 ? 3 : 1; l <= 3; l++) {
-                            const int64_t from = (step == 0 || l < 3) ? ZS_BLUR : ZS_SUB, to = step == 0 ? ZS_SUB : ZS_PATCH_REACH[l];
-                            if (q.lo) {
-                                zs_rank &p = R[(size_t)r - 1];
-                                const int64_t s0 = std::max(q.e0, q.z0 - to), s1 = q.z0 - from;
-                                if (s1 > s0) {
-                                    ZS_X(zs_xfer(h->tr, 1, r - 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
-                                                 (size_t)((s1 - s0) * XY)));
-                                    st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
-                                    if (step == 0) st.halo_bytes_subsample += (int64_t)sizeof(float) * (s1 - s0) * XY;
-                                }
-                            }
-                            if (q.hi) {
-                                zs_rank &p = R[(size_t)r + 1];
-                                const int64_t s0 = q.z1 + from, s1 = std::min(q.e1, q.z1 + to);
-                                if (s1 > s0) {
-                                    ZS_X(zs_xfer(h->tr, 1, r + 1, p.L[l] + (s0 - p.e0) * XY, p.copy_stream, p.ev_l3, r, q.L[l] + (s0 - q.e0) * XY, q.copy_stream,
-                                                 (size_t)((s1 - s0) * XY)));
-                                    st.halo_bytes_deferred += (int64_t)sizeof(float) * (s1 - s0) * XY;
-                                    if (step == 0) st.halo_bytes_subsample += (int64_t)sizeof(float) * (s1 - s0) * XY;
-                                }
-                            }
-                        }
-                        st.exchanges++;
+                    ZR_HIP(sift3d_launch_dog(q.c->stream, q.L[j - 1] + (q.z1 - q.e0) * XY, q.L[j] + (q.z1 - q.e0) * XY, q.D[j - 1] + (q.z1 - q.e0) * XY, (b - (q.z1 - q.e0)) * XY));
+            };
+            auto after_deferred = [&](int r, int step) {
+                zs_rank &q = R[(size_t)r];
+                if (!q.lo && !q.hi) return;
+                ZR_HIP(hipSetDevice(q.dev));
+                if (step == h->patch_wait) ZR_HIP(hipEventRecord(q.ev_patch, q.copy_stream)); /* the subsample's slices are in */
+                if (step == 1 && h->poison_halo) /* tests: a patch that reaches beyond what was fetched reads NaN and shows in the records */
+                    for (int l = 1; l <= 3; l++) {
+                        const int64_t reach = std::max(ZS_PATCH_REACH[l] - (h->poison_halo - 1), l == 3 ? ZS_SUB : ZS_BLUR);
+                        if (q.lo && q.z0 - reach > q.e0)
+                            ZR_HIP(hipMemsetD32Async((hipDeviceptr_t)q.L[l], 0x7FC00000, (size_t)((q.z0 - reach - q.e0) * XY), q.copy_stream));
+                        if (q.hi && q.e1 > q.z1 + reach)
+                            ZR_HIP(hipMemsetD32Async((hipDeviceptr_t)(q.L[l] + (q.z1 + reach - q.e0) * XY), 0x7FC00000, (size_t)((q.e1 - q.z1 - reach) * XY), q.copy_stream));
                     }
-                    ZS_X(zs_xfer_end(h->tr));
-                    if (step == h->patch_wait)
+            };
+            if (zs_transport_kind(h->tr) == ZS_TRANSPORT_RCCL) {
+                ZS_X(zs_xfer_begin(h->tr));
+                for (r = 0; r < nr; r++) ZS_X(incoming(r));
+                ZS_X(zs_xfer_end(h->tr)); /* RCCL queues the step's sends and receives here: what follows is behind them */
+                h->crew.run(nr, after_arrival);
+                if (crew_failed()) goto done;
+                if (j == 3)
+                    for (int step = 0; step < 2; step++) {
+                        ZS_X(zs_xfer_begin(h->tr));
+                        for (r = 0; r < nr; r++) ZS_X(incoming_deferred(r, step));
+                        ZS_X(zs_xfer_end(h->tr));
                         for (r = 0; r < nr; r++) {
-                            zs_rank &q = R[(size_t)r];
-                            if (!q.lo && !q.hi) continue;
-                            ZS_HIP(hipSetDevice(q.dev));
-                            ZS_HIP(hipEventRecord(q.ev_patch, q.copy_stream)); /* the subsample's slices are in */
-                        }
-                }
-                if (h->poison_halo) /* tests: a patch that reaches beyond what was fetched reads NaN and shows in the records */
-                    for (r = 0; r < nr; r++) {
-                        zs_rank &q = R[(size_t)r];
-                        if (!q.lo && !q.hi) continue;
-                        ZS_HIP(hipSetDevice(q.dev));
-                        for (int l = 1; l <= 3; l++) {
-                            const int64_t reach = std::max(ZS_PATCH_REACH[l] - (h->poison_halo - 1), l == 3 ? ZS_SUB : ZS_BLUR);
-                            if (q.lo && q.z0 - reach > q.e0)
-                                ZS_HIP(hipMemsetD32Async((hipDeviceptr_t)q.L[l], 0x7FC00000, (size_t)((q.z0 - reach - q.e0) * XY), q.copy_stream));
-                            if (q.hi && q.e1 > q.z1 + reach)
-                                ZS_HIP(hipMemsetD32Async((hipDeviceptr_t)(q.L[l] + (q.z1 + reach - q.e0) * XY), 0x7FC00000, (size_t)((q.e1 - q.z1 - reach) * XY), q.copy_stream));
+                            after_deferred(r, step);
+                            if (crew_failed()) goto done;
                         }
                     }
+            } else {
+                h->crew.run(nr, [&](int r) {
+                    ZR_X(incoming(r));
+                    after_arrival(r);
+                    if (rrc[(size_t)r] != SIFT3D_OK || j != 3) return;
+                    for (int step = 0; step < 2; step++) {
+                        ZR_X(incoming_deferred(r, step));
+                        after_deferred(r, step);
+                        if (rrc[(size_t)r] != SIFT3D_OK) return;
+                    }
+                });
+                if (crew_failed()) goto done;
             }
         }
         /* extrema of the rank's own slices; the level table in whole-volume terms.  Round 5: on the context's extrema stream,
          * behind everything the main stream holds so far (this octave's levels, their halos, the DoG slices redone on them), so
          * that the passes of octave o run beside the levels of octave o + 1 as they do on one device (run_pipeline); the main
-         * stream waits for them once, before the counts are read. */
-        for (r = 0; r < nr; r++) {
+         * stream waits for them once, before the counts are read.  Then level 0 of the next octave where that is the rank's own
+         * business (the next octave sharded too: slab +- 16 of L3 -> next slab +- 8). */
+        const bool more = o + 1 < (int)plan.oct.size();
+        const int64_t Xn = more ? plan.oct[(size_t)o + 1][0] : 0, Yn = more ? plan.oct[(size_t)o + 1][1] : 0, zn = more ? plan.oct[(size_t)o + 1][2] : 0, XYn = Xn * Yn;
+        h->crew.run(nr, [&](int r) {
             zs_rank &q = R[(size_t)r];
-            ZS_HIP(hipSetDevice(q.dev));
-            ZS_HIP(hipEventRecord(q.c->ev_oct[0], q.c->stream));
-            ZS_HIP(hipStreamWaitEvent(q.c->ex_stream, q.c->ev_oct[0], 0));
+            ZR_HIP(hipSetDevice(q.dev));
+            ZR_HIP(hipEventRecord(q.c->ev_oct[0], q.c->stream));
+            ZR_HIP(hipStreamWaitEvent(q.c->ex_stream, q.c->ev_oct[0], 0));
             q.c->cand_stream = q.c->ex_stream;
             for (int l = 0; l < 3; l++) {
                 const int id = o * 3 + l;
@@ -652,11 +710,10 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                     jb.next_ntaps = ntaps5;
                     for (int t = 0; t < ntaps5; t++) jb.next_taps[t] = taps5[t];
                 }
-                rc = cand_append(q.c, jb, true);
-                if (rc != SIFT3D_OK) {
+                const int rc_ = cand_append(q.c, jb, true);
+                if (rc_ != SIFT3D_OK) {
                     q.c->cand_stream = nullptr;
-                    snprintf(errbuf, sizeof errbuf, "rank %d: %s", r, sift3d_last_error(q.c));
-                    goto done;
+                    ZR_FAIL(rc_, "rank %d: %s", r, sift3d_last_error(q.c));
                 }
                 sift3d_level &lv = q.levels[(size_t)id];
                 lv.img = q.L[l + 1]; lv.dogc = q.D[l + 1];
@@ -666,25 +723,24 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 lv.Zl = (int)(q.e1 - q.e0); lv.z_off = (int)q.e0; lv.pad = 0;
             }
             q.c->cand_stream = nullptr;
-            if (q.lo || q.hi) ZS_HIP(hipStreamWaitEvent(q.c->stream, q.ev_patch, 0)); /* before the subsample reads L3 beyond +- 8: the first deferred step only */
-        }
-        fscale *= 2.0f;
-        if (o + 1 >= (int)plan.oct.size()) break;
-        /* ---- level 0 of the next octave ---- */
-        const int64_t Xn = plan.oct[(size_t)o + 1][0], Yn = plan.oct[(size_t)o + 1][1], zn = plan.oct[(size_t)o + 1][2], XYn = Xn * Yn;
-        if (sharded && o + 1 < K) { /* next octave sharded too: slab +- 16 of L3 -> next slab +- 8 */
-            for (r = 0; r < S; r++) {
-                zs_rank &q = R[(size_t)r];
+            if (q.lo || q.hi) ZR_HIP(hipStreamWaitEvent(q.c->stream, q.ev_patch, 0)); /* before the subsample reads L3 beyond +- 8: the first deferred step only */
+            if (more && sharded && o + 1 < K) {
                 int64_t n0, n1;
                 plan.slab(r, o + 1, n0, n1);
                 const int64_t ne0 = q.lo ? std::max<int64_t>(0, n0 - ZS_HALO) : n0, ne1 = q.hi ? std::min<int64_t>(zn, n1 + ZS_HALO) : n1;
                 const int64_t s0 = q.lo ? std::max(ne0, n0 - ZS_BLUR) : ne0, s1 = q.hi ? std::min(ne1, n1 + ZS_BLUR) : ne1;
-                ZS_HIP(hipSetDevice(q.dev));
                 float *nx0 = q.alloc((ne1 - ne0) * XYn);
-                if (!nx0) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-                ZS_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (2 * s0 - q.e0) * XY, X, X, Y, 2 * (s1 - s0), nx0 + (s0 - ne0) * XYn, Xn));
+                if (!nx0) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
+                ZR_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (2 * s0 - q.e0) * XY, X, X, Y, 2 * (s1 - s0), nx0 + (s0 - ne0) * XYn, Xn));
                 next0[r] = nx0;
             }
+        });
+        if (crew_failed()) goto done;
+        fscale *= 2.0f;
+        if (!more) break;
+        /* ---- level 0 of the next octave where it is not a rank's own business ---- */
+        if (sharded && o + 1 < K) {
+            /* (done above, rank by rank) */
         } else if (sharded) { /* last sharded octave: every rank subsamples exactly its slab, rank 0 assembles the whole octave */
             zs_rank &root = R[0];
             ZS_HIP(hipSetDevice(root.dev));
@@ -726,45 +782,46 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         }
     }
 
-    /* ---- per-keypoint stage on every rank, phase by phase across the ranks so that no device waits for another's host
-     * round trip: (1) every rank's extrema count is requested; (2) rank by rank the count is awaited, the candidates are
-     * sorted and the keypoint side of the stage is queued -- the devices before it are already computing; (3) rank by rank
-     * the descriptor launches follow the keypoint chunks; (4) one synchronisation per rank at the end. ---- */
+    /* ---- per-keypoint stage: every rank by its own host thread, so that no device waits for another's host round trip (rounds 3 - 4
+     * walked the ranks phase by phase on one thread): the extrema count is requested and awaited, the candidates are sorted, the
+     * keypoint kernel is queued and its records per group are read back; then -- the one step that needs every rank's numbers --
+     * the places of all records in the merged list are laid out, and every rank's descriptor kernel stores into its own. ---- */
     {
         std::vector<int64_t> ncands((size_t)S, 0);
-        for (r = 0; r < S; r++) {
+        std::vector<std::vector<int>> cnt((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0));
+        h->crew.run(S, [&](int r) {
             zs_rank &q = R[(size_t)r];
-            ZS_HIP(hipSetDevice(q.dev));
+            ZR_HIP(hipSetDevice(q.dev));
             /* the patch halos of every sharded octave (the second deferred step: the copy stream, in order) must be in before
              * the keypoint kernel samples them: everything the copy stream holds is behind this event */
-            ZS_HIP(hipEventRecord(q.ev_l3, q.copy_stream)); /* (ev_l3 is free here: its last use was the last octave's sends) */
-            ZS_HIP(hipStreamWaitEvent(q.c->stream, q.ev_l3, 0));
-            ZS_HIP(hipEventRecord(q.c->ev_oct[1], q.c->ex_stream)); /* every extrema pass of the run is behind this */
-            ZS_HIP(hipStreamWaitEvent(q.c->stream, q.c->ev_oct[1], 0));
-            ZS_RC(cand_count_queue(q.c));
-        }
+            ZR_HIP(hipEventRecord(q.ev_l3, q.copy_stream)); /* (ev_l3 is free here: its last use was the last octave's sends) */
+            ZR_HIP(hipStreamWaitEvent(q.c->stream, q.ev_l3, 0));
+            ZR_HIP(hipEventRecord(q.c->ev_oct[1], q.c->ex_stream)); /* every extrema pass of the run is behind this */
+            ZR_HIP(hipStreamWaitEvent(q.c->stream, q.c->ev_oct[1], 0));
+            ZR_RC(cand_count_queue(q.c));
+        });
+        if (crew_failed()) goto done;
         st.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-        for (r = 0; r < S; r++) {
+        h->crew.run(S, [&](int r) {
             zs_rank &q = R[(size_t)r];
-            ZS_HIP(hipSetDevice(q.dev));
-            ZS_RC(cand_finalize(q.c, &ncands[(size_t)r]));
-            st.n_extrema += ncands[(size_t)r];
+            ZR_HIP(hipSetDevice(q.dev));
+            ZR_RC(cand_finalize(q.c, &ncands[(size_t)r]));
             describe_want_group_counts(q.c, true);
             q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the placement below needs the whole list's counts before the one descriptor launch */
-            ZS_RC(describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false));
-        }
-        /* every rank's records per group (level, is_max): the merged list is, group by group, a run of every rank in rank order --
-         * within a group slabs are in z order, so rank order is the serial raster order */
-        std::vector<std::vector<int>> cnt((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0));
-        int64_t total = 0;
-        for (r = 0; r < S; r++) {
+            ZR_RC(describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false));
+            /* this rank's records per group (level, is_max): the merged list is, group by group, a run of every rank in rank order --
+             * within a group slabs are in z order, so rank order is the serial raster order */
             const int *hc = nullptr;
             int64_t tr = 0;
-            ZS_HIP(hipSetDevice(R[(size_t)r].dev));
-            ZS_RC(describe_group_counts(R[(size_t)r].c, &hc, &tr));
+            ZR_RC(describe_group_counts(q.c, &hc, &tr));
             cnt[(size_t)r].assign(hc, hc + SIFT3D_GROUPS);
             nrecs[(size_t)r] = tr;
-            total += tr;
+        });
+        if (crew_failed()) goto done;
+        int64_t total = 0;
+        for (r = 0; r < S; r++) {
+            st.n_extrema += ncands[(size_t)r];
+            total += nrecs[(size_t)r];
         }
         const auto merge0 = std::chrono::steady_clock::now(); /* (the waits for the keypoint kernels are behind us) */
         if (total > h->merged_cap) { /* nothing stores into the list yet: the descriptor launches follow */
@@ -789,28 +846,24 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                     pos += cnt[(size_t)r][(size_t)g];
                     local[(size_t)r] += cnt[(size_t)r][(size_t)g];
                 }
-            for (r = 0; r < S; r++) {
-                zs_rank &q = R[(size_t)r];
-                if (nrecs[(size_t)r] <= 0) continue;
-                ZS_HIP(hipSetDevice(q.dev));
-                sift3d_feature *dview = nullptr; /* the list as this rank's device sees it */
-                ZS_HIP(hipHostGetDevicePointer((void **)&dview, h->merged, 0));
-                ZS_RC(describe_placement(q.c, dview, shift[(size_t)r].data()));
-            }
         }
         st.merge_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge0).count();
-        for (r = 0; r < S; r++) {
-            ZS_HIP(hipSetDevice(R[(size_t)r].dev));
-            ZS_RC(describe_launch(R[(size_t)r].c));
-        }
-        for (r = 0; r < S; r++) {
+        h->crew.run(S, [&](int r) {
             zs_rank &q = R[(size_t)r];
+            ZR_HIP(hipSetDevice(q.dev));
+            if (nrecs[(size_t)r] > 0) {
+                sift3d_feature *dview = nullptr; /* the list as this rank's device sees it */
+                ZR_HIP(hipHostGetDevicePointer((void **)&dview, h->merged, 0));
+                ZR_RC(describe_placement(q.c, dview, shift[(size_t)r].data()));
+            }
+            ZR_RC(describe_launch(q.c));
             int64_t nrec = 0;
-            ZS_HIP(hipSetDevice(q.dev));
-            ZS_RC(describe_finish(q.c, &nrec));
-            if (nrec != nrecs[(size_t)r]) { rc = SIFT3D_ERR_DEVICE; snprintf(errbuf, sizeof errbuf, "rank %d: %lld records where its groups add up to %lld", r, (long long)nrec, (long long)nrecs[(size_t)r]); goto done; }
-            st.n_keypoints += q.c->last.n_keypoints;
-        }
+            ZR_RC(describe_finish(q.c, &nrec));
+            if (nrec != nrecs[(size_t)r])
+                ZR_FAIL(SIFT3D_ERR_DEVICE, "rank %d: %lld records where its groups add up to %lld", r, (long long)nrec, (long long)nrecs[(size_t)r]);
+        });
+        if (crew_failed()) goto done;
+        for (r = 0; r < S; r++) st.n_keypoints += R[(size_t)r].c->last.n_keypoints;
         /* the list is complete where every rank's kernel put it */
         if (out) {
             sift3d_feature *res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));
@@ -843,6 +896,13 @@ done:
         zs_transport_destroy(h->tr);
         h->tr = nullptr;
     }
+    for (const zs_tally &t : tally) {
+        st.halo_bytes_critical += t.critical;
+        st.halo_bytes_hidden += t.hidden;
+        st.halo_bytes_deferred += t.deferred;
+        st.halo_bytes_subsample += t.subsample;
+        st.exchanges += t.exchanges;
+    }
     st.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = st;
     if (rc != SIFT3D_OK && err && err_len > 0) snprintf(err, (size_t)err_len, "%s", errbuf);
@@ -873,25 +933,27 @@ extern "C" int sift3d_zslab_set_volume(sift3d_zslab *h, const float *vol, char *
     const int S = (int)h->R.size();
     const int64_t XY = plan.nx * plan.ny;
     h->has_volume = false;
-    for (int r = 0; r < S; r++) {
+    /* every rank's slices by its own host thread: an upload from pageable memory is staged by the thread that asked for it */
+    std::vector<int> rcs((size_t)S, SIFT3D_OK);
+    std::vector<zs_errline> errs((size_t)S);
+    h->crew.run(S, [&](int r) {
         zs_rank &q = h->R[(size_t)r];
         int64_t i0 = 0, i1 = plan.nz;
         if (S > 1) plan.input_range(r, i0, i1);
         hipError_t e = hipSetDevice(q.dev);
         if (e == hipSuccess && !q.vol_dev) e = hipMalloc((void **)&q.vol_dev, sizeof(float) * (size_t)((i1 - i0) * XY));
         if (e == hipSuccess) e = hipMemcpyAsync(q.vol_dev, vol + i0 * XY, sizeof(float) * (size_t)((i1 - i0) * XY), hipMemcpyHostToDevice, q.c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(q.c->stream); /* the caller's buffer is free again when this returns */
         if (e != hipSuccess) {
-            if (err && err_len > 0) snprintf(err, (size_t)err_len, "rank %d: input slices [%lld, %lld): %s", r, (long long)i0, (long long)i1, hipGetErrorString(e));
-            return e == hipErrorOutOfMemory ? SIFT3D_ERR_MEMORY : SIFT3D_ERR_DEVICE;
+            snprintf(errs[(size_t)r].b, sizeof errs[0].b, "rank %d: input slices [%lld, %lld): %s", r, (long long)i0, (long long)i1, hipGetErrorString(e));
+            rcs[(size_t)r] = e == hipErrorOutOfMemory ? SIFT3D_ERR_MEMORY : SIFT3D_ERR_DEVICE;
         }
-    }
-    for (int r = 0; r < S; r++) { /* the caller's buffer is free again when this returns */
-        hipSetDevice(h->R[(size_t)r].dev);
-        if (hipStreamSynchronize(h->R[(size_t)r].c->stream) != hipSuccess) {
-            if (err && err_len > 0) snprintf(err, (size_t)err_len, "rank %d: upload failed", r);
-            return SIFT3D_ERR_DEVICE;
+    });
+    for (int r = 0; r < S; r++)
+        if (rcs[(size_t)r] != SIFT3D_OK) {
+            if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", errs[(size_t)r].b);
+            return rcs[(size_t)r];
         }
-    }
     h->has_volume = true;
     return SIFT3D_OK;
 }

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,7 @@ struct zs_transport {
     std::vector<ncclComm_t> comm[ZS_CHANNELS]; /* with ZS_FLAG_SERIAL_CHANNELS comm[1] is a copy of comm[0]'s handles */
     int comm_sets = 0;
     bool in_group = false;
+    std::mutex err_m; /* peer copies are queued by the receiving rank's host thread: two of them may fail at once */
     char err[384] = "";
 };
 
@@ -161,14 +163,16 @@ extern "C" int zs_xfer(zs_transport *t, int channel, int src_rank, const float *
 {
     const int n = (int)t->devices.size();
     if (channel < 0 || channel >= ZS_CHANNELS || src_rank < 0 || src_rank >= n || dst_rank < 0 || dst_rank >= n || !src || !dst) {
+        std::lock_guard<std::mutex> lk(t->err_m);
         snprintf(t->err, sizeof t->err, "slab exchange: bad transfer %d -> %d on channel %d", src_rank, dst_rank, channel);
         return -1;
     }
     hipError_t e;
     if (t->kind == ZS_TRANSPORT_PEER) {
-        /* on the receiver's stream, behind the sender's event; the calling thread's current device is the receiver's */
+        /* on the receiver's stream, behind the sender's event; the calling thread is the receiving rank's (zslab_driver.hip: zs_crew) */
         if ((e = hipSetDevice(t->devices[(size_t)dst_rank])) != hipSuccess || (e = hipStreamWaitEvent(dst_stream, src_ready, 0)) != hipSuccess ||
             (e = hipMemcpyPeerAsync(dst, t->devices[(size_t)dst_rank], src, t->devices[(size_t)src_rank], sizeof(float) * nfloats, dst_stream)) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(t->err_m);
             snprintf(t->err, sizeof t->err, "slab exchange: peer copy %d -> %d failed: %s", src_rank, dst_rank, hipGetErrorString(e));
             return -1;
         }

@@ -469,6 +469,22 @@ def test_nifti_reader_vox_offset_and_analyze(built, tmp_path):
     assert (got == v).all() and hdr["qform_code"] == 0 and hdr["sform_code"] == 0
 
 
+def test_slab_driver_host_threads_under_thread_sanitizer():
+    """The one-process slab driver runs every rank's launches on a host thread of its own (csrc/zs_crew.h: a step is published to
+    all workers, acknowledged by all, and what a step reads of a neighbour was written a step earlier).  tests/crew_check.cpp steps
+    such a crew through tens of thousands of steps on plain memory under ThreadSanitizer (`make tsan`), with workers spinning, asleep
+    and outnumbering the cores."""
+    csrc = os.path.join(ROOT, "3d_sift_cuda_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "tsan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exe = os.path.join(csrc, "_build", "crew_check_tsan")
+    for workers, steps in ((1, 5000), (3, 20000), (7, 10000), (15, 3000)):
+        r = subprocess.run([exe, str(workers), str(steps)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+        assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "crew ok: %d workers, %d steps" % (workers, steps) in r.stdout, \
+            r.stdout[-500:] + r.stderr[-3000:]
+
+
 def test_host_code_under_sanitizers(built, tmp_path):
     """ASan + UBSan over the plain-C host code (nifti_min.c, world.c, keyfile.c, synth.c, match_votes.c: `make asan`) on every file shape
     above plus malformed ones, and over the oracle CLI (restatement + reader) on a small volume with the -2+ / -b / -w

@@ -26,6 +26,8 @@ with pkg.ZSlab(nx, ny, nz, [0] * ranks) as h:
             h.set_tuning(pkg.ZSLAB_SERIAL_CHANNELS, int(rng.integers(0, 2)))
         h.set_tuning(pkg.TUNE_BANDS_FIRST, int(rng.choice([1, 1, 0])))
         h.set_tuning(pkg.TUNE_LAZY_LEVELS, int(rng.choice([1, 1, 0])))
+        h.set_tuning(pkg.ZSLAB_PATCH_WAIT, int(rng.choice([0, 0, 1])))
+        h.set_tuning(pkg.ZSLAB_POISON_HALO, int(rng.choice([0, 1])))
         recs, st = h.extract_resident(desc_mode=mode, copy=False)
         if hashlib.sha256(recs.tobytes()).hexdigest() != want[mode]:
             bad += 1
