@@ -141,24 +141,7 @@ struct zs_rank {
 };
 
 
-#define ZS_HIP(call)                                                                                                   \
-    do {                                                                                                               \
-        hipError_t e_ = (call);                                                                                        \
-        if (e_ != hipSuccess) {                                                                                        \
-            snprintf(errbuf, sizeof errbuf, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            rc = SIFT3D_ERR_DEVICE;                                                                                    \
-            goto done;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
-#define ZS_X(call) /* a step of the exchange through the handle's transport (peer copies or RCCL) */                 \
-    do {                                                                                                               \
-        if ((call) != 0) {                                                                                             \
-            snprintf(errbuf, sizeof errbuf, "%s", zs_transport_error(h->tr));                                          \
-            rc = SIFT3D_ERR_COMM;                                                                                      \
-            goto done;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
-/* The same inside a rank's step (a lambda run by the rank's host thread, `r` its rank): the failure goes to the rank's own slot and the
+/* Failures inside a rank's step (a lambda run by the rank's host thread, `r` its rank): the failure goes to the rank's own slot and the
  * step returns; the calling thread looks at the slots when every rank is back (crew_failed). */
 #define ZR_FAIL(code, ...)                                             \
     do {                                                               \
@@ -209,6 +192,8 @@ struct sift3d_zslab {
     sift3d_feature *merged = nullptr;
     int64_t merged_cap = 0;
     zs_crew crew; /* one host thread per rank beyond the first (started with the handle) */
+    int n_slabs = 1; /* R[0 .. n_slabs): the slabs.  R[coarse] (if >= 0): the rank of the gathered octaves, see zslab_create_impl */
+    int coarse = -1;
     sift3d_zslab(int64_t nx, int64_t ny, int64_t nz, int n) : plan(nx, ny, nz, n) {}
 };
 
@@ -305,14 +290,22 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
         }
     sift3d_zslab *h = new sift3d_zslab(nx, ny, nz, n_devices);
     const int S = h->plan.K > 0 ? n_devices : 1; /* too thin to shard: the whole volume on the first device */
+    /* The octaves below the sharded ones are gathered on the first device -- into a rank of their own (round 5): a context, streams
+     * and a host thread beside rank 0's, so that the chain of small launches that builds them (0.5 - 0.8 ms at 512^3, latency all
+     * of it) and their few hundred keypoints run BESIDE rank 0's per-keypoint stage instead of in front of it.  Every rank's
+     * descriptor launch waits for every rank's record counts, so what rank 0 did alone, all ranks waited for. */
+    const bool has_coarse = S > 1 && (size_t)h->plan.K < h->plan.oct.size();
+    const int T = S + (has_coarse ? 1 : 0);
+    h->n_slabs = S;
+    h->coarse = has_coarse ? S : -1;
     h->devices.assign(devices, devices + n_devices);
-    h->R.resize((size_t)S);
+    h->R.resize((size_t)T);
     {
         /* One rank's context, streams and events.  Round 5: the ranks are set up by one host thread each -- a context is 30 - 45 ms of
          * allocations, and on eight devices the one-shot call (featExtract -d0,..,7) spent a third of a second creating them one
          * after the other.  */
-        std::vector<int> rcs((size_t)S, SIFT3D_OK);
-        std::vector<std::string> errs((size_t)S);
+        std::vector<int> rcs((size_t)T, SIFT3D_OK);
+        std::vector<std::string> errs((size_t)T);
         auto setup = [&](int r) {
             zs_rank &q = h->R[(size_t)r];
             char eb[256];
@@ -321,21 +314,19 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
                 errs[(size_t)r] = eb;
                 rcs[(size_t)r] = SIFT3D_ERR_DEVICE;
             };
-            q.dev = devices[r];
+            q.dev = r < S ? devices[r] : devices[0];
             int64_t i0 = 0, i1 = nz;
-            if (S > 1) h->plan.input_range(r, i0, i1);
+            if (S > 1 && r < S) h->plan.input_range(r, i0, i1);
             hipError_t e = hipSetDevice(q.dev);
             if (e != hipSuccess) return hipfail(e, "hipSetDevice");
             /* a slab context owns no level buffers (they come from the rank's arena); its pass intermediates must hold the
-             * largest volume the rank ever blurs: its slab with halos, and on rank 0 the first unsharded octave, which is
-             * gathered there (nz / 2^K slices of a plane a 4^K-th the size: smaller than the slab unless the slabs are many) */
-            int64_t ctx_nz = (i1 - i0) + 2 * ZS_HALO;
-            if (r == 0 && S > 1 && (size_t)h->plan.K < h->plan.oct.size()) {
+             * largest volume the rank ever blurs: its slab with halos -- or, for the rank of the gathered octaves, the first of them */
+            if (r < S) {
+                q.c = ctx_create(q.dev, nx, ny, (i1 - i0) + 2 * ZS_HALO, S > 1);
+            } else {
                 const std::vector<int64_t> &g = h->plan.oct[(size_t)h->plan.K];
-                const int64_t need = (pitch_of(g[0]) * g[1] * g[2] + pitch_of(nx) * ny - 1) / (pitch_of(nx) * ny);
-                ctx_nz = std::max(ctx_nz, need);
+                q.c = ctx_create(q.dev, g[0], g[1], g[2], true);
             }
-            q.c = ctx_create(q.dev, nx, ny, ctx_nz, S > 1);
             if (!q.c) {
                 snprintf(eb, sizeof eb, "rank %d: no context on device %d (memory?)", r, q.dev);
                 errs[(size_t)r] = eb;
@@ -353,10 +344,10 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
         };
         /* (also when ranks share a device -- the rehearsal on one GPU -- so that the tests run the path a node runs) */
         std::vector<std::thread> th;
-        for (int r = 1; r < S; r++) th.emplace_back(setup, r);
+        for (int r = 1; r < T; r++) th.emplace_back(setup, r);
         setup(0);
         for (std::thread &t : th) t.join();
-        for (int r = 0; r < S && rc == SIFT3D_OK; r++)
+        for (int r = 0; r < T && rc == SIFT3D_OK; r++)
             if (rcs[(size_t)r] != SIFT3D_OK) {
                 rc = rcs[(size_t)r];
                 snprintf(errbuf, sizeof errbuf, "%s", errs[(size_t)r].c_str());
@@ -368,9 +359,9 @@ static sift3d_zslab *zslab_create_impl(const int *devices, int n_devices, int64_
         return fail(errbuf);
     }
     {
-        std::vector<int> devs((size_t)S);
-        for (int r = 0; r < S; r++) devs[(size_t)r] = h->R[(size_t)r].dev;
-        h->crew.start(S - 1, [devs](int r) { (void)hipSetDevice(devs[(size_t)r]); });
+        std::vector<int> devs((size_t)T);
+        for (int r = 0; r < T; r++) devs[(size_t)r] = h->R[(size_t)r].dev;
+        h->crew.start(T - 1, [devs](int r) { (void)hipSetDevice(devs[(size_t)r]); });
     }
     return h;
 }
@@ -405,7 +396,8 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
     const zs_plan &plan = h->plan;
     const int64_t nx = plan.nx, ny = plan.ny, nz = plan.nz;
     std::vector<zs_rank> &R = h->R;
-    const int S = (int)R.size();
+    const int S = h->n_slabs, T = (int)R.size();
+    const int cr = h->coarse >= 0 ? h->coarse : 0; /* the rank that holds the octaves that are not sharded */
     const int K = plan.K;
     sift3d_zslab_stats st;
     memset(&st, 0, sizeof st);
@@ -427,13 +419,13 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
     st.rccl_version = zs_transport_version(h->tr);
     st.comm_sets = zs_transport_comm_sets(h->tr);
     st.resident_volume = vol ? 0 : 1;
-    std::vector<int64_t> nrecs((size_t)S, 0);
+    std::vector<int64_t> nrecs((size_t)T, 0);
     std::vector<std::vector<int>> shift; /* per rank: where its records of a group go in the merged list (alive until the streams are drained) */
-    std::vector<int> rrc((size_t)S, SIFT3D_OK); /* what a rank's step reports (ZR_*), looked at when the step's ranks are back */
-    std::vector<zs_errline> rerr((size_t)S);
-    std::vector<zs_tally> tally((size_t)S);
+    std::vector<int> rrc((size_t)T, SIFT3D_OK); /* what a rank's step reports (ZR_*), looked at when the step's ranks are back */
+    std::vector<zs_errline> rerr((size_t)T);
+    std::vector<zs_tally> tally((size_t)T);
     auto crew_failed = [&]() -> bool {
-        for (int i = 0; i < S; i++)
+        for (int i = 0; i < T; i++)
             if (rrc[(size_t)i] != SIFT3D_OK) {
                 rc = rrc[(size_t)i];
                 snprintf(errbuf, sizeof errbuf, "%s", rerr[(size_t)i].b);
@@ -458,20 +450,21 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             sig[j + 1] = sg;
         }
     }
-    float *next0[64]; /* level 0 of the next octave per rank */
-    for (int i = 0; i < 64; i++) next0[i] = nullptr;
+    std::vector<float *> next0((size_t)T, nullptr); /* level 0 of the next octave per rank */
     float fscale = 1.0f;
 
+    auto extraction = [&]() { /* returns early on a failure (rc / errbuf set); what follows it is done either way */
     /* ---- input slabs, level 0 of octave 0: every rank by its own host thread (an upload from pageable memory is a chain of
      * staged copies the calling thread takes part in: S of them side by side) ---- */
-    h->crew.run(S, [&](int r) {
+    h->crew.run(T, [&](int r) {
         zs_rank &q = R[(size_t)r];
         int64_t i0 = 0, i1 = nz;
-        if (S > 1) plan.input_range(r, i0, i1);
+        if (S > 1 && r < S) plan.input_range(r, i0, i1);
         ZR_HIP(hipSetDevice(q.dev));
         q.levels.assign(plan.oct.size() * 3, sift3d_level());
         ZR_RC(cand_reset(q.c));
         timing_begin(q.c);
+        if (r >= S) return; /* the rank of the gathered octaves has no slab of the input */
         /* level 0 = initial blur of the input, on slab +- 8 from input slab +- 16 */
         const int64_t XY = nx * ny;
         float *din = vol ? q.alloc((i1 - i0) * XY) : q.vol_dev;
@@ -499,13 +492,25 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         }
         next0[r] = l0;
     });
-    if (crew_failed()) goto done;
+    if (crew_failed()) return;
 
-    /* ---- octaves ---- */
-    for (int o = 0; o < (int)plan.oct.size(); o++) {
+    /* ---- one octave.  A sharded one is called from the calling thread and walks its steps with the crew; one that is not sharded
+     * belongs to rank cr alone and is called from cr's own thread, inside the step that starts the per-keypoint stage (below): its
+     * "steps" then run inline.  Failures go to the slots (rrc / rerr) either way. ---- */
+    auto octave = [&](int o) {
         const int64_t X = plan.oct[(size_t)o][0], Y = plan.oct[(size_t)o][1], zo = plan.oct[(size_t)o][2], XY = X * Y;
         const bool sharded = S > 1 && o < K;
-        const int nr = sharded ? S : 1; /* the gathered octaves live on rank 0 (one rank: crew.run runs it on the calling thread) */
+        const int r0 = sharded ? 0 : cr, r1 = sharded ? S : cr + 1; /* the ranks that hold a part of this octave */
+        int r = r0;                                                  /* (ZR_* in this lambda's own statements: the slot of the rank at hand) */
+        auto step = [&](auto &&f) { /* f(rank) for the octave's ranks */
+            if (sharded) h->crew.run(S, f); else f(cr);
+        };
+        auto step_failed = [&]() -> bool { /* (an octave of cr's own runs beside other ranks' steps: it looks at its own slot only) */
+            if (!sharded) return rrc[(size_t)cr] != SIFT3D_OK;
+            for (int i = 0; i < T; i++)
+                if (rrc[(size_t)i] != SIFT3D_OK) return true;
+            return false;
+        };
         /* As on one device (run_pipeline): D_0 is read as L_0 - L_1 around the extrema of D_1, and L_5 -- hence D_4 -- is
          * filtered only around the candidates of D_3, from L_4.  A slab then blurs four levels instead of five and exchanges
          * four halos per octave instead of five; the third extrema phase reads L_4 nine slices beyond a candidate, so L_4's
@@ -515,20 +520,21 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         const int ntaps5 = sift3d_gauss_taps(extras[4], 0.01f, taps5);
         const bool lazy = ntaps5 == 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X >= 8 && XY < (1ll << 29) && Y >= 3 && zo >= 3 && h->lazy_levels;
         const int nlev = lazy ? 4 : 5;
-        for (r = 0; r < nr; r++) { /* (bump allocations from the rank's arena: nothing to share out) */
+        for (r = r0; r < r1; r++) { /* (bump allocations from the rank's arena: nothing to share out) */
             zs_rank &q = R[(size_t)r];
             if (sharded) plan.slab(r, o, q.z0, q.z1); else { q.z0 = 0; q.z1 = zo; }
             q.lo = sharded && r > 0;
             q.hi = sharded && r < S - 1;
             q.e0 = q.lo ? std::max<int64_t>(0, q.z0 - ZS_HALO) : q.z0;
             q.e1 = q.hi ? std::min<int64_t>(zo, q.z1 + ZS_HALO) : q.z1;
-            ZS_HIP(hipSetDevice(q.dev));
-            q.L[0] = next0[r];
+            ZR_HIP(hipSetDevice(q.dev));
+            q.L[0] = next0[(size_t)r];
             for (int j = 1; j < 6; j++) q.L[j] = j <= nlev ? q.alloc((q.e1 - q.e0) * XY) : nullptr;
             for (int j = 0; j < 5; j++) q.D[j] = (lazy && (j == 0 || j == 4)) ? nullptr : q.alloc((q.e1 - q.e0) * XY);
             for (int j = 1; j <= nlev; j++)
-                if (!q.L[j] || (!q.D[j - 1] && !(lazy && j == 1))) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
+                if (!q.L[j] || (!q.D[j - 1] && !(lazy && j == 1))) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
         }
+        r = r0;
         for (int j = 1; j <= nlev; j++) {
             const int64_t hb = (lazy && j == 4) ? ZS_BLUR + 1 : ZS_BLUR; /* slices of this level's halo refreshed from the neighbours */
             /* Boundary bands first (round 3).  What a neighbour fetches of this level are a rank's own first and last hb
@@ -542,7 +548,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             const bool banded = sharded && blur_window_supported(X, Y, extras[j - 1], 0.01f) && h->bands_first;
             /* -- the level's launches: every rank by its own thread (bands, event, interior).  The transfers of the bands are
              *    queued in the step after this one -- in host time behind the interior launch, on the device behind the event only -- */
-            h->crew.run(nr, [&](int r) {
+            step([&](int r) {
                 zs_rank &q = R[(size_t)r];
                 const int64_t c0 = q.lo ? std::max(q.e0, q.z0 - ZS_BLUR) : q.e0, c1 = q.hi ? std::min(q.e1, q.z1 + ZS_BLUR) : q.e1;
                 const int64_t a = c0 - q.e0, b = c1 - q.e0, nzl = q.e1 - q.e0;
@@ -562,7 +568,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                     if (j == 3) ZR_HIP(hipEventRecord(q.ev_l3, q.c->stream));
                 }
             });
-            if (crew_failed()) goto done;
+            if (step_failed()) return;
             if (!sharded) continue; /* one rank holds the whole octave: no halo, nothing to redo */
             /* -- the hb-slice halo of the new level from the two neighbours (their own slices, exact), queued behind the sender's
              *    event -- on the receiver's halo stream beside its interior launch (bands first), or on its main stream; then the
@@ -655,33 +661,32 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                     }
             };
             if (zs_transport_kind(h->tr) == ZS_TRANSPORT_RCCL) {
-                ZS_X(zs_xfer_begin(h->tr));
-                for (r = 0; r < nr; r++) ZS_X(incoming(r));
-                ZS_X(zs_xfer_end(h->tr)); /* RCCL queues the step's sends and receives here: what follows is behind them */
-                h->crew.run(nr, after_arrival);
-                if (crew_failed()) goto done;
+                r = 0; /* (the calling thread's own statements: rank 0's slot) */
+                ZR_X(zs_xfer_begin(h->tr));
+                for (int i = 0; i < S; i++) ZR_X(incoming(i));
+                ZR_X(zs_xfer_end(h->tr)); /* RCCL queues the step's sends and receives here: what follows is behind them */
+                h->crew.run(S, after_arrival);
+                if (step_failed()) return;
                 if (j == 3)
-                    for (int step = 0; step < 2; step++) {
-                        ZS_X(zs_xfer_begin(h->tr));
-                        for (r = 0; r < nr; r++) ZS_X(incoming_deferred(r, step));
-                        ZS_X(zs_xfer_end(h->tr));
-                        for (r = 0; r < nr; r++) {
-                            after_deferred(r, step);
-                            if (crew_failed()) goto done;
-                        }
+                    for (int part = 0; part < 2; part++) {
+                        ZR_X(zs_xfer_begin(h->tr));
+                        for (int i = 0; i < S; i++) ZR_X(incoming_deferred(i, part));
+                        ZR_X(zs_xfer_end(h->tr));
+                        for (int i = 0; i < S; i++) after_deferred(i, part);
+                        if (step_failed()) return;
                     }
             } else {
-                h->crew.run(nr, [&](int r) {
+                h->crew.run(S, [&](int r) {
                     ZR_X(incoming(r));
                     after_arrival(r);
                     if (rrc[(size_t)r] != SIFT3D_OK || j != 3) return;
-                    for (int step = 0; step < 2; step++) {
-                        ZR_X(incoming_deferred(r, step));
-                        after_deferred(r, step);
+                    for (int part = 0; part < 2; part++) {
+                        ZR_X(incoming_deferred(r, part));
+                        after_deferred(r, part);
                         if (rrc[(size_t)r] != SIFT3D_OK) return;
                     }
                 });
-                if (crew_failed()) goto done;
+                if (step_failed()) return;
             }
         }
         /* extrema of the rank's own slices; the level table in whole-volume terms.  Round 5: on the context's extrema stream,
@@ -691,7 +696,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
          * business (the next octave sharded too: slab +- 16 of L3 -> next slab +- 8). */
         const bool more = o + 1 < (int)plan.oct.size();
         const int64_t Xn = more ? plan.oct[(size_t)o + 1][0] : 0, Yn = more ? plan.oct[(size_t)o + 1][1] : 0, zn = more ? plan.oct[(size_t)o + 1][2] : 0, XYn = Xn * Yn;
-        h->crew.run(nr, [&](int r) {
+        step([&](int r) {
             zs_rank &q = R[(size_t)r];
             ZR_HIP(hipSetDevice(q.dev));
             ZR_HIP(hipEventRecord(q.c->ev_oct[0], q.c->stream));
@@ -732,20 +737,26 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 float *nx0 = q.alloc((ne1 - ne0) * XYn);
                 if (!nx0) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
                 ZR_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (2 * s0 - q.e0) * XY, X, X, Y, 2 * (s1 - s0), nx0 + (s0 - ne0) * XYn, Xn));
-                next0[r] = nx0;
+                next0[(size_t)r] = nx0;
             }
         });
-        if (crew_failed()) goto done;
+        if (step_failed()) return;
         fscale *= 2.0f;
-        if (!more) break;
+        if (!more) return;
+        r = r0;
         /* ---- level 0 of the next octave where it is not a rank's own business ---- */
         if (sharded && o + 1 < K) {
             /* (done above, rank by rank) */
         } else if (sharded) { /* last sharded octave: every rank subsamples exactly its slab, rank 0 assembles the whole octave */
-            zs_rank &root = R[0];
-            ZS_HIP(hipSetDevice(root.dev));
+            /* (the calling thread queues all of it: a few launches and S - 1 transfers, once per extraction.)  The octave lands in
+             * the buffers of rank cr -- the gathered octaves' own rank, on the first device -- and is ordered in ITS main stream:
+             * the first device's part is a launch of rank 0's stream, the others arrive through the transport as transfers to
+             * transport rank 0 (= that device). */
+            zs_rank &root = R[(size_t)cr];
+            r = cr;
+            ZR_HIP(hipSetDevice(root.dev));
             float *full = root.alloc(zn * XYn);
-            if (!full) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank 0: out of device memory"); goto done; }
+            if (!full) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
             int64_t at = 0;
             struct gather_part { int rank; const float *src; int64_t at, t; };
             std::vector<gather_part> parts;
@@ -753,33 +764,44 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 zs_rank &q = R[(size_t)r];
                 const int64_t t = std::min<int64_t>((q.z1 - q.z0) / 2, zn - at); /* an odd last slice of the whole volume is dropped, as in the serial code */
                 if (t <= 0) continue;
-                ZS_HIP(hipSetDevice(q.dev));
+                ZR_HIP(hipSetDevice(q.dev));
                 float *part = r == 0 ? full + at * XYn : q.alloc(t * XYn);
-                if (!part) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank %d: out of device memory", r); goto done; }
-                ZS_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (q.z0 - q.e0) * XY, X, X, Y, 2 * t, part, Xn));
+                if (!part) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
+                ZR_HIP(sift3d_launch_subsample(q.c->stream, q.L[3] + (q.z0 - q.e0) * XY, X, X, Y, 2 * t, part, Xn));
+                ZR_HIP(hipEventRecord(q.ev_level, q.c->stream));
                 if (r > 0) {
-                    ZS_HIP(hipEventRecord(q.ev_level, q.c->stream));
                     parts.push_back({r, part, at, t});
+                } else {
+                    ZR_HIP(hipSetDevice(root.dev));
+                    ZR_HIP(hipStreamWaitEvent(root.c->stream, q.ev_level, 0)); /* same device, another rank's stream */
                 }
                 at += t;
             }
-            ZS_X(zs_xfer_begin(h->tr)); /* every rank's part of the octave to rank 0, ordered in rank 0's main stream */
+            r = cr;
+            ZR_X(zs_xfer_begin(h->tr)); /* every other device's part of the octave, ordered in the receiving rank's main stream */
             for (const gather_part &g : parts) {
                 zs_rank &q = R[(size_t)g.rank];
-                ZS_X(zs_xfer(h->tr, 0, g.rank, g.src, q.c->stream, q.ev_level, 0, full + g.at * XYn, root.c->stream, (size_t)(g.t * XYn)));
+                ZR_X(zs_xfer(h->tr, 0, g.rank, g.src, q.c->stream, q.ev_level, 0, full + g.at * XYn, root.c->stream, (size_t)(g.t * XYn)));
                 st.gather_bytes += (int64_t)sizeof(float) * g.t * XYn;
             }
-            ZS_X(zs_xfer_end(h->tr));
-            if (at != zn) { rc = SIFT3D_ERR_ARG; snprintf(errbuf, sizeof errbuf, "slab plan does not tile octave %d (%lld of %lld slices)", o + 1, (long long)at, (long long)zn); goto done; }
-            next0[0] = full;
-        } else { /* unsharded: rank 0 alone */
-            zs_rank &q = R[0];
-            ZS_HIP(hipSetDevice(q.dev));
+            ZR_X(zs_xfer_end(h->tr));
+            if (at != zn) ZR_FAIL(SIFT3D_ERR_ARG, "slab plan does not tile octave %d (%lld of %lld slices)", o + 1, (long long)at, (long long)zn);
+            next0[(size_t)cr] = full;
+        } else { /* not sharded: rank cr alone */
+            zs_rank &q = R[(size_t)cr];
+            r = cr;
+            ZR_HIP(hipSetDevice(q.dev));
             float *nx0 = q.alloc(zn * XYn);
-            if (!nx0) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "rank 0: out of device memory"); goto done; }
-            ZS_HIP(sift3d_launch_subsample(q.c->stream, q.L[3], X, X, Y, zo, nx0, Xn));
-            next0[0] = nx0;
+            if (!nx0) ZR_FAIL(SIFT3D_ERR_MEMORY, "rank %d: out of device memory", r);
+            ZR_HIP(sift3d_launch_subsample(q.c->stream, q.L[3], X, X, Y, zo, nx0, Xn));
+            next0[(size_t)cr] = nx0;
         }
+    };
+    /* ---- the sharded octaves, step by step across the ranks (the others follow inside the per-keypoint stage's first step) ---- */
+    const int n_sharded = S > 1 ? std::min<int>(K, (int)plan.oct.size()) : 0;
+    for (int o = 0; o < n_sharded; o++) {
+        octave(o);
+        if (crew_failed()) return;
     }
 
     /* ---- per-keypoint stage: every rank by its own host thread, so that no device waits for another's host round trip (rounds 3 - 4
@@ -787,10 +809,16 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
      * keypoint kernel is queued and its records per group are read back; then -- the one step that needs every rank's numbers --
      * the places of all records in the merged list are laid out, and every rank's descriptor kernel stores into its own. ---- */
     {
-        std::vector<int64_t> ncands((size_t)S, 0);
-        std::vector<std::vector<int>> cnt((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0));
-        h->crew.run(S, [&](int r) {
+        std::vector<int64_t> ncands((size_t)T, 0);
+        std::vector<double> queued_ms((size_t)T, 0.0); /* when a rank's thread had queued its pyramid, extrema passes and count request */
+        std::vector<std::vector<int>> cnt((size_t)T, std::vector<int>(SIFT3D_GROUPS, 0));
+        h->crew.run(T, [&](int r) {
             zs_rank &q = R[(size_t)r];
+            if (r == cr) /* the octaves that are not sharded: this rank's, queued by its own thread while the slabs' ranks go on */
+                for (int o = n_sharded; o < (int)plan.oct.size(); o++) {
+                    octave(o);
+                    if (rrc[(size_t)r] != SIFT3D_OK) return;
+                }
             ZR_HIP(hipSetDevice(q.dev));
             /* the patch halos of every sharded octave (the second deferred step: the copy stream, in order) must be in before
              * the keypoint kernel samples them: everything the copy stream holds is behind this event */
@@ -799,12 +827,7 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             ZR_HIP(hipEventRecord(q.c->ev_oct[1], q.c->ex_stream)); /* every extrema pass of the run is behind this */
             ZR_HIP(hipStreamWaitEvent(q.c->stream, q.c->ev_oct[1], 0));
             ZR_RC(cand_count_queue(q.c));
-        });
-        if (crew_failed()) goto done;
-        st.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-        h->crew.run(S, [&](int r) {
-            zs_rank &q = R[(size_t)r];
-            ZR_HIP(hipSetDevice(q.dev));
+            queued_ms[(size_t)r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
             ZR_RC(cand_finalize(q.c, &ncands[(size_t)r]));
             describe_want_group_counts(q.c, true);
             q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the placement below needs the whole list's counts before the one descriptor launch */
@@ -817,11 +840,12 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             cnt[(size_t)r].assign(hc, hc + SIFT3D_GROUPS);
             nrecs[(size_t)r] = tr;
         });
-        if (crew_failed()) goto done;
+        if (crew_failed()) return;
         int64_t total = 0;
-        for (r = 0; r < S; r++) {
+        for (r = 0; r < T; r++) {
             st.n_extrema += ncands[(size_t)r];
             total += nrecs[(size_t)r];
+            st.enqueue_ms = std::max(st.enqueue_ms, queued_ms[(size_t)r]);
         }
         const auto merge0 = std::chrono::steady_clock::now(); /* (the waits for the keypoint kernels are behind us) */
         if (total > h->merged_cap) { /* nothing stores into the list yet: the descriptor launches follow */
@@ -833,22 +857,22 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 h->merged_cap = 0;
                 rc = SIFT3D_ERR_MEMORY;
                 snprintf(errbuf, sizeof errbuf, "out of pinned host memory for %lld merged records", (long long)total);
-                goto done;
+                return;
             }
         }
         {
             int64_t pos = 0;
-            shift.assign((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0)); /* (declared with the function's vectors: the uploads below read it) */
-            std::vector<int64_t> local((size_t)S, 0); /* a rank's own position: its records before this group */
+            shift.assign((size_t)T, std::vector<int>(SIFT3D_GROUPS, 0)); /* (declared with the function's vectors: the uploads below read it) */
+            std::vector<int64_t> local((size_t)T, 0); /* a rank's own position: its records before this group */
             for (int g = 0; g < SIFT3D_GROUPS; g++)
-                for (r = 0; r < S; r++) {
+                for (r = 0; r < T; r++) { /* (the gathered octaves' rank comes last; its groups are nobody else's) */
                     shift[(size_t)r][(size_t)g] = (int)(pos - local[(size_t)r]);
                     pos += cnt[(size_t)r][(size_t)g];
                     local[(size_t)r] += cnt[(size_t)r][(size_t)g];
                 }
         }
         st.merge_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge0).count();
-        h->crew.run(S, [&](int r) {
+        h->crew.run(T, [&](int r) {
             zs_rank &q = R[(size_t)r];
             ZR_HIP(hipSetDevice(q.dev));
             if (nrecs[(size_t)r] > 0) {
@@ -862,12 +886,12 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             if (nrec != nrecs[(size_t)r])
                 ZR_FAIL(SIFT3D_ERR_DEVICE, "rank %d: %lld records where its groups add up to %lld", r, (long long)nrec, (long long)nrecs[(size_t)r]);
         });
-        if (crew_failed()) goto done;
-        for (r = 0; r < S; r++) st.n_keypoints += R[(size_t)r].c->last.n_keypoints;
+        if (crew_failed()) return;
+        for (r = 0; r < T; r++) st.n_keypoints += R[(size_t)r].c->last.n_keypoints;
         /* the list is complete where every rank's kernel put it */
         if (out) {
             sift3d_feature *res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));
-            if (!res) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "out of host memory"); goto done; }
+            if (!res) { rc = SIFT3D_ERR_MEMORY; snprintf(errbuf, sizeof errbuf, "out of host memory"); return; }
             if (total) memcpy(res, h->merged, sizeof(sift3d_feature) * (size_t)total);
             *out = res;
         } else {
@@ -877,7 +901,8 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         st.n_records = total;
     }
 
-done:
+    };
+    extraction();
     if (rc != SIFT3D_OK) zs_xfer_abort(h->tr); /* a step that failed between its begin and its end leaves no group open */
     for (size_t i = 0; i < R.size(); i++) { /* everything queued has to be done before the buffers go back */
         zs_rank &q = R[i];
@@ -930,7 +955,7 @@ extern "C" int sift3d_zslab_set_volume(sift3d_zslab *h, const float *vol, char *
         return SIFT3D_ERR_ARG;
     }
     const zs_plan &plan = h->plan;
-    const int S = (int)h->R.size();
+    const int S = h->n_slabs; /* (the rank of the gathered octaves has no slab of the input) */
     const int64_t XY = plan.nx * plan.ny;
     h->has_volume = false;
     /* every rank's slices by its own host thread: an upload from pageable memory is staged by the thread that asked for it */

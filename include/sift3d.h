@@ -316,17 +316,18 @@ int sift3d_describe_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_
 /* ---- Z-slab extraction from C: one process, several devices ---------------------
  * The whole volume (host memory) is cut into one Z-slab per entry of `devices` (the same partitioning, halo widths and
  * exchange schedule as the per-process driver above), each slab on its own device, halos moved between the devices with
- * hipMemcpyPeerAsync -- xGMI between the GPUs of a node -- queued behind events, so the host never waits inside the pyramid.
+ * hipMemcpyPeerAsync -- xGMI between the GPUs of a node -- queued behind events, so the host never waits inside the pyramid
+ * (one host thread per device queues its launches).
  * The records come back merged in the single-GPU order and are the single-GPU records bit for bit.  A device may be listed
  * more than once (the slab logic rehearsed on one GPU).  A volume too thin to shard (a slab must be 32 slices thick) runs
  * whole on devices[0].  SIFT3D_ERR_COMM: a halo copy or its ordering failed; *err (err_len bytes, may be NULL) gets the text.
  * *out is malloc'ed (sift3d_free). */
 typedef struct {
-    int32_t n_ranks, sharded_octaves;
+    int32_t n_ranks, sharded_octaves; /* n_ranks: the slabs (the octaves below the sharded ones have a rank of their own on devices[0], not counted) */
     int64_t exchanges;            /* halo copies queued on the critical path + deferred batches */
     int64_t halo_bytes_critical;  /* the 8-slice halo every level needs before the next blur (9 of L4), all ranks */
     int64_t halo_bytes_deferred;  /* the rest of the L1..L3 patch halos, copied beside L4 / L5 / extrema */
-    int64_t gather_bytes;         /* the first unsharded octave assembled on rank 0 */
+    int64_t gather_bytes;         /* the first unsharded octave assembled on devices[0] */
     int64_t n_extrema, n_keypoints, n_records;
     double wall_ms;               /* host wall time of the extraction: upload of the slabs, pyramid, per-keypoint stage, download, merge */
     int64_t halo_bytes_hidden;    /* the part of halo_bytes_critical issued bands-first: copied while the receiver filters its interior */
@@ -342,8 +343,8 @@ typedef struct {
                                    * upload (microseconds) plus, when the list has to grow, its allocation -- there is no merge left */
     int64_t halo_bytes_subsample; /* the part of halo_bytes_deferred the next octave waits for: the eight slices of L3 beyond +- 8 that the
                                    * subsample reads (first deferred step); the rest is waited for before the per-keypoint stage only */
-    double enqueue_ms;            /* host time from the start of the call until every rank's pyramid and extrema passes are queued (before the
-                                   * first host wait): what ONE host thread spends enqueueing for all devices */
+    double enqueue_ms;            /* host time from the start of the call until the last rank's pyramid, extrema passes and count request are
+                                   * queued (before its first host wait).  One host thread per rank since the second half of round 5 */
 } sift3d_zslab_stats;
 /* How a block of slices travels from one rank's device to another's (sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, v),
  * sift3d_extract_zslab_over): peer copies -- hipMemcpyPeerAsync on the receiver's stream behind the sender's event, the
