@@ -145,6 +145,10 @@ def hip_lib():
     _sig(L.sift3d_extrema_append_lazy_dev, I, P, P, P, P, P, P, P, F, I64, I64, I64, I, I64, I64)
     _sig(L.sift3d_candidates_dev, I, P, P, I, P, P)
     _sig(L.sift3d_describe_dev, I, P, P, I, I, F, F, P, P, P)
+    _sig(L.sift3d_describe_dev_counts, I, P, P, I, I, F, F, P, P)
+    _sig(L.sift3d_describe_dev_place, I, P, P, P, P, P, P)
+    _sig(L.sift3d_host_register, I, P, I64)
+    _sig(L.sift3d_host_unregister, I, P)
     _sig(L.sift3d_set_max_octaves, I, P, I)
     _sig(L.sift3d_extract_zslab, I, P, I, P, I64, I64, I64, F, I, F, F, P, P, P, C.c_char_p, I64)
     _sig(L.sift3d_extract_zslab_over, I, I, P, I, P, I64, I64, I64, F, I, F, F, P, P, P, C.c_char_p, I64)
@@ -307,6 +311,20 @@ class ZSlab:
             self.close()
         except Exception:
             pass
+
+
+GROUPS = 193   # include/sift3d.h: SIFT3D_GROUPS
+
+
+def host_register(address, nbytes):
+    """hipHostRegister (portable, mapped) on the caller's pages: every device of this process may store into them."""
+    rc = hip_lib().sift3d_host_register(C.c_void_p(int(address)), int(nbytes))
+    if rc != 0:
+        raise Sift3DError("sift3d_host_register failed (%d)" % rc)
+
+
+def host_unregister(address):
+    hip_lib().sift3d_host_unregister(C.c_void_p(int(address)))
 
 
 def device_count():
@@ -712,6 +730,32 @@ class Context:
         gb = (C.c_char * (n.value * 4)).from_address(grp.value)
         recs, grp = np.frombuffer(rb, FEATURE_DTYPE, n.value), np.frombuffer(gb, np.int32, n.value)
         return (recs.copy(), grp.copy()) if copy else (recs, grp)
+
+    def describe_dev_counts(self, levels, desc_mode=DESC_SIFT, eig_thres=140.0, size_factor=1.0):
+        """First half of describe_dev for a caller that places several contexts' records in one list (include/sift3d.h): this
+        context's records per group (GROUPS int32, a copy) and their sum.  describe_dev_place must follow."""
+        arr = self._level_array(levels)
+        cnt, n = C.c_void_p(), C.c_int64(0)
+        self._chk(self._L.sift3d_describe_dev_counts(self._h, arr, len(levels), int(desc_mode), float(eig_thres), float(size_factor),
+                                                     C.byref(cnt), C.byref(n)), "sift3d_describe_dev_counts")
+        return np.frombuffer((C.c_char * (GROUPS * 4)).from_address(cnt.value), np.int32, GROUPS).copy(), n.value
+
+    def describe_dev_place(self, list_address, shift):
+        """Second half: the descriptor kernel stores record i of group g at list[i + shift[g]] (list_address: registered host memory,
+        host_register).  Returns this context's record count -- or, with list_address None (the list turned out too small), what
+        describe_dev(copy=False) returns: views of the context's own buffers."""
+        n, own, grp = C.c_int64(0), C.c_void_p(), C.c_void_p()
+        sh = np.ascontiguousarray(shift, np.int32) if shift is not None else None
+        self._chk(self._L.sift3d_describe_dev_place(self._h, C.c_void_p(int(list_address)) if list_address else None,
+                                                    sh.ctypes.data_as(C.c_void_p) if sh is not None else None, C.byref(own), C.byref(grp),
+                                                    C.byref(n)), "sift3d_describe_dev_place")
+        if list_address:
+            return n.value
+        if n.value == 0:
+            return np.zeros(0, FEATURE_DTYPE), np.zeros(0, np.int32)
+        rb = (C.c_char * (n.value * FEATURE_DTYPE.itemsize)).from_address(own.value)
+        gb = (C.c_char * (n.value * 4)).from_address(grp.value)
+        return np.frombuffer(rb, FEATURE_DTYPE, n.value), np.frombuffer(gb, np.int32, n.value)
 
     def set_max_octaves(self, n):
         """0 = the reference's stop rule (default); n > 0 = at most n octaves."""

@@ -2139,6 +2139,77 @@ extern "C" int sift3d_describe_dev(sift3d_ctx *c, const sift3d_level_desc *level
     return SIFT3D_OK;
 }
 
+/* sift3d_describe_dev in two halves, for a caller that places the records of several contexts -- the ranks of a Z-slab run, one
+ * process each -- in ONE list (include/sift3d.h).  First half: everything up to and including the keypoint kernel, and this context's
+ * records per (level, is_max) group. */
+extern "C" int sift3d_describe_dev_counts(sift3d_ctx *c, const sift3d_level_desc *levels, int n_levels, int desc_mode, float eig_thres,
+                                          float size_factor, const int32_t **group_counts, int64_t *n_records)
+{
+    if (!c || !group_counts || !n_records) return SIFT3D_ERR_ARG;
+    if (desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) return set_err(c, SIFT3D_ERR_ARG, "bad descriptor mode");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<sift3d_level> lv;
+    int rc = levels_from_desc(c, levels, n_levels, lv);
+    if (rc) return rc;
+    rc = fence_in(c);
+    if (rc) return rc;
+    int64_t ncand = 0;
+    rc = cand_finalize(c, &ncand);
+    if (rc) return rc;
+    c->last.n_extrema = ncand;
+    describe_want_group_counts(c, true);
+    const int chunks = c->tune[SIFT3D_TUNE_KP_CHUNKS];
+    c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the places need the whole list's counts before the one descriptor launch */
+    rc = describe_queue(c, lv, ncand, desc_mode, eig_thres, size_factor, false);
+    c->tune[SIFT3D_TUNE_KP_CHUNKS] = chunks;
+    const int *hc = nullptr;
+    if (!rc) rc = describe_group_counts(c, &hc, n_records);
+    describe_want_group_counts(c, false);
+    if (rc) return rc;
+    *group_counts = hc;
+    c->staged = 1;
+    return SIFT3D_OK;
+}
+
+/* Second half: the descriptor kernel stores record i of group g at list[i + shift[g]]; list is host memory this context's device can
+ * write (sift3d_host_register, or any pinned mapped allocation).  Ends with a host synchronisation. */
+extern "C" int sift3d_describe_dev_place(sift3d_ctx *c, sift3d_feature *list, const int32_t *shift, const sift3d_feature **own_view,
+                                         const int32_t **group_view, int64_t *n_out)
+{
+    if (!c || !n_out) return SIFT3D_ERR_ARG;
+    if (!c->staged) return set_err(c, SIFT3D_ERR_ARG, "sift3d_describe_dev_place without sift3d_describe_dev_counts before it");
+    c->staged = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (own_view) *own_view = nullptr;
+    if (group_view) *group_view = nullptr;
+    if (list && !shift) return set_err(c, SIFT3D_ERR_ARG, "sift3d_describe_dev_place: a list without its shifts");
+    if (list && c->kp.ncand > 0 && c->kp.nchunks == 1) {
+        sift3d_feature *dview = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer((void **)&dview, list, 0));
+        int rc = describe_placement(c, dview, shift);
+        if (rc) return rc;
+    }
+    int rc = describe_launch(c);
+    if (!rc) rc = describe_finish(c, n_out);
+    if (rc) return rc;
+    if (own_view && !list) *own_view = c->h_recs; /* list == NULL: the records are where sift3d_describe_dev leaves them */
+    if (group_view) *group_view = c->h_group;
+    return SIFT3D_OK;
+}
+
+/* Host memory of the caller (e.g. a shared-memory segment every rank's process maps) made writable by every device of the process. */
+extern "C" int sift3d_host_register(void *p, int64_t bytes)
+{
+    if (!p || bytes <= 0) return SIFT3D_ERR_ARG;
+    return hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess ? SIFT3D_OK : SIFT3D_ERR_DEVICE;
+}
+
+extern "C" int sift3d_host_unregister(void *p)
+{
+    if (!p) return SIFT3D_ERR_ARG;
+    return hipHostUnregister(p) == hipSuccess ? SIFT3D_OK : SIFT3D_ERR_DEVICE;
+}
+
 /* One z-slice of a resident Gaussian level of the last run, dense (nx_o * ny_o floats of octave o): what the reference's
  * debug output image.pgm shows (fioFeatureSliceXY of octave 0's first blurred level, R/src_common/MultiScale.cpp:373-384). */
 extern "C" int sift3d_get_level_slice(sift3d_ctx *c, int octave, int level, int64_t z, float *out, int64_t *nx_out, int64_t *ny_out)

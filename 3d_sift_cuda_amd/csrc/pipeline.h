@@ -140,6 +140,7 @@ struct sift3d_ctx {
     int max_octaves; /* 0: the reference's only stop rule (a dimension <= 2); n > 0: at most n octaves */
     int tune[SIFT3D_TUNE_COUNT]; /* sift3d_set_tuning */
     int64_t host_grows;          /* times describe_launch had to grow the pinned record buffers (tests) */
+    int staged = 0;              /* sift3d_describe_dev_counts has run, sift3d_describe_dev_place has not */
     bool lean;       /* a slab context: the caller owns the level buffers, none are allocated here */
     int timing; /* 0 off; 1 every launch bracketed by events; 2 only the blur launches of the finest octave */
     std::vector<timed_launch> launches;

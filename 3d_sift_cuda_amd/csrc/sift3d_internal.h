@@ -139,7 +139,7 @@ struct sift3d_kp_params {
     const int *rec_shift; /* descriptor kernel: NULL, or SIFT3D_GROUPS ints -- record r of group g is stored at slot r + rec_shift[g] (several
                            * contexts writing one merged list: the slab driver) */
 };
-#define SIFT3D_GROUPS 193 /* level id * 2 + is_max for up to 96 levels, and one slot for anything beyond */
+/* SIFT3D_GROUPS (include/sift3d.h, 193): level id * 2 + is_max for up to 96 levels, and one slot for anything beyond */
 hipError_t sift3d_launch_group_counts(hipStream_t s, const unsigned long long *keys, const int *nrec, int64_t ncand, int *counts);
 #define SIFT3D_CU_SLOTS 2048
 #define SIFT3D_MAX_FRAMES 11 /* determineCanonicalOrientation3D stops at FEATURE_3D_DIM frames */

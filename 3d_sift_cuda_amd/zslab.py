@@ -212,6 +212,12 @@ class HipBackend:
     def describe(self, levels, desc_mode, eig_thres, size_factor, copy=True):
         return self.ctx.describe_dev(levels, desc_mode, eig_thres, size_factor, copy=copy)
 
+    def describe_counts(self, levels, desc_mode, eig_thres, size_factor):
+        return self.ctx.describe_dev_counts(levels, desc_mode, eig_thres, size_factor)
+
+    def describe_place(self, list_address, shift):
+        return self.ctx.describe_dev_place(list_address, shift)
+
     def before_exchange(self):
         pass  # the context runs on torch's current stream (ZSlabExtractor sets it), so ordering is the stream's
 
@@ -517,6 +523,102 @@ class ZSlabExtractor:
         if copy:
             return self.be.describe(self._table(), desc_mode, eig_thres, size_factor)
         return self.be.describe(self._table(), desc_mode, eig_thres, size_factor, copy=False)
+
+    def describe_into(self, shared, desc_mode=0, eig_thres=140.0, size_factor=1.0, group=None, device=None):
+        """The per-keypoint stage with every rank's records stored by its own descriptor kernel at their places in `shared` (a
+        SharedRecordList): keypoint kernel, the ranks' records per group exchanged (one small all_gather), descriptor kernel, barrier.
+        Returns (n, None): n records of the whole volume, and on every rank shared.records[:n] is the single-GPU list (rank 0 is the
+        one that uses it; it stays valid until a rank's next describe_into).  Or, when the list is too small for the volume's records,
+        (None, (records, group)): nothing was stored in it, this rank's records are views of its context's own buffers as after
+        describe(copy=False), and the caller gathers them the old way (gather_records) -- every rank takes the same branch."""
+        import torch
+        d, be = self.dist, self.be
+        groups = shared.pkg.GROUPS
+        if self.levels:
+            counts, _ = be.describe_counts(self._table(), desc_mode, eig_thres, size_factor)
+        else:
+            counts = np.zeros(groups, np.int32)
+        if d is not None:
+            world = d.get_world_size(group)
+            dev = "cpu" if d.get_backend(group) == "gloo" else device
+            mine = torch.from_numpy(counts).to(dev)
+            every = [torch.zeros(groups, dtype=torch.int32, device=dev) for _ in range(world)]
+            d.all_gather(every, mine, group=group)
+            allc = np.stack([t.cpu().numpy() for t in every])
+        else:
+            allc = counts[None, :]
+        shift, total = placed_shifts(allc, self.rank if d is not None else 0)
+        fits = total <= shared.capacity
+        own = (None, np.zeros(0, np.int32))
+        if self.levels:
+            res = be.describe_place(shared.address if fits else None, shift if fits else None)
+            if not fits:
+                own = res
+        if not fits:
+            return None, own
+        if d is not None:
+            d.barrier(group=group)   # every rank's kernel has stored its records (describe_place ends with a stream synchronisation)
+        return total, None
+
+
+class SharedRecordList:
+    """ONE list of records in shared memory that every rank's process maps and registers with its device: the ranks' descriptor
+    kernels store their records straight into their places of the single-GPU order (ZSlabExtractor.describe_into), so nothing is
+    gathered and nothing is merged -- what csrc/zslab_driver.hip does inside one process, across processes.  (gather_records sends
+    every rank's records to rank 0 through the collective backend: with RCCL that is an upload of the records each rank has just
+    downloaded, the gather, and a download of all of them on rank 0 -- 63 MB at 512^3, behind the last kernel.)
+    Collective: every rank of `dist` calls it with the same capacity."""
+
+    _count = 0
+
+    def __init__(self, pkg, dist, rank, capacity, dtype, group=None):
+        import mmap
+        import os
+        self.pkg, self.capacity, self.rank = pkg, int(capacity), rank
+        self.nbytes = max(1, self.capacity) * np.dtype(dtype).itemsize
+        SharedRecordList._count += 1
+        name = ["/dev/shm/sift3d_records_%d_%d" % (os.getpid(), SharedRecordList._count)] if rank == 0 else [None]
+        if rank == 0:
+            fd = os.open(name[0], os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o600)
+            os.ftruncate(fd, self.nbytes)
+        if dist is not None:
+            dist.broadcast_object_list(name, src=0, group=group)
+        if rank != 0:
+            fd = os.open(name[0], os.O_RDWR)
+        self._mm = mmap.mmap(fd, self.nbytes)
+        os.close(fd)
+        if dist is not None:
+            dist.barrier(group=group)   # every rank has it mapped: the name can go (the pages live as long as a mapping does)
+        if rank == 0:
+            os.unlink(name[0])
+        import ctypes
+        self._cbuf = (ctypes.c_char * self.nbytes).from_buffer(self._mm)
+        self.address = ctypes.addressof(self._cbuf)
+        pkg.host_register(self.address, self.nbytes)
+        self.records = np.frombuffer(self._cbuf, dtype, self.capacity)
+
+    def close(self):
+        if self._mm is None:
+            return
+        self.pkg.host_unregister(self.address)
+        self.records = None
+        self._cbuf = None
+        try:
+            self._mm.close()
+        except BufferError:   # a view of the list is still referenced somewhere: the mapping goes with the last of them
+            pass
+        self._mm = None
+
+
+def placed_shifts(all_counts, rank):
+    """all_counts[r][g]: rank r's records of group g.  The single-GPU order is, group by group, one run per rank in rank order
+    (within a group slabs are in z order); a rank's own records are sorted by group already, so its record i of group g goes to
+    i + shift[g].  Returns (shift of `rank`, total)."""
+    c = np.asarray(all_counts, np.int64)                      # (world, GROUPS)
+    before_groups = np.concatenate([[0], np.cumsum(c.sum(axis=0))[:-1]])          # records of all ranks in groups < g
+    before_ranks = np.cumsum(c, axis=0)[rank] - c[rank]                            # records of lower ranks in group g
+    own_before = np.concatenate([[0], np.cumsum(c[rank])[:-1]])                    # this rank's own records in groups < g
+    return (before_groups + before_ranks - own_before).astype(np.int32), int(c.sum())
 
 
 def merge_by_group(parts):

@@ -221,15 +221,47 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
         dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Where the records end up (round 5).  `shared`: ONE list in shared memory that every rank's process maps and registers with its
+    # device; a rank's descriptor kernel stores its records at their places in the single-GPU order (a 193-word all_gather of the
+    # ranks' records per group is all that is exchanged), so there is no gather and no merge behind the last kernel.  Without it
+    # (--zslab-gather, or if the list cannot be set up): every rank's records travel to rank 0 through the collective backend -- with
+    # RCCL an upload of what was just downloaded, the gather, and a download of all of it on rank 0 -- and are merged on the host.
+    shared = [None]
+    cdev = "cuda:%d" % dev
+
     def step():
         with be.stream_scope():
             ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup)
             ex.run(slab, i0)
-            recs, grp = ex.describe(desc_mode=desc, copy=False)   # views of the pinned download buffers
-            merged = zs.gather_records(dist, rank, world, recs, grp, "cuda:%d" % dev, dtype=pkg.FEATURE_DTYPE)
-        return ex, merged
+            if shared[0] is not None:
+                n, own = ex.describe_into(shared[0], desc_mode=desc, device=cdev)
+                if n is not None:
+                    return ex, (shared[0].records[:n] if rank == 0 else None), "placed"
+                recs, grp = own                                  # the list is too small for this volume's records: the old way
+            else:
+                recs, grp = ex.describe(desc_mode=desc, copy=False)   # views of the pinned download buffers
+            merged = zs.gather_records(dist, rank, world, recs, grp, cdev, dtype=pkg.FEATURE_DTYPE)
+        return ex, merged, "gathered"
 
     phase("zslab: warm-up steps (first halo exchange)")
+    ex, merged, how = step()
+    if not args.zslab_gather:
+        phase("zslab: the shared record list")
+        total = [len(merged) if (rank == 0 and merged is not None) else 0]
+        dist.broadcast_object_list(total, src=0)
+        ok = 1
+        try:
+            shared[0] = zs.SharedRecordList(pkg, dist, rank, total[0] + total[0] // 8 + 4096, pkg.FEATURE_DTYPE)
+        except Exception as e:   # (a rank that cannot map or register the list: every rank goes back to the gather)
+            sys.stderr.write("bench.py: rank %d: no shared record list (%s): gathering the records instead\n" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if shared[0] is not None:
+                shared[0].close()
+            shared[0] = None
+    phase("zslab: warm-up steps")
     for _ in range(max(1, args.warmup)):
         step()
     phase("zslab: barrier before the timed steps")
@@ -237,7 +269,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     phase("zslab: timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ex, merged = step()
+        ex, merged, how = step()
     phase("zslab: barrier after the timed steps")
     barrier()
     elapsed = time.perf_counter() - t0
@@ -255,6 +287,9 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
                "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
                "parallelism": "zslab%d: halo exchange with torch.distributed (%s, %s), coarse octaves on rank 0"
                               % (world, dist.get_backend(), "one communicator" if dgroup is None else "two communicators: per-level halos / deferred patch halos"),
+               "records_to_rank0": ("placed: every rank's descriptor kernel stores its records at their places of the single-GPU order in ONE "
+                                    "shared, device-registered list (193 words per rank exchanged; no gather, no merge)") if how == "placed"
+                                   else "gathered: every rank's records through the collective backend to rank 0, merged on the host",
                "halo_exchanges_per_step": ex.stats["exchanges"], "halo_bytes_per_rank_per_step": ex.stats["exchange_bytes"],
                "halo_bytes_critical_per_rank_per_step": ex.stats["exchange_bytes"] - ex.stats["deferred_bytes"],
                "halo_bytes_deferred_per_rank_per_step": ex.stats["deferred_bytes"],
@@ -271,6 +306,10 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
         if expect is not None:
             res["same_bytes_as_single_gpu"] = bool(merged is not None and len(merged) == len(expect)
                                                    and (merged.view(np.uint8) == expect.view(np.uint8)).all())
+    if merged is not None:
+        merged = None   # (a view of the shared list: dropped before the list is)
+    if shared[0] is not None:
+        shared[0].close()
     ctx.close()
     return res
 
@@ -286,7 +325,7 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank, phase=lambda *a:
             "config": {k: res[k] for k in ("workload", "records", "sharded_octaves", "slab_bounds", "parallelism",
                                            "halo_exchanges_per_step", "halo_bytes_per_rank_per_step",
                                            "halo_bytes_critical_per_rank_per_step", "halo_bytes_deferred_per_rank_per_step",
-                                           "halo_bytes_hidden_per_rank_per_step", "exchange_schedule", "records_sha256")}}))
+                                           "halo_bytes_hidden_per_rank_per_step", "exchange_schedule", "records_to_rank0", "records_sha256")}}))
     phase("zslab: leaving the process group")
     dist.barrier()
     dist.destroy_process_group()
@@ -307,7 +346,8 @@ def zslab_child(args, world, expect, limit_s):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
            str(args.warmup), "--dims", "%d,%d,%d" % resolve_volume(args)[:3], "--desc", str(resolve_volume(args)[3]), "--mode", "zslab",
-           "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)] + (["--zslab-one-group"] if args.zslab_one_group else [])
+           "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)] + (["--zslab-one-group"] if args.zslab_one_group else []) \
+        + (["--zslab-gather"] if args.zslab_gather else [])
     # End exactly the job started here (run_child): torch.distributed.run puts every rank in a session of its own, so the
     # launcher's process group does not contain them -- their PIDs are noted first, the launcher is asked to stop (it
     # terminates its ranks on SIGTERM), then whatever of it is still there is killed.
@@ -460,6 +500,9 @@ def main():
     ap.add_argument("--zslab-one-group", action="store_true",
                     help="N > 1: the Z-slab run's deferred patch-halo batch on the SAME communicator as the per-level halos (default: a "
                          "second one); for the C driver the same switch is SIFT3D_ZSLAB_SERIAL_CHANNELS")
+    ap.add_argument("--zslab-gather", action="store_true",
+                    help="N > 1: the Z-slab run's records gathered on rank 0 through the collective backend and merged on the host (rounds 1 - 4) "
+                         "instead of stored by every rank's kernel in one shared list")
     ap.add_argument("--phase-limit", type=int, default=300,
                     help="N > 1: seconds any one phase of a rank (set-up, warm-up, the timed steps, a reduction) may take before "
                          "the rank ends the job with exit code 3 and the phase name (0 = no limit)")
@@ -902,6 +945,7 @@ def main():
     out["speedup_vs_single_gpu"] = round(vol_out["ms_per_step"] / z["ms_per_step"], 3) if ok and z.get("ms_per_step") else None
     out["config"]["workload"] = z.get("workload") or ("ONE %s float32 blob-field volume cut into %d Z-slabs (the child job failed: see `zslab`)" % (vol_label, world))
     out["config"]["parallelism"] = z.get("parallelism") or "zslab%d" % world
+    out["config"]["records_to_rank0"] = z.get("records_to_rank0")
     out["config"]["single_gpu_workload"] = "%s volume on one GPU (`volumes_*`; `roofline`, `pyramid`, `stages` are rank 0's single-GPU kernels)" % vol_label
     out["zslab"] = z
     out["zslab_c"] = zc

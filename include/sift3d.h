@@ -313,6 +313,27 @@ int sift3d_candidates_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int 
 int sift3d_describe_dev(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_levels, int desc_mode, float eig_thres,
                         float size_factor, const sift3d_feature **view, const int32_t **group_view, int64_t *n_out);
 
+/* sift3d_describe_dev in two halves (round 5), for a caller that places the records of SEVERAL contexts -- the ranks of a Z-slab run,
+ * one process each -- in ONE list, so that nothing is gathered or merged afterwards.  A context's records come out sorted by group
+ * (level_id*2 + is_max; SIFT3D_GROUPS of them), and the single-device order is, group by group, one run per rank in rank order; so:
+ *   sift3d_describe_dev_counts  sorts, runs the keypoint kernel and returns this context's records per group (*group_counts: SIFT3D_GROUPS
+ *                               words owned by the context) and their sum;
+ *   the caller                  exchanges the counts between the ranks and lays the runs out: shift[g] = (records of groups < g of all ranks)
+ *                               + (records of group g of lower ranks) - (this rank's own records of groups < g);
+ *   sift3d_describe_dev_place   runs the descriptor kernel, which stores this context's record i (of group g) at list[i + shift[g]], and
+ *                               waits for it.  list: host memory the device can write -- e.g. a shared-memory segment that every rank's
+ *                               process maps and has passed to sift3d_host_register; the per-record group words stay in the context
+ *                               (*group_view).  list == NULL (it turned out too small): the records go to the context's own pinned
+ *                               buffers, *own_view, exactly as after sift3d_describe_dev.
+ * sift3d_host_register / _unregister: hipHostRegister (portable, mapped) / hipHostUnregister on the caller's pages. */
+#define SIFT3D_GROUPS 193
+int sift3d_describe_dev_counts(sift3d_ctx *ctx, const sift3d_level_desc *levels, int n_levels, int desc_mode, float eig_thres,
+                               float size_factor, const int32_t **group_counts, int64_t *n_records);
+int sift3d_describe_dev_place(sift3d_ctx *ctx, sift3d_feature *list, const int32_t *shift, const sift3d_feature **own_view,
+                              const int32_t **group_view, int64_t *n_out);
+int sift3d_host_register(void *p, int64_t bytes);
+int sift3d_host_unregister(void *p);
+
 /* ---- Z-slab extraction from C: one process, several devices ---------------------
  * The whole volume (host memory) is cut into one Z-slab per entry of `devices` (the same partitioning, halo widths and
  * exchange schedule as the per-process driver above), each slab on its own device, halos moved between the devices with

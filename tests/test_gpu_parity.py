@@ -1424,10 +1424,30 @@ def _zslab_worker(rank, world, port, dims, seed, mode, q):
             ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup, poison_halo=True)
             ex.run(vol[i0:i1], i0)
             recs, grp = ex.describe(desc_mode=mode)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (recs, grp))
+            stats = dict(ex.stats)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (recs, grp))
+            merged = zs.merge_by_group(gathered) if rank == 0 else None
+            # round 5: the same volume once more, the records stored by every rank's descriptor kernel at their places in ONE list in
+            # shared memory (no gather, no merge) -- and once into a list that is too small, which must fall back to each rank's own buffers
+            total = [len(merged) if rank == 0 else 0]
+            dist.broadcast_object_list(total, src=0)
+            placed, small = None, None
+            if dims[0] * dims[1] * dims[2] <= 2 ** 28:
+                shared = zs.SharedRecordList(pkg, dist, rank, total[0] + 100, pkg.FEATURE_DTYPE)
+                ex.run(vol[i0:i1], i0)
+                n, own = ex.describe_into(shared, desc_mode=mode, device="cuda:0")
+                assert n == total[0] and own is None, (n, total)
+                placed = shared.records[:n].copy() if rank == 0 else None
+                tiny = zs.SharedRecordList(pkg, dist, rank, 10, pkg.FEATURE_DTYPE)
+                ex.run(vol[i0:i1], i0)
+                n, own = ex.describe_into(tiny, desc_mode=mode, device="cuda:0")
+                assert n is None and own is not None
+                small = zs.gather_records(dist, rank, world, own[0], own[1], "cuda:0", dtype=pkg.FEATURE_DTYPE)
+                tiny.close()
+                shared.close()
         if rank == 0:
-            q.put((plan.n_sharded, zs.merge_by_group(gathered), ex.stats))
+            q.put((plan.n_sharded, merged, stats, placed, small))
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -1453,7 +1473,7 @@ def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
     procs = [mpc.Process(target=_zslab_worker, args=(r, world, port, dims, seed, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    n_sharded, merged, stats = q.get(timeout=600)
+    n_sharded, merged, stats, placed, small = q.get(timeout=600)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -1476,6 +1496,10 @@ def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
         want = ctx.extract(desc_mode=mode)
     assert len(want) > 50 and len(merged) == len(want)
     assert (merged.view(np.uint8) == want.view(np.uint8)).all()   # bit-identical records, same order
+    if placed is not None:   # every rank's kernel stored its records in the one shared list / the list was too small: same bytes
+        assert placed.tobytes() == want.tobytes() and small.tobytes() == want.tobytes()
+    else:
+        assert dims[0] * dims[1] * dims[2] > 2 ** 28
 
 
 def test_roofline_ceiling_probe_runs(built):
