@@ -129,6 +129,14 @@ def slab_context_slices(plan, rank):
     return need
 
 
+def coarse_octave_dims(plan):
+    """(nx, ny, nz) of the first octave that is not sharded -- the size of the second context rank 0 may give the octaves below the
+    sharded ones (ZSlabExtractor(coarse_backend=...)) -- or None when there is nothing to give it."""
+    if 0 < plan.n_sharded < len(plan.octaves):
+        return tuple(plan.octaves[plan.n_sharded])
+    return None
+
+
 class HipBackend:
     """Compute on torch CUDA tensors through the C-ABI *_dev operators."""
 
@@ -228,7 +236,7 @@ class HipBackend:
 class ZSlabExtractor:
     """Runs the pyramid of ONE volume across the ranks of a torch.distributed group."""
 
-    def __init__(self, backend, plan, rank, dist=None, group=None, deferred_group=None, poison_halo=False):
+    def __init__(self, backend, plan, rank, dist=None, group=None, deferred_group=None, poison_halo=False, coarse_backend=None):
         """deferred_group: a second process group over the same ranks (dist.new_group()) for the once-per-octave batch of
         deferred patch halos.  RCCL serialises the operations of one communicator on one internal stream, so on the main
         group that batch (3 x 24 slices) would sit in front of the next level's 8-slice exchange; a group of its own has its
@@ -237,6 +245,15 @@ class ZSlabExtractor:
         self.be, self.plan, self.rank, self.dist, self.group = backend, plan, rank, dist, group
         self.deferred_group = deferred_group
         self.poison_halo = poison_halo   # tests: the halo slices of L1..L3 that no exchange fetches hold NaN
+        # Rank 0 only, optional (round 5): a second backend (its own context and stream on rank 0's device) for the octaves that are
+        # not sharded.  They are gathered on rank 0, and building them is a chain of some eighty small launches -- 0.5 - 0.8 ms of
+        # pure latency at 512^3 -- that used to sit between rank 0's slab and its per-keypoint stage, i.e. on the critical path of
+        # the whole step.  With a backend of their own they are queued by a second host thread (the library calls release the GIL)
+        # and run BESIDE rank 0's per-keypoint stage; their few hundred keypoints are one more run at the end of the record list
+        # (csrc/zslab_driver.hip gives them a rank of their own for the same reason).
+        self.coarse_be = coarse_backend if (rank == 0 and 0 < plan.n_sharded < len(plan.octaves)) else None
+        self._coarse_thread, self._coarse_error = None, None
+        self.c_levels, self.c_level_ids = [], []
         self.levels = []       # level table entries, index = level id
         self.level_ids = []
         # exchange_bytes: everything this rank received and sent; of that, deferred_bytes moved in the once-per-octave
@@ -310,10 +327,12 @@ class ZSlabExtractor:
         return None
 
     # ---- one octave on one rank ---------------------------------------------------------------
-    def _octave(self, o, L0, z0, z1, e0, e1, zo, has_lo, has_hi, extras, sig, factor, want_next):
+    def _octave(self, o, L0, z0, z1, e0, e1, zo, has_lo, has_hi, extras, sig, factor, want_next, be=None, sink=None):
         """L0: level-0 buffer covering global slices [e0, e1), exact on slab +- BLUR_HALO (clipped to the volume).
-        Returns the L3 buffer (exact on its whole extent) for the subsample that seeds the next octave."""
-        be = self.be
+        Returns the L3 buffer (exact on its whole extent) for the subsample that seeds the next octave.
+        be / sink: the backend and the (levels, level_ids, keepalive) lists to use (default: the rank's own)."""
+        be = self.be if be is None else be
+        levels, level_ids, keepalive = (self.levels, self.level_ids, self._keepalive) if sink is None else sink
         nzl = e1 - e0
         shape = (nzl, L0.shape[1], L0.shape[2])
         # As on one device: D0 is read as L0 - L1 around the extrema of D1, and L5 -- hence D4 -- is filtered only around the
@@ -383,10 +402,10 @@ class ZSlabExtractor:
                 be.extrema_append_lazy_next(D[2], D[3], L[4], extras[4], lid, z0 - e0, z1 - e0)
             else:
                 be.extrema_append(D[l], D[l + 1], D[l + 2], lid, z0 - e0, z1 - e0)
-            self.levels.append(be.level_entry(L[l + 1], D[l + 1], zo, e0, sig[l], sig[l + 1], sig[l + 2], factor))
-            self.level_ids.append(lid)
+            levels.append(be.level_entry(L[l + 1], D[l + 1], zo, e0, sig[l], sig[l + 1], sig[l + 2], factor))
+            level_ids.append(lid)
         patch_halos()   # before the subsample below reads L3 beyond +- BLUR_HALO (the patch-only slices: end of run())
-        self._keepalive.append((D, L))   # a replay of the extrema passes reads D1..D3 and, in the unstored form, L0, L1 and L4
+        keepalive.append((D, L))   # a replay of the extrema passes reads D1..D3 and, in the unstored form, L0, L1 and L4
         return L[3] if want_next else None
 
     # ---- the whole pyramid ----------------------------------------------------------------------
@@ -396,9 +415,13 @@ class ZSlabExtractor:
         plan, be, rank, S = self.plan, self.be, self.rank, self.plan.nranks
         extra0, extras, sig = sigma_schedule(initial_image_scale)
         K = plan.n_sharded
+        self._join_coarse()   # (a run whose results nobody asked for)
         be.reset()
         self.levels, self.level_ids = [], []
-        self._keepalive = []
+        self.c_levels, self.c_level_ids = [], []
+        self._keepalive, self._c_keepalive = [], []
+        if self.coarse_be is not None:
+            self.coarse_be.reset()
         self._pending = []   # the patch-only halo batches of the sharded octaves, completed before run() returns
         try:
             return self._run(input_slab, input_z0, plan, be, rank, S, extra0, extras, sig, K)
@@ -462,64 +485,161 @@ class ZSlabExtractor:
                 t = (z1 - z0) // 2   # an odd last slice of the whole volume is dropped, as in the serial code
                 part = be.empty((t, Yn, Xn))
                 be.subsample(L3[z0 - e0:z0 - e0 + 2 * t], part)
-                nxt = self._gather_to_root(part, zn, Yn, Xn)
+                nxt = self._gather_to_root(part, zn, Yn, Xn, o)
+                if self.coarse_be is not None:
+                    # the rest is the other backend's, on a thread of its own: this one goes on to its per-keypoint stage
+                    self._start_coarse(o + 1, nxt, factor, extras, sig)
+                    break
             else:
                 nxt = be.empty((zn, Yn, Xn))
                 be.subsample(L3, nxt)
         return self
 
-    def _gather_to_root(self, part, zn, Yn, Xn):
-        """Concatenate the per-rank parts of the first gathered octave on rank 0 (other ranks get None)."""
+    def _gather_to_root(self, part, zn, Yn, Xn, o):
+        """The per-rank parts of the first gathered octave (the subsampled slabs of octave o) assembled on rank 0 (other ranks get
+        None).  Every rank knows every part's size from the plan, so the parts travel as point-to-point transfers straight into their
+        slices of the octave: no size exchange (rounds 1 - 4 all_gathered the sizes and read them back -- a host synchronisation on
+        every rank in the middle of the pyramid), no padding, no copy out of a gather buffer."""
         d, S = self.dist, self.plan.nranks
         if d is None:
             return part
         torch = __import__("torch")
+        places, at = [], 0
+        for r in range(S):
+            z0, z1 = self.plan.slab(r, o)
+            n = max(0, min((z1 - z0) // 2, zn - at))   # an odd last slice of the whole volume is dropped, as in the serial code
+            places.append((at, n))
+            at += n
+        assert at == zn, (at, zn, places)
         stage = part.is_cuda and d.get_backend(self.group) == "gloo"
-        dev = "cpu" if stage else part.device
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(S)]
         self.be.before_exchange()
-        d.all_gather(sizes, torch.tensor([part.shape[0]], dtype=torch.int64, device=dev), group=self.group)
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(sizes)
-        pad = torch.zeros((mx, Yn, Xn), dtype=torch.float32, device=dev)
-        pad[:part.shape[0]].copy_(part)
-        if self.rank == 0:
-            bufs = [torch.zeros((mx, Yn, Xn), dtype=torch.float32, device=dev) for _ in range(S)]
-            d.gather(pad, bufs, dst=0, group=self.group)
-            full = self.be.empty((zn, Yn, Xn))
-            at = 0
-            for r in range(S):
-                n = min(sizes[r], zn - at)
-                full[at:at + n].copy_(bufs[r][:n])
-                at += n
-            assert at == zn, (at, zn, sizes)
+        if self.rank != 0:
+            a, n = places[self.rank]
+            if n:
+                src = part[:n].cpu() if stage else part[:n]
+                for w in d.batch_isend_irecv([d.P2POp(d.isend, src, 0, self.group)]):
+                    w.wait()
             self.be.after_exchange()
-            return full
-        d.gather(pad, None, dst=0, group=self.group)
+            return None
+        full = self.be.empty((zn, Yn, Xn))
+        a, n = places[0]
+        full[a:a + n].copy_(part[:n])
+        ops, back = [], []
+        for r in range(1, S):
+            a, n = places[r]
+            if not n:
+                continue
+            dst = full[a:a + n]
+            if stage:
+                h = torch.empty(dst.shape, dtype=dst.dtype, device="cpu")
+                back.append((dst, h))
+                dst = h
+            ops.append(d.P2POp(d.irecv, dst, r, self.group))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        for t, h in back:
+            t.copy_(h)
         self.be.after_exchange()
-        return None
+        return full
+
+    # ---- the octaves that are not sharded, on rank 0's second backend and thread --------------------------------
+    def _start_coarse(self, o_first, L0, factor, extras, sig):
+        import threading
+        torch = self.be.torch
+        ready = torch.cuda.Event()
+        ready.record(getattr(self.be, "stream", None) or torch.cuda.current_stream())   # the gathered octave is complete behind this
+        cbe, plan = self.coarse_be, self.plan
+        if hasattr(cbe, "stream"):
+            L0.record_stream(cbe.stream)   # allocated on this backend's stream, read on the other's
+        sink = (self.c_levels, self.c_level_ids, self._c_keepalive)
+        self._c_keepalive.append(L0)
+
+        def work():
+            try:
+                with cbe.stream_scope():
+                    torch.cuda.current_stream().wait_event(ready)
+                    lvl0, f = L0, factor
+                    for o in range(o_first, len(plan.octaves)):
+                        X, Y, zo = plan.octaves[o]
+                        want_next = o + 1 < len(plan.octaves)
+                        L3 = self._octave(o, lvl0, 0, zo, 0, zo, zo, False, False, extras, sig, f, want_next, be=cbe, sink=sink)
+                        f *= 2.0
+                        if not want_next:
+                            break
+                        Xn, Yn, zn = plan.octaves[o + 1]
+                        lvl0 = cbe.empty((zn, Yn, Xn))
+                        cbe.subsample(L3, lvl0)
+                        self._c_keepalive.append(lvl0)
+            except BaseException as e:   # handed to the thread that joins
+                self._coarse_error = e
+        self._coarse_error = None
+        self._coarse_thread = threading.Thread(target=work, name="sift3d-coarse-octaves")
+        self._coarse_thread.start()
+
+    def _join_coarse(self):
+        t, self._coarse_thread = self._coarse_thread, None
+        if t is not None:
+            t.join()
+        e, self._coarse_error = self._coarse_error, None
+        if e is not None:
+            raise e
+
+    @staticmethod
+    def _table_of(levels, level_ids):
+        n = max(level_ids) + 1 if level_ids else 0
+        table = [None] * n
+        for lid, lv in zip(level_ids, levels):
+            table[lid] = lv
+        filler = levels[0] if levels else None
+        return [t if t is not None else filler for t in table]
 
     # ---- results ----------------------------------------------------------------------------------
     def _table(self):
-        n = max(self.level_ids) + 1 if self.level_ids else 0
-        table = [None] * n
-        for lid, lv in zip(self.level_ids, self.levels):
-            table[lid] = lv
-        filler = self.levels[0] if self.levels else None
-        return [t if t is not None else filler for t in table]
+        return self._table_of(self.levels, self.level_ids)
+
+    def _coarse_call(self, fn):
+        """fn(backend, level table) for the backend of the octaves that are not sharded, on a thread of its own (after that thread's
+        pyramid is queued); returns a function that waits for it and returns its result."""
+        import threading
+        box = {}
+
+        def work():
+            try:
+                self._join_coarse()
+                with self.coarse_be.stream_scope():
+                    box["r"] = fn(self.coarse_be, self._table_of(self.c_levels, self.c_level_ids))
+            except BaseException as e:
+                box["e"] = e
+        t = threading.Thread(target=work, name="sift3d-coarse-keypoints")
+        t.start()
+
+        def result():
+            t.join()
+            if "e" in box:
+                raise box["e"]
+            return box["r"]
+        return result
 
     def candidates(self):
         """This rank's validated extrema (whole-volume coordinates), sorted."""
         if not self.levels:
             return np.zeros(0, dtype=[("octave", "<i4"), ("level", "<i4"), ("is_max", "<i4"), ("x", "<i4"), ("y", "<i4"),
                                       ("z", "<i4"), ("value", "<f4"), ("h_value", "<f4"), ("l_value", "<f4")])
-        return self.be.candidates(self._table())
+        coarse = self._coarse_call(lambda be, table: be.candidates(table)) if self.coarse_be is not None else None
+        mine = self.be.candidates(self._table())
+        return mine if coarse is None else np.concatenate([mine, coarse()])   # (the coarser octaves sort behind the sharded ones)
 
     def describe(self, desc_mode=0, eig_thres=140.0, size_factor=1.0, copy=True):
         """This rank's records and their group ids (level_id*2 + is_max).  copy=False: views of the context's
         download buffers (HIP backend), valid until the next call on the context."""
         if not self.levels:
             return None, np.zeros(0, np.int32)
+        if self.coarse_be is not None:   # two contexts, two sets of buffers: one array (the coarser octaves' groups come last)
+            coarse = self._coarse_call(lambda be, table: be.describe(table, desc_mode, eig_thres, size_factor, copy=False))
+            r0, g0 = self.be.describe(self._table(), desc_mode, eig_thres, size_factor, copy=False)
+            r1, g1 = coarse()
+            return np.concatenate([r0, r1]), np.concatenate([g0, g1])
         if copy:
             return self.be.describe(self._table(), desc_mode, eig_thres, size_factor)
         return self.be.describe(self._table(), desc_mode, eig_thres, size_factor, copy=False)
@@ -529,31 +649,41 @@ class ZSlabExtractor:
         SharedRecordList): keypoint kernel, the ranks' records per group exchanged (one small all_gather), descriptor kernel, barrier.
         Returns (n, None): n records of the whole volume, and on every rank shared.records[:n] is the single-GPU list (rank 0 is the
         one that uses it; it stays valid until a rank's next describe_into).  Or, when the list is too small for the volume's records,
-        (None, (records, group)): nothing was stored in it, this rank's records are views of its context's own buffers as after
-        describe(copy=False), and the caller gathers them the old way (gather_records) -- every rank takes the same branch."""
+        (None, (records, group)): nothing was stored in it, this rank's records are views (copies on a rank with two backends) of its
+        context's own buffers as after describe(copy=False), and the caller gathers them the old way (gather_records) -- every rank
+        takes the same branch."""
         import torch
         d, be = self.dist, self.be
         groups = shared.pkg.GROUPS
-        if self.levels:
-            counts, _ = be.describe_counts(self._table(), desc_mode, eig_thres, size_factor)
-        else:
-            counts = np.zeros(groups, np.int32)
+        zeros = np.zeros(groups, np.int32)
+        two = self.coarse_be is not None and bool(self.levels)
+        coarse = self._coarse_call(lambda cb, table: cb.describe_counts(table, desc_mode, eig_thres, size_factor)[0]) if two else None
+        counts = be.describe_counts(self._table(), desc_mode, eig_thres, size_factor)[0] if self.levels else zeros
+        ccounts = coarse() if two else zeros
+        # every rank's records per group -- and, from rank 0, those of the octaves that are not sharded, which come last in every group
+        # they have (nobody else has records there)
         if d is not None:
             world = d.get_world_size(group)
             dev = "cpu" if d.get_backend(group) == "gloo" else device
-            mine = torch.from_numpy(counts).to(dev)
-            every = [torch.zeros(groups, dtype=torch.int32, device=dev) for _ in range(world)]
+            mine = torch.from_numpy(np.concatenate([counts, ccounts])).to(dev)
+            every = [torch.zeros(2 * groups, dtype=torch.int32, device=dev) for _ in range(world)]
             d.all_gather(every, mine, group=group)
-            allc = np.stack([t.cpu().numpy() for t in every])
+            rows = np.stack([t.cpu().numpy() for t in every])
+            rank = self.rank
         else:
-            allc = counts[None, :]
-        shift, total = placed_shifts(allc, self.rank if d is not None else 0)
+            world, rows, rank = 1, np.concatenate([counts, ccounts])[None, :], 0
+        allc = np.concatenate([rows[:, :groups], rows[:, groups:].sum(axis=0, keepdims=True)])   # world ranks + the coarse octaves
+        shift, total = placed_shifts(allc, rank)
         fits = total <= shared.capacity
         own = (None, np.zeros(0, np.int32))
         if self.levels:
+            if two:
+                cshift = placed_shifts(allc, world)[0]
+                coarse = self._coarse_call(lambda cb, table: cb.describe_place(shared.address if fits else None, cshift if fits else None))
             res = be.describe_place(shared.address if fits else None, shift if fits else None)
+            cres = coarse() if two else None
             if not fits:
-                own = res
+                own = (np.concatenate([res[0], cres[0]]), np.concatenate([res[1], cres[1]])) if two else res
         if not fits:
             return None, own
         if d is not None:

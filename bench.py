@@ -199,6 +199,11 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     i0, i1 = plan.input_range(rank)
     ctx = pkg.Context(nx, ny, zs.slab_context_slices(plan, rank), device=dev, slab=True)   # no level buffers of its own
     be = zs.HipBackend(pkg, ctx, torch)
+    # rank 0: the octaves below the sharded ones (gathered there) on a second context and stream, queued by a second host thread, so that
+    # their chain of small launches runs beside rank 0's per-keypoint stage instead of in front of it (--zslab-coarse-inline: as before)
+    cdims = None if args.zslab_coarse_inline else zs.coarse_octave_dims(plan)
+    cctx = pkg.Context(cdims[0], cdims[1], cdims[2], device=dev, slab=True) if (rank == 0 and cdims) else None
+    cbe = zs.HipBackend(pkg, cctx, torch) if cctx is not None else None
     # the deferred patch-halo batch on a communicator of its own, so that it cannot queue in front of a level's halo
     # (--zslab-one-group: no second communicator; the deferred batch then queues behind the per-level halos on the first -- the
     # fallback to try in the same lease if a first run on real links stalls with two communicators per device)
@@ -231,7 +236,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
 
     def step():
         with be.stream_scope():
-            ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup)
+            ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup, coarse_backend=cbe)
             ex.run(slab, i0)
             if shared[0] is not None:
                 n, own = ex.describe_into(shared[0], desc_mode=desc, device=cdev)
@@ -285,8 +290,9 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
                "workload": "ONE %s float32 blob-field volume cut into %d Z-slabs, full featExtract path (%s descriptor), all octaves"
                            % (label, world, ["SIFT-rank", "BRIEF", "RRIEF", "NRRIEF"][desc]),
                "sharded_octaves": plan.n_sharded, "slab_bounds": plan.bounds,
-               "parallelism": "zslab%d: halo exchange with torch.distributed (%s, %s), coarse octaves on rank 0"
-                              % (world, dist.get_backend(), "one communicator" if dgroup is None else "two communicators: per-level halos / deferred patch halos"),
+               "parallelism": "zslab%d: halo exchange with torch.distributed (%s, %s), coarse octaves on rank 0 (%s)"
+                              % (world, dist.get_backend(), "one communicator" if dgroup is None else "two communicators: per-level halos / deferred patch halos",
+                                 "a second context and host thread beside rank 0's per-keypoint stage" if cbe is not None else "in front of its per-keypoint stage"),
                "records_to_rank0": ("placed: every rank's descriptor kernel stores its records at their places of the single-GPU order in ONE "
                                     "shared, device-registered list (193 words per rank exchanged; no gather, no merge)") if how == "placed"
                                    else "gathered: every rank's records through the collective backend to rank 0, merged on the host",
@@ -310,6 +316,8 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
         merged = None   # (a view of the shared list: dropped before the list is)
     if shared[0] is not None:
         shared[0].close()
+    if cctx is not None:
+        cctx.close()
     ctx.close()
     return res
 
@@ -347,7 +355,7 @@ def zslab_child(args, world, expect, limit_s):
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
            str(args.warmup), "--dims", "%d,%d,%d" % resolve_volume(args)[:3], "--desc", str(resolve_volume(args)[3]), "--mode", "zslab",
            "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)] + (["--zslab-one-group"] if args.zslab_one_group else []) \
-        + (["--zslab-gather"] if args.zslab_gather else [])
+        + (["--zslab-gather"] if args.zslab_gather else []) + (["--zslab-coarse-inline"] if args.zslab_coarse_inline else [])
     # End exactly the job started here (run_child): torch.distributed.run puts every rank in a session of its own, so the
     # launcher's process group does not contain them -- their PIDs are noted first, the launcher is asked to stop (it
     # terminates its ranks on SIGTERM), then whatever of it is still there is killed.
@@ -503,6 +511,9 @@ def main():
     ap.add_argument("--zslab-gather", action="store_true",
                     help="N > 1: the Z-slab run's records gathered on rank 0 through the collective backend and merged on the host (rounds 1 - 4) "
                          "instead of stored by every rank's kernel in one shared list")
+    ap.add_argument("--zslab-coarse-inline", action="store_true",
+                    help="N > 1: the Z-slab run's octaves below the sharded ones on rank 0's own context and thread, in front of its per-keypoint "
+                         "stage (rounds 1 - 4), instead of on a second context queued by a second host thread")
     ap.add_argument("--phase-limit", type=int, default=300,
                     help="N > 1: seconds any one phase of a rank (set-up, warm-up, the timed steps, a reduction) may take before "
                          "the rank ends the job with exit code 3 and the phase name (0 = no limit)")

@@ -1419,9 +1419,13 @@ def _zslab_worker(rank, world, port, dims, seed, mode, q):
         ctx = pkg.Context(dims[0], dims[1], max(zs.slab_context_slices(plan, rank), 8 + 2 * zs.HALO), device=0, slab=True)
         be = zs.HipBackend(pkg, ctx, torch)
         dgroup = dist.new_group(ranks=list(range(world)), backend="gloo")   # the deferred patch halos on a group of their own
+        # rank 0: the octaves that are not sharded on a second context and stream, queued by a second host thread (round 5)
+        cdims = zs.coarse_octave_dims(plan)
+        cctx = pkg.Context(cdims[0], cdims[1], cdims[2], device=0, slab=True) if (rank == 0 and cdims) else None
+        cbe = zs.HipBackend(pkg, cctx, torch) if cctx is not None else None
         with be.stream_scope():
             # poison_halo: the halo slices of L1..L3 that the exchange does not fetch hold NaN (zslab.PATCH_REACH is the claim)
-            ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup, poison_halo=True)
+            ex = zs.ZSlabExtractor(be, plan, rank, dist, deferred_group=dgroup, poison_halo=True, coarse_backend=cbe)
             ex.run(vol[i0:i1], i0)
             recs, grp = ex.describe(desc_mode=mode)
             stats = dict(ex.stats)
@@ -1448,6 +1452,8 @@ def _zslab_worker(rank, world, port, dims, seed, mode, q):
                 shared.close()
         if rank == 0:
             q.put((plan.n_sharded, merged, stats, placed, small))
+        if cctx is not None:
+            cctx.close()
         ctx.close()
     finally:
         dist.destroy_process_group()
