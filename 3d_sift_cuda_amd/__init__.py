@@ -415,6 +415,15 @@ class _NiftiMinImage(C.Structure):
                 ("qto_xyz", C.c_float * 16), ("sto_xyz", C.c_float * 16), ("data", C.POINTER(C.c_float))]
 
 
+def nifti_fast_inflate(on):
+    """csrc/nifti_min.h: 0 = gzip'ed files through zlib only; 1 (default) = through libdeflate where the system has it."""
+    host_lib().nifti_min_fast_inflate(int(bool(on)))
+
+
+def nifti_fast_inflate_count():
+    return int(host_lib().nifti_min_fast_inflate_count())
+
+
 def read_nifti(path):
     """nifti_min_read: (volume float32 of shape (nt*nz, ny, nx), header dict).  Raises Sift3DError with the reader's code."""
     img = _NiftiMinImage()

@@ -38,6 +38,10 @@ typedef struct nifti_min_stream nifti_min_stream;
 int nifti_min_open(const char *path, nifti_min_image *img, nifti_min_stream **s);
 int nifti_min_read_voxels(nifti_min_stream *s, float *dst, size_t nvox);
 void nifti_min_close(nifti_min_stream *s);
+/* 0: gzip'ed files through zlib's streaming inflate only; 1 (default): in one call through libdeflate where the system has it and the
+ * file is one gzip member of at most 4 GiB (nifti_min.c: fast_inflate).  The voxels are the same. */
+void nifti_min_fast_inflate(int on);
+int nifti_min_fast_inflate_count(void); /* files that went through libdeflate so far in this process */
 /* Writes a float32 single-file .nii (or .nii.gz by extension), voxel size (dx,dy,dz). */
 int nifti_min_write_f32(const char *path, const float *data, int nx, int ny, int nz, float dx, float dy, float dz);
 /* As above with a qform (quaternion b,c,d, offsets, qfac = pixdim[0]) and/or an sform (3 rows of 4):

@@ -410,6 +410,71 @@ def test_nifti_reader_all_datatypes(built, tmp_path, code):
         assert np.allclose(np.diag(hdr["qto_xyz"]), [1.0, 1.5, 2.0, 1.0])            # method 1: voxel scaling only
 
 
+@pytest.mark.parametrize("code", [4, 512, 64, 2])
+def test_nifti_reader_casts_a_large_run_in_parallel(built, tmp_path, code):
+    """From 2^20 voxels on the cast to float runs over the host cores (csrc/nifti_min.c): the same floats as numpy's cast."""
+    rng = np.random.default_rng(code)
+    v = _test_values(code, (70, 128, 128), rng)
+    for name, kw in (("big.nii", {}), ("big_be.nii.gz", {"big_endian": True})):
+        got, _ = built.read_nifti(_write_case(tmp_path, name, v, code, **kw))
+        assert (got.view(np.uint32) == v.astype(np.float32).view(np.uint32)).all(), name
+
+
+def test_nifti_gz_in_one_call_and_through_zlib_give_the_same_voxels(built, tmp_path):
+    """A gzip'ed data file is inflated in one call by libdeflate where the system has it (csrc/nifti_min.c: fast_inflate; 2 - 3 x zlib's
+    streaming inflate, which is what `featExtract in.nii.gz` spends its time in) and by zlib otherwise -- and whenever the file is not
+    what that path expects: several gzip members, bytes behind the stream, a stream cut short.  Every datatype, both byte orders,
+    single files and .hdr + .img.gz pairs: the same voxels, the same return codes."""
+    import ctypes.util
+    import gzip
+    have = ctypes.util.find_library("deflate") is not None
+    rng = np.random.default_rng(5)
+    cases = []
+    for code in sorted(NIFTI_TYPES):
+        v = _test_values(code, (6, 10, 12), rng)
+        cases.append((_write_case(tmp_path, "a%d.nii.gz" % code, v, code), v))
+        cases.append((_write_case(tmp_path, "b%d.nii.gz" % code, v, code, big_endian=True), v))
+        cases.append((_write_case(tmp_path, "c%d.hdr" % code, v, code, img_gz=True), v))
+    v = _test_values(4, (9, 8, 7), rng)
+    cases.append((_write_case(tmp_path, "off.nii.gz", v, 4, vox_offset=400.0, slope=1.0), None))    # a header that promises 48 bytes more than the file has
+    h, d = _nifti_bytes(v, 4)
+    blob = h + b"\0\0\0\0" + d
+    two = str(tmp_path / "two_members.nii.gz")                                                  # one file, two gzip members
+    open(two, "wb").write(gzip.compress(blob[:1000]) + gzip.compress(blob[1000:]))
+    tail = str(tmp_path / "tail.nii.gz")                                                        # bytes behind the stream
+    open(tail, "wb").write(gzip.compress(blob) + b"not gzip")
+    cut = str(tmp_path / "cut.nii.gz")                                                          # a stream cut short
+    open(cut, "wb").write(gzip.compress(blob)[:-40])
+    longer = str(tmp_path / "longer.nii.gz")                                                    # more bytes than the header's voxels
+    open(longer, "wb").write(gzip.compress(blob + b"\x07" * 1000))
+
+    def read(p):
+        try:
+            return built.read_nifti(p)[0]
+        except built.Sift3DError as e:
+            return str(e)
+    results = {}
+    for on in (1, 0):
+        built.nifti_fast_inflate(on)
+        n0 = built.nifti_fast_inflate_count()
+        results[on] = [read(p) for p, _ in cases] + [read(two), read(tail), read(cut), read(longer)]
+        taken = built.nifti_fast_inflate_count() - n0
+        if on and have:
+            assert taken == len(cases), taken              # every well-formed single-member file and `longer`; never off / two / tail / cut
+        else:
+            assert taken == 0
+    built.nifti_fast_inflate(1)
+    for a, b, (p, want) in zip(results[1], results[0], cases + [(two, None), (tail, None), (cut, None), (longer, None)]):
+        assert type(a) is type(b), p
+        if isinstance(a, str):
+            assert a == b, p
+        else:
+            assert a.tobytes() == b.tobytes(), p
+            if want is not None:
+                assert (a.view(np.uint32) == want.astype(np.float32).view(np.uint32)).all(), p
+    assert isinstance(results[1][-2], str) and not isinstance(results[1][-1], str) and not isinstance(results[1][-4], str)
+
+
 def test_nifti_reader_rejects_what_it_cannot_read(built, tmp_path):
     v = np.arange(4 * 5 * 6, dtype=np.int16).reshape(4, 5, 6)
 

@@ -11,6 +11,7 @@ the oracle's CLI (`oracle/_build/featExtract_oracle`, the CPU restatement behind
 timed here as the CPU side of the same box).  The .key files of the two are compared byte for byte.
 """
 import hashlib
+import numpy as np
 import importlib
 import os
 import re
@@ -76,3 +77,17 @@ for n in sizes:
         print("%-28s %8.3f | (CPU restatement, one thread; rc %d) .key sha %s%s" % ("featExtract_oracle .nii", wall, rc, sha(key) if rc == 0 else "-",
                                                                                   "  == GPU CLI bytes" if rc == 0 and sha(key) == keys[".nii"] else "  DIFFERENT"))
     assert keys[".nii"] == keys[".nii.gz"]
+    # the reader alone on the gzip'ed file: one call of libdeflate (default where the system has the library) against zlib's stream
+    i16 = os.path.join(d, "v%d_i16.nii.gz" % n)
+    h = bytearray(open(nii, "rb").read(352))
+    h[70:72] = (4).to_bytes(2, "little"); h[72:74] = (16).to_bytes(2, "little")     # DT_INT16: what scanners write
+    import gzip
+    with gzip.open(i16, "wb", compresslevel=1) as f:
+        f.write(bytes(h)); f.write(np.clip(vol * 8.0 + 100.0, -32000, 32000).astype(np.int16).tobytes())
+    for path, tag in ((gz, "float32 .nii.gz"), (i16, "int16 .nii.gz (%.0f MB)" % (os.path.getsize(i16) / 1e6))):
+        for on in (1, 0, 1, 0):
+            pkg.nifti_fast_inflate(on)
+            c0 = pkg.nifti_fast_inflate_count()
+            t0 = time.perf_counter(); v, _ = pkg.read_nifti(path); dt = time.perf_counter() - t0
+            print("%-28s %8.3f | read_nifti alone, %s" % (tag, dt, "libdeflate, one call" if pkg.nifti_fast_inflate_count() > c0 else "zlib, streaming"))
+    pkg.nifti_fast_inflate(1)
