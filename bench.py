@@ -810,7 +810,8 @@ def main():
                 c_gbs = c_bytes / (c_ms * 1e-3) / 1e9
                 roofline["ceiling"] = {
                     "what": "zero-arithmetic march of the same tiles (tools/roof_lib.hip), measured in this process after the timed region: "
-                            "what a kernel that only moves the fused blur's tiles sustains on this box",
+                            "what a kernel that only moves the fused blur's tiles sustains on this box (the best of 10 launches and of three "
+                            "placements of its buffers per tile shape and store count)",
                     "achieved": round(c_gbs, 1), "unit": "GB/s", "frac": round(c_gbs / HBM_PEAK_GBS, 4),
                     "march_ms": {"64x32_1_store": round(ms4[0], 4), "128x16_1_store": round(ms4[1], 4),
                                  "64x32_2_stores": round(ms4[2], 4), "128x16_2_stores": round(ms4[3], 4)},
