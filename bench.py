@@ -187,7 +187,8 @@ def self_launch(args, argv):
 
 
 def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, phase=lambda *a: None):
-    """ONE volume cut into Z-slabs, one slab per rank; step = whole extraction + gather of the records on rank 0.
+    """ONE volume cut into Z-slabs, one slab per rank; step = whole extraction with all its records on rank 0 at the end (stored there
+    by every rank's descriptor kernel through one shared list, or -- `--zslab-gather` -- gathered through the backend and merged).
     Returns the result object on rank 0 (None elsewhere).  expect: the single-GPU records of the same volume, if the
     caller has them (rank 0), to state whether the merged records are the same bytes."""
     phase("zslab: plan, slab context, upload")
