@@ -311,6 +311,69 @@ def test_slab_entry_points_are_ordered_with_the_default_stream(built):
                 assert got.tobytes() == want.tobytes(), (lazy, rnd)
 
 
+def test_describe_in_two_parts_places_the_records_where_the_shifts_say(built):
+    """sift3d_describe_dev_counts / sift3d_describe_dev_place (round 5): the per-keypoint stage of a context whose records go into a list
+    it shares with others.  One context here, and an imaginary rank in front of it whose records per group are made up: this context's
+    records of group g must land behind that rank's run of group g, in their own order, and the group counts must be the histogram of
+    the group words.  Also: the list too small (place with no list: the context's own buffers, as describe_dev), and place without
+    counts refused."""
+    import importlib
+    import torch
+    zs = importlib.import_module("3d_sift_cuda_amd.zslab")
+    dims = (96, 88, 80)
+    nx, ny, nz = dims
+    vol = vol_of(built, dims, 33)
+    extra0, extras, sig = zs.sigma_schedule(1.0)
+    with built.Context(nx, ny, nz, slab=True) as ctx:
+        d_vol = torch.from_numpy(vol).cuda()
+        L = [torch.empty_like(d_vol) for _ in range(6)]
+        D = [torch.empty_like(d_vol) for _ in range(5)]
+        levels = [{"img": L[l + 1].data_ptr(), "dogc": D[l + 1].data_ptr(), "nx": nx, "ny": ny, "nz_local": nz, "nz_global": nz, "z_offset": 0,
+                   "sigma_h": sig[l], "sigma_c": sig[l + 1], "sigma_l": sig[l + 2], "octave_factor": 1.0} for l in range(3)]
+
+        def pyramid():
+            ctx.gauss_blur_dev(d_vol.data_ptr(), L[0].data_ptr(), nx, ny, nz, extra0)
+            for j in range(1, 6):
+                ctx.gauss_blur_dog_dev(L[j - 1].data_ptr(), L[j].data_ptr(), D[j - 1].data_ptr(), nx, ny, nz, extras[j - 1])
+            ctx.candidates_reset()
+            for l in range(3):
+                ctx.extrema_append_dev(D[l].data_ptr(), D[l + 1].data_ptr(), D[l + 2].data_ptr(), nx, ny, nz, l, 0, nz)
+        pyramid()
+        want, wgrp = ctx.describe_dev(levels)
+        assert len(want) > 100
+        with pytest.raises(built.Sift3DError):
+            ctx.describe_dev_place(None, None)                                # no counts before it
+        pyramid()
+        counts, n = ctx.describe_dev_counts(levels)
+        assert n == len(want) and (counts == np.bincount(wgrp, minlength=built.GROUPS)).all()
+        rng = np.random.default_rng(1)
+        other = np.where(counts > 0, rng.integers(0, 7, built.GROUPS), 0).astype(np.int32)   # the imaginary rank 0 in front
+        shift0, total = zs.placed_shifts(np.stack([other, counts]), 0)
+        shift1, _ = zs.placed_shifts(np.stack([other, counts]), 1)
+        assert total == n + int(other.sum())
+        lst = np.zeros(total + 5, built.FEATURE_DTYPE)
+        lst["scale"] = -1.0                                                    # what nobody stores stays as it is
+        built.host_register(lst.ctypes.data, lst.nbytes)
+        try:
+            assert ctx.describe_dev_place(lst.ctypes.data, shift1) == n
+            at, mine = 0, np.zeros(total + 5, bool)
+            pos = 0
+            for g in range(built.GROUPS):
+                pos += int(other[g])                                           # the other rank's run of the group comes first
+                k = int(counts[g])
+                assert lst[pos:pos + k].tobytes() == want[at:at + k].tobytes(), g
+                mine[pos:pos + k] = True
+                pos += k; at += k
+            assert (lst["scale"][~mine] == -1.0).all()
+            # the list too small: every rank would fall back to its own buffers -- place with no list
+            pyramid()
+            ctx.describe_dev_counts(levels)
+            own, ogrp = ctx.describe_dev_place(None, None)
+            assert own.tobytes() == want.tobytes() and (ogrp == wgrp).all()
+        finally:
+            built.host_unregister(lst.ctypes.data)
+
+
 def test_lds_float_atomic_add_rounds_like_the_alu(built):
     """The orientation-histogram splat adds with ds_add_f32: it must be the IEEE add the reference's CPU performs."""
     rng = np.random.default_rng(7)
