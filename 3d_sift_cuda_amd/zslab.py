@@ -557,8 +557,10 @@ class ZSlabExtractor:
 
         def work():
             try:
+                if hasattr(cbe, "ctx"):
+                    torch.cuda.set_device(cbe.ctx.device)   # a new thread starts on device 0, whatever rank 0's device is
                 with cbe.stream_scope():
-                    torch.cuda.current_stream().wait_event(ready)
+                    (getattr(cbe, "stream", None) or torch.cuda.current_stream()).wait_event(ready)
                     lvl0, f = L0, factor
                     for o in range(o_first, len(plan.octaves)):
                         X, Y, zo = plan.octaves[o]
@@ -607,6 +609,8 @@ class ZSlabExtractor:
         def work():
             try:
                 self._join_coarse()
+                if hasattr(self.coarse_be, "ctx"):
+                    self.coarse_be.torch.cuda.set_device(self.coarse_be.ctx.device)   # (a new thread starts on device 0)
                 with self.coarse_be.stream_scope():
                     box["r"] = fn(self.coarse_be, self._table_of(self.c_levels, self.c_level_ids))
             except BaseException as e:
