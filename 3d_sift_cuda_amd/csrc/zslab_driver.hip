@@ -26,9 +26,11 @@
  * 3d_sift_cuda_amd/zslab.py (which runs one process per GPU over RCCL for bench.py): slabs along z with boundaries that are
  * multiples of 2^K, every level recomputed on slab +- 8 slices and its 8-slice halo refreshed from the two neighbours, the
  * rest of the L1..L3 halos copied on a second stream while L4, L5 and the extrema passes run (the eight slices of L3 the
- * subsample reads, then what the patches of each level can reach: ZS_PATCH_REACH), the first unsharded octave assembled on rank 0.  A halo copy is queued on the RECEIVER's stream behind an event the
- * sender records when the level is complete, so no host thread ever waits inside the pyramid; the host enqueues the work
- * of all devices round-robin.  The same device may be listed several times (a rehearsal of the slab logic on one GPU).
+ * subsample reads, then what the patches of each level can reach: ZS_PATCH_REACH), the octaves below the sharded ones gathered
+ * on the first device into a rank of their own.  A halo copy is queued on the RECEIVER's stream behind an event the sender
+ * records when the level is complete, so no host thread ever waits inside the pyramid; every rank's launches are queued by a
+ * host thread of its own (zs_crew.h), step by step of the schedule.  The same device may be listed several times (a rehearsal
+ * of the slab logic on one GPU).
  * ====================================================================================================================== */
 namespace {
 const int64_t ZS_HALO = 32; /* slices of L1..L3 a slab's buffers keep around it (and the least a slab must be thick) */

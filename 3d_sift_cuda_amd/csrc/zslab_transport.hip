@@ -4,7 +4,7 @@
  *
  *   peer copies  hipMemcpyPeerAsync on the RECEIVER's stream behind the event the sender recorded (rounds 2 - 3);
  *   RCCL         ncclSend on the sender's stream + ncclRecv on the receiver's, all transfers of one exchange step inside
- *                one ncclGroupStart / ncclGroupEnd (one host thread drives every device, so the group is what lets the
+ *                one ncclGroupStart / ncclGroupEnd (the calling thread queues them for every device, so the group is what lets the
  *                pairs progress together) -- BASELINE.json's north star: "halo exchange over RCCL/xGMI".  One communicator
  *                set per CHANNEL: RCCL orders the operations of a communicator, and the deferred patch halos (channel 1)
  *                must not queue in front of the next level's halo (channel 0).
