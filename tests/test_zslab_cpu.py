@@ -187,3 +187,34 @@ def test_single_rank_plan_is_the_serial_path(oracle, built):
     ex = zs.ZSlabExtractor(OracleBackend(oracle, torch), plan, 0, None)
     ex.run(vol, 0)
     _same(ex.candidates(), oracle.candidates(vol))
+
+
+def test_placed_shifts_are_the_merge_by_group_order():
+    """zslab.placed_shifts (where a rank's descriptor kernel stores its records in the shared list) against merge_by_group (the host
+    merge of rounds 1 - 4): for random per-rank group counts, record i of rank r, group g lands exactly where the stable sort by
+    group of the concatenated ranks puts it."""
+    zs = importlib.import_module("3d_sift_cuda_amd.zslab")
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 5, 9):
+        groups = 193
+        counts = rng.integers(0, 6, (world, groups)) * (rng.random((world, groups)) < 0.3)
+        parts, where = [], []
+        for r in range(world):
+            grp = np.repeat(np.arange(groups), counts[r])              # a rank's own records are sorted by group
+            recs = np.zeros(len(grp), [("rank", "<i4"), ("i", "<i4")])
+            recs["rank"], recs["i"] = r, np.arange(len(grp))
+            parts.append((recs, grp.astype(np.int32)))
+            shift, total = zs.placed_shifts(counts, r)
+            where.append(np.arange(len(grp)) + shift[grp])
+        assert total == counts.sum()
+        merged = zs.merge_by_group(parts)
+        if merged is None:
+            assert total == 0
+            continue
+        placed = np.zeros(total, merged.dtype)
+        seen = np.zeros(total, bool)
+        for (recs, _), w in zip(parts, where):
+            assert not seen[w].any()
+            placed[w] = recs
+            seen[w] = True
+        assert seen.all() and placed.tobytes() == merged.tobytes()
