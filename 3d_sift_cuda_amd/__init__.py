@@ -202,11 +202,11 @@ class ZSlabStats(C.Structure):
                 ("halo_bytes_deferred", C.c_int64), ("gather_bytes", C.c_int64), ("n_extrema", C.c_int64), ("n_keypoints", C.c_int64),
                 ("n_records", C.c_int64), ("wall_ms", C.c_double), ("halo_bytes_hidden", C.c_int64), ("transport", C.c_int32),
                 ("transport_fell_back", C.c_int32), ("rccl_version", C.c_int32), ("comm_sets", C.c_int32), ("resident_volume", C.c_int32),
-                ("reserved", C.c_int32), ("merge_ms", C.c_double), ("halo_bytes_subsample", C.c_int64), ("enqueue_ms", C.c_double)]
+                ("list_grown", C.c_int32), ("merge_ms", C.c_double), ("halo_bytes_subsample", C.c_int64), ("enqueue_ms", C.c_double)]
 
 
 ZSLAB_TRANSPORT, TRANSPORT_PEER_COPY, TRANSPORT_RCCL = 1000, 0, 1   # sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_TRANSPORT, ...)
-ZSLAB_SERIAL_CHANNELS, ZSLAB_DUPLICATE_RANKS, ZSLAB_POISON_HALO, ZSLAB_PATCH_WAIT = 1001, 1002, 1003, 1004   # include/sift3d.h
+ZSLAB_SERIAL_CHANNELS, ZSLAB_DUPLICATE_RANKS, ZSLAB_POISON_HALO, ZSLAB_PATCH_WAIT, ZSLAB_LIST_ROOM = 1001, 1002, 1003, 1004, 1005   # include/sift3d.h
 
 
 def zslab_set_transport_library(path):

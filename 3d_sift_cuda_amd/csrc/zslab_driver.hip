@@ -184,6 +184,7 @@ struct sift3d_zslab {
     int transport_want = ZS_TRANSPORT_PEER; /* SIFT3D_ZSLAB_TRANSPORT */
     int transport_flags = 0;                /* ZS_FLAG_*: SIFT3D_ZSLAB_SERIAL_CHANNELS, SIFT3D_ZSLAB_DUPLICATE_RANKS */
     int patch_wait = 0;                     /* SIFT3D_ZSLAB_PATCH_WAIT: 0 the patch-only halos are waited for before the per-keypoint stage, 1 at their octave's end */
+    int list_room = -1;                     /* SIFT3D_ZSLAB_LIST_ROOM (tests): records of room behind the slabs' in a newly allocated list; -1: an eighth + 4096 */
     int poison_halo = 0;                    /* SIFT3D_ZSLAB_POISON_HALO (tests): the halo slices of L1..L3 that are not fetched hold NaN */
     zs_transport *tr = nullptr;             /* created by the first extraction after the choice (zslab_transport.hip) */
     bool has_volume = false;                /* sift3d_zslab_set_volume has put every rank's input slices on its device */
@@ -246,6 +247,13 @@ extern "C" int sift3d_zslab_set_tuning(sift3d_zslab *h, int knob, int value)
     if (knob == SIFT3D_ZSLAB_PATCH_WAIT) {
         if (value != 0 && value != 1) return SIFT3D_ERR_ARG;
         h->patch_wait = value;
+        return SIFT3D_OK;
+    }
+    if (knob == SIFT3D_ZSLAB_LIST_ROOM) {
+        h->list_room = value < 0 ? -1 : value;
+        if (h->merged) (void)hipHostFree(h->merged); /* the next extraction allocates its list anew */
+        h->merged = nullptr;
+        h->merged_cap = 0;
         return SIFT3D_OK;
     }
     if (knob == SIFT3D_ZSLAB_POISON_HALO) {
@@ -806,21 +814,29 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
         if (crew_failed()) return;
     }
 
-    /* ---- per-keypoint stage: every rank by its own host thread, so that no device waits for another's host round trip (rounds 3 - 4
-     * walked the ranks phase by phase on one thread): the extrema count is requested and awaited, the candidates are sorted, the
-     * keypoint kernel is queued and its records per group are read back; then -- the one step that needs every rank's numbers --
-     * the places of all records in the merged list are laid out, and every rank's descriptor kernel stores into its own. ---- */
+    /* ---- per-keypoint stage: every rank by its own host thread, in ONE step of the crew.  A slab's rank requests and awaits its
+     * extrema count, sorts, queues the keypoint kernel and reads back its records per (level, is_max) group; when every SLAB's rank
+     * has those (a barrier among them inside the step) the places of their records in the merged list are known -- group by group,
+     * rank by rank -- and every rank's descriptor kernel stores into its own.  The rank of the octaves that are not sharded takes
+     * no part in that: its records come last in the list whatever the slabs' counts are, so it builds its octaves and runs its
+     * per-keypoint stage into its own pinned buffer, and its few hundred records are appended at the end.  (First form of this
+     * round: it was a rank like the others -- and every slab's descriptor launch waited for the chain of small launches that
+     * builds the coarse octaves, which on a device shared with a keypoint kernel ends long after that kernel.) ---- */
     {
         std::vector<int64_t> ncands((size_t)T, 0);
         std::vector<double> queued_ms((size_t)T, 0.0); /* when a rank's thread had queued its pyramid, extrema passes and count request */
-        std::vector<std::vector<int>> cnt((size_t)T, std::vector<int>(SIFT3D_GROUPS, 0));
-        h->crew.run(T, [&](int r) {
+        std::vector<std::vector<int>> cnt((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0));
+        std::atomic<int> arrived{0};    /* slabs' ranks that have their counts -- or have failed */
+        std::atomic<int> list_state{0}; /* 1: the merged list holds the slabs' records' places; -1: a rank failed, nobody stores */
+        int64_t slab_total = 0;
+        double layout_ms = 0.0;
+        shift.assign((size_t)S, std::vector<int>(SIFT3D_GROUPS, 0)); /* (declared with the function's vectors: the uploads below read it) */
+        auto spin_until = [](auto &&cond) {
+            for (int spins = 0; !cond(); spins++)
+                if (spins < 20000) __builtin_ia32_pause(); else std::this_thread::yield();
+        };
+        auto count_side = [&](int r, bool want_groups) { /* everything up to and including the keypoint kernel */
             zs_rank &q = R[(size_t)r];
-            if (r == cr) /* the octaves that are not sharded: this rank's, queued by its own thread while the slabs' ranks go on */
-                for (int o = n_sharded; o < (int)plan.oct.size(); o++) {
-                    octave(o);
-                    if (rrc[(size_t)r] != SIFT3D_OK) return;
-                }
             ZR_HIP(hipSetDevice(q.dev));
             /* the patch halos of every sharded octave (the second deferred step: the copy stream, in order) must be in before
              * the keypoint kernel samples them: everything the copy stream holds is behind this event */
@@ -831,9 +847,10 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             ZR_RC(cand_count_queue(q.c));
             queued_ms[(size_t)r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
             ZR_RC(cand_finalize(q.c, &ncands[(size_t)r]));
-            describe_want_group_counts(q.c, true);
-            q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the placement below needs the whole list's counts before the one descriptor launch */
+            describe_want_group_counts(q.c, want_groups);
+            if (want_groups) q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the places need the whole list's counts before the one descriptor launch */
             ZR_RC(describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false));
+            if (!want_groups) return;
             /* this rank's records per group (level, is_max): the merged list is, group by group, a run of every rank in rank order --
              * within a group slabs are in z order, so rank order is the serial raster order */
             const int *hc = nullptr;
@@ -841,41 +858,66 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             ZR_RC(describe_group_counts(q.c, &hc, &tr));
             cnt[(size_t)r].assign(hc, hc + SIFT3D_GROUPS);
             nrecs[(size_t)r] = tr;
-        });
-        if (crew_failed()) return;
-        int64_t total = 0;
-        for (r = 0; r < T; r++) {
-            st.n_extrema += ncands[(size_t)r];
-            total += nrecs[(size_t)r];
-            st.enqueue_ms = std::max(st.enqueue_ms, queued_ms[(size_t)r]);
-        }
-        const auto merge0 = std::chrono::steady_clock::now(); /* (the waits for the keypoint kernels are behind us) */
-        if (total > h->merged_cap) { /* nothing stores into the list yet: the descriptor launches follow */
-            if (h->merged) hipHostFree(h->merged);
-            h->merged = nullptr;
-            h->merged_cap = total + total / 8 + 1024;
-            if (hipHostMalloc((void **)&h->merged, sizeof(sift3d_feature) * (size_t)h->merged_cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
-                h->merged = nullptr;
-                h->merged_cap = 0;
-                rc = SIFT3D_ERR_MEMORY;
-                snprintf(errbuf, sizeof errbuf, "out of pinned host memory for %lld merged records", (long long)total);
-                return;
-            }
-        }
-        {
-            int64_t pos = 0;
-            shift.assign((size_t)T, std::vector<int>(SIFT3D_GROUPS, 0)); /* (declared with the function's vectors: the uploads below read it) */
-            std::vector<int64_t> local((size_t)T, 0); /* a rank's own position: its records before this group */
-            for (int g = 0; g < SIFT3D_GROUPS; g++)
-                for (r = 0; r < T; r++) { /* (the gathered octaves' rank comes last; its groups are nobody else's) */
-                    shift[(size_t)r][(size_t)g] = (int)(pos - local[(size_t)r]);
-                    pos += cnt[(size_t)r][(size_t)g];
-                    local[(size_t)r] += cnt[(size_t)r][(size_t)g];
-                }
-        }
-        st.merge_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge0).count();
+        };
         h->crew.run(T, [&](int r) {
             zs_rank &q = R[(size_t)r];
+            if (h->coarse >= 0 && r == h->coarse) { /* the octaves that are not sharded: queued by this rank's own thread while the slabs' ranks go on */
+                for (int o = n_sharded; o < (int)plan.oct.size(); o++) {
+                    octave(o);
+                    if (rrc[(size_t)r] != SIFT3D_OK) return;
+                }
+                count_side(r, false);
+                if (rrc[(size_t)r] != SIFT3D_OK) return;
+                ZR_RC(describe_launch(q.c)); /* into the context's own pinned buffers, as a context on its own does */
+                ZR_RC(describe_finish(q.c, &nrecs[(size_t)r]));
+                return;
+            }
+            if (S == 1) /* one rank, nothing sharded: the whole pyramid is this rank's */
+                for (int o = 0; o < (int)plan.oct.size(); o++) {
+                    octave(o);
+                    if (rrc[(size_t)r] != SIFT3D_OK) break;
+                }
+            if (rrc[(size_t)r] == SIFT3D_OK) count_side(r, true);
+            arrived.fetch_add(1); /* with counts or with a failure: nobody waits for a rank that has given up */
+            if (r == 0) {
+                spin_until([&] { return arrived.load() == S; });
+                const auto t0 = std::chrono::steady_clock::now();
+                bool ok = true;
+                for (int i = 0; i < S; i++) ok = ok && rrc[(size_t)i] == SIFT3D_OK;
+                if (ok) {
+                    for (int i = 0; i < S; i++) slab_total += nrecs[(size_t)i];
+                    const int64_t room = h->list_room >= 0 ? h->list_room : slab_total / 8 + 4096; /* for the coarse octaves' records, appended at the end */
+                    if (slab_total + (h->list_room >= 0 ? 0 : slab_total / 64) > h->merged_cap || !h->merged) { /* nothing stores into the list yet */
+                        if (h->merged) (void)hipHostFree(h->merged);
+                        h->merged = nullptr;
+                        h->merged_cap = slab_total + room;
+                        if (hipHostMalloc((void **)&h->merged, sizeof(sift3d_feature) * (size_t)(h->merged_cap ? h->merged_cap : 1),
+                                          hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+                            h->merged = nullptr;
+                            h->merged_cap = 0;
+                            rrc[0] = SIFT3D_ERR_MEMORY;
+                            snprintf(rerr[0].b, sizeof rerr[0].b, "out of pinned host memory for %lld merged records", (long long)slab_total);
+                            ok = false;
+                        }
+                    }
+                }
+                layout_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                list_state.store(ok ? 1 : -1);
+            } else {
+                spin_until([&] { return list_state.load() != 0; });
+            }
+            if (list_state.load() < 0 || rrc[(size_t)r] != SIFT3D_OK) return;
+            { /* this rank's places: its records of group g go behind those of groups < g of every slab and of group g of the slabs before it */
+                int64_t pos = 0, local = 0;
+                for (int g = 0; g < SIFT3D_GROUPS; g++)
+                    for (int i = 0; i < S; i++) {
+                        if (i == r) {
+                            shift[(size_t)r][(size_t)g] = (int)(pos - local);
+                            local += cnt[(size_t)i][(size_t)g];
+                        }
+                        pos += cnt[(size_t)i][(size_t)g];
+                    }
+            }
             ZR_HIP(hipSetDevice(q.dev));
             if (nrecs[(size_t)r] > 0) {
                 sift3d_feature *dview = nullptr; /* the list as this rank's device sees it */
@@ -889,7 +931,30 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
                 ZR_FAIL(SIFT3D_ERR_DEVICE, "rank %d: %lld records where its groups add up to %lld", r, (long long)nrec, (long long)nrecs[(size_t)r]);
         });
         if (crew_failed()) return;
-        for (r = 0; r < T; r++) st.n_keypoints += R[(size_t)r].c->last.n_keypoints;
+        const auto merge0 = std::chrono::steady_clock::now();
+        const int64_t ncoarse = h->coarse >= 0 ? nrecs[(size_t)h->coarse] : 0;
+        const int64_t total = slab_total + ncoarse;
+        for (r = 0; r < T; r++) {
+            st.n_extrema += ncands[(size_t)r];
+            st.enqueue_ms = std::max(st.enqueue_ms, queued_ms[(size_t)r]);
+            st.n_keypoints += R[(size_t)r].c->last.n_keypoints;
+        }
+        if (total > h->merged_cap) { /* the coarse octaves' records do not fit behind the slabs': a larger list, the slabs' part carried over (rare) */
+            sift3d_feature *big = nullptr;
+            const int64_t cap = total + total / 8 + 4096;
+            if (hipHostMalloc((void **)&big, sizeof(sift3d_feature) * (size_t)cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+                rc = SIFT3D_ERR_MEMORY;
+                snprintf(errbuf, sizeof errbuf, "out of pinned host memory for %lld merged records", (long long)total);
+                return;
+            }
+            if (slab_total) memcpy(big, h->merged, sizeof(sift3d_feature) * (size_t)slab_total);
+            if (h->merged) (void)hipHostFree(h->merged);
+            h->merged = big;
+            h->merged_cap = cap;
+            st.list_grown = 1;
+        }
+        if (ncoarse) memcpy(h->merged + slab_total, R[(size_t)h->coarse].c->h_recs, sizeof(sift3d_feature) * (size_t)ncoarse);
+        st.merge_ms = layout_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge0).count();
         /* the list is complete where every rank's kernel put it */
         if (out) {
             sift3d_feature *res = (sift3d_feature *)malloc(sizeof(sift3d_feature) * (size_t)(total ? total : 1));

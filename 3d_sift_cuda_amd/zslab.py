@@ -650,48 +650,54 @@ class ZSlabExtractor:
 
     def describe_into(self, shared, desc_mode=0, eig_thres=140.0, size_factor=1.0, group=None, device=None):
         """The per-keypoint stage with every rank's records stored by its own descriptor kernel at their places in `shared` (a
-        SharedRecordList): keypoint kernel, the ranks' records per group exchanged (one small all_gather), descriptor kernel, barrier.
-        Returns (n, None): n records of the whole volume, and on every rank shared.records[:n] is the single-GPU list (rank 0 is the
-        one that uses it; it stays valid until a rank's next describe_into).  Or, when the list is too small for the volume's records,
-        (None, (records, group)): nothing was stored in it, this rank's records are views (copies on a rank with two backends) of its
-        context's own buffers as after describe(copy=False), and the caller gathers them the old way (gather_records) -- every rank
-        takes the same branch."""
+        SharedRecordList): keypoint kernel, the ranks' records per group exchanged (one small all_gather), descriptor kernel, and one
+        small all_reduce at the end that tells every rank the record count of the whole volume and that all kernels are done.
+        Returns (n, None): shared.view(n) is then the single-GPU list on every rank (rank 0 is the one that uses it; it stays valid
+        until a rank's next describe_into).  Or, when the list is too small for the slabs' records, (None, (records, group)): nothing
+        was stored in it, this rank's records are views (copies on a rank with two backends) of its context's own buffers as after
+        describe(copy=False), and the caller gathers them the old way (gather_records) -- every rank takes the same branch.
+        The octaves that are not sharded (rank 0's second backend) take no part in the exchange: their records come last in the
+        list whatever the slabs' counts are, so they are described into their own buffers beside everything else and appended by
+        rank 0 at the end (a few hundred records)."""
         import torch
         d, be = self.dist, self.be
         groups = shared.pkg.GROUPS
-        zeros = np.zeros(groups, np.int32)
         two = self.coarse_be is not None and bool(self.levels)
-        coarse = self._coarse_call(lambda cb, table: cb.describe_counts(table, desc_mode, eig_thres, size_factor)[0]) if two else None
-        counts = be.describe_counts(self._table(), desc_mode, eig_thres, size_factor)[0] if self.levels else zeros
-        ccounts = coarse() if two else zeros
-        # every rank's records per group -- and, from rank 0, those of the octaves that are not sharded, which come last in every group
-        # they have (nobody else has records there)
+        coarse = self._coarse_call(lambda cb, table: cb.describe(table, desc_mode, eig_thres, size_factor, copy=False)) if two else None
+        counts = be.describe_counts(self._table(), desc_mode, eig_thres, size_factor)[0] if self.levels else np.zeros(groups, np.int32)
         if d is not None:
             world = d.get_world_size(group)
             dev = "cpu" if d.get_backend(group) == "gloo" else device
-            mine = torch.from_numpy(np.concatenate([counts, ccounts])).to(dev)
-            every = [torch.zeros(2 * groups, dtype=torch.int32, device=dev) for _ in range(world)]
-            d.all_gather(every, mine, group=group)
-            rows = np.stack([t.cpu().numpy() for t in every])
+            every = [torch.zeros(groups, dtype=torch.int32, device=dev) for _ in range(world)]
+            d.all_gather(every, torch.from_numpy(counts).to(dev), group=group)
+            allc = np.stack([t.cpu().numpy() for t in every])
             rank = self.rank
         else:
-            world, rows, rank = 1, np.concatenate([counts, ccounts])[None, :], 0
-        allc = np.concatenate([rows[:, :groups], rows[:, groups:].sum(axis=0, keepdims=True)])   # world ranks + the coarse octaves
-        shift, total = placed_shifts(allc, rank)
-        fits = total <= shared.capacity
+            dev, allc, rank = "cpu", counts[None, :], 0
+        shift, slab_total = placed_shifts(allc, rank)
+        fits = slab_total <= shared.capacity
         own = (None, np.zeros(0, np.int32))
         if self.levels:
-            if two:
-                cshift = placed_shifts(allc, world)[0]
-                coarse = self._coarse_call(lambda cb, table: cb.describe_place(shared.address if fits else None, cshift if fits else None))
             res = be.describe_place(shared.address if fits else None, shift if fits else None)
-            cres = coarse() if two else None
             if not fits:
-                own = (np.concatenate([res[0], cres[0]]), np.concatenate([res[1], cres[1]])) if two else res
+                own = res
+        crecs, cgrp = coarse() if two else (None, None)
         if not fits:
+            if two:
+                own = (np.concatenate([own[0], crecs]), np.concatenate([own[1], cgrp]))
             return None, own
-        if d is not None:
-            d.barrier(group=group)   # every rank's kernel has stored its records (describe_place ends with a stream synchronisation)
+        total = slab_total
+        shared.overflow = None
+        if two and len(crecs):
+            total = slab_total + len(crecs)
+            if total <= shared.capacity:
+                shared.records[slab_total:total] = crecs
+            else:   # no room behind the slabs' records (a list sized too tightly): rank 0 keeps a list of its own for this run
+                shared.overflow = np.concatenate([shared.records[:slab_total], crecs])
+        if d is not None:   # every rank's kernel has stored its records (describe_place ends with a stream synchronisation); rank 0 knows the total
+            t = torch.tensor([total if rank == 0 else 0], dtype=torch.int64, device=dev)
+            d.all_reduce(t, op=d.ReduceOp.MAX, group=group)
+            total = int(t.item())
         return total, None
 
 
@@ -730,6 +736,11 @@ class SharedRecordList:
         self.address = ctypes.addressof(self._cbuf)
         pkg.host_register(self.address, self.nbytes)
         self.records = np.frombuffer(self._cbuf, dtype, self.capacity)
+        self.overflow = None   # rank 0, after a describe_into whose coarse octaves' records did not fit behind the slabs': the whole list
+
+    def view(self, n):
+        """The n records of the last describe_into."""
+        return self.overflow if self.overflow is not None else self.records[:n]
 
     def close(self):
         if self._mm is None:

@@ -242,7 +242,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
             if shared[0] is not None:
                 n, own = ex.describe_into(shared[0], desc_mode=desc, device=cdev)
                 if n is not None:
-                    return ex, (shared[0].records[:n] if rank == 0 else None), "placed"
+                    return ex, (shared[0].view(n) if rank == 0 else None), "placed"
                 recs, grp = own                                  # the list is too small for this volume's records: the old way
             else:
                 recs, grp = ex.describe(desc_mode=desc, copy=False)   # views of the pinned download buffers

@@ -358,7 +358,8 @@ typedef struct {
     int32_t rccl_version;         /* ncclGetVersion() of the library that was loaded (0 with peer copies) */
     int32_t comm_sets;            /* RCCL communicator sets in use: 2, or 1 with SIFT3D_ZSLAB_SERIAL_CHANNELS (0 with peer copies) */
     int32_t resident_volume;      /* 1: the input slices were on the devices already (sift3d_zslab_extract_resident): no upload in wall_ms */
-    int32_t reserved;
+    int32_t list_grown;           /* 1: the merged list had to be replaced by a larger one AFTER the slabs' records were in it (the coarse octaves'
+                                   * records did not fit behind them): the slabs' part was copied over.  Rare; tests force it */
     double merge_ms;              /* host time spent on the merged order (part of wall_ms).  Round 5: the ranks' descriptor kernels store their
                                    * records straight into their places in ONE pinned list, so this is the per-group offset table and its
                                    * upload (microseconds) plus, when the list has to grow, its allocation -- there is no merge left */
@@ -396,6 +397,10 @@ typedef struct {
  * 0 (default): before its per-keypoint stage -- they have every later octave to arrive in; 1: at the end of their own octave, with
  * the subsample's slices (rounds 2 - 4).  Same bytes either way. */
 #define SIFT3D_ZSLAB_PATCH_WAIT 1004
+/* sift3d_zslab_set_tuning(h, SIFT3D_ZSLAB_LIST_ROOM, n) (tests): a newly allocated merged list has room for n records behind the slabs'
+ * (the octaves that are not sharded append theirs there); -1 (default): an eighth of the slabs' records + 4096.  0 forces the growth
+ * path whenever those octaves have a record.  The handle's list is dropped by the call. */
+#define SIFT3D_ZSLAB_LIST_ROOM 1005
 void sift3d_zslab_set_transport_library(const char *path);
 int sift3d_extract_zslab(const int *devices, int n_devices, const float *vol, int64_t nx, int64_t ny, int64_t nz,
                          float initial_image_scale, int desc_mode, float eig_thres, float size_factor, sift3d_feature **out,

@@ -1234,6 +1234,35 @@ def test_c_zslab_patches_stay_within_the_fetched_halos(built, dims, seed, devs, 
     assert np.isfinite(want["scale"]).all() and (want["scale"] >= np.float32(1.6 * (1 + 2 ** (1.0 / 3)) * (1 - 1e-6))).all()
 
 
+def test_c_zslab_coarse_octaves_append_behind_the_slabs(built):
+    """The octaves that are not sharded have a rank of their own whose records are appended behind the slabs' (round 5): with no room
+    left behind them (SIFT3D_ZSLAB_LIST_ROOM 0) the list is replaced by a larger one after the slabs' kernels have stored into it --
+    the same bytes, and the stats say that it happened; with the default room it does not happen."""
+    dims = (192, 160, 256)
+    vol = vol_of(built, dims, 7)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract()
+    with built.ZSlab(dims[0], dims[1], dims[2], [0] * 4) as h:
+        got, st = h.extract(vol)
+        assert got.tobytes() == want.tobytes() and st["list_grown"] == 0
+        K = st["sharded_octaves"]
+        n_coarse = int((want["scale"] >= 3.6 * 2 ** K).sum())     # records of octave o have scales in [3.616, 7.232] * 2^o
+        assert 1 <= K <= 3 and 0 < n_coarse < len(want) // 8
+        h.set_tuning(built.ZSLAB_LIST_ROOM, 0)
+        got, st = h.extract(vol)
+        assert got.tobytes() == want.tobytes() and st["list_grown"] == 1
+        got, st = h.extract(vol)                      # the larger list is kept
+        assert got.tobytes() == want.tobytes() and st["list_grown"] == 0
+        h.set_volume(vol)
+        h.set_tuning(built.ZSLAB_LIST_ROOM, 0)
+        got, st = h.extract_resident()
+        assert got.tobytes() == want.tobytes() and st["list_grown"] == 1
+        h.set_tuning(built.ZSLAB_LIST_ROOM, n_coarse)   # exactly enough
+        got, st = h.extract_resident()
+        assert got.tobytes() == want.tobytes() and st["list_grown"] == 0
+
+
 def test_c_zslab_handle_is_reusable(built):
     """sift3d_zslab_create / _extract / _destroy: several volumes of one shape through one handle (the first run sizes the
     arena the later ones use), alternating descriptor modes; every result is the single-GPU one, byte for byte."""
@@ -1505,14 +1534,27 @@ def _zslab_worker(rank, world, port, dims, seed, mode, q):
                 ex.run(vol[i0:i1], i0)
                 n, own = ex.describe_into(shared, desc_mode=mode, device="cuda:0")
                 assert n == total[0] and own is None, (n, total)
-                placed = shared.records[:n].copy() if rank == 0 else None
+                placed = shared.view(n).copy() if rank == 0 else None
                 tiny = zs.SharedRecordList(pkg, dist, rank, 10, pkg.FEATURE_DTYPE)
                 ex.run(vol[i0:i1], i0)
                 n, own = ex.describe_into(tiny, desc_mode=mode, device="cuda:0")
                 assert n is None and own is not None
                 small = zs.gather_records(dist, rank, world, own[0], own[1], "cuda:0", dtype=pkg.FEATURE_DTYPE)
                 tiny.close()
+                # one record too few: the slabs' records fit and the coarser octaves' (appended by rank 0) do not -- rank 0 then keeps a
+                # list of its own for the run; or, if those octaves have no record here, the slabs' do not fit and everything is gathered
+                tight = zs.SharedRecordList(pkg, dist, rank, total[0] - 1, pkg.FEATURE_DTYPE)
+                ex.run(vol[i0:i1], i0)
+                n, own = ex.describe_into(tight, desc_mode=mode, device="cuda:0")
+                if n is None:
+                    close = zs.gather_records(dist, rank, world, own[0], own[1], "cuda:0", dtype=pkg.FEATURE_DTYPE)
+                else:
+                    assert n == total[0] and (rank != 0 or tight.overflow is not None)
+                    close = tight.view(n).copy() if rank == 0 else None
+                tight.close()
                 shared.close()
+                if rank == 0:
+                    small = (small, close)
         if rank == 0:
             q.put((plan.n_sharded, merged, stats, placed, small))
         if cctx is not None:
@@ -1566,7 +1608,7 @@ def test_zslab_processes_match_single_gpu(built, dims, seed, mode, world):
     assert len(want) > 50 and len(merged) == len(want)
     assert (merged.view(np.uint8) == want.view(np.uint8)).all()   # bit-identical records, same order
     if placed is not None:   # every rank's kernel stored its records in the one shared list / the list was too small: same bytes
-        assert placed.tobytes() == want.tobytes() and small.tobytes() == want.tobytes()
+        assert placed.tobytes() == want.tobytes() and small[0].tobytes() == want.tobytes() and small[1].tobytes() == want.tobytes()
     else:
         assert dims[0] * dims[1] * dims[2] > 2 ** 28
 
