@@ -1234,6 +1234,21 @@ def test_c_zslab_patches_stay_within_the_fetched_halos(built, dims, seed, devs, 
     assert np.isfinite(want["scale"]).all() and (want["scale"] >= np.float32(1.6 * (1 + 2 ** (1.0 / 3)) * (1 - 1e-6))).all()
 
 
+def test_c_zslab_every_octave_sharded(built):
+    """A long thin volume whose every octave is sharded (slabs of 1024, 512, 256, 128 slices): no octave is gathered, so there is no rank
+    for gathered octaves either -- the branch of the driver in which the slabs' ranks are all there is."""
+    dims = (40, 36, 2048)
+    vol = vol_of(built, dims, 17)
+    with built.Context(*dims) as ctx:
+        ctx.set_volume(vol)
+        want = ctx.extract()
+    for devs in ([0, 0], [0, 0, 0, 0]):
+        got, st = built.extract_zslab(vol, devs)
+        assert got.tobytes() == want.tobytes() and len(want) > 20, (len(got), len(want))
+        if len(devs) == 2:
+            assert st["sharded_octaves"] == 4 and st["gather_bytes"] == 0 and st["list_grown"] == 0
+
+
 def test_c_zslab_coarse_octaves_append_behind_the_slabs(built):
     """The octaves that are not sharded have a rank of their own whose records are appended behind the slabs' (round 5): with no room
     left behind them (SIFT3D_ZSLAB_LIST_ROOM 0) the list is replaced by a larger one after the slabs' kernels have stored into it --
