@@ -146,7 +146,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("dims,seed,world,bands", [((40, 36, 160), 3, 2, False), ((36, 40, 130), 9, 2, True), ((28, 24, 208), 5, 3, True),
-                                                   ((24, 20, 272), 8, 4, False), ((24, 20, 272), 8, 4, True)])
+                                                   ((24, 20, 272), 8, 4, False), ((24, 20, 272), 8, 4, True),
+                                                   ((20, 16, 1100), 2, 2, False)])   # (the last: every octave sharded, none gathered)
 def test_gloo_ranks_match_serial_oracle(oracle, built, dims, seed, world, bands):
     """World size 2, 3 and 4: from 3 on there are ranks with a neighbour on both sides (what every interior rank of an
     8-GPU run is).  The schedule under test exchanges 8 slices per level and defers the rest of the L1..L3 halos
