@@ -418,8 +418,10 @@ def zslab_c_main(args, pkg):
                             "transport": "rccl" if st["transport"] == pkg.TRANSPORT_RCCL else "peer_copy",
                             "transport_fell_back": bool(st["transport_fell_back"]), "rccl_version": st["rccl_version"], "comm_sets": st["comm_sets"],
                             "halo_bytes_critical": st["halo_bytes_critical"], "halo_bytes_hidden": st["halo_bytes_hidden"],
-                            "halo_bytes_deferred": st["halo_bytes_deferred"], "gather_bytes": st["gather_bytes"],
-                            "merge_ms": round(st["merge_ms"], 3), "resident_volume": bool(st["resident_volume"]),
+                            "halo_bytes_deferred": st["halo_bytes_deferred"], "halo_bytes_subsample": st["halo_bytes_subsample"],
+                            "gather_bytes": st["gather_bytes"], "merge_ms": round(st["merge_ms"], 3),
+                            "enqueue_ms": round(st["enqueue_ms"], 3),   # host time until the last rank's thread had queued its pyramid and count request
+                            "resident_volume": bool(st["resident_volume"]),
                             "workload": "ONE %s volume, %d Z-slabs, one process over devices %s (sift3d_zslab_extract_resident)" % (label, N, devices)})
             except pkg.Sift3DError as e:
                 res.update({"status": "failed", "error": str(e)[-400:]})
