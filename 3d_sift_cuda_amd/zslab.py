@@ -712,31 +712,58 @@ class SharedRecordList:
     _count = 0
 
     def __init__(self, pkg, dist, rank, capacity, dtype, group=None):
+        import ctypes
         import mmap
         import os
         self.pkg, self.capacity, self.rank = pkg, int(capacity), rank
         self.nbytes = max(1, self.capacity) * np.dtype(dtype).itemsize
+        self._mm, self._cbuf, self.records, self.overflow, self.address = None, None, None, None, 0
         SharedRecordList._count += 1
-        name = ["/dev/shm/sift3d_records_%d_%d" % (os.getpid(), SharedRecordList._count)] if rank == 0 else [None]
+        # Every collective below is reached by every rank whatever went wrong locally: a rank that cannot create, map or register the
+        # segment says so in the last one, and then EVERY rank raises -- nobody is left waiting in a broadcast for a rank that gave up.
+        err, name, fd = None, [None], -1
         if rank == 0:
-            fd = os.open(name[0], os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o600)
-            os.ftruncate(fd, self.nbytes)
+            try:
+                name = ["/dev/shm/sift3d_records_%d_%d" % (os.getpid(), SharedRecordList._count)]
+                fd = os.open(name[0], os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o600)
+                os.ftruncate(fd, self.nbytes)
+            except Exception as e:
+                err, name = e, [None]
         if dist is not None:
             dist.broadcast_object_list(name, src=0, group=group)
-        if rank != 0:
-            fd = os.open(name[0], os.O_RDWR)
-        self._mm = mmap.mmap(fd, self.nbytes)
-        os.close(fd)
+        try:
+            if name[0] is None:
+                raise err or RuntimeError("rank 0 could not create the shared segment")
+            if rank != 0:
+                fd = os.open(name[0], os.O_RDWR)
+            self._mm = mmap.mmap(fd, self.nbytes)
+        except Exception as e:
+            err = err or e
+        if fd >= 0:
+            os.close(fd)
         if dist is not None:
-            dist.barrier(group=group)   # every rank has it mapped: the name can go (the pages live as long as a mapping does)
-        if rank == 0:
-            os.unlink(name[0])
-        import ctypes
-        self._cbuf = (ctypes.c_char * self.nbytes).from_buffer(self._mm)
-        self.address = ctypes.addressof(self._cbuf)
-        pkg.host_register(self.address, self.nbytes)
-        self.records = np.frombuffer(self._cbuf, dtype, self.capacity)
-        self.overflow = None   # rank 0, after a describe_into whose coarse octaves' records did not fit behind the slabs': the whole list
+            dist.barrier(group=group)   # every rank has it mapped (or has failed): the name can go -- the pages live as long as a mapping does
+        if rank == 0 and name[0] is not None:
+            try:
+                os.unlink(name[0])
+            except OSError:
+                pass
+        if err is None:
+            try:
+                self._cbuf = (ctypes.c_char * self.nbytes).from_buffer(self._mm)
+                self.address = ctypes.addressof(self._cbuf)
+                pkg.host_register(self.address, self.nbytes)
+                self.records = np.frombuffer(self._cbuf, dtype, self.capacity)
+            except Exception as e:
+                err, self.address = e, 0
+        oks = [err is None]
+        if dist is not None:
+            oks = [None] * dist.get_world_size(group)
+            dist.all_gather_object(oks, err is None, group=group)
+        if not all(oks):
+            self.close()
+            raise RuntimeError("no shared record list: %s" % (err if err is not None else "rank(s) %s could not set it up" % [i for i, k in enumerate(oks) if not k]))
+        # self.overflow: rank 0, after a describe_into whose coarse octaves' records did not fit behind the slabs': the whole list
 
     def view(self, n):
         """The n records of the last describe_into."""
@@ -745,7 +772,9 @@ class SharedRecordList:
     def close(self):
         if self._mm is None:
             return
-        self.pkg.host_unregister(self.address)
+        if self.address:
+            self.pkg.host_unregister(self.address)
+            self.address = 0
         self.records = None
         self._cbuf = None
         try:

@@ -1570,6 +1570,20 @@ def _zslab_worker(rank, world, port, dims, seed, mode, q):
                 shared.close()
                 if rank == 0:
                     small = (small, close)
+                # a rank that cannot register the segment: EVERY rank's constructor raises (nobody waits in a collective for it)
+                orig = pkg.host_register
+                if rank == world - 1:
+                    def refuse(address, nbytes):
+                        raise pkg.Sift3DError("injected: no registration on this rank")
+                    pkg.host_register = refuse
+                try:
+                    zs.SharedRecordList(pkg, dist, rank, 1000, pkg.FEATURE_DTYPE)
+                    raised = False
+                except RuntimeError:
+                    raised = True
+                finally:
+                    pkg.host_register = orig
+                assert raised, rank
         if rank == 0:
             q.put((plan.n_sharded, merged, stats, placed, small))
         if cctx is not None:
