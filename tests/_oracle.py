@@ -10,6 +10,9 @@ ODIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ODIR, "_build", "libsift3d_oracle.so")
 LIB_OMP = os.path.join(ODIR, "_build", "libsift3d_oracle_omp.so")   # the multi-core build: bench.py's "fair CPU" line
 CLI = os.path.join(ODIR, "_build", "featExtract_oracle")
+# the restatement with the arithmetic of the reference's shipped CPU binary (-DO3_REFBIN_VARIANT: oracle/Makefile)
+LIB_REFBIN = os.path.join(ODIR, "_build", "libsift3d_oracle_refbin.so")
+CLI_REFBIN = os.path.join(ODIR, "_build", "featExtract_oracle_refbin")
 
 # the -w / -ws test case: an anisotropic blob field with a qform (qfac -1) and an sform that differ
 WORLD_CASE = dict(dims=(96, 80, 56), seed=4242, voxel=(1.0, 1.25, 1.5),
@@ -213,6 +216,21 @@ def load_omp():
             build()
         _inst_omp = Oracle(C.CDLL(LIB_OMP))
     return _inst_omp
+
+
+_inst_refbin = None
+
+
+def load_refbin():
+    """The -DO3_REFBIN_VARIANT build: the restatement with the one arithmetic difference the shipped CPU binary of the reference
+    shows in its disassembly (exp(float) is the C exp(double) in GaussianMask.cpp).  tests/test_oracle_pins.py holds it to the
+    binary's own .key files byte for byte; nothing else may use it."""
+    global _inst_refbin
+    if _inst_refbin is None:
+        if not os.path.exists(LIB_REFBIN):
+            build()
+        _inst_refbin = Oracle(C.CDLL(LIB_REFBIN))
+    return _inst_refbin
 
 
 def load_ref():

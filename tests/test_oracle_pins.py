@@ -116,6 +116,43 @@ def test_against_shipped_reference_binary(oracle, built, tmp_path, n, gold):
     assert o.max() < 2e-3
 
 
+def test_refbin_variant_is_byte_identical(built, tmp_path):
+    """Round 6: the stage-level pin.  The CPU binary the reference repository ships (R/bin/Linux/featExtract: GCC 5.4, not stripped,
+    no FMA instruction) was read function by function (objdump -d, never executed) against this repository's source.  Its
+    arithmetic differs from what a current g++ makes of the same lines in ONE place: GaussianMask.cpp includes <math.h>, and in
+    that toolchain exp(float) is the C function exp(double) (0x451c87, 0x451d0e, 0x4523b7: cvtss2sd; call exp@plt; the tap's
+    product with the scale formed in double, mulsd at 0x4523c0, and rounded once), where libstdc++ >= 6 picks expf and a float
+    product.  The oracle built with -DO3_REFBIN_VARIANT -- that one difference, three call sites -- reproduces all four .key files
+    the binary wrote, BYTE FOR BYTE: 74 and 1 698 records in voxel space, and the anisotropic -w / -ws case (resampling, qform and
+    sform, frames rotated to world space).  So blur, DoG, subsample, extrema, refinement, orientation, descriptor, rank and
+    writer of the oracle are the binary's to the last bit, and the 1e-6 .. 2e-5 spread test_against_shipped_reference_binary
+    tolerates is the last bit of the taps (expf against exp), nothing else -- not an FMA, not another revision of the source."""
+    import subprocess
+    orb = _oracle.load_refbin()
+    for n, gold in ((64, "refbin_blob64.key"), (128, "refbin_blob128.key.gz")):
+        p, recs = _oracle_key(orb, built, tmp_path, n)
+        path = os.path.join(GOLD, gold)
+        want = gzip.open(path, "rb").read() if gold.endswith(".gz") else open(path, "rb").read()
+        assert open(p, "rb").read() == want, gold
+        assert len(recs) == {64: 74, 128: 1698}[n]
+    nii = str(tmp_path / "aniso.nii")
+    subprocess.run(_oracle.world_case_args(nii), check=True)
+    for flag in ("-w", "-ws"):
+        key = str(tmp_path / ("v%s.key" % flag))
+        r = subprocess.run([_oracle.CLI_REFBIN, flag, nii, key], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert open(key, "rb").read() == open(os.path.join(GOLD, "refbin_aniso_%s.key" % flag[1:]), "rb").read(), flag
+    # and the variant differs from the oracle proper ONLY in the taps: same filter lengths, last-bit differences
+    o = _oracle.load()
+    worst = 0
+    for sigma in (1.5198684930801392, 1.2262736558914185, 1.5450079441070557, 1.9465880393981934, 2.452547311782837,
+                  3.0900158882141113, 0.5, 0.95, 1.2489995956420898):
+        a, b = o.taps(sigma), orb.taps(sigma)
+        assert len(a) == len(b)
+        worst = max(worst, int(np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64)).max()))
+    assert 1 <= worst <= 2          # units in the last place of a tap
+
+
 def _close_to_refbin(a, b):
     """World-coordinate records of the oracle CLI vs the shipped binary's.  The binary stores the first frame of
     about 1 % of keypoints with two image-axis components negated although its descriptor is the one sampled
