@@ -33,12 +33,12 @@ LIB_HOST = os.path.join(CSRC, "_build", "libsift3d_host.so")
 FEATEXTRACT = os.path.join(CSRC, "_build", "featExtract")
 
 DESC_SIFT, DESC_BRIEF, DESC_RRIEF, DESC_NRRIEF = 0, 1, 2, 3
-ABI_VERSION = 5   # SIFT3D_ABI_VERSION of include/sift3d.h: the structure layouts this file mirrors
+ABI_VERSION = 6   # SIFT3D_ABI_VERSION of include/sift3d.h: the structure layouts this file mirrors
 INFO_MIN0MAX1, INFO_REORIENT = 0x10, 0x20
 STAGES = ("blur_x", "blur_y", "blur_z_dog", "subsample", "extrema", "keypoint", "descriptor", "blur_fused", "octave_tiny")
 
 # sift3d_tuning (include/sift3d.h)
-TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST, TUNE_HOST_RECORDS, TUNE_FUSED_TILE, TUNE_FUSED_SUB, TUNE_SPLIT_TAIL, TUNE_DESC_SEGMENT, TUNE_FUSED_ORDER = range(14)
+TUNE_BLUR_FUSED, TUNE_FUSED_CHUNKS, TUNE_FUSED_ROWS, TUNE_LAZY_LEVELS, TUNE_TINY_OCTAVE, TUNE_SAMPLER_CAP, TUNE_KP_CHUNKS, TUNE_BANDS_FIRST, TUNE_HOST_RECORDS, TUNE_FUSED_TILE, TUNE_FUSED_SUB, TUNE_SPLIT_TAIL, TUNE_DESC_SEGMENT, TUNE_FUSED_ORDER, TUNE_FUSED_STAGGER = range(15)
 
 EXTREMUM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("value", "<f4")])
 FEATURE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("scale", "<f4"), ("ori", "<f4", (9,)),
@@ -112,6 +112,8 @@ def hip_lib():
     _sig(L.sift3d_sync, I, P)
     _sig(L.sift3d_free, None, P)
     _sig(L.sift3d_gauss_taps, I, F, F, P)
+    _sig(L.sift3d_set_libm_variant, I, I)
+    _sig(L.sift3d_get_libm_variant, I)
     _sig(L.sift3d_gauss_blur, I, P, P, P, I64, I64, I64, F, F)
     _sig(L.sift3d_gauss_blur_dev, I, P, P, P, I64, I64, I64, F, F)
     _sig(L.sift3d_gauss_blur_dog_dev, I, P, P, P, P, I64, I64, I64, F, F)
@@ -382,6 +384,17 @@ def match_votes(first, labels, n_labels, nn_idx, nn_dist2):
     if rc != 0:
         raise Sift3DError("sift3d_match_votes -> %d" % rc)
     return votes, counts
+
+
+LIBM_CURRENT, LIBM_GCC5 = 0, 1   # sift3d_set_libm_variant
+
+
+def set_libm_variant(which):
+    """Process-wide: which build of the reference the Gaussian taps follow (include/sift3d.h); returns the previous setting."""
+    r = hip_lib().sift3d_set_libm_variant(int(which))
+    if r < 0:
+        raise Sift3DError("sift3d_set_libm_variant(%r) -> %d" % (which, r))
+    return r
 
 
 def gauss_taps(sigma, min_value=0.01):

@@ -122,20 +122,31 @@ static std::vector<octave_dims> octave_list(int64_t X, int64_t Y, int64_t Z)
     return v;
 }
 
+/* (Re)size the candidate, sort and key buffers.  The new buffers are made first and the old ones released only when every
+ * allocation succeeded: a failed growth leaves the context as it was (old buffers, old capacity) and reports SIFT3D_ERR_MEMORY,
+ * so a caller that ignores the result of sift3d_reserve still runs on valid buffers (round-5 advisor finding). */
 static int alloc_cands(sift3d_ctx *c, int64_t cap)
 {
+    unsigned long long *ka = nullptr, *kb = nullptr;
+    sift3d_cval *va = nullptr, *vb = nullptr;
+    void *tmp = nullptr;
+    const size_t tmp_bytes = sift3d_sort_temp_bytes(cap) + 256;
+    const bool ok = hipMalloc((void **)&ka, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
+                    hipMalloc((void **)&kb, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
+                    hipMalloc((void **)&va, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess &&
+                    hipMalloc((void **)&vb, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess && hipMalloc(&tmp, tmp_bytes) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        hipFree(ka); hipFree(kb); hipFree(va); hipFree(vb); hipFree(tmp);
+        return SIFT3D_ERR_MEMORY;
+    }
     hipFree(c->keys_a); hipFree(c->keys_b); hipFree(c->vals_a); hipFree(c->vals_b); hipFree(c->sort_tmp);
-    c->keys_a = c->keys_b = nullptr;
-    c->vals_a = c->vals_b = nullptr;
-    c->sort_tmp = nullptr;
+    c->keys_a = ka; c->keys_b = kb;
+    c->vals_a = va; c->vals_b = vb;
+    c->sort_tmp = tmp;
+    c->sort_tmp_bytes = tmp_bytes;
     c->cand_cap = cap;
-    c->sort_tmp_bytes = sift3d_sort_temp_bytes(cap) + 256;
-    bool ok = hipMalloc((void **)&c->keys_a, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
-              hipMalloc((void **)&c->keys_b, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
-              hipMalloc((void **)&c->vals_a, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess &&
-              hipMalloc((void **)&c->vals_b, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess &&
-              hipMalloc(&c->sort_tmp, c->sort_tmp_bytes) == hipSuccess;
-    return ok ? SIFT3D_OK : SIFT3D_ERR_MEMORY;
+    return SIFT3D_OK;
 }
 
 static void destroy_sync_objects(sift3d_ctx *c)
@@ -248,8 +259,8 @@ extern "C" void sift3d_destroy(sift3d_ctx *c)
 extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
 {
     if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2, 1 << 20, 3};
+    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0},
+                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2, 1 << 20, 3, 2};
     if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
         return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
     c->tune[knob] = value;
@@ -503,7 +514,7 @@ int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, 
     /* One fused launch per level where the volume fills the chip (it marches along z with few, fat workgroups);
      * coarse octaves keep the three-pass path.  SIFT3D_TUNE_BLUR_FUSED: 0 never / 2 always (tests, A/B timing). */
     const int fmode = c->tune[SIFT3D_TUNE_BLUR_FUSED];
-    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE], c->tune[SIFT3D_TUNE_FUSED_ORDER]};
+    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE], c->tune[SIFT3D_TUNE_FUSED_ORDER], c->tune[SIFT3D_TUNE_FUSED_STAGGER]};
     /* measured standalone (tools/bench_blur_ab.sh 128 / 64): below 2^22 voxels the one launch still beats the three for 7 and
      * 9 taps (0.020 / 0.026 against 0.042 / 0.043 ms at 128^3), ties at 11-13 and loses at 17 */
     if (fmode == 2 || (fmode == 1 && (N >= (double)(1 << 22) || (N >= (double)(1 << 18) && n <= 9)))) {
@@ -593,7 +604,7 @@ int blur_window_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int6
     float taps[SIFT3D_MAX_TAPS];
     const int n = sift3d_gauss_taps(sigma, min_value, taps);
     if (n < 3 || zo0 < 0 || zo1 > Z || zo1 <= zo0) return set_err(c, SIFT3D_ERR_ARG, "bad blur window [%lld, %lld) of %lld planes", (long long)zo0, (long long)zo1, (long long)Z);
-    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE], c->tune[SIFT3D_TUNE_FUSED_ORDER]};
+    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE], c->tune[SIFT3D_TUNE_FUSED_ORDER], c->tune[SIFT3D_TUNE_FUSED_STAGGER]};
     const double N = (double)X * Y * (double)(zo1 - zo0);
     stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N);
     hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, X, Y, Z, taps, n, &bt, zo0, zo1);
@@ -1032,17 +1043,9 @@ static int load_volume_prepare(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz
 static int load_volume(sift3d_ctx *c, const float *src, bool from_host, int64_t nx, int64_t ny, int64_t nz)
 {
     const int64_t xp = pitch_of(nx);
-    if (xp != nx && (c->pad_nx != nx || c->pad_ny != ny || c->pad_nz != nz)) {
-        for (int i = 0; i < 6; i++)
-            if (c->L[i]) HIPCHK(c, hipMemsetAsync(c->L[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
-        for (int i = 0; i < 5; i++)
-            if (c->D[i]) HIPCHK(c, hipMemsetAsync(c->D[i], 0, sizeof(float) * (size_t)c->capTot, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->vol, 0, sizeof(float) * (size_t)c->capN, c->stream));
-        c->pad_nx = nx; c->pad_ny = ny; c->pad_nz = nz;
-    }
+    const int rcp = load_volume_prepare(c, nx, ny, nz);
+    if (rcp) return rcp;
     if (xp == nx) {
-        c->pad_nx = 0; /* dense rows overwrite what would be pad columns of another geometry */
         if (src != c->vol)
             HIPCHK(c, hipMemcpyAsync(c->vol, src, sizeof(float) * (size_t)(nx * ny * nz), from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
     } else {
@@ -1139,6 +1142,7 @@ extern "C" int sift3d_set_volume_begin(sift3d_ctx *c, int64_t nx, int64_t ny, in
     c->up.nx = nx; c->up.ny = ny; c->up.nz = nz;
     c->up.got = 0;
     c->up.resize = resize;
+    c->up.seen.assign((size_t)nz, false);
     return SIFT3D_OK;
 }
 
@@ -1149,6 +1153,12 @@ extern "C" int sift3d_set_volume_planes(sift3d_ctx *c, const float *planes, int6
         c->up.open = false; /* a caller that hands over planes the volume does not have starts again */
         return set_err(c, SIFT3D_ERR_ARG, "set_volume_planes: planes [%lld, %lld) of %lld", (long long)z0, (long long)(z0 + n), (long long)c->up.nz);
     }
+    for (int64_t z = z0; z < z0 + n; z++)
+        if (c->up.seen[(size_t)z]) { /* counting planes alone would accept a plane twice in place of one that never came */
+            c->up.open = false;
+            return set_err(c, SIFT3D_ERR_ARG, "set_volume_planes: plane %lld arrived twice", (long long)z);
+        }
+    for (int64_t z = z0; z < z0 + n; z++) c->up.seen[(size_t)z] = true;
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t nx = c->up.nx, ny = c->up.ny, xp = pitch_of(nx);
     if (c->up.resize != 0) {

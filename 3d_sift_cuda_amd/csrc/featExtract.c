@@ -234,6 +234,20 @@ int main(int argc, char **argv)
             if (argv[arg][2] == 's' || argv[arg][2] == 'S') world_mode = 2;
             arg++;
             break;
+        case '-':
+            /* beyond the reference (its switch has no '-' case: there "--..." is an unknown argument): --libm=gcc5 makes the
+             * Gaussian taps those of the CPU binary the reference repository ships (exp() of a float evaluated by the C
+             * exp(double), include/sift3d.h: sift3d_set_libm_variant), so that the .key file is that binary's byte for byte;
+             * --libm=current is the default, the reference as a current g++ compiles it */
+            if (strcmp(argv[arg], "--libm=gcc5") == 0) sift3d_set_libm_variant(SIFT3D_LIBM_GCC5);
+            else if (strcmp(argv[arg], "--libm=current") == 0) sift3d_set_libm_variant(SIFT3D_LIBM_CURRENT);
+            else {
+                printf("Error: unknown command line argument: %s\n", argv[arg]);
+                print_options();
+                return -1;
+            }
+            arg++;
+            break;
         default:
             printf("Error: unknown command line argument: %s\n", argv[arg]);
             print_options();
@@ -324,7 +338,8 @@ int main(int argc, char **argv)
         return -1;
     }
     if (job.ndev <= 0 || device >= job.ndev) {
-        fprintf(stderr, "Error: no usable HIP device %d (this build has no CPU fallback).\n", device);
+        fprintf(stderr, "Error: no usable HIP device %d.  This build has no CPU fallback: the reference's CPU mode (no -d) is "
+                        "oracle/_build/featExtract_oracle in this repository (same options, same .key; test infrastructure, single thread).\n", device);
         return -1;
     }
     if (world_mode) { /* the resampled image is what is processed */

@@ -135,7 +135,22 @@ struct fb_ring_cfg {
  * even plane's sum first) -- from the finished planes it holds in registers: a thread's 2 x 2 block of a plane IS one such
  * block, and the block of the plane before waits in one register.  The subsample launch, which read the whole level again
  * (0.10 ms at 512^3), is gone; the z chunks start on even planes so that a pair never straddles two workgroups. */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false>
+/* STG (round 6): the second-dispatched half of the wavefronts runs half a step behind the first.  Every wavefront runs the same
+ * program with one barrier per plane, so without it the two wavefronts of a SIMD (w and w + 4 of a 512-thread workgroup share one)
+ * reach their LDS read burst, their arithmetic and the barrier together: the SIMD idles while both wait for the y pass's rows and
+ * both want its issue slots afterwards (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  With STG, wavefronts NT/128 .. keep
+ * the y-pass result g of a plane (and the DoG's input voxel) in registers across the barrier and run that plane's z pass, DoG
+ * and stores at the START of the next step -- pure arithmetic, nothing to wait for -- while their SIMD partners wait for LDS;
+ * the same operations on the same operands in the same order per accumulator, so the same bits.  Each (half, role) pair runs its
+ * own copy of the march (wave-uniform branches in front of it), so every copy is straight-line code with exactly counted vmcnt
+ * waits (and 170 registers at 13 taps instead of 222).  Measured (profiles/r06_stagger_ab.txt): the copies ALONE are 10 % slower
+ * at 11 - 13 taps (exact waits let a wavefront start its x pass the moment its window is in, and both wavefronts of a SIMD then
+ * collide on the y pass's LDS burst harder than before); with the stagger on top the 11- and 13-tap launches come out 2 - 3 %
+ * ahead of the round-5 kernel, the 9-tap + DoG launch equal, the level-only launches 2 - 3 % behind -- so the launcher turns it
+ * on from 11 taps up.  Under rocprofv3's counter runs, where the chip clocks differently, the same build is 12 - 14 % ahead at
+ * 11 - 13 taps; un-profiled it is not.  Also measured and not kept: the stagger with the role tested at run time (3 % slower than
+ * the round-5 kernel at 13 taps), three planes of prefetch under the stagger (no better than two), one plane (20 % slower). */
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false, bool STG = false>
 __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES_PER_SIMD)) void blur_fused_ring_kernel(
     const float *__restrict__ in, float *__restrict__ out, float *__restrict__ dog, int X, int Y, int Z, int zo0, int zo1, int zlen,
     int tiles_x, int tiles_y, long long total, int order, fb_taps2 t, float *__restrict__ sub = nullptr)
@@ -333,60 +348,73 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1 % PF>;
     using B2 = std::integral_constant<int, 2 % PF>;
-    if (xrole) { /* plane zfirst + k lives in window buffer k % PF */
-        load_window(zfirst, B0{});
-        x_pass(P1b, pvb, B0{});        /* plane zfirst (zeros when it lies before the volume) */
-        if constexpr (PF == 3) {
-            load_window(zfirst + 1, B1{});
-            load_window(zfirst + 2, B2{});
-            load_window(zfirst + 3, B0{});
-        } else if constexpr (PF == 2) {
-            load_window(zfirst + 1, B1{});
-            load_window(zfirst + 2, B0{});
-        } else {
-            load_window(zfirst + 1, B0{});
-        }
-    }
-    {
+    /* XC: 0 = the x-pass role is tested at run time (the form of rounds 2 - 5), 1 / 2 = this copy of the code is run by wavefronts
+     * that have it / do not have it.  With the role known at compile time a step is straight-line code on every path and the
+     * compiler's wait in front of the x pass is exact: vmcnt(19) .. (14) for the six vectors of a 13-tap window loaded two steps
+     * earlier (two steps of 6 loads + 4 stores lie behind it); with the run-time test it has to assume that a step in between
+     * may have skipped its loads and waits with vmcnt(13) .. (8), i.e. also for the first loads of the NEXT plane's window. */
+    auto dropped_stores = [&]() { /* one step's stores through descriptors of no records: they only count in vmcnt */
         v2f z2[BR];
 #pragma unroll
         for (int r = 0; r < BR; r++) z2[r] = v2f(0.0f);
-        store_plane(false, 0u, z2, z2); /* dropped; same vmcnt state as the loop's back edge */
+        store_plane(false, 0u, z2, z2);
         if constexpr (HAS_SUB) {
             const __amdgpu_buffer_rsrc_t rsub = __builtin_amdgcn_make_buffer_rsrc((void *)sub, 0, 0, FB_RSRC_FLAGS);
             __builtin_amdgcn_raw_buffer_store_b32(0, rsub, (int)suboff, 0, 0);
         }
-    }
-    wslot = 1;
-    lds_barrier();
+    };
+    /* The windows of the first PF planes are requested with the loop's own pattern of stores between them, so that the
+     * compiler's count of the operations behind a window at the loop's entry is the steady state's (it waits for the smaller of
+     * the two): a step of the first half is "loads, stores", of the staggered half "stores, loads". */
+    auto prologue = [&](auto late_c, auto xc) {
+        constexpr bool LATE = decltype(late_c)::value;
+        constexpr int XC = decltype(xc)::value;
+        const bool xr = XC == 0 ? xrole : XC == 1;
+        if (xr) { /* plane zfirst + k lives in window buffer k % PF */
+            load_window(zfirst, B0{});
+            x_pass(P1b, pvb, B0{});        /* plane zfirst (zeros when it lies before the volume) */
+            if constexpr (XC == 0) { /* the form of rounds 2 - 5 */
+                if constexpr (PF == 3) {
+                    load_window(zfirst + 1, B1{});
+                    load_window(zfirst + 2, B2{});
+                    load_window(zfirst + 3, B0{});
+                } else if constexpr (PF == 2) {
+                    load_window(zfirst + 1, B1{});
+                    load_window(zfirst + 2, B0{});
+                } else {
+                    load_window(zfirst + 1, B0{});
+                }
+            } else {
+                if constexpr (PF == 3) {
+                    load_window(zfirst + 1, B1{});
+                    dropped_stores();
+                    load_window(zfirst + 2, B2{});
+                    dropped_stores();
+                    load_window(zfirst + 3, B0{});
+                } else if constexpr (PF == 2) {
+                    load_window(zfirst + 1, B1{});
+                    dropped_stores();
+                    load_window(zfirst + 2, B0{});
+                } else {
+                    load_window(zfirst + 1, B0{});
+                }
+            }
+        }
+        if constexpr (!LATE || XC == 0) dropped_stores(); /* same vmcnt state as the loop's back edge */
+        wslot = 1;
+        lds_barrier();
+    };
 
-    /* one step: y pass of plane zin from P1[cur], x pass of plane zin + 1 into the other buffer, z pass; EMIT: plane
-     * zin - R is complete and is stored */
-    auto step = [&](int zin, auto bsel) { /* bsel: the window buffer that holds plane zin + 1 */
-        const bool emit = zin - R >= zc0; /* wave-uniform: plane zin - R is complete (it is < zc1 by construction of zlast) */
-        const float *P1 = P1b + cur * P1PL;
-        v2f p[U + BR - 1];
-#pragma unroll
-        for (int q = 0; q < U + BR - 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(brow + q) * TX + 2 * bcp]);
-        v2f g[BR];
-#pragma unroll
-        for (int r = 0; r < BR; r++) {
-            v2f a = v2f(0.0f);
-#pragma unroll
-            for (int j = 0; j < U; j++) a = a + t.f[j] * p[j + r];
-            g[r] = a;
-        }
-        if (xrole) {
-            x_pass(P1b + (cur ^ 1) * P1PL, pvb + wslot * PVPL, bsel);
-            load_window(zin + 1 + PF, bsel); /* the buffer is free again */
-        }
-        /* ---- C: z pass, shift form.  Slot i holds the output plane that completes in i + 1 steps and therefore takes
-         * tap U-1-i of the new plane; the sum moves one slot down as it is updated (a three-operand add reads slot i+1 and
-         * writes slot i, so the shift costs nothing), slot U-1 restarts from 0 + f[0]*g.  Every slot index is a
-         * compile-time register without a switch on the plane's phase: the first form's switch cost 2R+1 register
-         * copies per step (the phi nodes of its cases), 2R+1 copies of the z-pass code and a basic-block boundary
-         * between the passes.  The taps are bit-symmetric (checked by the launcher), so f[j]*g and f[U-1-j]*g are
-         * one product: R+1 multiplies instead of 2R+1, the additions and their order unchanged. ---- */
+    /* z pass of the plane whose y-pass result is g, shift form, and the stores of the output plane it completes (zp - R).
+     * Slot i holds the output plane that completes in i + 1 steps and therefore takes tap U-1-i of the new plane; the sum moves
+     * one slot down as it is updated (a three-operand add reads slot i+1 and writes slot i, so the shift costs nothing), slot
+     * U-1 restarts from 0 + f[0]*g.  Every slot index is a compile-time register without a switch on the plane's phase: the
+     * first form's switch cost 2R+1 register copies per step (the phi nodes of its cases), 2R+1 copies of the z-pass code and a
+     * basic-block boundary between the passes.  The taps are bit-symmetric (checked by the launcher), so f[j]*g and
+     * f[U-1-j]*g are one product: R+1 multiplies instead of 2R+1, the additions and their order unchanged.
+     * pv: the DoG's input voxels of plane zp - R (from the LDS ring). */
+    auto z_tail = [&](int zp, const v2f(&g)[BR], const v2f(&pv)[BR]) {
+        const bool emit = zp - R >= zc0; /* wave-uniform: plane zp - R is complete (it is < zc1 by construction of zlast) */
         v2f a[BR];
 #pragma unroll
         for (int r = 0; r < BR; r++) {
@@ -401,57 +429,123 @@ __global__ __launch_bounds__(1024 / BR, (fb_ring_cfg<R, BR, PF, TXv, TYv>::WAVES
             }
             a[r] = acc[r][0];
         }
-        {
-            const unsigned so = emit ? (unsigned)(zin - R - zc0) * plane_bytes : 0u;
-            v2f dg[BR];
-            if constexpr (HAS_DOG) {
-                const int rslot = wslot + 1 == S ? 0 : wslot + 1;
-                const float *pvp = pvb + rslot * PVPL + brow * TX + 2 * bcp;
+        const unsigned so = emit ? (unsigned)(zp - R - zc0) * plane_bytes : 0u;
+        v2f dg[BR];
 #pragma unroll
-                for (int r = 0; r < BR; r++) dg[r] = *reinterpret_cast<const v2f *>(pvp + r * TX) - a[r];
-            } else {
+        for (int r = 0; r < BR; r++) dg[r] = HAS_DOG ? pv[r] - a[r] : v2f(0.0f);
+        store_plane(emit, so, a, dg);
+        if constexpr (HAS_SUB) {
+            const int zo = zp - R; /* the plane just finished (meaningful when emit) */
+            const float pa = ((a[0].x + a[1].x) + a[0].y) + a[1].y;
+            float sm = 0.0f;
+            sm = sm + subacc;
+            sm = sm + pa;
+            const bool pair_done = emit && (zo & 1) && (zo >> 1) < oZ; /* wave-uniform */
+            /* issued on every step, like the other stores: through a descriptor of no records unless a pair is complete */
+            const __amdgpu_buffer_rsrc_t rsub =
+                __builtin_amdgcn_make_buffer_rsrc((void *)sub, 0, pair_done ? (int)((unsigned)oZ * sub_plane_bytes) : 0, FB_RSRC_FLAGS);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sm * 0.125f), rsub, (int)suboff,
+                                                  pair_done ? (int)((unsigned)(zo >> 1) * sub_plane_bytes) : 0, 0);
+            subacc = pa;
+        }
+    };
+    /* LATE wavefronts: y-pass result and DoG input of the plane whose z pass is still to run */
+    v2f gprev[BR], pvprev[BR];
 #pragma unroll
-                for (int r = 0; r < BR; r++) dg[r] = v2f(0.0f);
+    for (int r = 0; r < BR; r++) gprev[r] = pvprev[r] = v2f(0.0f);
+
+    /* one step: y pass of plane zin from P1[cur], x pass of plane zin + 1 into the other buffer, z pass; plane zin - R is
+     * complete and is stored (LATE: plane zin - 1 - R, at the start of the step; a first step with nothing pending shifts
+     * zeros through accumulators that are zero, and its stores are dropped like every lead-in step's) */
+    auto step = [&](int zin, auto bsel, auto late_c, auto xc) { /* bsel: the window buffer that holds plane zin + 1 */
+        constexpr bool LATE = decltype(late_c)::value;
+        constexpr int XC = decltype(xc)::value;
+        const bool xr = XC == 0 ? xrole : XC == 1;
+        const float *P1 = P1b + cur * P1PL;
+        v2f p[U + BR - 1];
+#pragma unroll
+        for (int q = 0; q < U + BR - 1; q++) p[q] = *reinterpret_cast<const v2f *>(&P1[(brow + q) * TX + 2 * bcp]);
+        if constexpr (LATE) {
+            /* the y pass's rows are requested, and while they travel (and the SIMD partner, which asked for its rows at the same
+             * moment, can only wait) the pending plane's z pass, DoG and stores run: nothing in them waits for anything.  The
+             * fences keep the instruction scheduler from moving that block behind the y pass again (it did). */
+            __builtin_amdgcn_sched_barrier(0);
+            z_tail(zin - 1, gprev, pvprev);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        v2f g[BR];
+#pragma unroll
+        for (int r = 0; r < BR; r++) {
+            v2f a = v2f(0.0f);
+#pragma unroll
+            for (int j = 0; j < U; j++) a = a + t.f[j] * p[j + r];
+            g[r] = a;
+        }
+        if (xr) {
+            x_pass(P1b + (cur ^ 1) * P1PL, pvb + wslot * PVPL, bsel);
+            load_window(zin + 1 + PF, bsel); /* the buffer is free again */
+        }
+        v2f pv[BR];
+        if constexpr (HAS_DOG) {
+            const int rslot = wslot + 1 == S ? 0 : wslot + 1;
+            const float *pvp = pvb + rslot * PVPL + brow * TX + 2 * bcp;
+#pragma unroll
+            for (int r = 0; r < BR; r++) pv[r] = *reinterpret_cast<const v2f *>(pvp + r * TX);
+        } else {
+#pragma unroll
+            for (int r = 0; r < BR; r++) pv[r] = v2f(0.0f);
+        }
+        if constexpr (LATE) {
+#pragma unroll
+            for (int r = 0; r < BR; r++) {
+                gprev[r] = g[r];
+                pvprev[r] = pv[r];
             }
-            store_plane(emit, so, a, dg);
-            if constexpr (HAS_SUB) {
-                const int zo = zin - R; /* the plane just finished (meaningful when emit) */
-                const float pa = ((a[0].x + a[1].x) + a[0].y) + a[1].y;
-                float sm = 0.0f;
-                sm = sm + subacc;
-                sm = sm + pa;
-                const bool pair_done = emit && (zo & 1) && (zo >> 1) < oZ; /* wave-uniform */
-                /* issued on every step, like the other stores: through a descriptor of no records unless a pair is complete */
-                const __amdgpu_buffer_rsrc_t rsub =
-                    __builtin_amdgcn_make_buffer_rsrc((void *)sub, 0, pair_done ? (int)((unsigned)oZ * sub_plane_bytes) : 0, FB_RSRC_FLAGS);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sm * 0.125f), rsub, (int)suboff,
-                                                      pair_done ? (int)((unsigned)(zo >> 1) * sub_plane_bytes) : 0, 0);
-                subacc = pa;
-            }
+        } else {
+            z_tail(zin, g, pv);
         }
         cur ^= 1;
         wslot = wslot + 1 == S ? 0 : wslot + 1;
         lds_barrier(); /* the other P1 buffer and the ring slot are complete, every wavefront has read this P1 buffer */
     };
     /* the first 2R steps are lead-in: their stores are dropped */
-    if constexpr (PF == 3) {
-        int zin = zfirst;
-        for (; zin + 2 <= zlast; zin += 3) {
-            step(zin, B1{});
-            step(zin + 1, B2{});
-            step(zin + 2, B0{});
+    auto march = [&](auto late_c, auto xc) {
+        constexpr bool LATE = decltype(late_c)::value;
+        prologue(late_c, xc);
+        if constexpr (PF == 3) {
+            int zin = zfirst;
+            for (; zin + 2 <= zlast; zin += 3) {
+                step(zin, B1{}, late_c, xc);
+                step(zin + 1, B2{}, late_c, xc);
+                step(zin + 2, B0{}, late_c, xc);
+            }
+            if (zin <= zlast) step(zin, B1{}, late_c, xc);
+            if (zin + 1 <= zlast) step(zin + 1, B2{}, late_c, xc);
+        } else if constexpr (PF == 2) {
+            int zin = zfirst;
+            for (; zin + 1 <= zlast; zin += 2) {
+                step(zin, B1{}, late_c, xc);     /* plane zfirst + 1 went to buffer 1 */
+                step(zin + 1, B0{}, late_c, xc);
+            }
+            if (zin <= zlast) step(zin, B1{}, late_c, xc);
+        } else {
+            for (int zin = zfirst; zin <= zlast; zin++) step(zin, B0{}, late_c, xc);
         }
-        if (zin <= zlast) step(zin, B1{});
-        if (zin + 1 <= zlast) step(zin + 1, B2{});
-    } else if constexpr (PF == 2) {
-        int zin = zfirst;
-        for (; zin + 1 <= zlast; zin += 2) {
-            step(zin, B1{});     /* plane zfirst + 1 went to buffer 1 */
-            step(zin + 1, B0{});
+        if constexpr (LATE) z_tail(zlast, gprev, pvprev); /* the last plane's z pass and stores */
+    };
+    using XRT = std::integral_constant<int, 0>; /* role tested at run time */
+    using XRY = std::integral_constant<int, 1>;
+    using XRN = std::integral_constant<int, 2>;
+    if constexpr (!STG) {
+        march(std::false_type{}, XRT{});
+    } else { /* wave-uniform branches: one copy of the march per (half, role) */
+        if (wv < C::NT / 128) { /* the first-dispatched half */
+            if (xrole) march(std::false_type{}, XRY{});
+            else march(std::false_type{}, XRN{});
+        } else {
+            if (xrole) march(std::true_type{}, XRY{});
+            else march(std::true_type{}, XRN{});
         }
-        if (zin <= zlast) step(zin, B1{});
-    } else {
-        for (int zin = zfirst; zin <= zlast; zin++) step(zin, B0{});
     }
 }
 
@@ -478,7 +572,7 @@ static int fused_chunks(int R, int64_t Z, long long tiles, int resident, int for
 
 /* Returns false when the shape is outside the kernel (32-bit buffer offsets: a chunk with its lead-in planes must stay
  * below 4 GiB -- a volume whose planes are that large gets more z chunks, and only a plane pair beyond 4 GiB has none) */
-template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false>
+template <int R, int BR, bool HAS_OUT, bool HAS_DOG, int PF, int TXv = FB_TX, int TYv = 32, bool HAS_SUB = false, bool STG = false>
 static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
                           const fb_taps2 &t, int forced_chunks, float *sub = nullptr, int order = 0)
 {
@@ -486,7 +580,7 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
     static int resident = 0; /* workgroups of this instantiation one CU holds (LDS, registers) */
     if (resident == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv, HAS_SUB>, C::NT, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv, HAS_SUB, STG>, C::NT, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     const int64_t plane_bytes = X * Y * 4;
@@ -510,18 +604,18 @@ static bool launch_ring_t(hipStream_t s, const float *in, float *out, float *dog
         const bool ok = tiles_x >= 8 ? tiles_x % 8 == 0 : (8 % tiles_x == 0 && M % (8 / tiles_x) == 0);
         if (!ok) order = 1;
     }
-    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv, HAS_SUB>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
+    hipLaunchKernelGGL((blur_fused_ring_kernel<R, BR, HAS_OUT, HAS_DOG, PF, TXv, TYv, HAS_SUB, STG>), dim3((unsigned)(8 * per)), dim3(C::NT), 0, s, in, out, dog, (int)X,
                        (int)Y, (int)Z, (int)zo0, (int)zo1, zlen, tiles_x, tiles_y, total, order, t, sub);
     return true;
 }
 
-template <int R, int BR, int PF, int TXv = FB_TX, int TYv = 32>
+template <int R, int BR, int PF, int TXv = FB_TX, int TYv = 32, bool STG = false>
 static bool launch_ring_pf(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
                            const fb_taps2 &t, int chunks, int order)
 {
-    if (out && dog) return launch_ring_t<R, BR, true, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
-    if (out) return launch_ring_t<R, BR, true, false, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
-    return launch_ring_t<R, BR, false, true, PF, TXv, TYv>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
+    if (out && dog) return launch_ring_t<R, BR, true, true, PF, TXv, TYv, false, STG>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
+    if (out) return launch_ring_t<R, BR, true, false, PF, TXv, TYv, false, STG>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
+    return launch_ring_t<R, BR, false, true, PF, TXv, TYv, false, STG>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, nullptr, order);
 }
 
 /* The two mappings, by measurement at 512^3 and 256^3: two rows per thread, two planes of window
@@ -539,11 +633,22 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     /* the half-size volume beside the level (HAS_SUB): built for the one filter the pyramid asks it of -- level 3 is 11 taps
      * in every octave (oracle: sigma_extra[3]) -- with both arrays stored, the whole volume produced and rows that halve into
      * whole 16-byte vectors; anything else leaves *sub_done 0 and the caller launches the subsample itself */
+    /* the half-step stagger of the second half of the wavefronts with one copy of the march per (half, role) -- the kernel's STG:
+     * tune->stagger 0 = by measurement, 1 = off (the kernel of rounds 2 - 5), 2 = on; built for the two-rows-per-thread mapping
+     * (eight wavefronts, two per SIMD) and the filters the pyramid launches (7 - 13 taps).  By measurement at 512^3
+     * (profiles/r06_stagger_ab.txt; ms per launch off -> on): 11 taps + DoG + half-size volume 0.357 - 0.363 -> 0.346 - 0.354, 13 taps
+     * + DoG 0.365 - 0.373 -> 0.352 - 0.367, 9 taps + DoG equal (0.300 - 0.307 / 0.297 - 0.305), the two level-only launches 2 - 3 %
+     * SLOWER (7 taps 0.201 - 0.203 -> 0.205 - 0.212, 9 taps 0.217 - 0.225 -> 0.220 - 0.228): on from 11 taps up. */
+    const int stg_knob = tune ? tune->stagger : 0;
+    const bool stg = R >= 3 && R <= 6 && (stg_knob == 2 || (stg_knob == 0 && R >= 5));
     if constexpr (R == 5)
         if (sub && br == 2 && out && dog && zo0 == 0 && zo1 == Z && X % 8 == 0 && Z >= 2 && Y >= 2) {
             const bool wide5 = (tune ? tune->tile : 0) == 2 && X >= 128;
-            const bool ok = wide5 ? launch_ring_t<5, 2, true, true, 2, 128, 16, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order)
-                                  : launch_ring_t<5, 2, true, true, 2, FB_TX, 32, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order);
+#define FB_SUB(TXv, TYv)                                                                                                         \
+    (stg ? launch_ring_t<5, 2, true, true, 2, TXv, TYv, true, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order)        \
+         : launch_ring_t<5, 2, true, true, 2, TXv, TYv, true, false>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order))
+            const bool ok = wide5 ? FB_SUB(128, 16) : FB_SUB(FB_TX, 32);
+#undef FB_SUB
             if (ok && sub_done) *sub_done = 1;
             return ok;
         }
@@ -556,18 +661,24 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     const int tile = tune ? tune->tile : 0;
     const bool both = out && dog;
     const bool wide = tile == 2 || (tile == 0 && ((R == 3) || (R == 4 && both)));
+#define FB_PF(PFv, TXv, TYv)                                                                                                     \
+    (stg ? launch_ring_pf<R, 2, PFv, TXv, TYv, (R >= 3 && R <= 6)>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order)           \
+         : launch_ring_pf<R, 2, PFv, TXv, TYv, false>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order))
     if constexpr (R <= 6)
         if (wide && X >= 128) {
             if constexpr (R <= 4)
-                if (!(out && dog)) return launch_ring_pf<R, 2, 3, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
-            return launch_ring_pf<R, 2, 2, 128, 16>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
+                if (!(out && dog)) return FB_PF(3, 128, 16);
+            return FB_PF(2, 128, 16);
         }
     /* three planes of window prefetch where the registers are there and only one array is stored (7 and 9 taps, level
      * only: 0.213 / 0.224 ms at 512^3 against 0.225 - 0.232 / 0.233 - 0.237 with two; with the DoG store beside it three planes
-     * change nothing: 0.324 / 0.338 against 0.328 / 0.334 - 0.342; four planes, level only: 0.225 / 0.220, no better than three) */
+     * change nothing: 0.324 / 0.338 against 0.328 / 0.334 - 0.342; four planes, level only: 0.225 / 0.220, no better than three;
+     * round 6, under the stagger, whose role copies leave the registers for it: 11 / 13 taps with three planes 0.351 - 0.354 /
+     * 0.362 - 0.369 against 0.346 - 0.351 / 0.352 - 0.359 with two; ONE plane: 0.43 / 0.44) */
     if constexpr (R <= 4)
-        if (!(out && dog)) return launch_ring_pf<R, 2, 3>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
-    return launch_ring_pf<R, 2, 2>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, order);
+        if (!(out && dog)) return FB_PF(3, FB_TX, 32);
+    return FB_PF(2, FB_TX, 32);
+#undef FB_PF
 }
 
 /* Returns hipErrorNotSupported when the shape is outside this kernel (the caller then runs the three-pass path): rows

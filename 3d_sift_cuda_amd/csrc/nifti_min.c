@@ -298,13 +298,13 @@ int nifti_min_open(const char *path, nifti_min_image *img, nifti_min_stream **ou
             free(ip);
             return -2;
         }
+        gzbuffer(df, 1u << 20); /* before anything reads or inspects the stream (gzdirect allocates zlib's buffers): later it is refused */
         const size_t off = vox_offset > 0 ? (size_t)(long)vox_offset : 0;
         if (!gzdirect(df) && fast_inflate(ip, off + nvox * es, &mem, &mem_n) == 0) {
             mem_pos = off;
             gzclose(df);
             df = 0;
         } else {
-            gzbuffer(df, 1u << 20);
             if (vox_offset > 0) gzseek(df, (long)vox_offset, SEEK_SET);
         }
         free(ip);

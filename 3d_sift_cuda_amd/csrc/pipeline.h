@@ -136,6 +136,7 @@ struct sift3d_ctx {
         bool open;
         int64_t nx, ny, nz, got; /* dims of what arrives; planes received so far */
         int resize;
+        std::vector<bool> seen; /* per plane: has it arrived (a plane twice, or runs that overlap, are refused) */
     } up;
     int max_octaves; /* 0: the reference's only stop rule (a dimension <= 2); n > 0: at most n octaves */
     int tune[SIFT3D_TUNE_COUNT]; /* sift3d_set_tuning */

@@ -71,6 +71,7 @@ struct sift3d_blur_tuning {
     int rows_per_thread; /* SIFT3D_TUNE_FUSED_ROWS: 2 = 512 threads, two planes of prefetch; 1 = 1024 threads, one plane */
     int tile;            /* SIFT3D_TUNE_FUSED_TILE: 1 = 64 x 32, 2 = 128 x 16 (two-rows-per-thread mapping, up to 13 taps) */
     int order;           /* SIFT3D_TUNE_FUSED_ORDER: which workgroup takes which tile (0 = by measurement, 1 .. 3: see the kernel) */
+    int stagger;         /* SIFT3D_TUNE_FUSED_STAGGER: the second half of a workgroup's wavefronts half a step behind the first (0 = by measurement, 1 = off, 2 = on) */
 };
 hipError_t sift3d_launch_blur_fused(hipStream_t s, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z,
                                     const float *taps, int ntaps, const sift3d_blur_tuning *tune, int64_t zo0 = 0, int64_t zo1 = -1,

@@ -848,8 +848,13 @@ static int zslab_extract_impl(sift3d_zslab *h, const float *vol, float initial_i
             queued_ms[(size_t)r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
             ZR_RC(cand_finalize(q.c, &ncands[(size_t)r]));
             describe_want_group_counts(q.c, want_groups);
-            if (want_groups) q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the places need the whole list's counts before the one descriptor launch */
-            ZR_RC(describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false));
+            /* the places need the whole list's counts before the one descriptor launch: one chunk for this call only (the knob the
+             * caller set on the handle is put back, as sift3d_describe_dev_counts does) */
+            const int kp_chunks = q.c->tune[SIFT3D_TUNE_KP_CHUNKS];
+            if (want_groups) q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1;
+            const int rc_desc = describe_queue(q.c, q.levels, ncands[(size_t)r], desc_mode, eig_thres, size_factor, false);
+            q.c->tune[SIFT3D_TUNE_KP_CHUNKS] = kp_chunks;
+            ZR_RC(rc_desc);
             if (!want_groups) return;
             /* this rank's records per group (level, is_max): the merged list is, group by group, a run of every rank in rank order --
              * within a group slabs are in z order, so rank order is the serial raster order */

@@ -259,7 +259,11 @@ class ZSlabExtractor:
         # exchange_bytes: everything this rank received and sent; of that, deferred_bytes moved in the once-per-octave
         # patch-halo batch that overlaps L4 / L5 / extrema (critical = exchange_bytes - deferred_bytes)
         # hidden_bytes: the part of the per-level halos issued bands-first, i.e. moving while this rank filters its interior
-        self.stats = {"exchanges": 0, "exchange_bytes": 0, "deferred_exchanges": 0, "deferred_bytes": 0, "hidden_bytes": 0}
+        # per_octave (round 6): [octave] -> bytes moved by that octave's batches and the host time this rank spent completing them
+        # (`host_wait_ms`: with gloo that is the transfer as this rank sees it; with nccl = RCCL a completed wait() only orders the
+        # rank's stream behind the communicator's, so it is the cost of queueing, and the transfer shows in the step time)
+        self.stats = {"exchanges": 0, "exchange_bytes": 0, "deferred_exchanges": 0, "deferred_bytes": 0, "hidden_bytes": 0, "per_octave": {}}
+        self._octave_now = 0
         # every DoG buffer an extrema pass was queued on: the library replays those passes from the recorded pointers when
         # a candidate list overflows (cand_finalize), so all five DoG levels of every octave -- not only the L1..L3 / D1..D3
         # the level table names -- must outlive candidates() / describe(); released by the next run()
@@ -314,13 +318,20 @@ class ZSlabExtractor:
             self.stats["deferred_bytes"] += nbytes
         elif defer:
             self.stats["hidden_bytes"] += nbytes
+        po = self.stats["per_octave"].setdefault(self._octave_now, {"bytes": 0, "critical_bytes": 0, "batches": 0, "host_wait_ms": 0.0})
+        po["bytes"] += nbytes
+        po["critical_bytes"] += 0 if (defer and patch) else nbytes
+        po["batches"] += 1
 
         def finish():
+            import time
+            t0 = time.perf_counter()
             for r in works:
                 r.wait()
             for t, h in back:
                 t.copy_(h)
             self.be.after_exchange()
+            po["host_wait_ms"] += 1e3 * (time.perf_counter() - t0)
         if defer:
             return finish
         finish()
@@ -437,6 +448,7 @@ class ZSlabExtractor:
         for o in range(len(plan.octaves)):
             X, Y, zo = plan.octaves[o]
             sharded = o < K
+            self._octave_now = o
             if sharded:
                 z0, z1 = plan.slab(rank, o)
                 has_lo, has_hi = rank > 0, rank < S - 1

@@ -191,6 +191,9 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     by every rank's descriptor kernel through one shared list, or -- `--zslab-gather` -- gathered through the backend and merged).
     Returns the result object on rank 0 (None elsewhere).  expect: the single-GPU records of the same volume, if the
     caller has them (rank 0), to state whether the merged records are the same bytes."""
+    if args.zslab_inject == "torch-leg":   # (a test: what a rank dying in RCCL set-up looks like to the parent)
+        sys.stderr.write("bench.py: rank %d: injected failure of the per-process Z-slab job\n" % rank)
+        sys.exit(9)
     phase("zslab: plan, slab context, upload")
     zs = importlib.import_module("3d_sift_cuda_amd.zslab")
     nx, ny, nz, desc, label = resolve_volume(args)
@@ -233,6 +236,7 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     # (--zslab-gather, or if the list cannot be set up): every rank's records travel to rank 0 through the collective backend -- with
     # RCCL an upload of what was just downloaded, the gather, and a download of all of it on rank 0 -- and are merged on the host.
     shared = [None]
+    why_gathered = ["--zslab-gather" if args.zslab_gather else None]
     cdev = "cuda:%d" % dev
 
     def step():
@@ -256,11 +260,19 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
         total = [len(merged) if (rank == 0 and merged is not None) else 0]
         dist.broadcast_object_list(total, src=0)
         ok = 1
+        real_register = pkg.host_register
+        if args.zslab_inject == "shared-list" and rank == 1:
+            def refuse(address, nbytes):
+                raise pkg.Sift3DError("injected: hipHostRegister of the foreign segment refused on this rank")
+            pkg.host_register = refuse
         try:
             shared[0] = zs.SharedRecordList(pkg, dist, rank, total[0] + total[0] // 8 + 4096, pkg.FEATURE_DTYPE)
         except Exception as e:   # (a rank that cannot map or register the list: every rank goes back to the gather)
             sys.stderr.write("bench.py: rank %d: no shared record list (%s): gathering the records instead\n" % (rank, e))
             ok = 0
+            why_gathered[0] = "the shared record list could not be set up (%s)" % (str(e)[:200],)
+        finally:
+            pkg.host_register = real_register
         flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
@@ -283,6 +295,12 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
     el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda:%d" % dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ms_per_step = 1e3 * float(el.item()) / args.steps
+    # every rank's exchange statistics of the last step, on rank 0 (a few hundred bytes per rank, after the timed region)
+    mine = {"rank": rank, "halo_bytes": ex.stats["exchange_bytes"], "halo_bytes_critical": ex.stats["exchange_bytes"] - ex.stats["deferred_bytes"],
+            "halo_bytes_hidden": ex.stats["hidden_bytes"], "halo_bytes_deferred": ex.stats["deferred_bytes"],
+            "per_octave": {str(o): {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()} for o, d in sorted(ex.stats["per_octave"].items())}}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
     res = None
     if rank == 0:
         nrec = 0 if merged is None else len(merged)
@@ -301,6 +319,12 @@ def zslab_measure(args, pkg, torch, dist, rank, world, local_rank, expect=None, 
                "halo_bytes_critical_per_rank_per_step": ex.stats["exchange_bytes"] - ex.stats["deferred_bytes"],
                "halo_bytes_deferred_per_rank_per_step": ex.stats["deferred_bytes"],
                "halo_bytes_hidden_per_rank_per_step": ex.stats["hidden_bytes"],
+               "per_rank": per_rank,
+               "per_rank_note": "every rank's halo bytes of one step (critical = waited for by the next launch; hidden = of those, issued bands-first "
+                                "and moving while the rank filters its interior; deferred = patch halos on the second communicator) and, per sharded "
+                                "octave, the bytes, batches and the host time the rank spent completing them (gloo: the transfer as the rank sees it; "
+                                "nccl: a completed wait only orders streams, so this is queueing cost and the transfer shows in the step)",
+               "records_gathered_because": why_gathered[0] if how != "placed" else None,
                "exchange_schedule": "per stored level (L1..L4: the 17-tap L5 is only evaluated around candidates, from L4): the 8-slice blur halo "
                                     "(what the next blur needs; 9 slices of L4), issued BANDS FIRST -- a rank filters its two boundary "
                                     "bands, hands them to the exchange and filters its interior while they travel (`hidden` bytes); per "
@@ -334,7 +358,8 @@ def zslab_main(args, pkg, torch, dist, rank, world, local_rank, phase=lambda *a:
             "config": {k: res[k] for k in ("workload", "records", "sharded_octaves", "slab_bounds", "parallelism",
                                            "halo_exchanges_per_step", "halo_bytes_per_rank_per_step",
                                            "halo_bytes_critical_per_rank_per_step", "halo_bytes_deferred_per_rank_per_step",
-                                           "halo_bytes_hidden_per_rank_per_step", "exchange_schedule", "records_to_rank0", "records_sha256")}}))
+                                           "halo_bytes_hidden_per_rank_per_step", "exchange_schedule", "records_to_rank0", "records_sha256",
+                                           "per_rank", "per_rank_note", "records_gathered_because")}}))
     phase("zslab: leaving the process group")
     dist.barrier()
     dist.destroy_process_group()
@@ -356,7 +381,8 @@ def zslab_child(args, world, expect, limit_s):
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
            str(args.warmup), "--dims", "%d,%d,%d" % resolve_volume(args)[:3], "--desc", str(resolve_volume(args)[3]), "--mode", "zslab",
            "--phase-limit", str(max(1, min(args.phase_limit, limit_s)) if args.phase_limit > 0 else 0)] + (["--zslab-one-group"] if args.zslab_one_group else []) \
-        + (["--zslab-gather"] if args.zslab_gather else []) + (["--zslab-coarse-inline"] if args.zslab_coarse_inline else [])
+        + (["--zslab-gather"] if args.zslab_gather else []) + (["--zslab-coarse-inline"] if args.zslab_coarse_inline else []) \
+        + (["--zslab-inject", args.zslab_inject] if args.zslab_inject else [])
     # End exactly the job started here (run_child): torch.distributed.run puts every rank in a session of its own, so the
     # launcher's process group does not contain them -- their PIDs are noted first, the launcher is asked to stop (it
     # terminates its ranks on SIGTERM), then whatever of it is still there is killed.
@@ -523,6 +549,10 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="sift3d_set_tuning on the context before the run, e.g. FUSED_TILE=2 (A/B measurements; no knob changes a "
                          "result; the line records what was set)")
+    ap.add_argument("--zslab-inject", default=None, choices=["shared-list", "torch-leg"],
+                    help="tests of the N > 1 fall-backs: 'shared-list' -- rank 1 fails to register the shared record list, every rank "
+                         "must go back to gathering the records and the line must say why; 'torch-leg' -- the per-process Z-slab job "
+                         "exits with code 9 before its first collective, the line's value must then be the one-process C driver's")
     ap.add_argument("--launch-check", default=None, choices=["ok", "fail"],
                     help="only bring the ranks up (process group over gloo, no GPU call), print a line with the world size "
                          "seen and leave -- 'fail': rank 1 exits with code 7 instead (tests of the self-launch path)")
@@ -944,9 +974,26 @@ def main():
     # ---- N > 1: the line's value is the Z-slab split of ONE volume over the N GPUs (strong scaling) ----
     torch.cuda.empty_cache()
     vol_out = {k: out[k] for k in ("value", "ms_per_step", "scaling")}
-    z = zslab_child(args, world, expect, args.zslab_limit)
+    # The one-process C driver first (no launcher, no rendezvous, peer copies before RCCL): whatever happens to the per-process job
+    # afterwards -- its nccl backend has only ever run over gloo on one GPU -- one lease of a node always yields a strong-scaling number.
     zc = zslab_c_child(args, world, expect, args.zslab_limit)
+    z = zslab_child(args, world, expect, args.zslab_limit)
     ok = z.get("status") == "ok" and z.get("value") is not None
+    value_source = "zslab: one process per GPU, halos over torch.distributed (%s)" % ("nccl = RCCL" if os.environ.get("SIFT3D_DIST_BACKEND", "nccl") == "nccl" else os.environ.get("SIFT3D_DIST_BACKEND"))
+    if not ok:   # the C driver's result stands in, and the line says so
+        for tr in ("peer_copy", "rccl"):
+            c = zc.get(tr) or {}
+            if c.get("ms_per_step") and c.get("records") and c.get("same_bytes_as_single_gpu") is not False:
+                z = dict(z, value=round(c["records"] / (c["ms_per_step"] * 1e-3), 1), ms_per_step=c["ms_per_step"],
+                         same_bytes_as_single_gpu=c.get("same_bytes_as_single_gpu"),
+                         workload="ONE %s float32 blob-field volume cut into %d Z-slabs, full featExtract path, all octaves" % (vol_label, world),
+                         parallelism="zslab%d: ONE process drives all %d devices from C (sift3d_zslab_extract_resident), halos by %s"
+                                     % (world, world, "peer copies" if tr == "peer_copy" else "RCCL send/recv"),
+                         records_to_rank0="the ranks' descriptor kernels store into one pinned list (C driver)",
+                         per_process_job={"status": z.get("status"), "exit_code": z.get("exit_code"), "stderr_tail": z.get("stderr_tail")})
+                value_source = "zslab_c/%s: the per-process job failed (%s), the one-process C driver's measurement of the same split stands in" % (tr, z.get("status"))
+                ok = True
+                break
     out["volumes_value"] = vol_out["value"] if replicas else None
     out["volumes_ms_per_step"] = vol_out["ms_per_step"]
     out["volumes_scaling"] = "weak" if replicas else None
@@ -962,13 +1009,15 @@ def main():
     out["config"]["parallelism"] = z.get("parallelism") or "zslab%d" % world
     out["config"]["records_to_rank0"] = z.get("records_to_rank0")
     out["config"]["single_gpu_workload"] = "%s volume on one GPU (`volumes_*`; `roofline`, `pyramid`, `stages` are rank 0's single-GPU kernels)" % vol_label
+    out["value_source"] = value_source if ok else None
     out["zslab"] = z
     out["zslab_c"] = zc
     # (kept for readers of the rounds 3-4 line)
     out["zslab_value"], out["zslab_ms_per_step"], out["zslab_same_bytes_as_single_gpu"] = z.get("value"), z.get("ms_per_step"), z.get("same_bytes_as_single_gpu")
     print(json.dumps(out), flush=True)
     if not ok:
-        sys.stderr.write("bench.py: the Z-slab job did not produce a result (%s): value is null, exit code 5\n" % z.get("status"))
+        sys.stderr.write("bench.py: neither the per-process Z-slab job (%s) nor the one-process C driver (%s) produced a result: value is null, exit code 5\n"
+                         % (z.get("status"), zc.get("status")))
         sys.exit(5)
 
 

@@ -33,7 +33,7 @@ extern "C" {
  * overrun: a binding checks sift3d_abi_version() == SIFT3D_ABI_VERSION once, when it loads the library (the in-tree ctypes
  * mirror and featExtract do).  5: sift3d_zslab_stats gained comm_sets, resident_volume, merge_ms, halo_bytes_subsample, enqueue_ms (round 5); 4: transport,
  * transport_fell_back, rccl_version (round 4). */
-#define SIFT3D_ABI_VERSION 5
+#define SIFT3D_ABI_VERSION 6
 int sift3d_abi_version(void);
 
 #define SIFT3D_DESC_LEN 64
@@ -115,6 +115,19 @@ void sift3d_free(void *p);
  * gb3d_blur3d_interleave (R/src_common/GaussBlur3D.cpp:1190-1201).
  * Returns the (odd) tap count, or a negative status; taps must hold 129 floats. */
 int sift3d_gauss_taps(float sigma, float min_value, float *taps);
+/* Which build of the reference the taps follow.  GaussianMask.cpp calls exp() on a float.  A current g++ (libstdc++ >= 6:
+ * <math.h> brings the C++ overloads) makes that expf() and forms the tap's product with the scale in float -- the reference
+ * as it compiles today, the default here and what the oracle follows.  The toolchain of the CPU binary the reference
+ * repository ships (R/bin/Linux/featExtract, GCC 5.4) made it the C exp(double), with the product formed in double and
+ * rounded once (its disassembly at 0x451c87, 0x451d0e, 0x4523b7-0x4523ca).  The two differ by one or two units in the last
+ * place of a tap, which every later stage carries into the last printed digits of a record.  With SIFT3D_LIBM_GCC5 the
+ * extraction reproduces that binary's .key files byte for byte (tests/test_gpu_parity.py::
+ * test_cli_reproduces_the_shipped_binary).  Process-wide (sift3d_gauss_taps takes no context); contexts keep the taps of
+ * their patch filters from creation, so choose before sift3d_create.  Returns the previous setting, or SIFT3D_ERR_ARG. */
+#define SIFT3D_LIBM_CURRENT 0
+#define SIFT3D_LIBM_GCC5 1
+int sift3d_set_libm_variant(int which);
+int sift3d_get_libm_variant(void);
 
 /* ---- operator level: the reference's four accelerator entry points ---------
  * Host-pointer forms copy in, run on the device and copy the result back
@@ -252,6 +265,10 @@ typedef enum {
                                  * 1: XCD x walks the x-th eighth of the tiles in (x, y, chunk) order -- whole rows of tiles per XCD (rounds 1 - 4);
                                  * 2: workgroup b takes tile b; 3: column strips -- XCD x owns the tiles of column x mod tiles_x, so that a
                                  * tile's y neighbours share its L2 and an XCD always reads the same byte columns of every row */
+    SIFT3D_TUNE_FUSED_STAGGER,  /* fused blur, two-rows-per-thread mapping, 7 - 13 taps: the second-dispatched half of a workgroup's wavefronts
+                                 * runs half a step behind the first (z pass and stores of a plane at the start of the next step), each
+                                 * (half, role) pair of wavefronts running its own straight-line copy of the march.  0: by measurement
+                                 * (default: from 11 taps up); 1: off (the kernel of rounds 2 - 5); 2: on */
     SIFT3D_TUNE_COUNT
 } sift3d_tuning;
 int sift3d_set_tuning(sift3d_ctx *ctx, int knob, int value);

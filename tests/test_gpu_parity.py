@@ -43,12 +43,15 @@ FUSED_SHAPES = [(32, 32, 32), (64, 48, 40), (256, 8, 8), (300, 20, 12), (132, 37
 
 
 @pytest.mark.parametrize("dims", FUSED_SHAPES)
-@pytest.mark.parametrize("chunks,rows,tile", [(0, 0, 0), (3, 1, 0), (2, 2, 1), (3, 2, 1), (1, 1, 0), (5, 0, 0), (0, 2, 2), (3, 2, 2)])
-def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows, tile):
+@pytest.mark.parametrize("chunks,rows,tile,stagger", [(0, 0, 0, 0), (3, 1, 0, 0), (2, 2, 1, 0), (3, 2, 1, 0), (1, 1, 0, 0), (5, 0, 0, 0), (0, 2, 2, 0), (3, 2, 2, 0),
+                                                      (0, 2, 1, 1), (3, 2, 2, 1), (0, 2, 1, 2), (3, 2, 2, 2), (2, 2, 0, 2), (1, 2, 2, 1)])
+def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows, tile, stagger):
     """The one-launch x+y+z+DoG kernel (forced on: the pipeline only uses it from 2^22 voxels up, 2^18 for narrow filters):
     partial tiles in x and y, volumes thinner than the filter, one or several z chunks, both thread mappings (one row per
     thread with one plane of window prefetch; two rows with two planes) on every shape and filter: level and DoG
-    bit-identical to the oracle, for level + DoG, level only and DoG only."""
+    bit-identical to the oracle, for level + DoG, level only and DoG only.  stagger (round 6, SIFT3D_TUNE_FUSED_STAGGER): 0 the
+    default (on from 11 taps up), 1 off (the kernel of rounds 2 - 5), 2 on for every filter it is built for (7 - 13 taps): one copy
+    of the march per wavefront role and the second half of the wavefronts half a step behind the first."""
     import torch
     vol = vol_of(built, dims, 5) - np.float32(1.5)
     nx, ny, nz = dims
@@ -57,6 +60,7 @@ def test_fused_blur_dog_bit_exact(built, oracle, dims, chunks, rows, tile):
         ctx.set_tuning(built.TUNE_FUSED_CHUNKS, chunks)
         ctx.set_tuning(built.TUNE_FUSED_ROWS, rows)
         ctx.set_tuning(built.TUNE_FUSED_TILE, tile)   # 2: the 128 x 16 tile (rows of at least 128 voxels; round 4)
+        ctx.set_tuning(built.TUNE_FUSED_STAGGER, stagger)
         d_in = torch.from_numpy(vol).cuda()
         d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
         torch.cuda.synchronize()
@@ -112,8 +116,8 @@ def test_fused_blur_tile_orders_cover_every_tile_once(built, oracle, dims, order
 
 
 @pytest.mark.parametrize("dims", [(64, 48, 40), (136, 37, 45), (72, 17, 3), (128, 64, 70), (264, 50, 21), (16, 2, 2), (40, 33, 12)])
-@pytest.mark.parametrize("chunks,tile", [(0, 0), (1, 1), (3, 1), (5, 2), (2, 2)])
-def test_fused_blur_carries_the_half_size_volume(built, oracle, dims, chunks, tile):
+@pytest.mark.parametrize("chunks,tile,stagger", [(0, 0, 0), (1, 1, 0), (3, 1, 0), (5, 2, 0), (2, 2, 0), (0, 0, 1), (3, 1, 2), (5, 2, 1), (2, 2, 2)])
+def test_fused_blur_carries_the_half_size_volume(built, oracle, dims, chunks, tile, stagger):
     """Round 4: the launch that makes level 3 (11 taps, two rows per thread) also writes the next octave's level 0, the
     2 x 2 x 2 mean of the level, from the planes it holds in registers.  Level, DoG and the half-size volume against the oracle's
     blur -> subsample, with odd ny / nz (the last row / plane has no partner), one and several z chunks (a pair of planes must not
@@ -129,6 +133,7 @@ def test_fused_blur_carries_the_half_size_volume(built, oracle, dims, chunks, ti
         ctx.set_tuning(built.TUNE_FUSED_CHUNKS, chunks)
         ctx.set_tuning(built.TUNE_FUSED_ROWS, 2)
         ctx.set_tuning(built.TUNE_FUSED_TILE, tile)
+        ctx.set_tuning(built.TUNE_FUSED_STAGGER, stagger)
         d_in = torch.from_numpy(vol).cuda()
         d_out, d_dog = torch.empty_like(d_in), torch.empty_like(d_in)
         d_half = torch.full((nz // 2, ny // 2, nx // 2), 7.0, dtype=torch.float32, device="cuda")
@@ -744,6 +749,8 @@ def test_volume_in_runs_of_planes_is_the_volume(built):
                 ctx.set_volume_in_runs(vol, [(0, nz - 1)], resize=resize)          # a plane never arrived
             with pytest.raises(built.Sift3DError):
                 ctx.set_volume_in_runs(vol, [(0, nz), (nz - 1, 2)], resize=resize)   # beyond the volume
+            with pytest.raises(built.Sift3DError):                                    # nz planes in all, but three of them twice and
+                ctx.set_volume_in_runs(vol, [(0, nz - 6), (nz - 9, 6)], resize=resize)   # the last three never (round-5 advisor finding)
             with pytest.raises(built.Sift3DError):
                 ctx._chk(ctx._L.sift3d_set_volume_planes(ctx._h, vol.ctypes.data, 0, 1), "planes without begin")
             ctx.set_volume(vol, resize=resize)                                        # the context is still usable
@@ -824,6 +831,48 @@ def test_cli_world_coordinates(built, tmp_path, flag):
     assert "Input image: i=96 j=100 k=84" in r.stdout
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_aniso_%s.key" % flag[1:])
     assert open(k, "rb").read() == open(gold, "rb").read()
+
+
+def test_cli_reproduces_the_shipped_binary(built, tmp_path):
+    """The HIP path against the reference's OWN output, byte for byte: tests/golden/refbin_*.key are the .key files the CPU binary
+    under the reference's bin/Linux wrote (round 1; frozen data) for the 64^3 and 128^3 blob fields and for the anisotropic -w / -ws
+    case.  That binary's toolchain evaluated exp() of a float with the C exp(double) (its disassembly; include/sift3d.h,
+    sift3d_set_libm_variant); `featExtract --libm=gcc5` builds the Gaussian taps that way and must then write the binary's files
+    exactly -- 74, 1 698 and 2 x 180-odd records of 81 printed columns, positions, scales, frames, eigenvalues, flags and rank
+    descriptors.  Without the switch (the reference as a current g++ compiles it) the same runs stay within the tolerances of
+    tests/test_oracle_pins.py::test_against_shipped_reference_binary, which is the last bit of two taps carried through."""
+    import gzip
+    import _oracle
+    from keyio import read_key
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for n, name in ((64, "refbin_blob64.key"), (128, "refbin_blob128.key.gz")):
+        nii, k, k0 = str(tmp_path / ("b%d.nii" % n)), str(tmp_path / ("b%d.key" % n)), str(tmp_path / ("b%d_default.key" % n))
+        built.write_nifti(nii, vol_of(built, (n, n, n), 12345))
+        r = subprocess.run([built.FEATEXTRACT, "--libm=gcc5", "-d0", nii, k], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        path = os.path.join(gold, name)
+        want = gzip.open(path, "rb").read() if name.endswith(".gz") else open(path, "rb").read()
+        assert open(k, "rb").read() == want, name
+        # the default build of the taps: same records, the reference binary's numbers within the north star's 1e-4
+        assert subprocess.run([built.FEATEXTRACT, "-d0", nii, k0], capture_output=True).returncode == 0
+        a, b = read_key(k0), read_key(gzip.open(path, "rt") if name.endswith(".gz") else path)
+        ra, rb = a["rows"], b["rows"]
+        assert a["count"] == b["count"] == len(ra) == len(rb) and (ra[:, 16] == rb[:, 16]).all()
+        d = np.abs(ra - rb)
+        assert d[:, :4].max() < 2e-4 and (d[:, 13:16] / np.abs(rb[:, 13:16])).max() < 2e-4
+        assert (d[:, 17:].max(1) == 0).mean() >= 0.995 and d[:, 17:].max() <= 2
+        assert np.minimum(np.abs(ra[:, 4:13] - rb[:, 4:13]), np.abs(ra[:, 4:13] + rb[:, 4:13])).max() < 2e-3
+    w = _oracle.WORLD_CASE
+    nii = str(tmp_path / "aniso.nii")
+    built.write_nifti(nii, vol_of(built, w["dims"], w["seed"]), w["voxel"], w["qform"], w["sform"])
+    for flag in ("-w", "-ws"):
+        k = str(tmp_path / ("aniso%s.key" % flag))
+        r = subprocess.run([built.FEATEXTRACT, "--libm=gcc5", flag, "-d0", nii, k], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert open(k, "rb").read() == open(os.path.join(gold, "refbin_aniso_%s.key" % flag[1:]), "rb").read(), flag
+    # an unknown long option is an unknown argument, as every "--..." is for the reference
+    r = subprocess.run([built.FEATEXTRACT, "--libm=gcc4", "-d0", nii, str(tmp_path / "x.key")], capture_output=True, text=True)
+    assert r.returncode == 255 and "Error: unknown command line argument: --libm=gcc4" in r.stdout
 
 
 def test_cli_ws_without_sform_falls_back_to_qform(built, tmp_path):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel timing of the blur passes at one volume size (HIP events via the C-ABI launch log).
-usage: python tools/bench_blur.py [N=512] [reps=10] [tile=0] [order=0]   (tile: SIFT3D_TUNE_FUSED_TILE, 1 = 64 x 32, 2 = 128 x 16;
+usage: python tools/bench_blur.py [N=512] [reps=10] [tile=0] [order=0] [stagger=0]   (stagger: SIFT3D_TUNE_FUSED_STAGGER, 1 = off, the
+kernel of rounds 2 - 5, 2 = on: one copy of the march per wavefront role and the half-step stagger; tile: SIFT3D_TUNE_FUSED_TILE, 1 = 64 x 32, 2 = 128 x 16;
 order: SIFT3D_TUNE_FUSED_ORDER, 1 = rows of tiles per XCD, 2 = workgroup b takes tile b, 3 = column strips per XCD)"""
 import importlib, os, sys
 import numpy as np
@@ -11,15 +12,17 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 tile = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 order = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+stagger = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = pkg.Context(n, n, n)
 ctx.set_tuning(pkg.TUNE_FUSED_TILE, tile)
 ctx.set_tuning(pkg.TUNE_FUSED_ORDER, order)
+ctx.set_tuning(pkg.TUNE_FUSED_STAGGER, stagger)
 a = torch.randn(n, n, n, device="cuda") * 50
 b = torch.empty_like(a); d = torch.empty_like(a)
 torch.cuda.synchronize()
 sig = {7: 1.2262736558914185, 9: 1.5450079441070557, 11: 1.9465880393981934, 13: 2.452547311782837, 17: 3.0900158882141113}
 N = n ** 3
-print("N=%d^3  bytes/pass: %.3f GB  tile knob %d  order knob %d" % (n, 8 * N / 1e9, tile, order))
+print("N=%d^3  bytes/pass: %.3f GB  tile knob %d  order knob %d  stagger knob %d" % (n, 8 * N / 1e9, tile, order, stagger))
 cases = [(taps, s, True) for taps, s in sig.items()] + [(7, sig[7], False), (9, 1.5198684930801392, False)]   # level-only: L1 and the initial blur
 for taps, s, with_dog in cases:
     outp = 0 if taps == 17 else b.data_ptr()   # the 17-tap level, when it is filtered in full (SIFT3D_TUNE_LAZY_LEVELS = 0), is not stored, only its DoG

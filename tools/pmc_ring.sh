@@ -27,13 +27,13 @@ for f in sorted(glob.glob("gpurun_out/%s/*/**/*counter_collection.csv" % out, re
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if flt not in k: continue
-        k = k[k.index(flt):].split("(")[0][:44]
+        k = k[k.index(flt):].split("(")[0][:72]
         agg[k + " grid=" + r.get("Grid_Size", "?")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in sorted(glob.glob("gpurun_out/%s/g1/**/*kernel_trace.csv" % out, recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if flt not in k: continue
-        k = k[k.index(flt):].split("(")[0][:44] + " grid=" + (r.get("Grid_Size") or r.get("Grid_Size_X") or "?")
+        k = k[k.index(flt):].split("(")[0][:72] + " grid=" + (r.get("Grid_Size") or r.get("Grid_Size_X") or "?")
         dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, d in sorted(agg.items()):
     print(k, "us=%.0f" % (sum(dur[k]) / max(1, len(dur[k]))), {c: round(sum(v) / len(v)) for c, v in sorted(d.items())})
