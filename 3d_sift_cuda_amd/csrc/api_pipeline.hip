@@ -1,7 +1,7 @@
 /*
- * api.hip -- the C-ABI of include/sift3d.h: context (device-resident pyramid
- * buffers, stream, timing events), operator-level entry points and the
- * scale-space / extraction pipeline that strings the kernels together.
+ * api_pipeline.hip -- the scale-space / extraction pipeline that strings the kernels
+ * together: volume upload, the per-keypoint stage, run_pipeline, sift3d_extract /
+ * sift3d_detect (round 6: one of the five translation units api.hip was cut into).
  *
  * Schedule = msGeneratePyramidDOG3D_efficient (R/src_common/MultiScale.cpp:236-570,
  * R/ = /root/reference/3dsift_cleanup-softVote_App_Weight_SoftMax/): initial
@@ -36,976 +36,6 @@
 #include "sift3d_internal.h"
 
 #include "pipeline.h"
-
-int set_err(sift3d_ctx *c, int code, const char *fmt, ...)
-{
-    if (c) {
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(c->err, sizeof(c->err), fmt, ap);
-        va_end(ap);
-    }
-    return code;
-}
-
-/* entry points that work in the context's own level buffers: not on a slab context, which has none */
-#define NEED_LEVELS(c)                                                                                                  \
-    do {                                                                                                                \
-        if ((c) && (c)->lean) return set_err((c), SIFT3D_ERR_ARG, "%s needs a full context (sift3d_create), not a slab context", __func__); \
-    } while (0)
-
-extern "C" int sift3d_abi_version(void) { return SIFT3D_ABI_VERSION; }
-
-extern "C" int sift3d_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-extern "C" void sift3d_free(void *p) { free(p); }
-
-extern "C" const char *sift3d_last_error(const sift3d_ctx *ctx) { return ctx ? ctx->err : "no context"; }
-
-static void free_dev(sift3d_ctx *c)
-{
-    hipFree(c->vol);
-    for (int i = 0; i < 6; i++) hipFree(c->L[i]);
-    for (int i = 0; i < 5; i++) hipFree(c->D[i]);
-    hipFree(c->D4tiny);
-    hipFree(c->T[0]);
-    hipFree(c->T[1]);
-    hipFree(c->d_taps);
-    hipFree(c->keys_a);
-    hipFree(c->keys_b);
-    hipFree(c->vals_a);
-    hipFree(c->vals_b);
-    hipFree(c->d_count);
-    hipFree(c->surv);
-    hipFree(c->surv2);
-    hipFree(c->list2[0]);
-    hipFree(c->list2[1]);
-    hipFree(c->list2_counts);
-    hipFree(c->surv_counts);
-    hipFree(c->sort_tmp);
-    hipFree(c->scan_tmp);
-    hipFree(c->d_levels);
-    hipFree(c->kps);
-    hipFree(c->patch0);
-    hipFree(c->sampler_tokens);
-    hipFree(c->d_rec_base);
-    hipFree(c->nrec);
-    hipFree(c->offs);
-    hipFree(c->rec_kp);
-    hipFree(c->rec_frame);
-    if (c->h_recs) hipHostFree(c->h_recs);
-    if (c->h_group) hipHostFree(c->h_group);
-    hipFree(c->place.d_counts);
-    hipFree(c->place.d_shift);
-    if (c->place.h_counts) hipHostFree(c->place.h_counts);
-}
-
-/* octave list of a volume: halve while every dimension stays above 2 (MultiScale.cpp:359-360,546-556) */
-
-/* Inside the pipeline every octave is stored with rows padded to whole 16-byte vectors; the pad columns hold zeros
- * (what the blur reads outside the volume), so the vector kernels serve any row length. */
-static std::vector<octave_dims> octave_list(int64_t X, int64_t Y, int64_t Z)
-{
-    std::vector<octave_dims> v;
-    int64_t off = 0;
-    while (X > 2 && Y > 2 && Z > 2 && v.size() < 32) {
-        const int64_t XP = pitch_of(X);
-        v.push_back({X, Y, Z, off, XP});
-        off += ((XP * Y * Z + 63) / 64) * 64; /* keep every octave 256-byte aligned */
-        X /= 2; Y /= 2; Z /= 2;
-    }
-    return v;
-}
-
-/* (Re)size the candidate, sort and key buffers.  The new buffers are made first and the old ones released only when every
- * allocation succeeded: a failed growth leaves the context as it was (old buffers, old capacity) and reports SIFT3D_ERR_MEMORY,
- * so a caller that ignores the result of sift3d_reserve still runs on valid buffers (round-5 advisor finding). */
-static int alloc_cands(sift3d_ctx *c, int64_t cap)
-{
-    unsigned long long *ka = nullptr, *kb = nullptr;
-    sift3d_cval *va = nullptr, *vb = nullptr;
-    void *tmp = nullptr;
-    const size_t tmp_bytes = sift3d_sort_temp_bytes(cap) + 256;
-    const bool ok = hipMalloc((void **)&ka, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
-                    hipMalloc((void **)&kb, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
-                    hipMalloc((void **)&va, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess &&
-                    hipMalloc((void **)&vb, sizeof(sift3d_cval) * (size_t)cap) == hipSuccess && hipMalloc(&tmp, tmp_bytes) == hipSuccess;
-    if (!ok) {
-        (void)hipGetLastError();
-        hipFree(ka); hipFree(kb); hipFree(va); hipFree(vb); hipFree(tmp);
-        return SIFT3D_ERR_MEMORY;
-    }
-    hipFree(c->keys_a); hipFree(c->keys_b); hipFree(c->vals_a); hipFree(c->vals_b); hipFree(c->sort_tmp);
-    c->keys_a = ka; c->keys_b = kb;
-    c->vals_a = va; c->vals_b = vb;
-    c->sort_tmp = tmp;
-    c->sort_tmp_bytes = tmp_bytes;
-    c->cand_cap = cap;
-    return SIFT3D_OK;
-}
-
-static void destroy_sync_objects(sift3d_ctx *c)
-{
-    hipStream_t streams[] = {c->ex_stream, c->ex_stream2, c->kp_stream};
-    for (hipStream_t st : streams)
-        if (st) {
-            hipStreamSynchronize(st);
-            hipStreamDestroy(st);
-        }
-    hipEvent_t events[] = {c->ev_ex2[0], c->ev_ex2[1], c->ev_reset, c->ev_desc, c->ev_oct[0], c->ev_oct[1], c->ev_fence[0], c->ev_fence[1],
-                           c->ev_split[0], c->ev_split[1], c->ev_split[2]};
-    for (hipEvent_t e : events)
-        if (e) hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_kpc)
-        if (e) hipEventDestroy(e);
-    if (c->h_cnt0) hipHostFree(c->h_cnt0);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
-}
-
-/* lean: a slab context (sift3d_create_slab) -- the caller owns the level buffers; only the pass intermediates, the
- * candidate lists and the per-keypoint buffers live here */
-sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean)
-{
-    if (nx <= 0 || ny <= 0 || nz <= 0) return nullptr;
-    int n = sift3d_device_count();
-    if (device < 0 || device >= n) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
-    sift3d_ctx *c = new sift3d_ctx(); /* value-initialised: every pointer null, every count zero */
-    c->device = device;
-    c->own_stream = true;
-    c->lean = lean;
-    c->capN = pitch_of(nx) * ny * nz; /* floats of the largest volume, rows padded to whole vectors */
-    c->surv_div = 64;
-    c->tune[SIFT3D_TUNE_BLUR_FUSED] = 1;
-    c->tune[SIFT3D_TUNE_LAZY_LEVELS] = 1;
-    c->tune[SIFT3D_TUNE_TINY_OCTAVE] = 1;
-    c->tune[SIFT3D_TUNE_SAMPLER_CAP] = 4;
-    c->tune[SIFT3D_TUNE_BANDS_FIRST] = 1;
-    c->tune[SIFT3D_TUNE_HOST_RECORDS] = 5;
-    c->tune[SIFT3D_TUNE_FUSED_SUB] = 1;
-    c->tune[SIFT3D_TUNE_SPLIT_TAIL] = 1;
-    c->tune[SIFT3D_TUNE_DESC_SEGMENT] = 32;
-    /* every octave of a capN volume, back to back: capN * (1 + 1/8 + 1/64 + ...) plus alignment */
-    c->capTot = c->capN + c->capN / 7 + 4 * ny * nz + 64 * 34; /* + up to three pad columns per row of every coarser octave */
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    hipStream_t *streams[] = {&c->ex_stream, &c->ex_stream2, &c->kp_stream};
-    for (hipStream_t *st : streams) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-    hipEvent_t *events[] = {&c->ev_ex2[0], &c->ev_ex2[1], &c->ev_reset, &c->ev_desc, &c->ev_oct[0], &c->ev_oct[1], &c->ev_fence[0], &c->ev_fence[1],
-                            &c->ev_split[0], &c->ev_split[1], &c->ev_split[2]};
-    for (hipEvent_t *e : events) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-    for (hipEvent_t &e : c->ev_kpc) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_cnt0, sizeof(unsigned long long) * (16 + SIFT3D_KP_MAX_CHUNKS), hipHostMallocDefault) == hipSuccess;
-    const size_t vb = sizeof(float) * (size_t)c->capN;
-    const size_t tb = sizeof(float) * (size_t)c->capTot;
-    /* nothing may depend on what hipMalloc hands back: the pad columns of pitched octaves are read as zeros.  The clears
-     * go on the context's own stream and are waited for here: hipMemset runs on the null stream, which the context's
-     * non-blocking streams are NOT ordered with, so it could still be wiping a buffer the first extraction already uses */
-    if (!lean) {
-        ok = ok && hipMalloc((void **)&c->vol, vb) == hipSuccess && hipMemsetAsync(c->vol, 0, vb, c->stream) == hipSuccess;
-        for (int i = 0; i < 5 && ok; i++) ok = hipMalloc((void **)&c->L[i], tb) == hipSuccess && hipMemsetAsync(c->L[i], 0, tb, c->stream) == hipSuccess;
-        for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&c->D[i], tb) == hipSuccess && hipMemsetAsync(c->D[i], 0, tb, c->stream) == hipSuccess;
-        ok = ok && hipMalloc((void **)&c->D4tiny, sizeof(float) * SIFT3D_D4TINY_FLOATS) == hipSuccess &&
-             hipMemsetAsync(c->D4tiny, 0, sizeof(float) * SIFT3D_D4TINY_FLOATS, c->stream) == hipSuccess;
-    }
-    /* the two pass intermediates of the three-launch blur: allocated here for the volumes the numbers are quoted on; a
-     * context beyond 2^31 voxels allocates them when a blur first takes that form, sized for it (its full-size levels go
-     * through the one-launch kernel, the coarse octaves need an eighth) -- 2 x 17 GB less at config C5's 2^32 voxels */
-    if (c->capN <= SIFT3D_EAGER_T_FLOATS)
-        for (int i = 0; i < 2 && ok; i++) {
-            ok = hipMalloc((void **)&c->T[i], vb) == hipSuccess;
-            if (ok) c->capT = c->capN;
-        }
-    ok = ok && hipMalloc((void **)&c->d_taps, sizeof(float) * SIFT3D_MAX_TAPS) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_count, sizeof(unsigned long long) * 8) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_levels, sizeof(sift3d_level) * 96) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->sampler_tokens, sizeof(int) * SIFT3D_CU_SLOTS) == hipSuccess &&
-         hipMemsetAsync(c->sampler_tokens, 0, sizeof(int) * SIFT3D_CU_SLOTS, c->stream) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_rec_base, sizeof(int) * (SIFT3D_KP_MAX_CHUNKS + 1)) == hipSuccess;
-    ok = ok && alloc_cands(c, c->capN / 32 + 8192) == SIFT3D_OK;
-    c->surv_cap = c->capN / 8 + 65536; /* own-level extrema are ~0.3 % of the voxels on blob fields, ~1 % on noise */
-    ok = ok && hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->surv_counts, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->list2_counts, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS) == hipSuccess;
-    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess; /* the clears above are done before the context is handed out */
-    if (!ok) {
-        free_dev(c);
-        destroy_sync_objects(c);
-        delete c;
-        return nullptr;
-    }
-    return c;
-}
-
-extern "C" sift3d_ctx *sift3d_create(int device, int64_t nx, int64_t ny, int64_t nz) { return ctx_create(device, nx, ny, nz, false); }
-
-extern "C" sift3d_ctx *sift3d_create_slab(int device, int64_t nx, int64_t ny, int64_t nz_local) { return ctx_create(device, nx, ny, nz_local, true); }
-
-extern "C" void sift3d_destroy(sift3d_ctx *c)
-{
-    if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    free_dev(c);
-    for (hipEvent_t e : c->pool) hipEventDestroy(e);
-    destroy_sync_objects(c);
-    delete c;
-}
-
-extern "C" int sift3d_set_tuning(sift3d_ctx *c, int knob, int value)
-{
-    if (!c) return SIFT3D_ERR_ARG;
-    static const int lo[SIFT3D_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0},
-                     hi[SIFT3D_TUNE_COUNT] = {2, 4096, 2, 1, 1, 64, SIFT3D_KP_MAX_CHUNKS, 1, 1 + SIFT3D_MAX_FRAMES, 2, 1, 2, 1 << 20, 3, 2};
-    if (knob < 0 || knob >= SIFT3D_TUNE_COUNT || value < lo[knob] || value > hi[knob])
-        return set_err(c, SIFT3D_ERR_ARG, "sift3d_set_tuning: knob %d does not take %d", knob, value);
-    c->tune[knob] = value;
-    return SIFT3D_OK;
-}
-
-extern "C" int64_t sift3d_host_buffer_grows(const sift3d_ctx *c) { return c ? c->host_grows : 0; }
-
-#ifdef SIFT3D_DEV
-extern "C" int sift3d_dev_set_stop(sift3d_ctx *c, int n)
-{
-    if (!c) return SIFT3D_ERR_ARG;
-    c->dev_stop = n;
-    return SIFT3D_OK;
-}
-#endif
-
-extern "C" int sift3d_set_stream(sift3d_ctx *c, void *s)
-{
-    if (!c) return SIFT3D_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (s) {
-        if (c->own_stream) hipStreamDestroy(c->stream);
-        c->stream = (hipStream_t)s;
-        c->own_stream = false;
-    } else if (!c->own_stream) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_set_max_octaves(sift3d_ctx *c, int n)
-{
-    if (!c || n < 0) return c ? set_err(c, SIFT3D_ERR_ARG, "max_octaves must be >= 0") : SIFT3D_ERR_ARG;
-    c->max_octaves = n;
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_sync(sift3d_ctx *c)
-{
-    if (!c) return SIFT3D_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SIFT3D_OK;
-}
-
-/* ---- self-test: LDS float atomic add == vector ALU add ------------------- */
-__global__ void selftest_lds_add_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n,
-                                        float *__restrict__ valu, float *__restrict__ lds)
-{
-    __shared__ float cell[256];
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const float x = i < n ? a[i] : 0.0f, y = i < n ? b[i] : 0.0f;
-    cell[threadIdx.x] = x;
-    __syncthreads();
-    __hip_atomic_fetch_add(&cell[threadIdx.x], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __syncthreads();
-    if (i < n) {
-        valu[i] = x + y;
-        lds[i] = cell[threadIdx.x];
-    }
-}
-
-extern "C" int sift3d_selftest_lds_add(sift3d_ctx *c, const float *a, const float *b, int64_t n, float *valu, float *lds)
-{
-    NEED_LEVELS(c);
-    if (!c || !a || !b || !valu || !lds || n <= 0 || 4 * n > c->capTot) return c ? set_err(c, SIFT3D_ERR_ARG, "bad self-test arguments") : SIFT3D_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    float *da = c->L[0], *db = c->L[0] + n, *dv = c->L[0] + 2 * n, *dl = c->L[0] + 3 * n;
-    HIPCHK(c, hipMemcpyAsync(da, a, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(db, b, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(selftest_lds_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, (long long)n, dv, dl);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(valu, dv, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(lds, dl, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->has_volume = false;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    return SIFT3D_OK;
-}
-
-/* ---- timing ------------------------------------------------------------ */
-static hipEvent_t get_event(sift3d_ctx *c)
-{
-    if (c->pool_used == c->pool.size()) {
-        hipEvent_t e;
-        hipEventCreate(&e);
-        c->pool.push_back(e);
-    }
-    return c->pool[c->pool_used++];
-}
-
-struct stage_scope {
-    sift3d_ctx *c;
-    int stage;
-    hipEvent_t e0, e1;
-    int ntaps;
-    int64_t nvox;
-    double bytes;
-    hipStream_t st;
-    bool timed;
-    stage_scope(sift3d_ctx *c_, int stage_, double bytes_, int ntaps_ = 0, int64_t nvox_ = 0, hipStream_t st_ = nullptr)
-        : c(c_), stage(stage_), e0(nullptr), e1(nullptr), ntaps(ntaps_), nvox(nvox_), bytes(bytes_), st(st_ ? st_ : c_->stream)
-    {
-        c->last.launches[stage] += 1;
-        c->last.alg_bytes[stage] += bytes;
-        /* events cost a few microseconds each (two per launch, ~170 launches: 1 ms of a 13 ms run at 512^3): mode 2
-         * keeps them to the dominant kernels, the blur launches on the full-size volume */
-        timed = c->timing == 1 || c->timing == 3 ||
-                (c->timing == 2 && nvox == pitch_of(c->nx) * c->ny * c->nz &&
-                 (stage == SIFT3D_STAGE_BLUR_FUSED || stage == SIFT3D_STAGE_BLUR_X || stage == SIFT3D_STAGE_BLUR_Y ||
-                  stage == SIFT3D_STAGE_BLUR_Z_DOG));
-        if (timed) {
-            e0 = get_event(c);
-            e1 = get_event(c);
-            hipEventRecord(e0, st);
-        }
-    }
-    void add_bytes(double more) /* the launch turned out to do more (the subsample riding on the level-3 blur) */
-    {
-        c->last.alg_bytes[stage] += more;
-        bytes += more;
-    }
-    void cancel() /* the launch did not happen */
-    {
-        c->last.launches[stage] -= 1;
-        c->last.alg_bytes[stage] -= bytes;
-        if (timed) c->pool_used -= 2;
-        stage = -1;
-    }
-    ~stage_scope()
-    {
-        if (stage < 0) return;
-        if (timed) {
-            hipEventRecord(e1, st);
-            c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f, 0.0f});
-        }
-    }
-};
-
-void timing_begin(sift3d_ctx *c)
-{
-    memset(&c->last, 0, sizeof(c->last));
-    c->launches.clear();
-    c->pool_used = 0;
-    c->resolved = 0;
-}
-
-/* Resolves the events of every launch recorded since the last call (idempotent). */
-static void timing_end(sift3d_ctx *c)
-{
-    if (!c->timing) return;
-    hipStreamSynchronize(c->stream);
-    for (size_t i = c->resolved; i < c->launches.size(); i++) {
-        timed_launch &t = c->launches[i];
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) c->last.ms[t.stage] += ms;
-        t.ms = ms;
-        float since = 0;
-        if (hipEventElapsedTime(&since, c->launches.front().e0, t.e0) != hipSuccess) since = 0;
-        t.start_ms = since;
-    }
-    c->resolved = c->launches.size();
-    if (!c->launches.empty()) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->launches.front().e0, c->launches.back().e1) == hipSuccess) c->last.total_ms = ms;
-    }
-}
-
-extern "C" int sift3d_enable_timing(sift3d_ctx *c, int on)
-{
-    if (!c) return SIFT3D_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->timing = on < 0 ? 0 : (on > 3 ? 1 : on);
-    timing_begin(c); /* operator-level *_dev calls accumulate from here until the log is read */
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_get_timings(const sift3d_ctx *c, sift3d_timings *t)
-{
-    if (!c || !t) return SIFT3D_ERR_ARG;
-    timing_end(const_cast<sift3d_ctx *>(c));
-    *t = c->last;
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_get_launch_log(const sift3d_ctx *c, sift3d_launch_record *out, int64_t cap, int64_t *n)
-{
-    if (!c || !n) return SIFT3D_ERR_ARG;
-    timing_end(const_cast<sift3d_ctx *>(c));
-    *n = (int64_t)c->launches.size();
-    for (int64_t i = 0; i < *n && i < cap && out; i++) {
-        const timed_launch &t = c->launches[(size_t)i];
-        out[i].stage = t.stage;
-        out[i].ntaps = t.ntaps;
-        out[i].nvox = t.nvox;
-        out[i].alg_bytes = t.bytes;
-        out[i].ms = t.ms;
-        out[i].start_ms = t.start_ms;
-    }
-    return *n > cap ? SIFT3D_ERR_CAPACITY : SIFT3D_OK;
-}
-
-/* T[0], T[1] hold at least `floats` floats each (see ctx_create).  Growing waits for the stream: a blur queued earlier may
- * still be using the old pair. */
-static int ensure_T(sift3d_ctx *c, int64_t floats)
-{
-    if (floats <= c->capT) return SIFT3D_OK;
-    if (floats > c->capN) return set_err(c, SIFT3D_ERR_ARG, "pass intermediates of %lld floats asked of a context of %lld", (long long)floats, (long long)c->capN);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(c->T[0]);
-    hipFree(c->T[1]);
-    c->T[0] = c->T[1] = nullptr;
-    c->capT = 0;
-    /* at least the second octave (capN / 8 and its row padding), so that the coarse octaves of one extraction grow it once */
-    int64_t want = c->capN / 8 + c->capN / 64 + 4096;
-    if (want < floats) want = floats;
-    if (want > c->capN) want = c->capN;
-    for (int i = 0; i < 2; i++)
-        if (hipMalloc((void **)&c->T[i], sizeof(float) * (size_t)want) != hipSuccess) {
-            (void)hipGetLastError();
-            return set_err(c, SIFT3D_ERR_MEMORY, "out of device memory for the pass intermediates (%lld floats)", (long long)want);
-        }
-    c->capT = want;
-    return SIFT3D_OK;
-}
-
-/* ---- device-level building blocks -------------------------------------- */
-/* out = blur(in); if dog != NULL also dog = in - out.  out may be NULL when only the DoG is wanted.  Uses T[0], T[1].
- * sub (optional): the next octave's level 0, the 2 x 2 x 2 mean of out as a dense (X / 2) x (Y / 2) x (Z / 2) volume; written
- * only where the fused launch can carry it, *sub_done says whether -- the caller launches the subsample itself if not. */
-int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma,
-                    float min_value, float *sub, bool *sub_done)
-{
-    if (sub_done) *sub_done = false;
-    float taps[SIFT3D_MAX_TAPS];
-    hipStream_t ws = c->stream;
-    int n = sift3d_gauss_taps(sigma, min_value, taps);
-    if (n < 0) return set_err(c, SIFT3D_ERR_ARG, "bad blur parameters sigma=%g min=%g", sigma, min_value);
-    const double N = (double)X * Y * Z;
-    if (n == 1) { /* delta filter: out = 1*in */
-        if (out) HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, ws));
-        if (dog) HIPCHK(c, hipMemsetAsync(dog, 0, sizeof(float) * (size_t)N, ws));
-        return SIFT3D_OK;
-    }
-    if (n / 2 > SIFT3D_FAST_MAX_R)
-        HIPCHK(c, hipMemcpyAsync(c->d_taps, taps, sizeof(float) * n, hipMemcpyHostToDevice, ws));
-    /* One fused launch per level where the volume fills the chip (it marches along z with few, fat workgroups);
-     * coarse octaves keep the three-pass path.  SIFT3D_TUNE_BLUR_FUSED: 0 never / 2 always (tests, A/B timing). */
-    const int fmode = c->tune[SIFT3D_TUNE_BLUR_FUSED];
-    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE], c->tune[SIFT3D_TUNE_FUSED_ORDER], c->tune[SIFT3D_TUNE_FUSED_STAGGER]};
-    /* measured standalone (tools/bench_blur_ab.sh 128 / 64): below 2^22 voxels the one launch still beats the three for 7 and
-     * 9 taps (0.020 / 0.026 against 0.042 / 0.043 ms at 128^3), ties at 11-13 and loses at 17 */
-    if (fmode == 2 || (fmode == 1 && (N >= (double)(1 << 22) || (N >= (double)(1 << 18) && n <= 9)))) {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N, ws);
-        int with_sub = 0;
-        hipError_t e = sift3d_launch_blur_fused(ws, in, out, dog, X, Y, Z, taps, n, &bt, 0, -1, c->tune[SIFT3D_TUNE_FUSED_SUB] ? sub : nullptr, &with_sub);
-        if (e == hipSuccess) {
-            if (with_sub) {
-                sc.add_bytes(0.5 * N); /* one float stored per eight voxels */
-                if (sub_done) *sub_done = true;
-            }
-            return SIFT3D_OK;
-        }
-        if (e != hipErrorNotSupported) HIPCHK(c, e);
-        sc.cancel();
-    }
-    /* the three-pass form goes through the context's two intermediates: a volume beyond them (a gathered octave on a slab
-     * context sized for its slab) must not overrun them */
-    if ((int64_t)N > c->capN)
-        return set_err(c, SIFT3D_ERR_ARG, "a %lldx%lldx%lld blur needs pass intermediates of %lld floats, the context has %lld", (long long)X,
-                       (long long)Y, (long long)Z, (long long)N, (long long)c->capN);
-    {
-        int rc_t = ensure_T(c, (int64_t)N);
-        if (rc_t) return rc_t;
-    }
-    float *const T0 = c->T[0], *const T1 = c->T[1];
-    {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_X, 8.0 * N, n, (int64_t)N, ws);
-        HIPCHK(c, sift3d_launch_blur_x(ws, in, T0, X, Y, Z, taps, n, c->d_taps));
-    }
-    {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_Y, 8.0 * N, n, (int64_t)N, ws);
-        HIPCHK(c, sift3d_launch_blur_y(ws, T0, T1, X, Y, Z, taps, n, c->d_taps));
-    }
-    {
-        stage_scope sc(c, SIFT3D_STAGE_BLUR_Z_DOG, (dog ? 16.0 : 8.0) * N, n, (int64_t)N, ws);
-        HIPCHK(c, sift3d_launch_blur_z(ws, T1, out ? out : T0, dog ? in : nullptr, dog, X, Y, Z, taps, n, c->d_taps));
-    }
-    return SIFT3D_OK;
-}
-
-static int check_shape(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz)
-{
-    if (!c) return SIFT3D_ERR_ARG;
-    if (nx <= 0 || ny <= 0 || nz <= 0 || pitch_of(nx) * ny * nz > c->capN)
-        return set_err(c, SIFT3D_ERR_ARG, "volume %lldx%lldx%lld does not fit the context (%lld voxels)", (long long)nx,
-                       (long long)ny, (long long)nz, (long long)c->capN);
-    if (nx >= (1ll << 31) || ny >= (1ll << 31) || nz >= 65536 + 2) return set_err(c, SIFT3D_ERR_ARG, "dimension too large");
-    return SIFT3D_OK;
-}
-
-/* Ordering of device buffers handed to the *_dev entry points.  The context's own stream is non-blocking, i.e. not
- * ordered with the legacy default stream -- the stream the reference itself runs on, and what a caller who never
- * touched streams (torch's default stream on ROCm included) produces and consumes on.  While the context runs on its own
- * stream, every *_dev entry point therefore (in) makes its stream wait for what the default stream has queued so far and
- * (out) makes the default stream wait for what the call queued: the call behaves as if it had been issued on the default
- * stream, without a host synchronisation.  A caller that works on a stream of its own hands it over once with
- * sift3d_set_stream(); the context then runs ON that stream and no fence is needed. */
-static int fence_in(sift3d_ctx *c)
-{
-    if (!c->own_stream) return SIFT3D_OK;
-    HIPCHK(c, hipEventRecord(c->ev_fence[0], nullptr));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fence[0], 0));
-    return SIFT3D_OK;
-}
-
-static int fence_out(sift3d_ctx *c)
-{
-    if (!c->own_stream) return SIFT3D_OK;
-    HIPCHK(c, hipEventRecord(c->ev_fence[1], c->stream));
-    HIPCHK(c, hipStreamWaitEvent(nullptr, c->ev_fence[1], 0));
-    return SIFT3D_OK;
-}
-
-/* The blur restricted to output planes [zo0, zo1) of the volume (the input is read as far as the filter reaches): what a
- * Z-slab rank uses to filter its two boundary bands before the interior.  Only the fused launch has that form. */
-bool blur_window_supported(int64_t X, int64_t Y, float sigma, float min_value)
-{
-    float taps[SIFT3D_MAX_TAPS];
-    const int n = sift3d_gauss_taps(sigma, min_value, taps);
-    return n >= 3 && n <= 2 * SIFT3D_FAST_MAX_R + 1 && X % 4 == 0 && X * Y < (1ll << 29);
-}
-
-int blur_window_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, int64_t zo0, int64_t zo1,
-                           float sigma, float min_value)
-{
-    float taps[SIFT3D_MAX_TAPS];
-    const int n = sift3d_gauss_taps(sigma, min_value, taps);
-    if (n < 3 || zo0 < 0 || zo1 > Z || zo1 <= zo0) return set_err(c, SIFT3D_ERR_ARG, "bad blur window [%lld, %lld) of %lld planes", (long long)zo0, (long long)zo1, (long long)Z);
-    const sift3d_blur_tuning bt = {c->tune[SIFT3D_TUNE_FUSED_CHUNKS], c->tune[SIFT3D_TUNE_FUSED_ROWS], c->tune[SIFT3D_TUNE_FUSED_TILE], c->tune[SIFT3D_TUNE_FUSED_ORDER], c->tune[SIFT3D_TUNE_FUSED_STAGGER]};
-    const double N = (double)X * Y * (double)(zo1 - zo0);
-    stage_scope sc(c, SIFT3D_STAGE_BLUR_FUSED, (dog && out ? 12.0 : 8.0) * N, n, (int64_t)N);
-    hipError_t e = sift3d_launch_blur_fused(c->stream, in, out, dog, X, Y, Z, taps, n, &bt, zo0, zo1);
-    if (e == hipErrorNotSupported) {
-        sc.cancel();
-        return set_err(c, SIFT3D_ERR_ARG, "this shape or filter has no windowed blur (sift3d_blur_window_supported)");
-    }
-    HIPCHK(c, e);
-    return SIFT3D_OK;
-}
-
-/* runs op between the two fences */
-#define FENCED(c, op)                 \
-    do {                              \
-        int rc_ = fence_in(c);        \
-        if (rc_) return rc_;          \
-        rc_ = (op);                   \
-        if (rc_) return rc_;          \
-        return fence_out(c);          \
-    } while (0)
-
-/* ---- operator level ----------------------------------------------------- */
-extern "C" int sift3d_gauss_blur_dev(sift3d_ctx *c, const float *d_in, float *d_out, int64_t nx, int64_t ny, int64_t nz,
-                                     float sigma, float min_value)
-{
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (nz < 2) return set_err(c, SIFT3D_ERR_ARG, "2-D images are outside this path (featExtract rejects z <= 1)");
-    HIPCHK(c, hipSetDevice(c->device));
-    FENCED(c, blur_dev(c, d_in, d_out, nullptr, nx, ny, nz, sigma, min_value));
-}
-
-extern "C" int sift3d_gauss_blur_dog_dev(sift3d_ctx *c, const float *d_in, float *d_out, float *d_dog, int64_t nx,
-                                         int64_t ny, int64_t nz, float sigma, float min_value)
-{
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (nz < 2) return set_err(c, SIFT3D_ERR_ARG, "2-D images are outside this path (featExtract rejects z <= 1)");
-    HIPCHK(c, hipSetDevice(c->device));
-    FENCED(c, blur_dev(c, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value));
-}
-
-/* level + DoG + the half-size volume the next octave starts from, as the pyramid produces them at level 3 */
-extern "C" int sift3d_gauss_blur_dog_half_dev(sift3d_ctx *c, const float *d_in, float *d_out, float *d_dog, float *d_half, int64_t nx,
-                                              int64_t ny, int64_t nz, float sigma, float min_value, int *in_one_launch)
-{
-    if (in_one_launch) *in_one_launch = 0;
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (!d_in || !d_out || !d_half) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
-    if (nx < 2 || ny < 2 || nz < 2) return set_err(c, SIFT3D_ERR_ARG, "subsample needs every dimension >= 2");
-    HIPCHK(c, hipSetDevice(c->device));
-    rc = fence_in(c);
-    if (rc) return rc;
-    bool carried = false;
-    /* the half-size volume is dense here (rows of nx / 2): the launch can carry it when those rows are whole 16-byte vectors */
-    rc = blur_dev(c, d_in, d_out, d_dog, nx, ny, nz, sigma, min_value, nx % 8 == 0 ? d_half : nullptr, &carried);
-    if (rc) return rc;
-    if (!carried) {
-        stage_scope sc(c, SIFT3D_STAGE_SUBSAMPLE, 4.5 * (double)nx * ny * nz, 0, nx * ny * nz);
-        HIPCHK(c, sift3d_launch_subsample(c->stream, d_out, nx, nx, ny, nz, d_half, nx / 2));
-    }
-    if (in_one_launch) *in_one_launch = carried ? 1 : 0;
-    return fence_out(c);
-}
-
-extern "C" int sift3d_blur_window_supported(int64_t nx, int64_t ny, float sigma, float min_value)
-{
-    return blur_window_supported(nx, ny, sigma, min_value) ? 1 : 0;
-}
-
-extern "C" int sift3d_gauss_blur_dog_window_dev(sift3d_ctx *c, const float *d_in, float *d_out, float *d_dog, int64_t nx, int64_t ny,
-                                                int64_t nz, int64_t z_lo, int64_t z_hi, float sigma, float min_value)
-{
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (nz < 2 || (!d_out && !d_dog)) return set_err(c, SIFT3D_ERR_ARG, "bad windowed blur arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    FENCED(c, blur_window_dev(c, d_in, d_out, d_dog, nx, ny, nz, z_lo, z_hi, sigma, min_value));
-}
-
-extern "C" int sift3d_gauss_blur(sift3d_ctx *c, const float *in, float *out, int64_t nx, int64_t ny, int64_t nz,
-                                 float sigma, float min_value)
-{
-    NEED_LEVELS(c);
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (!in || !out) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t b = sizeof(float) * (size_t)(nx * ny * nz);
-    HIPCHK(c, hipMemcpyAsync(c->vol, in, b, hipMemcpyHostToDevice, c->stream));
-    rc = sift3d_gauss_blur_dev(c, c->vol, c->L[0], nx, ny, nz, sigma, min_value);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->L[0], b, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->has_volume = false;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_dog_dev(sift3d_ctx *c, const float *d_a, const float *d_b, float *d_out, int64_t n)
-{
-    if (!c || n <= 0) return SIFT3D_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = fence_in(c);
-    if (rc) return rc;
-    HIPCHK(c, sift3d_launch_dog(c->stream, d_a, d_b, d_out, n));
-    return fence_out(c);
-}
-
-extern "C" int sift3d_dog(sift3d_ctx *c, const float *a, const float *b, float *out, int64_t n)
-{
-    NEED_LEVELS(c);
-    if (!c || !a || !b || !out || n <= 0 || n > c->capN) return set_err(c, SIFT3D_ERR_ARG, "bad dog arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t by = sizeof(float) * (size_t)n;
-    HIPCHK(c, hipMemcpyAsync(c->L[0], a, by, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->L[1], b, by, hipMemcpyHostToDevice, c->stream));
-    int rc = sift3d_dog_dev(c, c->L[0], c->L[1], c->D[0], n);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->D[0], by, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->has_volume = false;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_subsample2_dev(sift3d_ctx *c, const float *d_in, int64_t nx, int64_t ny, int64_t nz, float *d_out)
-{
-    if (!c || nx < 2 || ny < 2 || nz < 2) return set_err(c, SIFT3D_ERR_ARG, "subsample needs every dimension >= 2");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = fence_in(c);
-    if (rc) return rc;
-    HIPCHK(c, sift3d_launch_subsample(c->stream, d_in, nx, nx, ny, nz, d_out, nx / 2));
-    return fence_out(c);
-}
-
-extern "C" int sift3d_subsample2(sift3d_ctx *c, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out)
-{
-    NEED_LEVELS(c);
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (!in || !out) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->L[0], in, sizeof(float) * (size_t)(nx * ny * nz), hipMemcpyHostToDevice, c->stream));
-    rc = sift3d_subsample2_dev(c, c->L[0], nx, ny, nz, c->L[1]);
-    if (rc) return rc;
-    const size_t ob = sizeof(float) * (size_t)((nx / 2) * (ny / 2) * (nz / 2));
-    HIPCHK(c, hipMemcpyAsync(out, c->L[1], ob, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->has_volume = false;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_double_size(sift3d_ctx *c, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out)
-{
-    NEED_LEVELS(c);
-    if (!c || !in || !out || nx < 2 || ny < 2 || nz < 2 || 8 * nx * ny * nz > c->capN)
-        return set_err(c, SIFT3D_ERR_ARG, "double_size: the context must hold the doubled volume");
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->L[0], in, sizeof(float) * (size_t)(nx * ny * nz), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, sift3d_launch_double_size(c->stream, c->L[0], nx, ny, nz, c->L[1]));
-    HIPCHK(c, hipMemcpyAsync(out, c->L[1], sizeof(float) * (size_t)(8 * nx * ny * nz), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->has_volume = false;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_halve_size(sift3d_ctx *c, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out)
-{
-    NEED_LEVELS(c);
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (!in || !out || nx < 2 || ny < 2 || nz < 2) return set_err(c, SIFT3D_ERR_ARG, "halve_size needs every dimension >= 2");
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->L[0], in, sizeof(float) * (size_t)(nx * ny * nz), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, sift3d_launch_halve_size(c->stream, c->L[0], nx, ny, nz, c->L[1]));
-    const size_t ob = sizeof(float) * (size_t)((nx / 2) * (ny / 2) * (nz / 2));
-    HIPCHK(c, hipMemcpyAsync(out, c->L[1], ob, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->has_volume = false;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    return SIFT3D_OK;
-}
-
-/* Extrema of all levels go to one (key, value) buffer: reset, any number of appends (one kernel
- * launch each, nothing synchronises), then finalize = one host synchronisation for the count, a
- * replay of the recorded launches into a bigger buffer if it overflowed (the DoG levels stay
- * resident), and the device radix sort. */
-/* on: the stream the clears are queued on (the caller orders the extrema passes behind it) */
-int cand_reset(sift3d_ctx *c, hipStream_t on)
-{
-    if (!on) on = c->stream;
-    c->jobs.clear();
-    c->cand_split_at = 0;
-    c->cand_group = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 8, on));
-    /* every extrema pass of the run gets its own counter set: one memset here instead of one per pass */
-    HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, on));
-    HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, on));
-    HIPCHK(c, hipMemsetAsync(c->d_rec_base, 0, sizeof(int), on)); /* first record of the per-keypoint stage's first chunk (the split tail
-                                                                    * does not clear it again when the first count arrives) */
-    c->surv_set = 0;
-    return SIFT3D_OK;
-}
-
-/* where the extrema launches queued now append: the whole list, or the part of it the current group owns (split tail) */
-struct cand_target {
-    unsigned long long *keys;
-    sift3d_cval *vals;
-    unsigned long long *count;
-    int64_t cap;
-};
-static cand_target cand_target_of(const sift3d_ctx *c)
-{
-    if (c->cand_split_at <= 0) return {c->keys_a, c->vals_a, c->d_count, c->cand_cap};
-    if (c->cand_group == 0) return {c->keys_a, c->vals_a, c->d_count, c->cand_split_at};
-    return {c->keys_a + c->cand_split_at, c->vals_a + c->cand_split_at, c->d_count + 4, c->cand_cap - c->cand_split_at};
-}
-
-int cand_append(sift3d_ctx *c, const level_job &j, bool record)
-{
-    c->count_queued = false;
-    if (record) c->jobs.push_back(j);
-    hipStream_t st = c->cand_stream ? c->cand_stream : c->stream;
-    stage_scope sc(c, SIFT3D_STAGE_EXTREMA, 4.0 * (double)j.X * j.Y * j.Z, 0, j.X * j.Y * j.Z, st);
-    /* own-level extrema are ~0.3 % of the voxels on blob fields (7 % on white noise): the list of a level is
-     * sized at 1/surv_div of its voxels; an overflow is flagged on the device and handled in cand_finalize */
-    int64_t cover = j.X * j.Y * j.Z / c->surv_div + 64 * 1024; /* split evenly over 64 segments */
-    if (cover > c->surv_cap) cover = c->surv_cap;
-    sift3d_survivor *surv = c->surv;
-    if (c->surv_sel > 0) { /* a pass on the second extrema stream: that stream's own list, grown on demand */
-        if (c->surv2_cap < cover) {
-            HIPCHK(c, hipStreamSynchronize(st));
-            hipFree(c->surv2);
-            c->surv2 = nullptr;
-            c->surv2_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->surv2, sizeof(sift3d_survivor) * (size_t)cover));
-            c->surv2_cap = cover;
-        }
-        surv = c->surv2;
-    }
-    const bool fresh = c->surv_set < SIFT3D_SURV_SETS;
-    const int set = fresh ? c->surv_set++ : SIFT3D_SURV_SETS - 1;
-    unsigned long long *counters = c->surv_counts + (size_t)set * SIFT3D_SURV_COUNTERS;
-    sift3d_extrema_lazy lz;
-    memset(&lz, 0, sizeof(lz));
-    const bool lazy = j.prev_b || j.next_g;
-    if (lazy) {
-        lz.prev_b = j.prev_b;
-        lz.next_g = j.next_g;
-        if (j.next_g) {
-            /* the second list holds a subset of the own-level list: the same capacity always suffices */
-            const int li = c->surv_sel > 0 ? 1 : 0;
-            if (c->list2_cap[li] < cover) {
-                HIPCHK(c, hipStreamSynchronize(st)); /* an earlier pass may still be reading the list */
-                hipFree(c->list2[li]);
-                c->list2[li] = nullptr;
-                c->list2_cap[li] = 0;
-                HIPCHK(c, hipMalloc((void **)&c->list2[li], sizeof(sift3d_survivor2) * (size_t)cover));
-                c->list2_cap[li] = cover;
-            }
-            lz.ntaps = j.next_ntaps;
-            memcpy(lz.taps, j.next_taps, sizeof(lz.taps));
-            lz.list2 = c->list2[li];
-            lz.list2_count = c->list2_counts + (size_t)set * SIFT3D_LIST2_COUNTERS;
-            lz.list2_cap = c->list2_cap[li];
-            if (!fresh) HIPCHK(c, hipMemsetAsync(lz.list2_count, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS, st));
-        }
-    }
-    const cand_target tg = cand_target_of(c);
-    HIPCHK(c, sift3d_launch_extrema(st, j.dp, j.dc, j.dn, j.X, j.Xl ? j.Xl : j.X, j.Y, j.Z, j.z_lo, j.z_hi, j.lvl_id, tg.keys,
-                                    tg.vals, tg.count, tg.cap, surv, counters, c->d_count + 2, cover, !fresh,
-                                    lazy ? &lz : nullptr));
-    return SIFT3D_OK;
-}
-
-static int cand_replay(sift3d_ctx *c)
-{
-    c->cand_split_at = 0; /* a replay fills one list, whatever the first attempt did */
-    c->cand_group = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long) * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->surv_counts, 0, sizeof(unsigned long long) * SIFT3D_SURV_COUNTERS * SIFT3D_SURV_SETS, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->list2_counts, 0, sizeof(unsigned long long) * SIFT3D_LIST2_COUNTERS * SIFT3D_SURV_SETS, c->stream));
-    c->surv_set = 0;
-    for (const level_job &j : c->jobs) {
-        int rc = cand_append(c, j, false);
-        if (rc) return rc;
-    }
-    return SIFT3D_OK;
-}
-
-/* An own-level list was cut short (high_water = the length it would have needed): from now on the lists of this context are
- * sized for the worst case of a level, and the first one is grown to the mark.  Nothing may be running on the context. */
-static int surv_make_room(sift3d_ctx *c, unsigned long long high_water)
-{
-    c->surv_div = 1;
-    if ((int64_t)high_water > c->surv_cap) {
-        hipFree(c->surv);
-        c->surv = nullptr;
-        c->surv_cap = (int64_t)high_water + (int64_t)high_water / 4 + 4096;
-        HIPCHK(c, hipMalloc((void **)&c->surv, sizeof(sift3d_survivor) * (size_t)c->surv_cap));
-    }
-    return SIFT3D_OK;
-}
-
-/* The count of validated extrema comes back in two steps so that a driver with several contexts can queue the read-back
- * on all of them before it waits for the first: cand_count_queue (asynchronous), cand_finalize (waits, replays the extrema
- * launches into bigger lists if one overflowed, sorts). */
-int cand_count_queue(sift3d_ctx *c)
-{
-    unsigned long long *cnt = c->h_cnt0 + 4; /* validated extrema, survivors of the last level, survivor overflow */
-    cnt[0] = cnt[1] = cnt[2] = 0;
-    HIPCHK(c, hipMemcpyAsync(cnt, c->d_count, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->stream));
-    c->count_queued = true;
-    return SIFT3D_OK;
-}
-
-int cand_finalize(sift3d_ctx *c, int64_t *count_out)
-{
-    for (int attempt = 0; attempt < 4; attempt++) {
-        const unsigned long long *cnt = c->h_cnt0 + 4;
-        if (!c->count_queued) {
-            int rc = cand_count_queue(c);
-            if (rc) return rc;
-        }
-        c->count_queued = false;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (cnt[2] > 0) { /* an own-level list was cut short: make room and redo the extrema launches */
-            int rc = surv_make_room(c, cnt[2]);
-            if (rc) return rc;
-            rc = cand_replay(c);
-            if (rc) return rc;
-            continue;
-        }
-        if ((int64_t)cnt[0] > c->cand_cap) {
-            if (alloc_cands(c, (int64_t)cnt[0] + (int64_t)cnt[0] / 4 + 4096) != SIFT3D_OK)
-                return set_err(c, SIFT3D_ERR_MEMORY, "candidate buffer could not be grown to %llu entries", cnt[0]);
-            int rc = cand_replay(c);
-            if (rc) return rc;
-            continue;
-        }
-        if (cnt[0] > 0)
-            HIPCHK(c, sift3d_sort_candidates(c->stream, c->sort_tmp, c->sort_tmp_bytes, c->keys_a, c->keys_b, c->vals_a, c->vals_b, (int64_t)cnt[0]));
-        *count_out = (int64_t)cnt[0];
-        return SIFT3D_OK;
-    }
-    return set_err(c, SIFT3D_ERR_MEMORY, "extrema buffers could not be grown");
-}
-
-extern "C" int sift3d_extrema(sift3d_ctx *c, const float *d_prev, const float *d_cur, const float *d_next, int64_t nx,
-                              int64_t ny, int64_t nz, sift3d_extremum *minima, int64_t cap_min, int64_t *n_min,
-                              sift3d_extremum *maxima, int64_t cap_max, int64_t *n_max)
-{
-    NEED_LEVELS(c);
-    int rc = check_shape(c, nx, ny, nz);
-    if (rc) return rc;
-    if (!d_prev || !d_cur || !n_min || !n_max) return set_err(c, SIFT3D_ERR_ARG, "null pointer");
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t b = sizeof(float) * (size_t)(nx * ny * nz);
-    HIPCHK(c, hipMemcpyAsync(c->D[0], d_prev, b, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->D[1], d_cur, b, hipMemcpyHostToDevice, c->stream));
-    if (d_next) HIPCHK(c, hipMemcpyAsync(c->D[2], d_next, b, hipMemcpyHostToDevice, c->stream));
-    c->has_volume = false;
-    c->pad_nx = 0; /* the level buffers were used as dense scratch: their pad columns must be cleared again */
-    int64_t cnt = 0;
-    rc = cand_reset(c);
-    if (!rc) rc = cand_append(c, {c->D[0], c->D[1], d_next ? c->D[2] : nullptr, nx, ny, nz, 0, (int)nz, 0}, true);
-    if (!rc) rc = cand_finalize(c, &cnt);
-    if (rc) return rc;
-    std::vector<unsigned long long> keys((size_t)cnt);
-    std::vector<sift3d_cval> vals((size_t)cnt);
-    if (cnt) {
-        HIPCHK(c, hipMemcpyAsync(keys.data(), c->keys_b, sizeof(unsigned long long) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(vals.data(), c->vals_b, sizeof(sift3d_cval) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int64_t a = 0, m = 0;
-    bool over = false;
-    for (int64_t i = 0; i < cnt; i++) {
-        const int64_t idx = (int64_t)(keys[(size_t)i] & SIFT3D_KEY_IDX_MASK);
-        sift3d_extremum e;
-        e.x = (int32_t)(idx % nx);
-        e.y = (int32_t)((idx / nx) % ny);
-        e.z = (int32_t)(idx / (nx * ny));
-        e.value = vals[(size_t)i].value;
-        if ((keys[(size_t)i] >> SIFT3D_KEY_MAX_SHIFT) & 1ull) {
-            if (m < cap_max && maxima) maxima[m] = e; else over = true;
-            m++;
-        } else {
-            if (a < cap_min && minima) minima[a] = e; else over = true;
-            a++;
-        }
-    }
-    *n_min = a;
-    *n_max = m;
-    return over ? set_err(c, SIFT3D_ERR_CAPACITY, "extrema lists need %lld + %lld entries", (long long)a, (long long)m)
-                : SIFT3D_OK;
-}
 
 /* ---- pipeline ------------------------------------------------------------ */
 /* A level buffer the default pipeline does not need (D[4]): allocated, and cleared like the others, the first time an
@@ -1277,7 +307,7 @@ extern "C" int sift3d_reserve(sift3d_ctx *c, int64_t n_extrema)
 }
 
 /* Sorted candidates -> host list with whole-volume coordinates (sift3d_detect, slab tests). */
-static int candidates_to_host(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand,
+int candidates_to_host(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand,
                               sift3d_candidate **cands_out, int64_t *n_out)
 {
     std::vector<unsigned long long> keys((size_t)ncand);
@@ -1620,8 +650,8 @@ extern "C" int sift3d_dev_overlap_probe(sift3d_ctx *c, int kslice, int dslice, d
 }
 #endif
 
-static int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode,
-                           float eig_thres, float size_factor, int64_t *n_out, bool levels_on_device = false)
+int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode,
+                           float eig_thres, float size_factor, int64_t *n_out, bool levels_on_device)
 {
     int rc = describe_queue(c, levels, ncand, desc_mode, eig_thres, size_factor, levels_on_device);
     if (!rc) rc = describe_launch(c);
@@ -2027,220 +1057,6 @@ static int run_pipeline(sift3d_ctx *c, float init_scale, bool extract, int desc_
     return SIFT3D_OK;
 }
 
-/* ---- building blocks for Z-slab mode: the caller owns the level buffers (device memory), places
- * halos, and drives the exchange; the library detects and describes on whatever it is given. ---- */
-extern "C" int sift3d_candidates_reset(sift3d_ctx *c)
-{
-    if (!c) return SIFT3D_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    timing_begin(c);
-    return cand_reset(c);
-}
-
-extern "C" int sift3d_extrema_append_dev(sift3d_ctx *c, const float *d_prev, const float *d_cur, const float *d_next,
-                                         int64_t nx, int64_t ny, int64_t nz_local, int level_id, int64_t z_lo, int64_t z_hi)
-{
-    if (!c || !d_prev || !d_cur || !d_next) return SIFT3D_ERR_ARG;
-    if (nx <= 0 || ny <= 0 || nz_local <= 0 || nx >= (1ll << 31) || ny >= (1ll << 31) || nz_local >= 65538 ||
-        nx * ny * nz_local > (int64_t)SIFT3D_KEY_IDX_MASK || level_id < 0 || level_id >= 96)
-        return set_err(c, SIFT3D_ERR_ARG, "bad extrema_append arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = fence_in(c);
-    if (rc) return rc;
-    rc = cand_append(c, {d_prev, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id}, true);
-    if (rc) return rc;
-    return fence_out(c); /* the caller may reuse the buffers once the pass has read them */
-}
-
-/* shapes the second and third extrema phase take neighbour levels in unstored form for */
-static bool lazy_shape_ok(int64_t nx, int64_t ny, int64_t nz_local)
-{
-    return nx % 4 == 0 && nx >= 8 && ny >= 3 && nz_local >= 3 && nx * ny < (1ll << 29);
-}
-
-extern "C" int sift3d_lazy_levels_supported(int64_t nx, int64_t ny, int64_t nz_local, float next_sigma)
-{
-    float taps[SIFT3D_MAX_TAPS];
-    return lazy_shape_ok(nx, ny, nz_local) && sift3d_gauss_taps(next_sigma, 0.01f, taps) == 2 * SIFT3D_FAST_MAX_R + 1 ? 1 : 0;
-}
-
-extern "C" int sift3d_extrema_append_lazy_dev(sift3d_ctx *c, const float *d_prev, const float *g_prev_a, const float *g_prev_b,
-                                              const float *d_cur, const float *d_next, const float *g_next, float next_sigma,
-                                              int64_t nx, int64_t ny, int64_t nz_local, int level_id, int64_t z_lo, int64_t z_hi)
-{
-    if (!c || !d_cur || (!d_prev && !(g_prev_a && g_prev_b)) || (!d_next && !g_next)) return SIFT3D_ERR_ARG;
-    if (nx <= 0 || ny <= 0 || nz_local <= 0 || nx >= (1ll << 31) || ny >= (1ll << 31) || nz_local >= 65538 ||
-        nx * ny * nz_local > (int64_t)SIFT3D_KEY_IDX_MASK || level_id < 0 || level_id >= 96)
-        return set_err(c, SIFT3D_ERR_ARG, "bad extrema_append arguments");
-    float taps[SIFT3D_MAX_TAPS];
-    const int ntaps = d_next ? 0 : sift3d_gauss_taps(next_sigma, 0.01f, taps);
-    if (((!d_prev || !d_next) && !lazy_shape_ok(nx, ny, nz_local)) || (!d_next && ntaps != 2 * SIFT3D_FAST_MAX_R + 1))
-        return set_err(c, SIFT3D_ERR_ARG, "this shape or filter needs stored DoG levels (sift3d_lazy_levels_supported)");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = fence_in(c);
-    if (rc) return rc;
-    level_job jb = {d_prev ? d_prev : g_prev_a, d_cur, d_next, nx, ny, nz_local, (int)z_lo, (int)z_hi, level_id};
-    if (!d_prev) jb.prev_b = g_prev_b;
-    if (!d_next) {
-        jb.next_ntaps = ntaps;
-        for (int q = 0; q < ntaps; q++) jb.next_taps[q] = taps[q];
-        jb.next_g = g_next;
-    }
-    rc = cand_append(c, jb, true);
-    if (rc) return rc;
-    return fence_out(c);
-}
-
-static int levels_from_desc(sift3d_ctx *c, const sift3d_level_desc *ld, int n, std::vector<sift3d_level> &levels)
-{
-    if (!ld || n <= 0 || n > 96) return set_err(c, SIFT3D_ERR_ARG, "bad level table");
-    levels.resize((size_t)n);
-    for (int i = 0; i < n; i++) {
-        sift3d_level &lv = levels[(size_t)i];
-        lv.img = ld[i].img;
-        lv.XP = (int)ld[i].nx;
-        lv.dogc = ld[i].dogc;
-        lv.X = (int)ld[i].nx; lv.Y = (int)ld[i].ny; lv.Z = (int)ld[i].nz_global;
-        lv.Zl = (int)ld[i].nz_local;
-        lv.z_off = (int)ld[i].z_offset;
-        lv.sigma_h = ld[i].sigma_h; lv.sigma_c = ld[i].sigma_c; lv.sigma_l = ld[i].sigma_l;
-        lv.octave_factor = ld[i].octave_factor;
-        lv.pad = 0;
-    }
-    return SIFT3D_OK;
-}
-
-extern "C" int sift3d_candidates_dev(sift3d_ctx *c, const sift3d_level_desc *levels, int n_levels, sift3d_candidate **out,
-                                     int64_t *n_out)
-{
-    if (!c || !out || !n_out) return SIFT3D_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<sift3d_level> lv;
-    int rc = levels_from_desc(c, levels, n_levels, lv);
-    if (rc) return rc;
-    rc = fence_in(c); /* a replay of the extrema passes reads the caller's level buffers again */
-    if (rc) return rc;
-    int64_t ncand = 0;
-    rc = cand_finalize(c, &ncand);
-    if (rc) return rc;
-    return candidates_to_host(c, lv, ncand, out, n_out); /* ends with a host synchronisation: nothing is left in flight */
-}
-
-extern "C" int sift3d_describe_dev(sift3d_ctx *c, const sift3d_level_desc *levels, int n_levels, int desc_mode,
-                                   float eig_thres, float size_factor, const sift3d_feature **view, const int32_t **group_view,
-                                   int64_t *n_out)
-{
-    if (!c || !view || !n_out) return SIFT3D_ERR_ARG;
-    if (desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) return set_err(c, SIFT3D_ERR_ARG, "bad descriptor mode");
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<sift3d_level> lv;
-    int rc = levels_from_desc(c, levels, n_levels, lv);
-    if (rc) return rc;
-    rc = fence_in(c); /* the keypoint and descriptor kernels read img / dogc of the level table: the caller's buffers */
-    if (rc) return rc;
-    int64_t ncand = 0;
-    rc = cand_finalize(c, &ncand);
-    if (rc) return rc;
-    c->last.n_extrema = ncand;
-    rc = describe_sorted(c, lv, ncand, desc_mode, eig_thres, size_factor, n_out); /* ends with a host synchronisation */
-    if (rc) return rc;
-    *view = c->h_recs;
-    if (group_view) *group_view = c->h_group;
-    return SIFT3D_OK;
-}
-
-/* sift3d_describe_dev in two halves, for a caller that places the records of several contexts -- the ranks of a Z-slab run, one
- * process each -- in ONE list (include/sift3d.h).  First half: everything up to and including the keypoint kernel, and this context's
- * records per (level, is_max) group. */
-extern "C" int sift3d_describe_dev_counts(sift3d_ctx *c, const sift3d_level_desc *levels, int n_levels, int desc_mode, float eig_thres,
-                                          float size_factor, const int32_t **group_counts, int64_t *n_records)
-{
-    if (!c || !group_counts || !n_records) return SIFT3D_ERR_ARG;
-    if (desc_mode < SIFT3D_DESC_SIFT || desc_mode > SIFT3D_DESC_NRRIEF) return set_err(c, SIFT3D_ERR_ARG, "bad descriptor mode");
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<sift3d_level> lv;
-    int rc = levels_from_desc(c, levels, n_levels, lv);
-    if (rc) return rc;
-    rc = fence_in(c);
-    if (rc) return rc;
-    int64_t ncand = 0;
-    rc = cand_finalize(c, &ncand);
-    if (rc) return rc;
-    c->last.n_extrema = ncand;
-    describe_want_group_counts(c, true);
-    const int chunks = c->tune[SIFT3D_TUNE_KP_CHUNKS];
-    c->tune[SIFT3D_TUNE_KP_CHUNKS] = 1; /* the places need the whole list's counts before the one descriptor launch */
-    rc = describe_queue(c, lv, ncand, desc_mode, eig_thres, size_factor, false);
-    c->tune[SIFT3D_TUNE_KP_CHUNKS] = chunks;
-    const int *hc = nullptr;
-    if (!rc) rc = describe_group_counts(c, &hc, n_records);
-    describe_want_group_counts(c, false);
-    if (rc) return rc;
-    *group_counts = hc;
-    c->staged = 1;
-    return SIFT3D_OK;
-}
-
-/* Second half: the descriptor kernel stores record i of group g at list[i + shift[g]]; list is host memory this context's device can
- * write (sift3d_host_register, or any pinned mapped allocation).  Ends with a host synchronisation. */
-extern "C" int sift3d_describe_dev_place(sift3d_ctx *c, sift3d_feature *list, const int32_t *shift, const sift3d_feature **own_view,
-                                         const int32_t **group_view, int64_t *n_out)
-{
-    if (!c || !n_out) return SIFT3D_ERR_ARG;
-    if (!c->staged) return set_err(c, SIFT3D_ERR_ARG, "sift3d_describe_dev_place without sift3d_describe_dev_counts before it");
-    c->staged = 0;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (own_view) *own_view = nullptr;
-    if (group_view) *group_view = nullptr;
-    if (list && !shift) return set_err(c, SIFT3D_ERR_ARG, "sift3d_describe_dev_place: a list without its shifts");
-    if (list && c->kp.ncand > 0 && c->kp.nchunks == 1) {
-        sift3d_feature *dview = nullptr;
-        HIPCHK(c, hipHostGetDevicePointer((void **)&dview, list, 0));
-        int rc = describe_placement(c, dview, shift);
-        if (rc) return rc;
-    }
-    int rc = describe_launch(c);
-    if (!rc) rc = describe_finish(c, n_out);
-    if (rc) return rc;
-    if (own_view && !list) *own_view = c->h_recs; /* list == NULL: the records are where sift3d_describe_dev leaves them */
-    if (group_view) *group_view = c->h_group;
-    return SIFT3D_OK;
-}
-
-/* Host memory of the caller (e.g. a shared-memory segment every rank's process maps) made writable by every device of the process. */
-extern "C" int sift3d_host_register(void *p, int64_t bytes)
-{
-    if (!p || bytes <= 0) return SIFT3D_ERR_ARG;
-    return hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess ? SIFT3D_OK : SIFT3D_ERR_DEVICE;
-}
-
-extern "C" int sift3d_host_unregister(void *p)
-{
-    if (!p) return SIFT3D_ERR_ARG;
-    return hipHostUnregister(p) == hipSuccess ? SIFT3D_OK : SIFT3D_ERR_DEVICE;
-}
-
-/* One z-slice of a resident Gaussian level of the last run, dense (nx_o * ny_o floats of octave o): what the reference's
- * debug output image.pgm shows (fioFeatureSliceXY of octave 0's first blurred level, R/src_common/MultiScale.cpp:373-384). */
-extern "C" int sift3d_get_level_slice(sift3d_ctx *c, int octave, int level, int64_t z, float *out, int64_t *nx_out, int64_t *ny_out)
-{
-    if (!c || !out) return SIFT3D_ERR_ARG;
-    NEED_LEVELS(c);
-    if (!c->has_volume) return set_err(c, SIFT3D_ERR_ARG, "no volume set (sift3d_set_volume)");
-    std::vector<octave_dims> oct = octave_list(c->nx, c->ny, c->nz);
-    if (octave < 0 || (size_t)octave >= oct.size() || level < 0 || level > 4 || !c->L[level])
-        return set_err(c, SIFT3D_ERR_ARG, "no level %d of octave %d", level, octave);
-    const octave_dims &d = oct[(size_t)octave];
-    if (z < 0 || z >= d.Z) return set_err(c, SIFT3D_ERR_ARG, "slice %lld outside 0..%lld", (long long)z, (long long)d.Z - 1);
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy2DAsync(out, sizeof(float) * (size_t)d.X, c->L[level] + d.off + z * d.XP * d.Y, sizeof(float) * (size_t)d.XP,
-                               sizeof(float) * (size_t)d.X, (size_t)d.Y, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nx_out) *nx_out = d.X;
-    if (ny_out) *ny_out = d.Y;
-    return SIFT3D_OK;
-}
-
 extern "C" int sift3d_detect(sift3d_ctx *c, float initial_image_scale, sift3d_candidate **out, int64_t *n_out)
 {
     if (!c || !out || !n_out) return SIFT3D_ERR_ARG;
@@ -2270,4 +1086,3 @@ extern "C" int sift3d_extract(sift3d_ctx *c, float initial_image_scale, int desc
     if (*n_out) memcpy(*out, v, sizeof(sift3d_feature) * (size_t)*n_out);
     return SIFT3D_OK;
 }
-

@@ -1,6 +1,6 @@
 /*
  * pipeline.h -- what the translation units of libsift3d_hip.so share about a context: the sift3d_ctx structure and the
- * building blocks of api.hip (blur, candidate lists, the per-keypoint stage) that the one-process Z-slab driver
+ * building blocks of the api_*.hip translation units (blur, candidate lists, the per-keypoint stage) that the one-process Z-slab driver
  * (zslab_driver.hip) strings together per rank.  Internal: nothing here is part of the C-ABI (include/sift3d.h).
  */
 #ifndef SIFT3D_PIPELINE_H
@@ -166,10 +166,27 @@ int set_err(sift3d_ctx *c, int code, const char *fmt, ...);
 
 static inline int64_t pitch_of(int64_t X) { return (X + 3) / 4 * 4; }
 
+/* entry points that work in the context's own level buffers: not on a slab context, which has none */
+#define NEED_LEVELS(c)                                                                                                  \
+    do {                                                                                                                \
+        if ((c) && (c)->lean) return set_err((c), SIFT3D_ERR_ARG, "%s needs a full context (sift3d_create), not a slab context", __func__); \
+    } while (0)
+
+/* runs op between the two fences */
+#define FENCED(c, op)                 \
+    do {                              \
+        int rc_ = fence_in(c);        \
+        if (rc_) return rc_;          \
+        rc_ = (op);                   \
+        if (rc_) return rc_;          \
+        return fence_out(c);          \
+    } while (0)
+
+
 /* lean: a slab context (sift3d_create_slab): the caller owns the level buffers */
 sift3d_ctx *ctx_create(int device, int64_t nx, int64_t ny, int64_t nz, bool lean);
 void timing_begin(sift3d_ctx *c);
-/* out = blur(in); dog = in - out when not NULL (api.hip) */
+/* out = blur(in); dog = in - out when not NULL (api_ops.hip) */
 int blur_dev(sift3d_ctx *c, const float *in, float *out, float *dog, int64_t X, int64_t Y, int64_t Z, float sigma, float min_value,
              float *sub = nullptr, bool *sub_done = nullptr);
 bool blur_window_supported(int64_t X, int64_t Y, float sigma, float min_value);
@@ -193,5 +210,91 @@ int describe_group_counts(sift3d_ctx *c, const int **counts, int64_t *total);
 int describe_placement(sift3d_ctx *c, sift3d_feature *shared_list, const int *shift);
 int describe_launch(sift3d_ctx *c);
 int describe_finish(sift3d_ctx *c, int64_t *n_out);
+
+/* ---- shared by the api_*.hip translation units (round 6: api.hip cut at its seams) ---- */
+/* an event of the context's pool (timed launches) */
+static inline hipEvent_t get_event(sift3d_ctx *c)
+{
+    if (c->pool_used == c->pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        c->pool.push_back(e);
+    }
+    return c->pool[c->pool_used++];
+}
+
+struct stage_scope {
+    sift3d_ctx *c;
+    int stage;
+    hipEvent_t e0, e1;
+    int ntaps;
+    int64_t nvox;
+    double bytes;
+    hipStream_t st;
+    bool timed;
+    stage_scope(sift3d_ctx *c_, int stage_, double bytes_, int ntaps_ = 0, int64_t nvox_ = 0, hipStream_t st_ = nullptr)
+        : c(c_), stage(stage_), e0(nullptr), e1(nullptr), ntaps(ntaps_), nvox(nvox_), bytes(bytes_), st(st_ ? st_ : c_->stream)
+    {
+        c->last.launches[stage] += 1;
+        c->last.alg_bytes[stage] += bytes;
+        /* events cost a few microseconds each (two per launch, ~170 launches: 1 ms of a 13 ms run at 512^3): mode 2
+         * keeps them to the dominant kernels, the blur launches on the full-size volume */
+        timed = c->timing == 1 || c->timing == 3 ||
+                (c->timing == 2 && nvox == pitch_of(c->nx) * c->ny * c->nz &&
+                 (stage == SIFT3D_STAGE_BLUR_FUSED || stage == SIFT3D_STAGE_BLUR_X || stage == SIFT3D_STAGE_BLUR_Y ||
+                  stage == SIFT3D_STAGE_BLUR_Z_DOG));
+        if (timed) {
+            e0 = get_event(c);
+            e1 = get_event(c);
+            hipEventRecord(e0, st);
+        }
+    }
+    void add_bytes(double more) /* the launch turned out to do more (the subsample riding on the level-3 blur) */
+    {
+        c->last.alg_bytes[stage] += more;
+        bytes += more;
+    }
+    void cancel() /* the launch did not happen */
+    {
+        c->last.launches[stage] -= 1;
+        c->last.alg_bytes[stage] -= bytes;
+        if (timed) c->pool_used -= 2;
+        stage = -1;
+    }
+    ~stage_scope()
+    {
+        if (stage < 0) return;
+        if (timed) {
+            hipEventRecord(e1, st);
+            c->launches.push_back({stage, e0, e1, ntaps, nvox, bytes, 0.0f, 0.0f});
+        }
+    }
+};
+
+/* where the extrema passes of the current group append (the whole list, or its first / second part: SIFT3D_TUNE_SPLIT_TAIL) */
+struct cand_target {
+    unsigned long long *keys;
+    sift3d_cval *vals;
+    unsigned long long *count;
+    int64_t cap;
+};
+static inline cand_target cand_target_of(const sift3d_ctx *c)
+{
+    if (c->cand_split_at <= 0) return {c->keys_a, c->vals_a, c->d_count, c->cand_cap};
+    if (c->cand_group == 0) return {c->keys_a, c->vals_a, c->d_count, c->cand_split_at};
+    return {c->keys_a + c->cand_split_at, c->vals_a + c->cand_split_at, c->d_count + 4, c->cand_cap - c->cand_split_at};
+}
+
+std::vector<octave_dims> octave_list(int64_t X, int64_t Y, int64_t Z);            /* api_context.hip */
+int alloc_cands(sift3d_ctx *c, int64_t cap);                                      /* api_context.hip */
+int ensure_T(sift3d_ctx *c, int64_t floats);                                      /* api_context.hip */
+void timing_end(sift3d_ctx *c);                                                   /* api_timing.hip */
+int check_shape(sift3d_ctx *c, int64_t nx, int64_t ny, int64_t nz);               /* api_ops.hip */
+int fence_in(sift3d_ctx *c);                                                      /* api_ops.hip */
+int fence_out(sift3d_ctx *c);                                                     /* api_ops.hip */
+int cand_replay(sift3d_ctx *c);                                                   /* api_ops.hip */
+int surv_make_room(sift3d_ctx *c, unsigned long long high_water);                 /* api_ops.hip */
+int describe_sorted(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, int desc_mode, float eig_thres, float size_factor, int64_t *n_out, bool levels_on_device = false);    /* api_pipeline.hip */
+int candidates_to_host(sift3d_ctx *c, const std::vector<sift3d_level> &levels, int64_t ncand, sift3d_candidate **cands_out, int64_t *n_out);    /* api_pipeline.hip */
 #pragma GCC visibility pop
 #endif

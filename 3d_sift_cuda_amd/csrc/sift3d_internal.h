@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "sift3d.h"
+#include "sift3d_dev.h" /* the self-test and, in DEV builds, the development hooks: declared apart from the boundary */
 
 #define SIFT3D_MAX_TAPS 129
 #define SIFT3D_FAST_MAX_R 8 /* templated kernels cover 3..17 taps (every sigma the pyramid uses) */

@@ -1,6 +1,6 @@
 /*
  * zslab_driver.hip -- sift3d_zslab_* / sift3d_extract_zslab*: one volume cut into Z-slabs, ONE process, one context per
- * listed device, built from api.hip's per-context building blocks (pipeline.h) and the rank-to-rank transfers of
+ * listed device, built from the api_*.hip per-context building blocks (pipeline.h) and the rank-to-rank transfers of
  * zslab_transport.hip (peer copies or RCCL).  Split from api.hip in round 4 (round-3 review, weak 9).
  */
 #include <algorithm>

@@ -1,6 +1,6 @@
 /*
  * zslab_transport.h -- rank-to-rank block transfers of the C slab driver: peer copies or RCCL (see zslab_transport.hip).
- * Internal to the library (api.hip is the only caller); C linkage so that a test can reach it through dlsym if needed.
+ * Internal to the library (zslab_driver.hip is the only caller); C linkage so that a test can reach it through dlsym if needed.
  */
 #ifndef SIFT3D_ZSLAB_TRANSPORT_H
 #define SIFT3D_ZSLAB_TRANSPORT_H

@@ -1,5 +1,5 @@
 /*
- * zslab_transport.hip -- how the C slab driver (sift3d_extract_zslab, api.hip) moves a block of slices from one rank's
+ * zslab_transport.hip -- how the C slab driver (sift3d_extract_zslab, zslab_driver.hip) moves a block of slices from one rank's
  * device to another's.  Two transports behind one interface:
  *
  *   peer copies  hipMemcpyPeerAsync on the RECEIVER's stream behind the event the sender recorded (rounds 2 - 3);

@@ -57,7 +57,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TABLE = "r05_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
+PMC_TABLE = "r06_pmc_traffic.json"   # rocprofv3 --pmc passes of this build (tools/make_profiles.sh)
 BLUR_SOURCE = os.path.join("3d_sift_cuda_amd", "csrc", "kernels_blur_fused.hip")   # what the PMC table was measured on
 
 

@@ -182,12 +182,6 @@ int sift3d_extrema(sift3d_ctx *ctx, const float *d_prev, const float *d_cur, con
  * fioSubSample2DCenterPixel (:1670-1714), out is (nx/2)*(ny/2)*(nz/2): the -2+ / -2- options. */
 int sift3d_double_size(sift3d_ctx *ctx, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out);
 int sift3d_halve_size(sift3d_ctx *ctx, const float *in, int64_t nx, int64_t ny, int64_t nz, float *out);
-/* Hardware self-test behind one implementation choice (no reference counterpart): the orientation-histogram
- * splat accumulates with LDS float atomics (ds_add_f32), which is only a drop-in for the reference's float
- * additions if the LDS unit rounds exactly like the vector ALU.  For i < n: valu[i] = a[i] + b[i] on the vector
- * ALU, lds[i] = the same sum through ds_add_f32 (host arrays).  tests/ compare the two bit for bit on random,
- * denormal, signed-zero, infinite and NaN operands. */
-int sift3d_selftest_lds_add(sift3d_ctx *ctx, const float *a, const float *b, int64_t n, float *valu, float *lds);
 
 /* ---- pipeline level: msGeneratePyramidDOG3D_efficient + the descriptor loop --
  * (R/src_common/MultiScale.cpp:236-570, R/featExtract/featExtract.cpp:409,474-505).
@@ -503,20 +497,8 @@ typedef struct {
 } sift3d_launch_record;
 int sift3d_get_launch_log(const sift3d_ctx *ctx, sift3d_launch_record *out, int64_t cap, int64_t *n);
 
-#ifdef SIFT3D_DEV
-/* Development builds only (make DEV=1; tools/kp_ablate.py, tools/desc_ablate.py): the per-keypoint kernels return after
- * stage n (0 = run everything).  Not compiled into the product library. */
-int sift3d_dev_set_stop(sift3d_ctx *ctx, int n);
-/* Development builds only (tools/bench_match.py with KNN_PLAN=groups,segments): overrides how sift3d_knn64 cuts a search
- * (0 = the library's own choice). */
-void sift3d_dev_knn_plan(int groups, int segments);
-/* Development builds only (KNN_AHEAD=2 tools/bench_match.py): the search kernel with the matrix cores two subtiles ahead of the
- * vector unit (three accumulator sets) instead of one. */
-void sift3d_dev_knn_ahead(int ahead);
-/* Development builds only (tools/overlap_probe.py): the keypoint and the descriptor kernel of the last extraction run again,
- * one after the other (out_ms[0]) and in alternating slices on two streams (out_ms[1]). */
-int sift3d_dev_overlap_probe(sift3d_ctx *ctx, int kslice, int dslice, double *out_ms);
-#endif
+/* Development hooks (make DEV=1 builds only) and the one hardware self-test the product library carries are declared in
+ * include/sift3d_dev.h: they are not part of the boundary a caller of the reference binds. */
 
 #ifdef __cplusplus
 }

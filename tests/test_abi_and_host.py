@@ -12,8 +12,8 @@ from keyio import read_key
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "sift3d.h")).read()
+def declared_functions(header="sift3d.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"#ifdef SIFT3D_DEV.*?#endif", "", src, flags=re.S)   # development builds only (make DEV=1), not the product
     return sorted(set(re.findall(r"\b(sift3d_[a-z0-9_]+)\s*\(", src)))
@@ -28,9 +28,15 @@ def test_header_declares_the_expected_entry_points():
 
 def test_library_exports_every_declared_symbol(built):
     lib = C.CDLL(built.LIB_HIP)
-    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    missing = [n for n in declared_functions() + declared_functions("sift3d_dev.h") if not hasattr(lib, n)]
     assert not missing, missing
-    assert not hasattr(lib, "sift3d_dev_set_stop")   # the ablation hook is not in the product library
+    # include/sift3d.h is the boundary and nothing else (round-5 review): development hooks and the self-test are declared in
+    # include/sift3d_dev.h; of those the product library exports the self-test only
+    assert not [n for n in declared_functions() if n.startswith("sift3d_dev_") or "selftest" in n]
+    assert declared_functions("sift3d_dev.h") == ["sift3d_selftest_lds_add"]
+    dev = open(os.path.join(ROOT, "include", "sift3d_dev.h")).read()
+    for hook in re.findall(r"\b(sift3d_dev_[a-z0-9_]+)\s*\(", dev):
+        assert not hasattr(lib, hook), hook
 
 
 def test_python_tuning_constants_mirror_the_header(built):
@@ -55,7 +61,7 @@ def test_product_reads_no_environment_variable(built):
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".h")):
             assert "getenv" not in open(os.path.join(csrc, f)).read(), f
-    for obj in ("api.o", "kernels_volume.o", "kernels_blur_fused.o", "kernels_keypoint.o", "gauss_taps.o"):
+    for obj in ("api_context.o", "api_timing.o", "api_ops.o", "api_pipeline.o", "api_slab.o", "kernels_volume.o", "kernels_blur_fused.o", "kernels_keypoint.o", "gauss_taps.o"):
         nm = subprocess.run(["nm", "--undefined-only", os.path.join(csrc, "_build", obj)], capture_output=True, text=True)
         assert nm.returncode == 0 and "getenv" not in nm.stdout, obj
 
