@@ -8,6 +8,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 pkg = importlib.import_module("3d_sift_cuda_amd")
+if os.environ.get("SIFT3D_AB_BUILD"):   # A/B of two builds of the library on one box: csrc/<dir>/libsift3d_hip.so instead of csrc/_build
+    pkg.LIB_HIP = os.path.join(pkg.CSRC, os.environ["SIFT3D_AB_BUILD"], "libsift3d_hip.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 modes = [int(m) for m in (sys.argv[3] if len(sys.argv) > 3 else "1,2").split(",")]

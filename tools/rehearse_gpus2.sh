@@ -51,7 +51,8 @@ d = json.loads(lines[0])
 z, zc = d["zslab"], d["zslab_c"]
 assert d["n_gpus"] == ranks and d["scaling"] == "strong" and d["value"] and d["same_bytes_as_single_gpu"] is True
 if inj == "shared-list":
-    assert z["status"] == "ok" and z["records_to_rank0"].startswith("gathered") and "injected" in z["records_gathered_because"], z
+    why = z["records_gathered_because"]   # rank 0's view: "... rank(s) [1] could not set it up" (rank 1's own message names the injection)
+    assert z["status"] == "ok" and z["records_to_rank0"].startswith("gathered") and "shared record list" in why and ("[1]" in why or "injected" in why), z
     assert d["value_source"].startswith("zslab: one process per GPU")
     assert len(z["per_rank"]) == ranks and all(r["halo_bytes_critical"] > 0 and r["per_octave"] for r in z["per_rank"])
 else:
