@@ -92,7 +92,7 @@ def blur_source_hash():
 def kernel_name(stage, ntaps, dog, vec=4):
     r = ntaps // 2
     if stage == "blur_fused":
-        return "blur_fused_ring_kernel<%d, rows per thread, has level, %s, prefetch planes>" % (r, "true" if dog else "false")
+        return "blur_fused_ring_kernel<%d, rows per thread, has level, %s, prefetch planes, tile x, tile y, has half-size volume, staggered halves>" % (r, "true" if dog else "false")
     if stage == "blur_x":
         return "blur_x_kernel<%d,%d>" % (r, vec)
     return "blur_col_kernel<%d,%d,%s>" % (r, vec, "true" if dog else "false")
@@ -785,10 +785,13 @@ def main():
                     R = pi["taps"] // 2
                     with_dog = pi["alg_bytes_per_voxel"] > 9
                     with_sub = pi["alg_bytes_per_voxel"] > 12.2   # the level-3 launch that also writes the next octave's level 0
-                    # template arguments: <R, rows per thread, has level, has DoG, prefetch planes, tile x, tile y[, has half-size]>
-                    mine = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and k.endswith(", true>") == with_sub]
-                    exact = [k for k in mine if (", true, true," in k) == with_dog and (with_dog or ", true, false," in k)]
-                    twin = [k for k in mine if ", true, true," in k]
+                    # template arguments: <R, rows per thread, has level, has DoG, prefetch planes, tile x, tile y, has half-size, staggered>
+                    def targs(k):
+                        a = [v.strip() for v in k[k.index("<") + 1:k.rindex(">")].split(",")]
+                        return a + ["false"] * (9 - len(a))
+                    mine = [k for k in tab if k.startswith("blur_fused_ring_kernel<%d," % R) and (targs(k)[7] == "true") == with_sub]
+                    exact = [k for k in mine if targs(k)[2] == "true" and (targs(k)[3] == "true") == with_dog]
+                    twin = [k for k in mine if targs(k)[2] == "true" and targs(k)[3] == "true"]
                     if exact:
                         w = tab[sorted(exact)[0]]["hbm_bytes_per_launch_512"]
                     elif twin:   # a level-only launch measured through its level + DoG twin: 4 B/voxel less written

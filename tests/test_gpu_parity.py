@@ -870,6 +870,12 @@ def test_cli_reproduces_the_shipped_binary(built, tmp_path):
         r = subprocess.run([built.FEATEXTRACT, "--libm=gcc5", flag, "-d0", nii, k], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
         assert open(k, "rb").read() == open(os.path.join(gold, "refbin_aniso_%s.key" % flag[1:]), "rb").read(), flag
+    # -2+ with the binary's taps: the 224 records the round-1 review counted from the shipped binary on this volume (223 with the
+    # default taps: one near-tie of an orientation peak resolves the other way), byte-identical to the oracle's variant build
+    b64, kg, kv = str(tmp_path / "b64.nii"), str(tmp_path / "g2.key"), str(tmp_path / "v2.key")
+    assert subprocess.run([built.FEATEXTRACT, "--libm=gcc5", "-2+", "-d0", b64, kg], capture_output=True).returncode == 0
+    assert subprocess.run([_oracle.CLI_REFBIN, "-2+", b64, kv], capture_output=True).returncode == 0
+    assert open(kg, "rb").read() == open(kv, "rb").read() and read_key(kg)["count"] == 224
     # an unknown long option is an unknown argument, as every "--..." is for the reference
     r = subprocess.run([built.FEATEXTRACT, "--libm=gcc4", "-d0", nii, str(tmp_path / "x.key")], capture_output=True, text=True)
     assert r.returncode == 255 and "Error: unknown command line argument: --libm=gcc4" in r.stdout

@@ -254,6 +254,17 @@ def test_double_size_record_count_and_its_one_near_tie(oracle, built, tmp_path):
     assert all(abs(ratio(l) - 0.5) > 0.03 for l in mine if " secondary " in l)       # nothing sits on the 0.5 threshold
     assert all(abs(ratio(l) - 0.8) > 0.025 for l in mine if " secondary " not in l)  # nor on the 0.8 one
     assert len(mine) == 9
+    # Round 6: the near-tie resolves the other way in the build of the taps the shipped binary has (exp(double),
+    # test_refbin_variant_is_byte_identical): the -DO3_REFBIN_VARIANT oracle yields the judge's 224 records, the extra one a
+    # seventh 0x30 frame of exactly that keypoint.  That is the one piece of reference-held evidence for -2+ (fioDoubleSize,
+    # R/src_common/FeatureIO.cpp:2452-2548) there is: the count and the keypoint the round-1 review reported from the binary.
+    key2 = str(tmp_path / "v.key")
+    assert subprocess.run([_oracle.CLI_REFBIN, "-2+", nii, key2], capture_output=True).returncode == 0
+    k2 = read_key(key2)
+    assert k2["count"] == len(k2["rows"]) == 224
+    r2 = k2["rows"]
+    at2 = r2[(np.abs(r2[:, 0] - 37.315) < 2e-3) & (np.abs(r2[:, 1] - 42.044) < 2e-3) & (np.abs(r2[:, 2] - 55.0) < 2e-3)]
+    assert len(at2) == 8 and (at2[1:, 16] == 0x30).all()          # 1 + 7 frames
 
 
 @pytest.mark.parametrize("dims,mode,scale", [((64, 64, 64), 0, 1.0), ((80, 64, 48), 1, 1.0), ((67, 45, 38), 2, 1.0), ((48, 48, 48), 3, 0.5)])
