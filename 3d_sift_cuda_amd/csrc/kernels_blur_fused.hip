@@ -643,7 +643,10 @@ static bool launch_ring(hipStream_t s, const float *in, float *out, float *dog, 
     const bool stg = R >= 3 && R <= 6 && (stg_knob == 2 || (stg_knob == 0 && R >= 5));
     if constexpr (R == 5)
         if (sub && br == 2 && out && dog && zo0 == 0 && zo1 == Z && X % 8 == 0 && Z >= 2 && Y >= 2) {
-            const bool wide5 = (tune ? tune->tile : 0) == 2 && X >= 128;
+            /* 128 x 16 under the stagger (round 6, profiles/r06_stagger_ab.txt section 8: 0.354 -> 0.340 - 0.344 ms at 512^3; without the
+             * stagger the two tiles measured equal in round 4); SIFT3D_TUNE_FUSED_TILE forces either */
+            const int tile5 = tune ? tune->tile : 0;
+            const bool wide5 = (tile5 == 2 || (tile5 == 0 && stg)) && X >= 128;
 #define FB_SUB(TXv, TYv)                                                                                                         \
     (stg ? launch_ring_t<5, 2, true, true, 2, TXv, TYv, true, true>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order)        \
          : launch_ring_t<5, 2, true, true, 2, TXv, TYv, true, false>(s, in, out, dog, X, Y, Z, zo0, zo1, t, chunks, sub, order))

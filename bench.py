@@ -732,10 +732,10 @@ def main():
         fused_id = stage_names.index("blur_fused") if "blur_fused" in stage_names else -1
         sel = log[(log["stage"] == fused_id) & (log["nvox"] == nfullvox)]
         if len(sel):
-            dom_name = ("blur_fused_ring_kernel<R, rows per thread, has level, has DoG, prefetch planes> "
+            dom_name = ("blur_fused_ring_kernel<R, rows per thread, has level, has DoG, prefetch planes, tile x, tile y, has half-size volume, staggered halves> "
                         "(the %d launches per volume at %d^3: initial blur + the levels stored in full -- L1..L4 by default, the "
                         "17-tap level L5 only exists around the candidates of D3 (extrema_validate_lazy_kernel); two rows per "
-                        "thread, two planes of prefetch, one workgroup per CU)" % (len(sel) // args.steps, n))
+                        "thread, two or three planes of prefetch, one workgroup per CU; from 11 taps up the second half of the wavefronts half a step behind the first)" % (len(sel) // args.steps, n))
             if not (nx == ny == nz):
                 dom_name = dom_name.replace("%d^3" % n, vol_label)
             dom_all = full[full["stage"] == fused_id]

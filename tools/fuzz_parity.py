@@ -39,6 +39,7 @@ def sweep(cases=60, seed=1, max_edge=112):
         dseg = int(rng.choice([32, 32, 0, 1, 5]))   # round 4: the descriptor kernel's record order over the XCDs
         order = int(rng.choice([0, 0, 1, 2, 3]))    # round 5: which workgroup takes which tile of the fused blur
         runs = int(rng.choice([0, 0, 1, 3]))        # round 5: the volume handed over in runs of planes (sift3d_set_volume_begin / _planes / _end)
+        stagger = int(rng.choice([0, 0, 1, 2]))     # round 6: the fused blur's half-step stagger (0 by measurement, 1 off, 2 on)
         vol = pkg.synth_blobs(*dims, seed=vseed)
         if noise:
             vol = vol + (rng.standard_normal(vol.shape) * noise).astype(np.float32)
@@ -52,6 +53,7 @@ def sweep(cases=60, seed=1, max_edge=112):
             ctx.set_tuning(pkg.TUNE_SPLIT_TAIL, split)
             ctx.set_tuning(pkg.TUNE_DESC_SEGMENT, dseg)
             ctx.set_tuning(pkg.TUNE_FUSED_ORDER, order)
+            ctx.set_tuning(pkg.TUNE_FUSED_STAGGER, stagger)
             if i % 5 == 4:
                 ctx.reserve(int(rng.integers(0, 4000)))   # round 5: buffers made ahead of the run (more or fewer than it needs)
             if runs == 0:

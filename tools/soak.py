@@ -23,6 +23,7 @@ with pkg.Context(n, n, n) as ctx:
         ctx.set_tuning(pkg.TUNE_DESC_SEGMENT, int(rng.choice([32, 32, 0, 1, 7])))
         ctx.set_tuning(pkg.TUNE_KP_CHUNKS, int(rng.choice([0, 0, 0, 3])))
         ctx.set_tuning(pkg.TUNE_FUSED_ORDER, int(rng.choice([0, 0, 1, 2, 3])))   # round 5
+        ctx.set_tuning(pkg.TUNE_FUSED_STAGGER, int(rng.choice([0, 0, 1, 2])))    # round 6
         if i % 97 == 5:   # round 5: the volume handed over again, in runs of planes
             cut = int(rng.integers(1, n))
             ctx.set_volume_in_runs(vol, [(cut, n - cut), (0, cut)])
