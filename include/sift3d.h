@@ -18,6 +18,24 @@
  *
  * There is no CPU fallback: without a usable HIP device sift3d_create()
  * returns NULL and sift3d_device_count() returns 0.
+ *
+ * THE CALLS THAT MATTER to a maintainer of the reference (everything else in
+ * this header serves tests, measurements, several GPUs, or the matcher):
+ *   lifecycle     sift3d_device_count, sift3d_create, sift3d_destroy,
+ *                 sift3d_last_error, sift3d_free
+ *   the four accelerator wrappers of R/cuda_common/SIFT_cuda_Tools.cuh
+ *                 sift3d_gauss_blur   <- blur_3d_simpleborders_CUDA_Row_Col_Shared_mem
+ *                 sift3d_dog          <- fioCudaMultSum
+ *                 sift3d_subsample2   <- SubSampleInterpolateCuda
+ *                 sift3d_extrema      <- detectExtrema4D_test_cuda
+ *   the pipeline  sift3d_set_volume (or _resized for -2+ / -2-), sift3d_extract
+ *                 <- msGeneratePyramidDOG3D_efficient + the descriptor loop
+ *   output        sift3d_write_key (csrc/keyfile.h, libsift3d_host.so) <- msFeature3DVectorOutputText
+ * INTEGRATION.md shows the reference-side edit for each.  Section index:
+ * operator level; pipeline level; tuning; timing; Z-slab building blocks and
+ * sift3d_extract_zslab (several GPUs, beyond the reference); host helpers
+ * (.key, NIfTI, world coordinates); matcher.  Development hooks and the one
+ * hardware self-test are in sift3d_dev.h, not here.
  */
 #ifndef SIFT3D_H
 #define SIFT3D_H
@@ -31,7 +49,7 @@ extern "C" {
 /* Layout version of the structures this header passes by pointer (sift3d_zslab_stats, sift3d_timings, sift3d_feature, ...).
  * The library writes WHOLE structures through the caller's pointers, so a binding compiled against another layout would be
  * overrun: a binding checks sift3d_abi_version() == SIFT3D_ABI_VERSION once, when it loads the library (the in-tree ctypes
- * mirror and featExtract do).  5: sift3d_zslab_stats gained comm_sets, resident_volume, merge_ms, halo_bytes_subsample, enqueue_ms (round 5); 4: transport,
+ * mirror and featExtract do).  6: the tuning enum gained SIFT3D_TUNE_FUSED_STAGGER, sift3d_set_libm_variant (round 6); 5: sift3d_zslab_stats gained comm_sets, resident_volume, merge_ms, halo_bytes_subsample, enqueue_ms (round 5); 4: transport,
  * transport_fell_back, rccl_version (round 4). */
 #define SIFT3D_ABI_VERSION 6
 int sift3d_abi_version(void);
