@@ -152,6 +152,16 @@ def test_nifti_roundtrip_and_cli_usage(built, tmp_path, oracle):
     assert r.returncode == 255 and "Usage: featExtract [options] <input image> <output features>" in r.stdout
     r = subprocess.run([built.FEATEXTRACT, "-q", "a", "b"], capture_output=True, text=True)
     assert r.returncode == 255 and "Error: unknown command line argument: -q" in r.stdout
+    # round 6: the one long option this build adds (--libm=gcc5 | current); anything else behind "--" is an unknown argument
+    r = subprocess.run([built.FEATEXTRACT, "--libm=gcc4", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Error: unknown command line argument: --libm=gcc4" in r.stdout
+    # without a HIP device the command line says so, names the CPU route and exits: no CPU path hides in the product
+    if built.device_count() <= 0:
+        nii = str(tmp_path / "dev.nii")
+        built.write_nifti(nii, np.ones((8, 8, 8), np.float32))
+        r = subprocess.run([built.FEATEXTRACT, "--libm=gcc5", nii, str(tmp_path / "dev.key")], capture_output=True, text=True)
+        assert r.returncode == 255 and "no usable HIP device" in r.stderr and "featExtract_oracle" in r.stderr
+        assert not os.path.exists(str(tmp_path / "dev.key"))
 
 
 def test_key_writer_matches_oracle_writer(built, oracle, tmp_path):
